@@ -1,0 +1,190 @@
+/*
+ * pmc_hip.h -- C ABI of libpmc_hip.so, the MI355X (gfx950) adaptive-importance-sampling core.
+ *
+ * The reference (pypmc 1.2.6) has no FFI layer: its hot loops are Cython functions and methods
+ * called from Python.  This header declares, one entry point per reference loop nest, what a
+ * binding for that path has to call.  Citations are file:line under the reference tree.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer prefixed d_ is a DEVICE pointer (HIP), every
+ *     pointer prefixed h_ is a HOST pointer; `stream` is a hipStream_t passed as void*.
+ *   - all arithmetic is IEEE fp64 (the reference uses `double` memoryviews throughout).
+ *   - every function returns 0 on success, a negative PMC_E* code on failure and never throws or
+ *     aborts; pmc_last_error() returns a thread-local message for the last failure.
+ *   - launches are asynchronous on `stream`; outputs are valid after the stream is synchronised.
+ *   - results are deterministic run-to-run (fixed reduction trees, no floating-point atomics).
+ *
+ * Component parameter pack ("pack")
+ *   The kernels read mixture parameters through the scalar cache from one flat fp64 array built on
+ *   the host by pmc_pack_components().  Per component (stride pmc_pack_stride(Dp) doubles):
+ *     [0,Dp)            mean / shift  mu_k
+ *     [Dp,Dp+T)         R_k, upper triangular, row-major (i, j>=i), T=Dp(Dp+1)/2, with
+ *                       precision_k = R_k^T R_k  so that  (x-mu)^T precision (x-mu) = |R (x-mu)|^2
+ *                       (replaces bilinear_sym(inv_sigma, x-mu), pypmc/tools/_linalg.pyx:10-39)
+ *     [Dp+T+0..3]       c0..c3, kind specific (see pmc_kind)
+ *     [Dp+T+4]          linear component weight w_k (mixture.pyx:147, _regularize.pyx:72-81)
+ *     [Dp+T+5]          output column of this component in N x ld row-major outputs
+ *   Dp = pmc_padded_dim(D) >= D is the compiled kernel dimension used for D.
+ */
+#ifndef PMC_HIP_H
+#define PMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMC_ABI_VERSION 1
+
+enum pmc_status {
+    PMC_OK = 0,
+    PMC_EINVAL = -1,       /* bad argument (shape, NULL, unsupported dimension) */
+    PMC_ENOTPOSDEF = -2,   /* a precision matrix is not positive definite */
+    PMC_EHIP = -3,         /* HIP runtime error (message has hipGetErrorString) */
+    PMC_ENODEVICE = -4     /* no gfx950 device / kernels not loadable */
+};
+
+/* How the per-(sample, component) value a_nk is formed from maha_nk = |R_k (x_n - mu_k)|^2 */
+enum pmc_kind {
+    /* Gauss.multi_evaluate, pypmc/density/gauss.pyx:146-151:  a = c0 - 0.5*maha,  c0 = log_normalization */
+    PMC_KIND_GAUSS = 0,
+    /* StudentT.multi_evaluate, pypmc/density/student_t.pyx:159-164 (same operation order):
+     *   a = c0 + c1*log(1 + maha*c2),  c0 = log_norm, c1 = -(dof+D)/2, c2 = 1/dof, c3 = dof */
+    PMC_KIND_STUDENT_T = 1,
+    /* GaussianInference, pypmc/mix_adapt/variational.pyx:798 and :691 (same operation order):
+     *   E = c0 + c1*maha,  a = c2 + 0.5*(c3 - E);
+     *   c0 = D/beta_k, c1 = nu_k, c2 = E[ln pi_k], c3 = E[ln|Lambda_k|] - D*log(2 pi) */
+    PMC_KIND_VB = 2
+};
+
+/* What pmc_responsibilities() turns a row of a_nk into */
+enum pmc_resp_mode {
+    /* variational.pyx:728-755 _update_r: r = softmax_k(a), zeros -> tiny, log_rho normalised */
+    PMC_RESP_VB = 0,
+    /* pmc.pyx:23-43 calculate_rho_rb: rho = exp(a) w_k / (exp(logsumexp) + tiny) */
+    PMC_RESP_PMC_RB = 1,
+    /* pmc.pyx:45-51 calculate_rho_non_rb: rho = [latent_n == column_k] */
+    PMC_RESP_PMC_LATENT = 2
+};
+
+/* ---- library / device ------------------------------------------------------------------- */
+int pmc_abi_version(void);
+const char *pmc_last_error(void);
+/* number of visible HIP devices, or a negative status */
+int pmc_device_count(void);
+/* writes the gcnArchName of `device` (e.g. "gfx950:sramecc+:xnack-") into buf */
+int pmc_device_arch(int device, char *buf, size_t buflen);
+
+/* ---- dimensions ---------------------------------------------------------------------------- */
+/* largest supported sample dimension */
+int pmc_max_dim(void);
+/* compiled kernel dimension used for D (>= D), or PMC_EINVAL if D is unsupported */
+int pmc_padded_dim(int D);
+/* doubles per component in a pack for sample dimension D */
+int64_t pmc_pack_stride(int D);
+/* samples per tile of the internal tile-major N x K layout (64 = one wavefront) */
+int pmc_tile(void);
+
+/* ---- host-side parameter preparation ------------------------------------------------------- */
+/*
+ * Build the pack for K components on the HOST (Cholesky factor of each precision matrix,
+ * padding to the compiled dimension).  precision is K x D x D row-major symmetric positive
+ * definite: Gauss/StudentT `inv_sigma` (gauss.pyx:112, student_t.pyx:111) or the VB `W`
+ * (variational.pyx:783).  c0..c3 and weight are K vectors (c* may be NULL = 0, weight NULL = 1),
+ * column is a K vector of output columns (NULL = 0..K-1).  h_pack receives K*pmc_pack_stride(D)
+ * doubles.  Returns PMC_ENOTPOSDEF (and names the component) if a factorisation fails.
+ */
+int pmc_pack_components(int K, int D, const double *h_mu, const double *h_precision,
+                        const double *h_c0, const double *h_c1, const double *h_c2,
+                        const double *h_c3, const double *h_weight, const int32_t *h_column,
+                        double *h_pack);
+
+/* ---- workspace ------------------------------------------------------------------------------ */
+/* bytes of device scratch the calls below need for N samples, K components, dimension D */
+int64_t pmc_workspace_bytes(int64_t N, int K, int D);
+/* doubles in one tile-major N x K buffer (d_u, d_v1, d_v2): ceil(N/64)*K*64 */
+int64_t pmc_tile_buffer_len(int64_t N, int K);
+/* doubles per component in the statistics vector: 1 + D + D(D+1)/2 + 2 */
+int64_t pmc_stats_stride(int D);
+
+/* ---- mixture log-pdf and importance weights ---------------------------------------------- */
+/*
+ * MixtureDensity.multi_evaluate (pypmc/density/mixture.pyx:112-156) with the component loops
+ * (gauss.pyx:146-151 / student_t.pyx:154-164) and logsumexp2D (_regularize.pyx:57-84) fused
+ * into one pass over the samples.
+ *
+ *   d_x           N x D row-major samples
+ *   d_pack        K components (kind PMC_KIND_GAUSS or PMC_KIND_STUDENT_T)
+ *   max_init_zero 0: row maximum starts at -DBL_MAX (_regularize.pyx:73);
+ *                 1: it starts at 0.0 -- the mixture has dead (zero weight, all-zero column)
+ *                    components that take part in the maximum (pmc.pyx:24-34)
+ *   d_out         N, log q(x_n) = log sum_k w_k exp(a_nk)           (NULL: not wanted)
+ *   d_individual  N x ld row-major, a_nk written to column column_k (NULL: not wanted);
+ *                 with d_out == NULL this is the `components=` subset mode (mixture.pyx:153-156)
+ *   d_log_target  N, log P(x_n) (NULL: no importance weights).  If given:
+ *   d_weights     N, w_n = exp(log_target_n - log q_n) (importance_sampling.py:197-215)
+ *   d_sample_w    N, optional weights for the log-likelihood sum (NULL = 1)
+ *   d_scalars     8 doubles (NULL: not wanted):
+ *                 [0] sum w  [1] sum w*log w (zeros masked, convergence.py:31-39)  [2] sum w^2
+ *                 [3] sum sample_w_n * log q_n (pmc.pyx:388-391)  [4] number of non-finite w_n
+ *                 produced from a finite exponent (math.exp overflow, importance_sampling.py:207)
+ *                 [5..7] reserved (0)
+ *   d_workspace   pmc_workspace_bytes(N,K,D) bytes
+ */
+int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                       int max_init_zero, double *d_out, double *d_individual, int64_t ld,
+                       const double *d_log_target, double *d_weights, const double *d_sample_w,
+                       double *d_scalars, void *d_workspace, void *stream);
+
+/*
+ * perp / ess sums over a weight vector (pypmc/tools/convergence.py:31-39, :67-72):
+ * d_scalars[0..2] = sum w, sum w log w (zeros masked), sum w^2.
+ */
+int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_workspace,
+                    void *stream);
+
+/* ---- responsibilities ------------------------------------------------------------------------ */
+/*
+ * The N x K responsibility matrix of the VB E-step (variational.pyx:774-798 exponent,
+ * :675-691 log_rho, :711-757 r) or of the PMC update (pmc.pyx:23-51, and for Student-t
+ * gamma_nk = (nu_k+D)/(nu_k+maha_nk), pmc.pyx:602-610), produced directly in the tile-major layout
+ * the statistics kernel consumes:  buffer[(tile*K + k)*64 + lane], sample n = tile*64 + lane.
+ *
+ *   d_pack       K live components; kind VB with mode PMC_RESP_VB, GAUSS/STUDENT_T otherwise
+ *   d_sample_w   N sample weights (NULL = 1): VB `self.weights` (variational.pyx:94) / importance
+ *                weights (pmc.pyx:188)
+ *   d_latent     N int64 generating component per sample (mode PMC_RESP_PMC_LATENT only)
+ *   d_u          tile-major: sample_w*r (VB), sample_w*rho (Gauss PMC), sample_w*rho*gamma (Student-t)
+ *   d_v1, d_v2   tile-major, Student-t PMC only (else NULL): sample_w*rho and
+ *                sample_w*rho*log(0.5*(maha+nu)) (the N-sized part of pmc.pyx:659-679)
+ *   d_r, d_log_rho, d_exponent   optional N x ld row-major public matrices (NULL: not wanted):
+ *                r / rho; normalised log_rho (VB); expectation_gauss_exponent (VB)
+ *   d_scalars    8 doubles: [0] VB: sum_n sample_w sum_k r log_rho (variational.pyx:1003-1013);
+ *                [3] PMC: sum_n sample_w log q_n;  others 0
+ */
+int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                         int mode, int max_init_zero, const double *d_sample_w,
+                         const int64_t *d_latent, double *d_u, double *d_v1, double *d_v2,
+                         double *d_r, double *d_log_rho, double *d_exponent, int64_t ld,
+                         double *d_scalars, void *d_workspace, void *stream);
+
+/* ---- sufficient statistics ------------------------------------------------------------------- */
+/*
+ * One pass over the samples accumulating, per component k and with d = x_n - mu_k (the pack's
+ * shift):  sum_n u_nk | sum_n u_nk d (D) | sum_n u_nk d d^T (lower triangle, row-major i, j<=i) |
+ * sum_n v1_nk | sum_n v2_nk     ->  d_stats[k*pmc_stats_stride(D) + ...]
+ * These are the shifted, un-normalised forms of N_k, x-bar_k, S_k (variational.pyx:699-932) and
+ * of alpha_k, mu_k, Sigma_k (pmc.pyx:188-222, :612-652); the K-sized conversion to the
+ * reference's centred conventions is done by the caller.  With several GPUs each rank calls this
+ * on its shard and the ranks all-reduce (sum) d_stats -- the only cross-GPU exchange of the path.
+ */
+int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+                         const double *d_u, const double *d_v1, const double *d_v2,
+                         double *d_stats, void *d_workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMC_HIP_H */

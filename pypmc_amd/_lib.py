@@ -1,0 +1,95 @@
+"""ctypes binding of libpmc_hip.so (C ABI: include/pmc_hip.h).
+
+The library is the product path.  There is no CPU fallback: if it cannot be loaded every
+operation raises ``HipLibraryError`` with the reason.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpmc_hip.so")
+
+PMC_KIND_GAUSS, PMC_KIND_STUDENT_T, PMC_KIND_VB = 0, 1, 2
+PMC_RESP_VB, PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT = 0, 1, 2
+PMC_OK, PMC_EINVAL, PMC_ENOTPOSDEF, PMC_EHIP, PMC_ENODEVICE = 0, -1, -2, -3, -4
+NSCALARS = 8
+
+
+class HipLibraryError(RuntimeError):
+    """libpmc_hip.so is missing / unloadable, or a call into it failed."""
+
+
+class NotPositiveDefinite(HipLibraryError):
+    """A precision matrix handed to pmc_pack_components is not positive definite."""
+
+
+_vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int
+_dp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); must list every symbol include/pmc_hip.h declares
+SIGNATURES = {
+    "pmc_abi_version": (_int, []),
+    "pmc_last_error": (C.c_char_p, []),
+    "pmc_device_count": (_int, []),
+    "pmc_device_arch": (_int, [_int, C.c_char_p, C.c_size_t]),
+    "pmc_max_dim": (_int, []),
+    "pmc_padded_dim": (_int, [_int]),
+    "pmc_pack_stride": (_i64, [_int]),
+    "pmc_tile": (_int, []),
+    "pmc_pack_components": (_int, [_int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i32, _dp]),
+    "pmc_workspace_bytes": (_i64, [_i64, _int, _int]),
+    "pmc_tile_buffer_len": (_i64, [_i64, _int]),
+    "pmc_stats_stride": (_i64, [_int]),
+    "pmc_mixture_logpdf": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp,
+                                  _vp, _vp, _vp, _vp]),
+    "pmc_weight_sums": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "pmc_responsibilities": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "pmc_sufficient_stats": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+_load_error = None
+
+
+def load():
+    """Return the loaded library or raise HipLibraryError (never falls back)."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is not None:
+        raise HipLibraryError(_load_error)
+    if not os.path.exists(LIB_PATH):
+        _load_error = ("%s not found: build it with `python -m pypmc_amd.build` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+        raise HipLibraryError(_load_error)
+    try:
+        # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  Import torch first so
+        # that libpmc_hip.so binds to that same runtime instance: two HIP runtimes in one process
+        # do not see each other's devices, streams or allocations.
+        import torch  # noqa: F401
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    except (OSError, AttributeError, ImportError) as exc:
+        _load_error = "cannot load %s: %s" % (LIB_PATH, exc)
+        raise HipLibraryError(_load_error)
+    _lib = lib
+    return _lib
+
+
+def last_error():
+    msg = load().pmc_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status, what=""):
+    """Turn a negative status into an exception carrying pmc_last_error()."""
+    if status is not None and status < 0:
+        msg = "%s failed (%d): %s" % (what or "libpmc_hip call", status, last_error())
+        if status == PMC_ENOTPOSDEF:
+            raise NotPositiveDefinite(msg)
+        raise HipLibraryError(msg)
+    return status

@@ -1,0 +1,229 @@
+"""Device backend: libpmc_hip.so driven through ctypes, with PyTorch-ROCm used only as plumbing
+(device memory, the current HIP stream, and -- in pypmc_amd.parallel -- torch.distributed/RCCL).
+
+``HipBackend`` is the only backend the package ships.  The front-end classes take a ``backend``
+argument solely so that the CPU-only test-suite can inject a checker from ``tests/``; the
+default is always the HIP path and it raises ``HipLibraryError`` when the library or the GPU is
+missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (HipLibraryError, NotPositiveDefinite, PMC_KIND_GAUSS, PMC_KIND_STUDENT_T,
+                   PMC_KIND_VB, PMC_RESP_VB, PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT, NSCALARS)
+
+__all__ = ["ComponentSet", "HipBackend", "get_backend", "set_default_backend", "HipLibraryError",
+           "NotPositiveDefinite"]
+
+
+class ComponentSet(object):
+    """Host description of K mixture components as the kernels consume them
+    (see ``enum pmc_kind`` in include/pmc_hip.h for the meaning of c0..c3).
+
+    ``column[k]`` is the column of component k in N x ``ld`` row-major outputs, so a subset of
+    a K_total-component mixture is described by its live components with ``ld = K_total``.
+    """
+
+    def __init__(self, kind, mu, precision, c0=None, c1=None, c2=None, c3=None, weight=None,
+                 column=None, ld=None):
+        self.kind = int(kind)
+        self.mu = np.ascontiguousarray(mu, dtype=np.float64)
+        assert self.mu.ndim == 2
+        self.K, self.D = self.mu.shape
+        self.precision = np.ascontiguousarray(precision, dtype=np.float64).reshape(self.K, self.D, self.D)
+
+        def vec(v, default):
+            if v is None:
+                return np.full(self.K, default, dtype=np.float64)
+            v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.K)
+            return v
+        self.c0, self.c1, self.c2, self.c3 = vec(c0, 0.), vec(c1, 0.), vec(c2, 0.), vec(c3, 0.)
+        self.weight = vec(weight, 1.)
+        if column is None:
+            column = np.arange(self.K)
+        self.column = np.ascontiguousarray(column, dtype=np.int32).reshape(self.K)
+        self.ld = int(ld) if ld is not None else int(self.column.max()) + 1
+        assert self.ld > int(self.column.max())
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HipBackend(object):
+    """MI355X backend.  All array results are torch CUDA tensors (float64)."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        try:
+            import torch
+        except Exception as exc:  # pragma: no cover
+            raise HipLibraryError("PyTorch (ROCm) is required for device memory: %s" % exc)
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise HipLibraryError("no HIP device visible (torch.cuda.is_available() is False); "
+                                  "pypmc_amd has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        arch = C.create_string_buffer(256)
+        _lib.check(self.lib.pmc_device_arch(self.device.index or 0, arch, 256), "pmc_device_arch")
+        self.arch = arch.value.decode()
+        if not self.arch.startswith("gfx950"):
+            raise HipLibraryError("kernels are built for gfx950 (MI355X); device reports %r" % self.arch)
+        self.tile = self.lib.pmc_tile()
+        self._ws = None
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def asdevice(self, a, dtype=None):
+        """numpy array / torch tensor -> contiguous tensor on this device."""
+        torch = self.torch
+        dtype = dtype or torch.float64
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        np_dtype = {torch.float64: np.float64, torch.int64: np.int64}[dtype]
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(self.device)
+
+    def tohost(self, t):
+        return t.detach().cpu().numpy()
+
+    def empty(self, shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        return self.torch.zeros(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def _workspace(self, N, K, D):
+        need = _lib.check(self.lib.pmc_workspace_bytes(N, K, D), "pmc_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.torch.empty(int(need), dtype=self.torch.uint8, device=self.device)
+        return self._ws
+
+    def _tilebuf(self, name, N, K):
+        need = _lib.check(self.lib.pmc_tile_buffer_len(N, K), "pmc_tile_buffer_len")
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < need:
+            buf = self.torch.empty(int(max(need, 1)), dtype=self.torch.float64, device=self.device)
+            self._bufs[name] = buf
+        return buf
+
+    def release(self):
+        """Drop cached scratch buffers."""
+        self._ws = None
+        self._bufs = {}
+
+    def pack(self, comps):
+        """ComponentSet -> device parameter pack (host Cholesky in pmc_pack_components)."""
+        stride = _lib.check(self.lib.pmc_pack_stride(comps.D), "pmc_pack_stride")
+        host = np.empty(comps.K * stride, dtype=np.float64)
+        _lib.check(self.lib.pmc_pack_components(
+            comps.K, comps.D, _dptr(comps.mu), _dptr(comps.precision), _dptr(comps.c0),
+            _dptr(comps.c1), _dptr(comps.c2), _dptr(comps.c3), _dptr(comps.weight),
+            comps.column.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(host)), "pmc_pack_components")
+        return self.torch.from_numpy(host).to(self.device)
+
+    # ------------------------------------------------------------------ operations
+    def logpdf(self, x, comps, want_out=True, individual=None, want_individual=False,
+               max_init_zero=False, log_target=None, sample_w=None, want_scalars=False, pack=None):
+        """pmc_mixture_logpdf.  ``x`` N x D device tensor.  Returns dict(out, individual, weights,
+        scalars) of device tensors (None where not requested)."""
+        x = self.asdevice(x)
+        N, D = x.shape
+        assert D == comps.D, "sample dimension %d != component dimension %d" % (D, comps.D)
+        pack = self.pack(comps) if pack is None else pack
+        out = self.empty(N) if want_out else None
+        if individual is None and want_individual:
+            individual = self.empty((N, comps.ld))
+        if individual is not None:
+            assert individual.shape == (N, comps.ld) and individual.is_contiguous()
+        lt = self.asdevice(log_target).reshape(N) if log_target is not None else None
+        weights = self.empty(N) if lt is not None else None
+        sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
+        scalars = self.zeros(NSCALARS) if want_scalars else None
+        ws = self._workspace(N, comps.K, D) if want_scalars else None
+        _lib.check(self.lib.pmc_mixture_logpdf(
+            self._p(x), N, D, self._p(pack), comps.K, comps.kind, int(bool(max_init_zero)),
+            self._p(out), self._p(individual), comps.ld, self._p(lt), self._p(weights), self._p(sw),
+            self._p(scalars), self._p(ws), self._stream()), "pmc_mixture_logpdf")
+        return dict(out=out, individual=individual, weights=weights, scalars=scalars)
+
+    def weight_sums(self, w):
+        """(sum w, sum w log w [zeros masked], sum w^2) as a device tensor of NSCALARS doubles."""
+        w = self.asdevice(w).reshape(-1)
+        N = w.shape[0]
+        scalars = self.zeros(NSCALARS)
+        ws = self._workspace(max(N, 1), 1, 1)
+        _lib.check(self.lib.pmc_weight_sums(self._p(w), N, self._p(scalars), self._p(ws),
+                                            self._stream()), "pmc_weight_sums")
+        return scalars
+
+    def estep(self, x, comps, mode, max_init_zero=False, sample_w=None, latent=None,
+              want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None):
+        """Responsibilities (pmc_responsibilities) followed by the sufficient statistics
+        (pmc_sufficient_stats) of the same samples.
+
+        Returns dict(stats = [scalars(NSCALARS) | K*stats_stride] one flat device tensor (so that a
+        multi-GPU caller all-reduces a single buffer), r, log_rho, exponent).
+        """
+        torch = self.torch
+        x = self.asdevice(x)
+        N, D = x.shape
+        assert D == comps.D
+        K = comps.K
+        pack = self.pack(comps) if pack is None else pack
+        sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
+        lat = self.asdevice(latent, torch.int64).reshape(N) if latent is not None else None
+        student = comps.kind == PMC_KIND_STUDENT_T
+        u = self._tilebuf("u", N, K)
+        v1 = self._tilebuf("v1", N, K) if student else None
+        v2 = self._tilebuf("v2", N, K) if student else None
+        r = self.zeros((N, comps.ld)) if want_r else None
+        log_rho = self.zeros((N, comps.ld)) if want_log_rho else None
+        expo = self.zeros((N, comps.ld)) if want_exponent else None
+        ps = int(self.lib.pmc_stats_stride(D))
+        flat = out if out is not None else self.zeros(NSCALARS + K * ps)
+        ws = self._workspace(N, K, D)
+        _lib.check(self.lib.pmc_responsibilities(
+            self._p(x), N, D, self._p(pack), K, comps.kind, int(mode), int(bool(max_init_zero)),
+            self._p(sw), self._p(lat), self._p(u), self._p(v1), self._p(v2), self._p(r),
+            self._p(log_rho), self._p(expo), comps.ld, self._p(flat), self._p(ws), self._stream()),
+            "pmc_responsibilities")
+        _lib.check(self.lib.pmc_sufficient_stats(
+            self._p(x), N, D, self._p(pack), K, self._p(u), self._p(v1), self._p(v2),
+            self._p(flat[NSCALARS:]), self._p(ws), self._stream()), "pmc_sufficient_stats")
+        return dict(stats=flat, r=r, log_rho=log_rho, exponent=expo)
+
+    def stats_stride(self, D):
+        return int(self.lib.pmc_stats_stride(D))
+
+
+_default = None
+
+
+def set_default_backend(backend):
+    """Install the process-wide default backend (tests inject their checker here)."""
+    global _default
+    _default = backend
+
+
+def get_backend(backend=None):
+    """The backend to use: an explicit one, the installed default, or a new HipBackend.
+    Raises HipLibraryError when the HIP path is unavailable -- there is no CPU fallback."""
+    global _default
+    if backend is not None:
+        return backend
+    if _default is None:
+        _default = HipBackend()
+    return _default

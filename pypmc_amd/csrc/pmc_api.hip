@@ -1,0 +1,408 @@
+// pmc_api.hip -- C ABI (include/pmc_hip.h) of libpmc_hip.so: argument checking, host-side
+// parameter packing, dispatch to the per-dimension kernel units, and the small fixed-order
+// finishing kernels.  Never throws; every failure becomes a status code + pmc_last_error().
+#include "../../include/pmc_hip.h"
+#include "pmc_dims.h"
+#include "pmc_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// kernel-set registry (one accessor per compiled dimension, defined in pmc_kernels.hip units)
+// ---------------------------------------------------------------------------------------------
+#define PMC_DECL_X(d) extern "C" const PmcKernelSet *pmc_kset_##d##_p0(void);
+#define PMC_DECL_XP(d) \
+    extern "C" const PmcKernelSet *pmc_kset_##d##_p0(void); \
+    extern "C" const PmcKernelSet *pmc_kset_##d##_p1(void);
+PMC_DIM_LIST(PMC_DECL_X, PMC_DECL_XP)
+
+namespace {
+
+struct DimEntry {
+    int dim;
+    const PmcKernelSet *(*exact)(void);
+    const PmcKernelSet *(*padded)(void);
+};
+#define PMC_ENT_X(d) {d, &pmc_kset_##d##_p0, nullptr},
+#define PMC_ENT_XP(d) {d, &pmc_kset_##d##_p0, &pmc_kset_##d##_p1},
+const DimEntry g_dims[] = {PMC_DIM_LIST(PMC_ENT_X, PMC_ENT_XP)};
+constexpr int g_ndims = sizeof(g_dims) / sizeof(g_dims[0]);
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hipfail(hipError_t e, const char *what)
+{
+    return fail(PMC_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+// kernel set + compiled dimension for a sample dimension D
+const PmcKernelSet *kernels_for(int D)
+{
+    for (int i = 0; i < g_ndims; ++i) {
+        if (g_dims[i].dim == D) return g_dims[i].exact();
+        if (g_dims[i].dim > D) return g_dims[i].padded ? g_dims[i].padded() : nullptr;
+    }
+    return nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finishing kernels (single workgroup, fixed summation order)
+// ---------------------------------------------------------------------------------------------
+// scalars[i] = sum_b partials[b*PMC_NSCALARS + i]
+__global__ __launch_bounds__(256) void k_finish_scalars(const double *__restrict__ partials,
+                                                        long long nblocks,
+                                                        double *__restrict__ scalars)
+{
+    __shared__ double red[256];
+    for (int i = 0; i < PMC_NSCALARS; ++i) {
+        double v = 0.0;
+        for (long long b = threadIdx.x; b < nblocks; b += 256) v += partials[b * PMC_NSCALARS + i];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) scalars[i] = red[0];
+        __syncthreads();
+    }
+}
+
+// stats[k][p] (real dimension D) = sum_chunk partials[chunk][k][p'] (compiled dimension Dc)
+__global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__ partials,
+                                                      int nchunks, int K, int D, int Dc,
+                                                      double *__restrict__ stats)
+{
+    const int PS = pmc_stats_stride_c(D), PSc = pmc_stats_stride_c(Dc);
+    const int T = pmc_tri(D), Tc = pmc_tri(Dc);
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)K * PS) return;
+    const int k = (int)(idx / PS), p = (int)(idx % PS);
+    int pc;
+    if (p < 1 + D) pc = p;                                // sum u, first moments
+    else if (p < 1 + D + T) pc = p - (1 + D) + (1 + Dc);  // lower triangle: i(i+1)/2+j is D-free
+    else pc = p - (1 + D + T) + (1 + Dc + Tc);            // v1 / v2 sums
+    double v = 0.0;
+    for (int c = 0; c < nchunks; ++c) v += partials[((size_t)c * K + k) * PSc + pc];
+    stats[idx] = v;
+}
+
+// importance-weight sums over an existing weight vector (convergence.py:31-39, :67-72)
+__global__ __launch_bounds__(256) void k_weight_sums(const double *__restrict__ w, long long N,
+                                                     double *__restrict__ partials)
+{
+    __shared__ double red[4][PMC_NSCALARS];
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    double sc[3] = {0.0, 0.0, 0.0};
+    if (n < N) {
+        const double v = w[n];
+        sc[0] = v;
+        sc[1] = (v != 0.0) ? v * log(v) : 0.0;
+        sc[2] = v * v;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = 0; i < 3; ++i) {
+        double v = sc[i];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PMC_NSCALARS) {
+        double v = 0.0;
+        if (threadIdx.x < 3)
+            for (int q = 0; q < 4; ++q) v += red[q][threadIdx.x];
+        partials[(size_t)blockIdx.x * PMC_NSCALARS + threadIdx.x] = v;
+    }
+}
+
+inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
+
+// statistics launch geometry
+struct StatsGeom {
+    int ngroups, nchunks, tiles_per_chunk;
+    long long ntiles;
+    unsigned grid;
+};
+StatsGeom stats_geom(long long N, int K, const PmcKernelSet *ks)
+{
+    StatsGeom g;
+    g.ntiles = ceil_div(N, PMC_TILE);
+    g.ngroups = (int)ceil_div((long long)K * ks->stats_nsub, ks->stats_waves);
+    // aim at ~8 resident wavefronts per SIMD-set: 256 CUs * 16 wavefronts
+    long long want = ceil_div(256LL * 16, (long long)g.ngroups * ks->stats_waves);
+    if (want > g.ntiles) want = g.ntiles;
+    if (want < 1) want = 1;
+    g.nchunks = (int)(ceil_div(want, 8) * 8);              // multiple of the XCD count
+    g.tiles_per_chunk = (int)ceil_div(g.ntiles, g.nchunks);
+    if (g.tiles_per_chunk < 1) g.tiles_per_chunk = 1;
+    g.grid = (unsigned)((long long)g.nchunks * g.ngroups);
+    return g;
+}
+
+size_t scalar_partials_bytes(long long N)
+{
+    const long long blocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    return (size_t)(blocks > 0 ? blocks : 1) * PMC_NSCALARS * sizeof(double);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int pmc_abi_version(void) { return PMC_ABI_VERSION; }
+const char *pmc_last_error(void) { return g_err; }
+
+int pmc_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(PMC_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int pmc_device_arch(int device, char *buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return fail(PMC_EINVAL, "pmc_device_arch: NULL buffer");
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return hipfail(e, "hipGetDeviceProperties");
+    snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return PMC_OK;
+}
+
+int pmc_max_dim(void) { return PMC_MAX_DIM; }
+
+int pmc_padded_dim(int D)
+{
+    if (D < 1) return fail(PMC_EINVAL, "dimension must be >= 1 (got %d)", D);
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    return ks->dim;
+}
+
+int64_t pmc_pack_stride(int D)
+{
+    const int Dp = pmc_padded_dim(D);
+    if (Dp < 0) return Dp;
+    return pmc_pack_stride_c(Dp);
+}
+
+int pmc_tile(void) { return PMC_TILE; }
+
+int64_t pmc_tile_buffer_len(int64_t N, int K)
+{
+    if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_tile_buffer_len: bad N/K");
+    return ceil_div(N, PMC_TILE) * (int64_t)K * PMC_TILE;
+}
+
+int64_t pmc_stats_stride(int D)
+{
+    if (D < 1) return fail(PMC_EINVAL, "dimension must be >= 1 (got %d)", D);
+    return pmc_stats_stride_c(D);
+}
+
+int64_t pmc_workspace_bytes(int64_t N, int K, int D)
+{
+    if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    const StatsGeom g = stats_geom(N > 0 ? N : 1, K, ks);
+    const size_t stats = (size_t)g.nchunks * K * pmc_stats_stride_c(ks->dim) * sizeof(double);
+    const size_t scal = scalar_partials_bytes(N);
+    size_t total = stats > scal ? stats : scal;
+    return (int64_t)((total + 255) & ~(size_t)255);
+}
+
+int pmc_pack_components(int K, int D, const double *mu, const double *prec, const double *c0,
+                        const double *c1, const double *c2, const double *c3, const double *weight,
+                        const int32_t *column, double *pack)
+{
+    if (K < 1 || !mu || !prec || !pack) return fail(PMC_EINVAL, "pmc_pack_components: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    const int Dp = ks->dim, Tp = pmc_tri(Dp), stride = pmc_pack_stride_c(Dp);
+    std::vector<double> R((size_t)D * D);
+    for (int k = 0; k < K; ++k) {
+        double *pk = pack + (size_t)k * stride;
+        std::memset(pk, 0, sizeof(double) * stride);
+        for (int j = 0; j < D; ++j) pk[j] = mu[(size_t)k * D + j];
+        // upper Cholesky factor: precision = R^T R  (row by row, reading the upper triangle)
+        const double *A = prec + (size_t)k * D * D;
+        for (int i = 0; i < D; ++i) {
+            for (int j = i; j < D; ++j) {
+                double s = A[(size_t)i * D + j];
+                for (int l = 0; l < i; ++l) s -= R[(size_t)l * D + i] * R[(size_t)l * D + j];
+                if (j == i) {
+                    if (!(s > 0.0) || !std::isfinite(s))
+                        return fail(PMC_ENOTPOSDEF,
+                                    "precision matrix of component %d is not positive definite "
+                                    "(pivot %d = %g)", k, i, s);
+                    R[(size_t)i * D + i] = std::sqrt(s);
+                } else {
+                    R[(size_t)i * D + j] = s / R[(size_t)i * D + i];
+                }
+            }
+        }
+        // packed row-major (i, j>=i) for the compiled dimension; padding rows/cols are zero
+        int idx = Dp;
+        for (int i = 0; i < Dp; ++i)
+            for (int j = i; j < Dp; ++j, ++idx)
+                pk[idx] = (i < D && j < D) ? R[(size_t)i * D + j] : 0.0;
+        double *c = pk + Dp + Tp;
+        c[0] = c0 ? c0[k] : 0.0;
+        c[1] = c1 ? c1[k] : 0.0;
+        c[2] = c2 ? c2[k] : 0.0;
+        c[3] = c3 ? c3[k] : 0.0;
+        c[4] = weight ? weight[k] : 1.0;
+        const long long col = column ? (long long)column[k] : (long long)k;
+        std::memcpy(&c[5], &col, sizeof(col));
+    }
+    return PMC_OK;
+}
+
+static int finish_scalars(const double *partials, long long nblocks, double *d_scalars,
+                          hipStream_t st)
+{
+    hipLaunchKernelGGL(k_finish_scalars, dim3(1), dim3(256), 0, st, partials, nblocks, d_scalars);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_finish_scalars launch");
+    return PMC_OK;
+}
+
+int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                       int max_init_zero, double *d_out, double *d_individual, int64_t ld,
+                       const double *d_log_target, double *d_weights, const double *d_sample_w,
+                       double *d_scalars, void *d_workspace, void *stream)
+{
+    if (N < 0 || K < 1 || !d_pack) return fail(PMC_EINVAL, "pmc_mixture_logpdf: bad N/K/pack");
+    if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T)
+        return fail(PMC_EINVAL, "pmc_mixture_logpdf: kind must be GAUSS or STUDENT_T (got %d)", kind);
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (d_individual && ld < K) return fail(PMC_EINVAL, "pmc_mixture_logpdf: ld (%lld) < K (%d)", (long long)ld, K);
+    if (d_log_target && !d_weights) return fail(PMC_EINVAL, "pmc_mixture_logpdf: d_log_target needs d_weights");
+    if (d_scalars && !d_workspace) return fail(PMC_EINVAL, "pmc_mixture_logpdf: d_scalars needs d_workspace");
+    if (N > 0 && !d_x) return fail(PMC_EINVAL, "pmc_mixture_logpdf: d_x is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    if (nblocks > 0) {
+        PmcArgsA a;
+        std::memset(&a, 0, sizeof(a));
+        a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
+        a.ld = ld; a.out = d_out; a.individual = d_individual; a.log_target = d_log_target;
+        a.weights = d_weights; a.sample_w = d_sample_w;
+        a.partials = d_scalars ? (double *)d_workspace : nullptr;
+        hipError_t e = ks->logpdf(kind, a, (unsigned)nblocks, st);
+        if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
+    }
+    if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+    return PMC_OK;
+}
+
+int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_workspace, void *stream)
+{
+    if (N < 0 || !d_scalars || !d_workspace || (N > 0 && !d_w))
+        return fail(PMC_EINVAL, "pmc_weight_sums: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nblocks = ceil_div(N, 256);
+    if (nblocks > 0) {
+        hipLaunchKernelGGL(k_weight_sums, dim3((unsigned)nblocks), dim3(256), 0, st, d_w,
+                           (long long)N, (double *)d_workspace);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hipfail(e, "k_weight_sums launch");
+    }
+    return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+}
+
+int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                         int mode, int max_init_zero, const double *d_sample_w,
+                         const int64_t *d_latent, double *d_u, double *d_v1, double *d_v2,
+                         double *d_r, double *d_log_rho, double *d_exponent, int64_t ld,
+                         double *d_scalars, void *d_workspace, void *stream)
+{
+    if (N < 0 || K < 1 || !d_pack || !d_u) return fail(PMC_EINVAL, "pmc_responsibilities: bad N/K/pack/u");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (mode == PMC_RESP_VB) {
+        if (kind != PMC_KIND_VB) return fail(PMC_EINVAL, "pmc_responsibilities: mode VB needs kind VB");
+    } else if (mode == PMC_RESP_PMC_RB || mode == PMC_RESP_PMC_LATENT) {
+        if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T)
+            return fail(PMC_EINVAL, "pmc_responsibilities: PMC modes need kind GAUSS or STUDENT_T");
+        if (mode == PMC_RESP_PMC_LATENT && !d_latent)
+            return fail(PMC_EINVAL, "pmc_responsibilities: mode LATENT needs d_latent");
+        if (kind == PMC_KIND_STUDENT_T && (!d_v1 || !d_v2))
+            return fail(PMC_EINVAL, "pmc_responsibilities: Student-t needs d_v1 and d_v2");
+    } else {
+        return fail(PMC_EINVAL, "pmc_responsibilities: unknown mode %d", mode);
+    }
+    if ((d_r || d_log_rho || d_exponent) && ld < K)
+        return fail(PMC_EINVAL, "pmc_responsibilities: ld (%lld) < K (%d)", (long long)ld, K);
+    if (d_scalars && !d_workspace) return fail(PMC_EINVAL, "pmc_responsibilities: d_scalars needs d_workspace");
+    if (N > 0 && !d_x) return fail(PMC_EINVAL, "pmc_responsibilities: d_x is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    if (nblocks > 0) {
+        PmcArgsA a;
+        std::memset(&a, 0, sizeof(a));
+        a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
+        a.mode = mode; a.ld = ld; a.sample_w = d_sample_w; a.latent = (const long long *)d_latent;
+        a.u = d_u; a.v1 = d_v1; a.v2 = d_v2; a.r = d_r; a.log_rho = d_log_rho; a.exponent = d_exponent;
+        a.partials = d_scalars ? (double *)d_workspace : nullptr;
+        hipError_t e = ks->resp(kind, a, (unsigned)nblocks, st);
+        if (e != hipSuccess) return hipfail(e, "k_resp launch");
+    }
+    if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+    return PMC_OK;
+}
+
+int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+                         const double *d_u, const double *d_v1, const double *d_v2, double *d_stats,
+                         void *d_workspace, void *stream)
+{
+    if (N < 0 || K < 1 || !d_pack || !d_u || !d_stats || !d_workspace)
+        return fail(PMC_EINVAL, "pmc_sufficient_stats: bad argument");
+    if ((d_v1 == nullptr) != (d_v2 == nullptr))
+        return fail(PMC_EINVAL, "pmc_sufficient_stats: d_v1 and d_v2 must both be given or both NULL");
+    if (N > 0 && !d_x) return fail(PMC_EINVAL, "pmc_sufficient_stats: d_x is NULL");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    hipStream_t st = (hipStream_t)stream;
+    const int PS = pmc_stats_stride_c(D);
+    if (N == 0) {
+        hipError_t e = hipMemsetAsync(d_stats, 0, sizeof(double) * (size_t)K * PS, st);
+        if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
+        return PMC_OK;
+    }
+    const StatsGeom g = stats_geom(N, K, ks);
+    PmcArgsB b;
+    std::memset(&b, 0, sizeof(b));
+    b.x = d_x; b.N = N; b.dreal = D; b.pack = d_pack; b.K = K; b.u = d_u; b.v1 = d_v1; b.v2 = d_v2;
+    b.partials = (double *)d_workspace; b.ntiles = g.ntiles; b.nchunks = g.nchunks;
+    b.tiles_per_chunk = g.tiles_per_chunk; b.ngroups = g.ngroups;
+    hipError_t e = ks->stats(b, g.grid, st);
+    if (e != hipSuccess) return hipfail(e, "k_stats launch");
+    const long long total = (long long)K * PS;
+    hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
+                       (const double *)d_workspace, g.nchunks, K, D, ks->dim, d_stats);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
+    return PMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// Internal (non-ABI) declarations shared by the per-dimension kernel units and the dispatcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+constexpr int PMC_TILE = 64;       // samples per tile = one wavefront
+constexpr int PMC_NSCALARS = 8;    // per-launch scalar reductions
+constexpr int PMC_A_WAVES = 4;     // wavefronts (tiles) per workgroup in the per-sample kernels
+
+__host__ __device__ constexpr int pmc_tri(int D) { return D * (D + 1) / 2; }
+__host__ __device__ constexpr int pmc_pack_stride_c(int D) { return (D + pmc_tri(D) + 6 + 7) & ~7; }
+__host__ __device__ constexpr int pmc_stats_stride_c(int D) { return 1 + D + pmc_tri(D) + 2; }
+
+// per-sample kernels (log-pdf, responsibilities)
+struct PmcArgsA {
+    const double *x;
+    long long N;
+    int dreal;            // real sample dimension (== compiled D unless padded)
+    const double *pack;
+    int K;
+    int max_init_zero;
+    int mode;             // pmc_resp_mode (responsibility kernels)
+    long long ld;
+    double *out;
+    double *individual;
+    const double *log_target;
+    double *weights;
+    const double *sample_w;
+    const long long *latent;
+    double *u, *v1, *v2;
+    double *r, *log_rho, *exponent;
+    double *partials;     // gridDim.x * PMC_NSCALARS
+};
+
+// statistics kernel
+struct PmcArgsB {
+    const double *x;
+    long long N;
+    int dreal;
+    const double *pack;
+    int K;
+    const double *u, *v1, *v2;
+    double *partials;     // nchunks * K * pmc_stats_stride_c(Dcompiled)
+    long long ntiles;
+    int nchunks;          // multiple of 8 (XCD count)
+    int tiles_per_chunk;
+    int ngroups;
+};
+
+struct PmcKernelSet {
+    int dim;              // compiled dimension
+    int padded;           // 1: accepts dreal <= dim
+    int stats_nsub;       // row subsets per component in the statistics kernel
+    int stats_waves;      // wavefronts per workgroup in the statistics kernel
+    hipError_t (*logpdf)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
+    hipError_t (*resp)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
+    hipError_t (*stats)(const PmcArgsB &, unsigned grid, hipStream_t);
+};

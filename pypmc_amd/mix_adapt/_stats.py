@@ -1,0 +1,47 @@
+"""K-sized host conversions of the statistics vector produced by pmc_sufficient_stats
+(include/pmc_hip.h) into the reference's centred conventions."""
+import numpy as np
+
+from .._lib import NSCALARS
+
+TINY = np.finfo('d').tiny
+
+
+def regularize(x):
+    """pypmc/tools/_regularize.pyx:6-17: zeros -> smallest positive float (in place)."""
+    x[x == 0] = TINY
+    return x
+
+
+def split_stats(flat, K, D):
+    """flat = [scalars(NSCALARS) | K x (1 + D + D(D+1)/2 + 2)] (host array) ->
+    scalars, S0 (K), M1 (K,D), M2 (K,D,D symmetric), V1 (K), V2 (K)."""
+    flat = np.asarray(flat, dtype=np.float64)
+    T = D * (D + 1) // 2
+    ps = 1 + D + T + 2
+    scalars = flat[:NSCALARS].copy()
+    body = flat[NSCALARS:NSCALARS + K * ps].reshape(K, ps)
+    S0 = body[:, 0].copy()
+    M1 = body[:, 1:1 + D].copy()
+    M2 = np.zeros((K, D, D))
+    il, jl = np.tril_indices(D)          # row-major (i, j<=i): the kernel's packing order
+    M2[:, il, jl] = body[:, 1 + D:1 + D + T]
+    M2[:, jl, il] = body[:, 1 + D:1 + D + T]
+    V1 = body[:, 1 + D + T].copy()
+    V2 = body[:, 2 + D + T].copy()
+    return scalars, S0, M1, M2, V1, V2
+
+
+def centred_moments(S0_mean, M1, M2, shift, S0_cov=None):
+    """mean_k = shift_k + M1_k / reg(S0_mean_k);
+    cov_k = (M2_k - S0_mean_k dbar dbar^T) / reg(S0_cov_k)   with dbar = M1_k / reg(S0_mean_k).
+
+    With S0_cov = S0_mean this is  sum u (x - mean)(x - mean)^T / sum u  (variational.pyx:855-932,
+    pmc.pyx:198-204); the Student-t update normalises the covariance by a different sum
+    (pmc.pyx:629-630)."""
+    n_mean = regularize(np.array(S0_mean, dtype=np.float64))
+    n_cov = n_mean if S0_cov is None else regularize(np.array(S0_cov, dtype=np.float64))
+    dbar = M1 / n_mean[:, None]
+    mean = shift + dbar
+    cov = (M2 - n_mean[:, None, None] * np.einsum('ki,kj->kij', dbar, dbar)) / n_cov[:, None, None]
+    return mean, cov

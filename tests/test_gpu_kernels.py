@@ -1,0 +1,327 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI, against the CPU oracle on
+the same seeded inputs and against the golden vectors generated from the reference."""
+import numpy as np
+import pytest
+from scipy.special import digamma, gammaln
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10      # BASELINE.json: within 1e-10 relative on log-weights and responsibilities
+
+
+@pytest.fixture(scope="module")
+def be():
+    from pypmc_amd.backend import HipBackend
+    return HipBackend()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def mk(K, D, seed):
+    rs = np.random.RandomState(seed)
+    mu = rs.normal(0, 3, size=(K, D))
+    cov = np.empty((K, D, D))
+    for k in range(K):
+        A = rs.normal(0, 1, size=(D, D))
+        cov[k] = A.dot(A.T) / D + 0.5 * np.eye(D)
+    w = rs.uniform(0.5, 1.5, size=K)
+    return mu, cov, w / w.sum()
+
+
+def draw(mu, cov, w, N, seed):
+    rs = np.random.RandomState(seed)
+    k = rs.choice(len(w), size=N, p=w)
+    L = np.linalg.cholesky(cov)
+    z = rs.normal(size=(N, mu.shape[1]))
+    return mu[k] + np.einsum('nij,nj->ni', L[k], z), k
+
+
+def gauss_set(mu, cov, w, columns=None, ld=None):
+    from pypmc_amd.backend import ComponentSet
+    D = mu.shape[1]
+    inv = np.linalg.inv(cov)
+    inv = 0.5 * (inv + inv.transpose(0, 2, 1))
+    logdet = np.linalg.slogdet(cov)[1]
+    ln = -0.5 * D * np.log(2 * np.pi) - 0.5 * logdet
+    return ComponentSet(0, mu, inv, c0=ln, weight=w, column=columns, ld=ld), inv, ln
+
+
+def student_set(mu, cov, w, dof):
+    from pypmc_amd.backend import ComponentSet
+    D = mu.shape[1]
+    inv = np.linalg.inv(cov)
+    inv = 0.5 * (inv + inv.transpose(0, 2, 1))
+    logdet = np.linalg.slogdet(cov)[1]
+    ln = gammaln(.5 * (dof + D)) - gammaln(.5 * dof) - 0.5 * D * np.log(dof * np.pi) - 0.5 * logdet
+    pf, idf = -.5 * (dof + D), 1. / dof
+    return ComponentSet(1, mu, inv, c0=ln, c1=pf, c2=idf, c3=dof, weight=w), inv, ln, pf, idf
+
+
+def assert_rel(a, b, rtol=RTOL, what=""):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    same = (a == b)                                   # covers matching +-inf
+    assert (np.isnan(a) == np.isnan(b)).all(), what + ": NaN pattern differs"
+    a, b = np.where(same, 0.0, a), np.where(same, 0.0, b)
+    scale = np.maximum(np.abs(b), 1e-300)
+    err = np.nanmax(np.abs(a - b) / scale) if a.size else 0.0
+    assert err <= rtol, "%s: max relative error %.3e > %.1e" % (what, err, rtol)
+
+
+@pytest.mark.parametrize("D,K,N", [(1, 2, 70), (2, 3, 257), (3, 1, 64), (5, 4, 300), (7, 5, 1000),
+                                   (8, 2, 129), (9, 3, 200), (11, 3, 333), (16, 4, 500),
+                                   (20, 16, 4096), (23, 3, 150), (30, 8, 700), (40, 6, 300),
+                                   (48, 3, 130), (57, 2, 100), (64, 2, 70)])
+def test_gauss_logpdf_vs_oracle(be, orc, D, K, N):
+    mu, cov, w = mk(K, D, 100 + D)
+    x, _ = draw(mu, cov, w, N, 7)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    ref_out, ref_ind = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    res = be.logpdf(x, cs, want_out=True, want_individual=True)
+    assert_rel(be.tohost(res["individual"]), ref_ind, what="individual")
+    assert_rel(be.tohost(res["out"]), ref_out, what="out")
+    # out-only and individual-only launches give bitwise the same numbers
+    res2 = be.logpdf(x, cs, want_out=True)
+    np.testing.assert_array_equal(be.tohost(res2["out"]), be.tohost(res["out"]))
+
+
+@pytest.mark.parametrize("D,K,N,dof", [(2, 3, 200, 1.0), (3, 2, 130, 4.5), (10, 4, 500, 3.0),
+                                       (30, 8, 1000, 8.0), (13, 2, 99, 50.)])
+def test_student_logpdf_vs_oracle(be, orc, D, K, N, dof):
+    mu, cov, w = mk(K, D, 200 + D)
+    x, _ = draw(mu, cov * 1.5, w, N, 8)
+    dofs = np.full(K, dof) + 0.25 * np.arange(K)
+    cs, inv, ln, pf, idf = student_set(mu, cov, w, dofs)
+    ref_out, ref_ind = orc.mixture_multi_evaluate(1, x, w, mu, inv, ln, pf, idf)
+    res = be.logpdf(x, cs, want_out=True, want_individual=True)
+    assert_rel(be.tohost(res["individual"]), ref_ind, what="individual")
+    assert_rel(be.tohost(res["out"]), ref_out, what="out")
+
+
+@pytest.mark.parametrize("tag", ["d2k3", "d5k4", "d20k16", "d1k2", "d7k1"])
+def test_gauss_logpdf_golden(be, tag):
+    from pypmc_amd.backend import ComponentSet
+    g = load_golden("logpdf_gauss_" + tag)
+    K = len(g["weights"])
+    cs = ComponentSet(0, g["mu"], g["inv_sigma"], c0=g["log_norm"], weight=g["weights"])
+    res = be.logpdf(g["x"], cs, want_out=True, want_individual=True)
+    assert_rel(be.tohost(res["out"]), g["out"], what="out")
+    assert_rel(be.tohost(res["individual"]), g["individual"], what="individual")
+    # components= subset: only those columns are touched
+    sub = list(g["subset"])
+    css = ComponentSet(0, g["mu"][sub], g["inv_sigma"][sub], c0=g["log_norm"][sub],
+                       weight=g["weights"][sub], column=sub, ld=K)
+    ind = be.zeros((len(g["x"]), K))
+    be.logpdf(g["x"], css, want_out=False, individual=ind)
+    got = be.tohost(ind)
+    assert_rel(got[:, sub], g["individual_subset"][:, sub], what="subset")
+    rest = [k for k in range(K) if k not in sub]
+    assert (got[:, rest] == 0).all()
+    # zero-weight component still takes part in the row maximum
+    cs0 = ComponentSet(0, g["mu"], g["inv_sigma"], c0=g["log_norm"], weight=g["weights_zero0"])
+    assert_rel(be.tohost(be.logpdf(g["x"], cs0)["out"]), g["out_zero0"], what="zero weight")
+
+
+@pytest.mark.parametrize("tag", ["d3k2", "d30k8", "d2k3"])
+def test_student_logpdf_golden(be, tag):
+    from pypmc_amd.backend import ComponentSet
+    g = load_golden("logpdf_student_" + tag)
+    D = g["x"].shape[1]
+    cs = ComponentSet(1, g["mu"], g["inv_sigma"], c0=g["log_norm"], c1=-.5 * (g["dof"] + D),
+                      c2=1. / g["dof"], c3=g["dof"], weight=g["weights"])
+    res = be.logpdf(g["x"], cs, want_out=True, want_individual=True)
+    assert_rel(be.tohost(res["out"]), g["out"], what="out")
+    assert_rel(be.tohost(res["individual"]), g["individual"], what="individual")
+
+
+@pytest.mark.parametrize("tag,student", [("gauss_d2", False), ("student_d5", True)])
+def test_importance_weights_golden(be, orc, tag, student):
+    from pypmc_amd.backend import ComponentSet
+    g = load_golden("is_" + tag)
+    D = g["samples"].shape[1]
+    if student:
+        cs = ComponentSet(1, g["prop_mu"], g["prop_inv_sigma"], c0=g["prop_log_norm"],
+                          c1=-.5 * (g["prop_dof"] + D), c2=1. / g["prop_dof"], c3=g["prop_dof"],
+                          weight=g["prop_weights"])
+    else:
+        cs = ComponentSet(0, g["prop_mu"], g["prop_inv_sigma"], c0=g["prop_log_norm"],
+                          weight=g["prop_weights"])
+    res = be.logpdf(g["samples"], cs, log_target=g["target_values"], want_scalars=True)
+    w = be.tohost(res["weights"])
+    assert_rel(w, g["weights"], what="weights")
+    sc = be.tohost(res["scalars"])
+    N = len(w)
+    perp = np.exp(-(sc[1] / sc[0] - np.log(sc[0]))) / N
+    ess = sc[0] ** 2 / (N * sc[2])
+    assert abs(perp - float(g["perp"])) < 1e-12
+    assert abs(ess - float(g["ess"])) < 1e-12
+    assert sc[4] == 0
+    sc2 = be.tohost(be.weight_sums(g["weights"]))
+    assert_rel(sc2[:3], [g["weights"].sum(), (g["weights"] * np.log(g["weights"])).sum(),
+                         (g["weights"] ** 2).sum()], rtol=1e-13, what="weight sums")
+
+
+def _vb_set(g, stage, D):
+    from pypmc_amd.backend import ComponentSet
+    p = lambda k: g[stage + k]
+    return ComponentSet(2, p("m"), p("W"), c0=D / p("beta"), c1=p("nu"),
+                        c2=p("expectation_ln_pi"),
+                        c3=p("expectation_det_ln_lambda") - D * np.log(2. * np.pi))
+
+
+@pytest.mark.parametrize("tag", ["d2k3", "d5k4w", "d20k8", "d3k5first"])
+@pytest.mark.parametrize("stage", ["e0_", "u1_"])
+def test_vb_estep_golden(be, tag, stage):
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    g = load_golden("vb_" + tag)
+    data = g["data"]
+    N, D = data.shape
+    K = g[stage + "m"].shape[0]
+    sw = g["sample_weights"]
+    sw = None if sw.size == 0 else N * (sw / sw.sum())
+    cs = _vb_set(g, stage, D)
+    res = be.estep(data, cs, 0, sample_w=sw, want_r=True, want_log_rho=True, want_exponent=True)
+    assert_rel(be.tohost(res["exponent"]), g[stage + "expectation_gauss_exponent"], what="exponent")
+    assert_rel(be.tohost(res["r"]), g[stage + "r"], what="r")
+    lr, lr_ref = be.tohost(res["log_rho"]), g[stage + "log_rho"]
+    # log_rho: 1e-10 relative, with an absolute floor for entries that are ~0
+    assert np.max(np.abs(lr - lr_ref) / np.maximum(np.abs(lr_ref), 1e-3)) < RTOL
+    sc, S0, M1, M2, _, _ = split_stats(be.tohost(res["stats"]), K, D)
+    x_mean, S = centred_moments(S0, M1, M2, g[stage + "m"])
+    assert_rel(S0, g[stage + "N_comp"], rtol=1e-11, what="N_comp")
+    np.testing.assert_allclose(x_mean, g[stage + "x_mean_comp"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(S, g[stage + "S"], rtol=1e-9, atol=1e-11)
+    assert abs(sc[0] - float(g[stage + "log_q_Z"])) <= 1e-10 * abs(float(g[stage + "log_q_Z"])) + 1e-12
+
+
+@pytest.mark.parametrize("D,K,N,weighted", [(2, 2, 64, False), (4, 7, 1000, True), (20, 32, 5000, False),
+                                            (6, 40, 777, True), (30, 5, 300, False), (12, 9, 64 * 9 + 1, True),
+                                            (17, 3, 500, False), (40, 4, 400, True), (64, 2, 200, False)])
+def test_vb_estep_vs_oracle(be, orc, D, K, N, weighted):
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    mu, cov, w = mk(K, D, 300 + D)
+    x, _ = draw(mu, cov, w, N, 9)
+    rs = np.random.RandomState(D * K)
+    sw = rs.uniform(0.5, 1.5, N) if weighted else None
+    if sw is not None:
+        sw = N * sw / sw.sum()
+    nu = D + 2. + rs.uniform(0, 5, K)
+    beta = 1. + rs.uniform(0, 5, K)
+    alpha = 1. + rs.uniform(0, 5, K)
+    W = np.linalg.inv(cov) / nu[:, None, None]
+    W = 0.5 * (W + W.transpose(0, 2, 1))
+    m = mu + 0.1 * rs.normal(size=mu.shape)
+    ln_lambda = sum(digamma(0.5 * (nu + 1. - i)) for i in range(1, D + 1)) + D * np.log(2.) + \
+        np.linalg.slogdet(W)[1]
+    ln_pi = digamma(alpha) - digamma(alpha.sum())
+    ref = orc.vb_estep(x, sw, m, W, beta, nu, ln_pi, ln_lambda)
+    cs = ComponentSet(2, m, W, c0=D / beta, c1=nu, c2=ln_pi, c3=ln_lambda - D * np.log(2. * np.pi))
+    res = be.estep(x, cs, 0, sample_w=sw, want_r=True, want_log_rho=True, want_exponent=True)
+    assert_rel(be.tohost(res["exponent"]), ref["expectation_gauss_exponent"], what="exponent")
+    assert_rel(be.tohost(res["r"]), ref["r"], what="r")
+    sc, S0, M1, M2, _, _ = split_stats(be.tohost(res["stats"]), K, D)
+    x_mean, S = centred_moments(S0, M1, M2, m)
+    assert_rel(S0, ref["N_comp"], rtol=1e-11, what="N_comp")
+    live = ref["N_comp"] > 1e-6
+    np.testing.assert_allclose(x_mean[live], ref["x_mean_comp"][live], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(S[live], ref["S"][live], rtol=1e-8, atol=1e-10)
+    assert abs(sc[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-11
+    # determinism: a second launch gives bitwise the same statistics
+    res2 = be.estep(x, cs, 0, sample_w=sw)
+    np.testing.assert_array_equal(be.tohost(res2["stats"]), be.tohost(res["stats"]))
+
+
+@pytest.mark.parametrize("tag", ["d2k3", "d5k4"])
+def test_pmc_gauss_rho_and_stats(be, orc, tag):
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    g = load_golden("pmc_gauss_" + tag)
+    x = g["samples"]
+    N, D = x.shape
+    K = len(g["in_weights"])
+    cs = ComponentSet(0, g["in_mu"], g["in_inv_sigma"], c0=g["in_log_norm"], weight=g["in_weights"])
+    for case, w, latent, mode in (("rb_w", g["weights"], None, 1), ("rb_u", None, None, 1),
+                                  ("nrb_w", g["weights"], g["latent"], 2),
+                                  ("nrb_u", None, g["latent"], 2)):
+        res = be.estep(x, cs, mode, sample_w=w, latent=latent, want_r=True)
+        if mode == 1:
+            rho_ref = orc.rho_rb(0, x, g["in_weights"], g["in_mu"], g["in_inv_sigma"],
+                                 g["in_log_norm"], None, None, list(range(K)))
+        else:
+            rho_ref = orc.rho_non_rb(N, K, latent, list(range(K)))
+        assert_rel(be.tohost(res["r"]), rho_ref, what="rho " + case)
+        sc, S0, M1, M2, _, _ = split_stats(be.tohost(res["stats"]), K, D)
+        mean, cov = centred_moments(S0, M1, M2, g["in_mu"])
+        norm = w.sum() if w is not None else float(N)
+        assert_rel(S0 / norm, g[case + "_weights"], rtol=1e-11, what="alpha " + case)
+        np.testing.assert_allclose(mean, g[case + "_mu"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(cov, g[case + "_sigma"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("tag", ["d2k3", "d4k3"])
+def test_pmc_student_stats(be, orc, tag):
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    g = load_golden("pmc_student_" + tag)
+    x = g["samples"]
+    N, D = x.shape
+    K = len(g["in_weights"])
+    dof = g["in_dof"]
+    cs = ComponentSet(1, g["in_mu"], g["in_inv_sigma"], c0=g["in_log_norm"], c1=-.5 * (dof + D),
+                      c2=1. / dof, c3=dof, weight=g["in_weights"])
+    for case, w, latent, mode in (("rb_w_nodof", g["weights"], None, 1),
+                                  ("nrb_u_nodof", None, g["latent"], 2)):
+        res = be.estep(x, cs, mode, sample_w=w, latent=latent)
+        sc, S0g, M1, M2, V1, V2 = split_stats(be.tohost(res["stats"]), K, D)
+        mean, cov = centred_moments(S0g, M1, M2, g["in_mu"], S0_cov=V1)
+        norm = w.sum() if w is not None else float(N)
+        assert_rel(V1 / norm, g[case + "_weights"], rtol=1e-11, what="alpha " + case)
+        np.testing.assert_allclose(mean, g[case + "_mu"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(cov, g[case + "_sigma"], rtol=1e-9, atol=1e-11)
+    # degree-of-freedom condition constant (pmc.pyx:654-691) from the device sums
+    w = g["weights"]
+    live = list(range(K))
+    res = be.estep(x, cs, 1, sample_w=w)
+    sc, S0g, M1, M2, V1, V2 = split_stats(be.tohost(res["stats"]), K, D)
+    pf, idf = -.5 * (dof + D), 1. / dof
+    rho = orc.rho_rb(1, x, g["in_weights"], g["in_mu"], g["in_inv_sigma"], g["in_log_norm"], pf, idf, live)
+    c_ref = orc.student_t_dof_const(x, rho, w, w.sum(), g["in_mu"], g["in_inv_sigma"], dof,
+                                    digamma(.5 * (D + dof)), digamma(.5 * dof), live)
+    W = w.sum()
+    total = V2 - digamma(.5 * (D + dof)) * V1 + (W - V1) * (np.log(.5 * dof) - digamma(.5 * dof)) + S0g + (W - V1)
+    c = 1. - total / W
+    np.testing.assert_allclose(c, c_ref, rtol=1e-9, atol=1e-11)
+
+
+def test_edge_cases(be, orc):
+    from pypmc_amd.backend import ComponentSet
+    mu, cov, w = mk(3, 4, 1)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    # empty input
+    res = be.logpdf(np.zeros((0, 4)), cs)
+    assert res["out"].shape[0] == 0
+    # ragged tail: N = 1 and N = 65
+    for N in (1, 63, 65):
+        x, _ = draw(mu, cov, w, N, N)
+        ref, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+        assert_rel(be.tohost(be.logpdf(x, cs)["out"]), ref)
+    # far-away sample: every component underflows relative to nothing -> finite log density
+    x = np.full((1, 4), 1e3)
+    ref, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    assert_rel(be.tohost(be.logpdf(x, cs)["out"]), ref)
+    # a non positive definite precision is refused with a status, not a crash
+    from pypmc_amd.backend import NotPositiveDefinite
+    bad = inv.copy()
+    bad[1] = -np.eye(4)
+    with pytest.raises(NotPositiveDefinite):
+        be.pack(ComponentSet(0, mu, bad, c0=ln, weight=w))
+    # unsupported dimension
+    from pypmc_amd.backend import HipLibraryError
+    with pytest.raises(HipLibraryError):
+        be.logpdf(np.zeros((2, 65)), ComponentSet(0, np.zeros((1, 65)), np.eye(65)[None]))
