@@ -104,9 +104,9 @@ int pmc_pack_components(int K, int D, const double *h_mu, const double *h_precis
 /* ---- workspace ------------------------------------------------------------------------------ */
 /* bytes of device scratch the calls below need for N samples, K components, dimension D */
 int64_t pmc_workspace_bytes(int64_t N, int K, int D);
-/* doubles in one tile-major N x K buffer (d_u, d_v1, d_v2): ceil(N/64)*K*64 */
+/* doubles in one tile-major N x K buffer (d_u, d_scratch): ceil(N/64)*K*64 */
 int64_t pmc_tile_buffer_len(int64_t N, int K);
-/* doubles per component in the statistics vector: 1 + D + D(D+1)/2 + 2 */
+/* doubles per component in the statistics vector: 1 + D + D(D+1)/2 */
 int64_t pmc_stats_stride(int D);
 
 /* ---- mixture log-pdf and importance weights ---------------------------------------------- */
@@ -157,8 +157,10 @@ int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_wor
  *                weights (pmc.pyx:188)
  *   d_latent     N int64 generating component per sample (mode PMC_RESP_PMC_LATENT only)
  *   d_u          tile-major: sample_w*r (VB), sample_w*rho (Gauss PMC), sample_w*rho*gamma (Student-t)
- *   d_v1, d_v2   tile-major, Student-t PMC only (else NULL): sample_w*rho and
- *                sample_w*rho*log(0.5*(maha+nu)) (the N-sized part of pmc.pyx:659-679)
+ *   d_scratch    tile-major scratch, Student-t PMC only (else NULL)
+ *   d_vsums      K x 2 doubles, Student-t PMC only (else NULL):  [k][0] = sum_n sample_w*rho_nk
+ *                (pmc.pyx:612),  [k][1] = sum_n sample_w*rho_nk*log(0.5*(maha_nk+nu_k)) (the
+ *                N-sized part of the degree-of-freedom condition, pmc.pyx:659-679)
  *   d_r, d_log_rho, d_exponent   optional N x ld row-major public matrices (NULL: not wanted):
  *                r / rho; normalised log_rho (VB); expectation_gauss_exponent (VB)
  *   d_scalars    8 doubles: [0] VB: sum_n sample_w sum_k r log_rho (variational.pyx:1003-1013);
@@ -166,23 +168,22 @@ int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_wor
  */
 int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                          int mode, int max_init_zero, const double *d_sample_w,
-                         const int64_t *d_latent, double *d_u, double *d_v1, double *d_v2,
+                         const int64_t *d_latent, double *d_u, double *d_scratch, double *d_vsums,
                          double *d_r, double *d_log_rho, double *d_exponent, int64_t ld,
                          double *d_scalars, void *d_workspace, void *stream);
 
 /* ---- sufficient statistics ------------------------------------------------------------------- */
 /*
  * One pass over the samples accumulating, per component k and with d = x_n - mu_k (the pack's
- * shift):  sum_n u_nk | sum_n u_nk d (D) | sum_n u_nk d d^T (lower triangle, row-major i, j<=i) |
- * sum_n v1_nk | sum_n v2_nk     ->  d_stats[k*pmc_stats_stride(D) + ...]
+ * shift):  sum_n u_nk | sum_n u_nk d (D) | sum_n u_nk d d^T (lower triangle, row-major i, j<=i)
+ *     ->  d_stats[k*pmc_stats_stride(D) + ...]
  * These are the shifted, un-normalised forms of N_k, x-bar_k, S_k (variational.pyx:699-932) and
  * of alpha_k, mu_k, Sigma_k (pmc.pyx:188-222, :612-652); the K-sized conversion to the
  * reference's centred conventions is done by the caller.  With several GPUs each rank calls this
  * on its shard and the ranks all-reduce (sum) d_stats -- the only cross-GPU exchange of the path.
  */
 int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
-                         const double *d_u, const double *d_v1, const double *d_v2,
-                         double *d_stats, void *d_workspace, void *stream);
+                         const double *d_u, double *d_stats, void *d_workspace, void *stream);
 
 #ifdef __cplusplus
 }

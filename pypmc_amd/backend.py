@@ -174,8 +174,9 @@ class HipBackend(object):
         """Responsibilities (pmc_responsibilities) followed by the sufficient statistics
         (pmc_sufficient_stats) of the same samples.
 
-        Returns dict(stats = [scalars(NSCALARS) | K*stats_stride] one flat device tensor (so that a
-        multi-GPU caller all-reduces a single buffer), r, log_rho, exponent).
+        Returns dict(stats = [scalars(NSCALARS) | K*stats_stride | K*2 Student-t sums] one flat
+        device tensor (so that a multi-GPU caller all-reduces a single buffer), r, log_rho,
+        exponent).
         """
         torch = self.torch
         x = self.asdevice(x)
@@ -187,23 +188,29 @@ class HipBackend(object):
         lat = self.asdevice(latent, torch.int64).reshape(N) if latent is not None else None
         student = comps.kind == PMC_KIND_STUDENT_T
         u = self._tilebuf("u", N, K)
-        v1 = self._tilebuf("v1", N, K) if student else None
-        v2 = self._tilebuf("v2", N, K) if student else None
+        scratch = self._tilebuf("scratch", N, K) if student else None
         r = self.zeros((N, comps.ld)) if want_r else None
         log_rho = self.zeros((N, comps.ld)) if want_log_rho else None
         expo = self.zeros((N, comps.ld)) if want_exponent else None
         ps = int(self.lib.pmc_stats_stride(D))
-        flat = out if out is not None else self.zeros(NSCALARS + K * ps)
+        nflat = NSCALARS + K * ps + 2 * K
+        flat = out if out is not None else self.zeros(nflat)
+        assert flat.numel() == nflat
+        vsums = flat[NSCALARS + K * ps:] if student else None
         ws = self._workspace(N, K, D)
         _lib.check(self.lib.pmc_responsibilities(
             self._p(x), N, D, self._p(pack), K, comps.kind, int(mode), int(bool(max_init_zero)),
-            self._p(sw), self._p(lat), self._p(u), self._p(v1), self._p(v2), self._p(r),
+            self._p(sw), self._p(lat), self._p(u), self._p(scratch), self._p(vsums), self._p(r),
             self._p(log_rho), self._p(expo), comps.ld, self._p(flat), self._p(ws), self._stream()),
             "pmc_responsibilities")
         _lib.check(self.lib.pmc_sufficient_stats(
-            self._p(x), N, D, self._p(pack), K, self._p(u), self._p(v1), self._p(v2),
-            self._p(flat[NSCALARS:]), self._p(ws), self._stream()), "pmc_sufficient_stats")
+            self._p(x), N, D, self._p(pack), K, self._p(u), self._p(flat[NSCALARS:]), self._p(ws),
+            self._stream()), "pmc_sufficient_stats")
         return dict(stats=flat, r=r, log_rho=log_rho, exponent=expo)
+
+    def stats_len(self, K, D):
+        """length of the flat statistics buffer of estep()"""
+        return NSCALARS + K * int(self.lib.pmc_stats_stride(D)) + 2 * K
 
     def stats_stride(self, D):
         return int(self.lib.pmc_stats_stride(D))

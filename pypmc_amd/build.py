@@ -68,13 +68,15 @@ def build(jobs=None, force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in ("pmc_dims.h", "pmc_internal.h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "pmc_hip.h"))
-    ksrc = os.path.join(CSRC, "pmc_kernels.hip")
+    headers.append(os.path.join(CSRC, "pmc_device.h"))
     asrc = os.path.join(CSRC, "pmc_api.hip")
     work = [(os.path.join(OBJ, "pmc_api.o"), asrc, [], [asrc] + headers, force)]
     for d, padded in dim_list():
         for p in ((0, 1) if padded else (0,)):
-            work.append((os.path.join(OBJ, "pmc_kernels_d%d_p%d.o" % (d, p)), ksrc,
-                         ["-DPMC_D=%d" % d, "-DPMC_PADDED=%d" % p], [ksrc] + headers, force))
+            for unit in ("persample", "stats"):
+                src = os.path.join(CSRC, "pmc_%s.hip" % unit)
+                work.append((os.path.join(OBJ, "pmc_%s_d%d_p%d.o" % (unit, d, p)), src,
+                             ["-DPMC_D=%d" % d, "-DPMC_PADDED=%d" % p], [src] + headers, force))
     # biggest units first so the pool drains evenly
     work.sort(key=lambda j: -int(re.search(r"_d(\d+)_", j[0]).group(1)) if "_d" in j[0] else 0)
     jobs = jobs or min(8, os.cpu_count() or 1)
@@ -84,6 +86,8 @@ def build(jobs=None, force=False, verbose=False):
             objs.append(out)
             if verbose and dt:
                 print("  built %-28s %5.1fs" % (os.path.basename(out), dt), flush=True)
+    for stale in set(os.path.join(OBJ, f) for f in os.listdir(OBJ) if f.endswith(".o")) - set(objs):
+        os.remove(stale)
     if force or not _newer(LIB, objs):
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + sorted(objs)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -14,22 +14,28 @@
 // ---------------------------------------------------------------------------------------------
 // kernel-set registry (one accessor per compiled dimension, defined in pmc_kernels.hip units)
 // ---------------------------------------------------------------------------------------------
-#define PMC_DECL_X(d) extern "C" const PmcKernelSet *pmc_kset_##d##_p0(void);
-#define PMC_DECL_XP(d) \
-    extern "C" const PmcKernelSet *pmc_kset_##d##_p0(void); \
-    extern "C" const PmcKernelSet *pmc_kset_##d##_p1(void);
+#define PMC_DECL_UNIT(d, p) \
+    extern "C" hipError_t pmc_launch_logpdf_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
+    extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t);   \
+    extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t);       \
+    extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);
+#define PMC_DECL_X(d) PMC_DECL_UNIT(d, 0)
+#define PMC_DECL_XP(d) PMC_DECL_UNIT(d, 0) PMC_DECL_UNIT(d, 1)
 PMC_DIM_LIST(PMC_DECL_X, PMC_DECL_XP)
 
 namespace {
 
+#define PMC_SET(d, p) \
+    {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, \
+     &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p}
 struct DimEntry {
     int dim;
-    const PmcKernelSet *(*exact)(void);
-    const PmcKernelSet *(*padded)(void);
+    bool has_padded;
+    PmcKernelSet exact, padded;
 };
-#define PMC_ENT_X(d) {d, &pmc_kset_##d##_p0, nullptr},
-#define PMC_ENT_XP(d) {d, &pmc_kset_##d##_p0, &pmc_kset_##d##_p1},
-const DimEntry g_dims[] = {PMC_DIM_LIST(PMC_ENT_X, PMC_ENT_XP)};
+#define PMC_ENT_X(d) {d, false, PMC_SET(d, 0), PMC_SET(d, 0)},
+#define PMC_ENT_XP(d) {d, true, PMC_SET(d, 0), PMC_SET(d, 1)},
+DimEntry g_dims[] = {PMC_DIM_LIST(PMC_ENT_X, PMC_ENT_XP)};
 constexpr int g_ndims = sizeof(g_dims) / sizeof(g_dims[0]);
 
 thread_local char g_err[512] = "";
@@ -48,12 +54,16 @@ int hipfail(hipError_t e, const char *what)
     return fail(PMC_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-// kernel set + compiled dimension for a sample dimension D
+// kernel set (and with it the compiled dimension) for a sample dimension D
 const PmcKernelSet *kernels_for(int D)
 {
     for (int i = 0; i < g_ndims; ++i) {
-        if (g_dims[i].dim == D) return g_dims[i].exact();
-        if (g_dims[i].dim > D) return g_dims[i].padded ? g_dims[i].padded() : nullptr;
+        PmcKernelSet *ks = nullptr;
+        if (g_dims[i].dim == D) ks = &g_dims[i].exact;
+        else if (g_dims[i].dim > D) ks = g_dims[i].has_padded ? &g_dims[i].padded : nullptr;
+        else continue;
+        if (ks && ks->stats_nsub == 0) ks->config(&ks->stats_nsub, &ks->stats_waves);   // idempotent
+        return ks;
     }
     return nullptr;
 }
@@ -87,17 +97,33 @@ __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__
                                                       double *__restrict__ stats)
 {
     const int PS = pmc_stats_stride_c(D), PSc = pmc_stats_stride_c(Dc);
-    const int T = pmc_tri(D), Tc = pmc_tri(Dc);
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)K * PS) return;
     const int k = (int)(idx / PS), p = (int)(idx % PS);
     int pc;
     if (p < 1 + D) pc = p;                                // sum u, first moments
-    else if (p < 1 + D + T) pc = p - (1 + D) + (1 + Dc);  // lower triangle: i(i+1)/2+j is D-free
-    else pc = p - (1 + D + T) + (1 + Dc + Tc);            // v1 / v2 sums
+    else pc = p - (1 + D) + (1 + Dc);                     // lower triangle: i(i+1)/2+j is D-free
     double v = 0.0;
     for (int c = 0; c < nchunks; ++c) v += partials[((size_t)c * K + k) * PSc + pc];
     stats[idx] = v;
+}
+
+// vsums[k*2+c] = sum_tile vpartials[(tile*K + k)*2 + c]   (one workgroup per output, fixed order)
+__global__ __launch_bounds__(256) void k_finish_vsums(const double *__restrict__ vpartials,
+                                                      long long ntiles, int K,
+                                                      double *__restrict__ vsums)
+{
+    __shared__ double red[256];
+    const int o = blockIdx.x;                             // k*2 + c
+    double v = 0.0;
+    for (long long t = threadIdx.x; t < ntiles; t += 256) v += vpartials[(size_t)t * K * 2 + o];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) vsums[o] = red[0];
 }
 
 // importance-weight sums over an existing weight vector (convergence.py:31-39, :67-72)
@@ -224,7 +250,8 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
     const StatsGeom g = stats_geom(N > 0 ? N : 1, K, ks);
     const size_t stats = (size_t)g.nchunks * K * pmc_stats_stride_c(ks->dim) * sizeof(double);
-    const size_t scal = scalar_partials_bytes(N);
+    const size_t scal = scalar_partials_bytes(N) +
+                        (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
     size_t total = stats > scal ? stats : scal;
     return (int64_t)((total + 255) & ~(size_t)255);
 }
@@ -332,7 +359,7 @@ int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_wor
 
 int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                          int mode, int max_init_zero, const double *d_sample_w,
-                         const int64_t *d_latent, double *d_u, double *d_v1, double *d_v2,
+                         const int64_t *d_latent, double *d_u, double *d_scratch, double *d_vsums,
                          double *d_r, double *d_log_rho, double *d_exponent, int64_t ld,
                          double *d_scalars, void *d_workspace, void *stream)
 {
@@ -346,8 +373,8 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
             return fail(PMC_EINVAL, "pmc_responsibilities: PMC modes need kind GAUSS or STUDENT_T");
         if (mode == PMC_RESP_PMC_LATENT && !d_latent)
             return fail(PMC_EINVAL, "pmc_responsibilities: mode LATENT needs d_latent");
-        if (kind == PMC_KIND_STUDENT_T && (!d_v1 || !d_v2))
-            return fail(PMC_EINVAL, "pmc_responsibilities: Student-t needs d_v1 and d_v2");
+        if (kind == PMC_KIND_STUDENT_T && (!d_scratch || !d_vsums || !d_workspace))
+            return fail(PMC_EINVAL, "pmc_responsibilities: Student-t needs d_scratch, d_vsums and d_workspace");
     } else {
         return fail(PMC_EINVAL, "pmc_responsibilities: unknown mode %d", mode);
     }
@@ -356,29 +383,35 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
     if (d_scalars && !d_workspace) return fail(PMC_EINVAL, "pmc_responsibilities: d_scalars needs d_workspace");
     if (N > 0 && !d_x) return fail(PMC_EINVAL, "pmc_responsibilities: d_x is NULL");
     hipStream_t st = (hipStream_t)stream;
-    const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    const long long ntiles = ceil_div(N, PMC_TILE);
+    const long long nblocks = ceil_div(ntiles, PMC_A_WAVES);
+    double *vpartials = d_workspace ? (double *)((char *)d_workspace + scalar_partials_bytes(N)) : nullptr;
     if (nblocks > 0) {
         PmcArgsA a;
         std::memset(&a, 0, sizeof(a));
         a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
         a.mode = mode; a.ld = ld; a.sample_w = d_sample_w; a.latent = (const long long *)d_latent;
-        a.u = d_u; a.v1 = d_v1; a.v2 = d_v2; a.r = d_r; a.log_rho = d_log_rho; a.exponent = d_exponent;
+        a.u = d_u; a.scratch = d_scratch; a.vpartials = vpartials;
+        a.r = d_r; a.log_rho = d_log_rho; a.exponent = d_exponent;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         hipError_t e = ks->resp(kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_resp launch");
+    }
+    if (kind == PMC_KIND_STUDENT_T) {
+        hipLaunchKernelGGL(k_finish_vsums, dim3((unsigned)(2 * K)), dim3(256), 0, st,
+                           (const double *)vpartials, ntiles, K, d_vsums);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hipfail(e, "k_finish_vsums launch");
     }
     if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
     return PMC_OK;
 }
 
 int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
-                         const double *d_u, const double *d_v1, const double *d_v2, double *d_stats,
-                         void *d_workspace, void *stream)
+                         const double *d_u, double *d_stats, void *d_workspace, void *stream)
 {
     if (N < 0 || K < 1 || !d_pack || !d_u || !d_stats || !d_workspace)
         return fail(PMC_EINVAL, "pmc_sufficient_stats: bad argument");
-    if ((d_v1 == nullptr) != (d_v2 == nullptr))
-        return fail(PMC_EINVAL, "pmc_sufficient_stats: d_v1 and d_v2 must both be given or both NULL");
     if (N > 0 && !d_x) return fail(PMC_EINVAL, "pmc_sufficient_stats: d_x is NULL");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
@@ -392,7 +425,7 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
     const StatsGeom g = stats_geom(N, K, ks);
     PmcArgsB b;
     std::memset(&b, 0, sizeof(b));
-    b.x = d_x; b.N = N; b.dreal = D; b.pack = d_pack; b.K = K; b.u = d_u; b.v1 = d_v1; b.v2 = d_v2;
+    b.x = d_x; b.N = N; b.dreal = D; b.pack = d_pack; b.K = K; b.u = d_u;
     b.partials = (double *)d_workspace; b.ntiles = g.ntiles; b.nchunks = g.nchunks;
     b.tiles_per_chunk = g.tiles_per_chunk; b.ngroups = g.ngroups;
     hipError_t e = ks->stats(b, g.grid, st);

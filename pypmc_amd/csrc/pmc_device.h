@@ -1,0 +1,171 @@
+// pmc_device.h -- device helpers shared by the per-dimension kernel units.
+#pragma once
+#include "pmc_internal.h"
+#include "../../include/pmc_hip.h"
+
+#include <cfloat>
+#include <type_traits>
+
+#ifndef PMC_D
+#error "compile with -DPMC_D=<dimension>"
+#endif
+#ifndef PMC_PADDED
+#define PMC_PADDED 0
+#endif
+
+namespace {
+
+constexpr double TINY = 2.2250738585072014e-308;  // numpy.finfo('d').tiny
+
+typedef __attribute__((address_space(4))) const double cdouble;        // scalar-cache loads
+typedef __attribute__((address_space(4))) const long long cint64;
+
+template <int I> using ic = std::integral_constant<int, I>;
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample row -> registers
+// ---------------------------------------------------------------------------------------------
+template <int D, bool PADDED>
+__device__ __forceinline__ void load_row(const double *__restrict__ x, long long n, long long N,
+                                         int dreal, double (&xv)[D])
+{
+    if (n < N) {
+        if constexpr (!PADDED) {
+            const double *p = x + n * D;
+#pragma unroll
+            for (int j = 0; j < D; ++j) xv[j] = p[j];
+        } else {
+            const double *p = x + n * (long long)dreal;
+#pragma unroll
+            for (int j = 0; j < D; ++j) xv[j] = j < dreal ? p[j] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) xv[j] = 0.0;
+    }
+}
+
+// Pull the 64-byte lines of one component's parameters into the scalar data cache and wait.
+// The pack of a K >= 16 mixture does not fit the 16 KB scalar cache, so without this every
+// s_load of the component loop would pay the L2 round trip behind its own s_waitcnt (70 % of the
+// requests were "miss, fill pending" in the PMC counters); with it a wavefront pays one such
+// round trip per component and its ~30 real loads hit.  Touch loads beyond the last line are
+// clamped onto it.  One asm statement including the wait, so no load is in flight on exit.
+template <int LINES, int FIRST> __device__ __forceinline__ void touch16(cdouble *p)
+{
+    constexpr int L = LINES - 1;
+#define PMC_OFF(i) "n"(((FIRST + (i)) < L ? (FIRST + (i)) : L) * 64)
+    int dummy;
+    asm volatile("s_load_dword %0, %1, %2\n s_load_dword %0, %1, %3\n s_load_dword %0, %1, %4\n"
+                 "s_load_dword %0, %1, %5\n s_load_dword %0, %1, %6\n s_load_dword %0, %1, %7\n"
+                 "s_load_dword %0, %1, %8\n s_load_dword %0, %1, %9\n s_load_dword %0, %1, %10\n"
+                 "s_load_dword %0, %1, %11\n s_load_dword %0, %1, %12\n s_load_dword %0, %1, %13\n"
+                 "s_load_dword %0, %1, %14\n s_load_dword %0, %1, %15\n s_load_dword %0, %1, %16\n"
+                 "s_load_dword %0, %1, %17\n s_waitcnt lgkmcnt(0)"
+                 : "=&s"(dummy)
+                 : "s"(p), PMC_OFF(0), PMC_OFF(1), PMC_OFF(2), PMC_OFF(3), PMC_OFF(4), PMC_OFF(5),
+                   PMC_OFF(6), PMC_OFF(7), PMC_OFF(8), PMC_OFF(9), PMC_OFF(10), PMC_OFF(11),
+                   PMC_OFF(12), PMC_OFF(13), PMC_OFF(14), PMC_OFF(15)
+                 : "memory");
+#undef PMC_OFF
+}
+template <int D> __device__ __forceinline__ void touch_component(cdouble *pk)
+{
+    constexpr int LINES = pmc_pack_stride_c(D) * 8 / 64;
+    static_for<0, (LINES + 15) / 16>([&](auto B) { touch16<LINES, decltype(B)::value * 16>(pk); });
+}
+
+// maha = |R (x - mu)|^2 ; R upper triangular, packed row-major in consumption order.
+// Replaces bilinear_sym(inv_sigma, x - mu) (pypmc/tools/_linalg.pyx:10-39).
+template <int D> __device__ __forceinline__ double mahalanobis(const double (&xv)[D], cdouble *pk)
+{
+    double d[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) d[j] = xv[j] - pk[j];
+    double maha = 0.0;
+    int idx = D;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double y = 0.0;
+#pragma unroll
+        for (int j = i; j < D; ++j) y = fma(pk[idx++], d[j], y);
+        maha = fma(y, y, maha);
+    }
+    return maha;
+}
+
+// a_nk from maha_nk, in the reference's operation order (see enum pmc_kind).
+template <int D, int KIND>
+__device__ __forceinline__ double component_value(double maha, cdouble *c, double &expo)
+{
+    if constexpr (KIND == PMC_KIND_GAUSS) {
+        return c[0] - 0.5 * maha;                       // gauss.pyx:151
+    } else if constexpr (KIND == PMC_KIND_STUDENT_T) {
+        double t = maha;                                  // student_t.pyx:159-164
+        t *= c[2];
+        t += 1.;
+        t = log(t);
+        t *= c[1];
+        t += c[0];
+        return t;
+    } else {
+        expo = c[0] + c[1] * maha;                        // variational.pyx:798
+        return c[2] + 0.5 * (c[3] - expo);                // variational.pyx:691
+    }
+}
+
+// One step of the streaming log-sum-exp  log sum_k w_k exp(a_k) = m + log s  with
+// m = running max, s = sum_k w_k exp(a_k - m)   (one exp per step).
+__device__ __forceinline__ void lse_step(double a, double w, double &m, double &s)
+{
+    const double e = exp(-fabs(a - m));
+    const bool gt = a > m;
+    s = gt ? fma(s, e, w) : fma(w, e, s);
+    m = gt ? a : m;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block (PMC_A_WAVES wavefronts) reduction of NS per-lane scalars -> partials[block*PMC_NSCALARS+i]
+template <int NS>
+__device__ __forceinline__ void block_scalars(double (&sc)[NS], double *partials)
+{
+    __shared__ double red[PMC_A_WAVES][PMC_NSCALARS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double v = wave_sum(sc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PMC_NSCALARS) {
+        double v = 0.0;
+        if (threadIdx.x < NS) {
+#pragma unroll
+            for (int w = 0; w < PMC_A_WAVES; ++w) v += red[w][threadIdx.x];
+        }
+        partials[(size_t)blockIdx.x * PMC_NSCALARS + threadIdx.x] = v;
+    }
+}
+
+
+constexpr int D_ = PMC_D;
+constexpr bool P_ = PMC_PADDED != 0;
+
+}  // namespace
+
+#define PMC_CAT4(a, b, c, d) a##b##c##d
+#define PMC_UNIT_NAME(stem, d, p) PMC_CAT4(stem, d, _p, p)
+#define PMC_UNIT_NAME_X(stem, d, p) PMC_UNIT_NAME(stem, d, p)

@@ -9,7 +9,7 @@ constexpr int PMC_A_WAVES = 4;     // wavefronts (tiles) per workgroup in the pe
 
 __host__ __device__ constexpr int pmc_tri(int D) { return D * (D + 1) / 2; }
 __host__ __device__ constexpr int pmc_pack_stride_c(int D) { return (D + pmc_tri(D) + 6 + 7) & ~7; }
-__host__ __device__ constexpr int pmc_stats_stride_c(int D) { return 1 + D + pmc_tri(D) + 2; }
+__host__ __device__ constexpr int pmc_stats_stride_c(int D) { return 1 + D + pmc_tri(D); }
 
 // per-sample kernels (log-pdf, responsibilities)
 struct PmcArgsA {
@@ -27,7 +27,9 @@ struct PmcArgsA {
     double *weights;
     const double *sample_w;
     const long long *latent;
-    double *u, *v1, *v2;
+    double *u;            // tile-major responsibilities (output)
+    double *scratch;      // tile-major scratch (Student-t: maha between the two passes)
+    double *vpartials;    // Student-t: ntiles * K * 2 per-wavefront sums of v1, v2
     double *r, *log_rho, *exponent;
     double *partials;     // gridDim.x * PMC_NSCALARS
 };
@@ -39,7 +41,7 @@ struct PmcArgsB {
     int dreal;
     const double *pack;
     int K;
-    const double *u, *v1, *v2;
+    const double *u;
     double *partials;     // nchunks * K * pmc_stats_stride_c(Dcompiled)
     long long ntiles;
     int nchunks;          // multiple of 8 (XCD count)
@@ -55,4 +57,5 @@ struct PmcKernelSet {
     hipError_t (*logpdf)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
     hipError_t (*resp)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
     hipError_t (*stats)(const PmcArgsB &, unsigned grid, hipStream_t);
+    void (*config)(int *nsub, int *waves);
 };

@@ -1,0 +1,210 @@
+// pmc_persample.hip / pmc_stats.hip -- the gfx950 kernels of the adaptive-importance-sampling hot
+// path, each compiled once per sample dimension:  hipcc -DPMC_D=<D> -DPMC_PADDED=<0|1> -c <file>
+//
+// Execution model (CDNA4, wave64):
+//   * Per-sample kernels (k_logpdf, k_resp): one lane owns one sample; its D coordinates stay in
+//     VGPRs for the whole component loop.  Everything that depends on the component only (mean,
+//     whitening factor R_k, constants) is wave-uniform, so it is fetched with scalar loads
+//     (address space 4 -> s_load_dwordx16 through the scalar cache) and used as the SGPR operand of
+//     v_fma_f64: the triangular product y = R_k (x - mu_k) costs D(D+1)/2 v_fmac_f64 and no LDS or
+//     vector-memory traffic at all.  fp64 MFMA has the same peak as fp64 VALU on gfx950 and cannot
+//     exploit the triangular structure or D not a multiple of 16, so it is not used.
+//   * Statistics kernel (k_stats): one wavefront owns one (component, row-subset) task and streams
+//     over a chunk of samples with ~50 per-lane fp64 accumulators; the 64 x D sample tile is
+//     loaded coalesced and transposed through LDS once per workgroup and shared by its wavefronts.
+//   * All reductions are fixed-order trees (per lane -> wavefront shuffle -> per-block partial ->
+//     one finishing kernel): bit-reproducible run to run, no fp64 atomics.
+//
+// Arithmetic follows the reference's operation order outside the Mahalanobis product; explicit
+// fma() is used only where stated and the unit is compiled with -ffp-contract=off.
+#include "pmc_device.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// k_logpdf: MixtureDensity.multi_evaluate (mixture.pyx:112-156) + logsumexp2D
+// (_regularize.pyx:57-84) [+ importance weights, importance_sampling.py:197-215] in one pass.
+// ---------------------------------------------------------------------------------------------
+template <int D, bool PADDED, int KIND>
+__global__ __launch_bounds__(PMC_A_WAVES * 64) void k_logpdf(const PmcArgsA a)
+{
+    constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
+    const long long n = ((long long)blockIdx.x * PMC_A_WAVES * 64) + threadIdx.x;
+    const bool valid = n < a.N;
+
+    double xv[D];
+    load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
+
+    double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0;
+    cdouble *pk = (cdouble *)a.pack;
+    for (int k = 0; k < a.K; ++k, pk += STRIDE) {
+        touch_component<D>(pk);
+        const double maha = mahalanobis<D>(xv, pk);
+        double expo;
+        const double v = component_value<D, KIND>(maha, pk + D + T, expo);
+        if (a.individual != nullptr) {
+            const long long col = ((cint64 *)pk)[D + T + 5];
+            if (valid) a.individual[n * a.ld + col] = v;
+        }
+        lse_step(v, pk[D + T + 4], m, s);
+    }
+    const double lse = log(s) + m;                       // _regularize.pyx:81
+    if (a.out != nullptr && valid) a.out[n] = lse;
+
+    if (a.partials == nullptr && a.log_target == nullptr) return;
+
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (a.log_target != nullptr && valid) {
+        const double tmp = a.log_target[n] - lse;        // importance_sampling.py:204
+        const double w = exp(tmp);                        // :207
+        a.weights[n] = w;
+        sc[0] = w;
+        sc[1] = (w != 0.0) ? w * tmp : 0.0;               // convergence.py:35-36 (zeros masked)
+        sc[2] = w * w;
+        sc[4] = (isinf(w) && !isinf(tmp)) ? 1.0 : 0.0;    // math.exp OverflowError
+    }
+    if (valid) sc[3] = (a.sample_w != nullptr) ? a.sample_w[n] * lse : lse;   // pmc.pyx:388-391
+    if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_resp: responsibilities in tile-major layout.  Pass 1 = a_nk (+ streaming log-sum-exp),
+// parked in the output buffer itself; pass 2 = normalisation.  A lane re-reads only what it
+// wrote, so no synchronisation is needed between the passes.
+// ---------------------------------------------------------------------------------------------
+template <int D, bool PADDED, int KIND>
+__global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
+{
+    constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * PMC_A_WAVES +
+                           __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long n = tile * 64 + lane;
+    const bool valid = n < a.N;
+    const bool tile_live = tile * 64 < a.N;               // wave-uniform
+    const int K = a.K;
+
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (tile_live) {
+        double xv[D];
+        load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
+        double *ut = a.u + (size_t)tile * K * 64 + lane;
+        double *mt = (KIND == PMC_KIND_STUDENT_T) ? a.scratch + (size_t)tile * K * 64 + lane : nullptr;
+        double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)tile * K * 2 : nullptr;
+
+        // ---- pass 1
+        double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0;
+        cdouble *pk = (cdouble *)a.pack;
+        for (int k = 0; k < K; ++k, pk += STRIDE) {
+            touch_component<D>(pk);
+            const double maha = mahalanobis<D>(xv, pk);
+            double expo = 0.0;
+            const double v = component_value<D, KIND>(maha, pk + D + T, expo);
+            ut[(size_t)k * 64] = v;
+            if constexpr (KIND == PMC_KIND_STUDENT_T) mt[(size_t)k * 64] = maha;
+            if constexpr (KIND == PMC_KIND_VB) {
+                if (a.exponent != nullptr) {
+                    const long long col = ((cint64 *)pk)[D + T + 5];
+                    if (valid) a.exponent[n * a.ld + col] = expo;
+                }
+            }
+            lse_step(v, pk[D + T + 4], m, s);
+        }
+        const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+
+        // ---- pass 2
+        pk = (cdouble *)a.pack;
+        if constexpr (KIND == PMC_KIND_VB) {
+            // variational.pyx:741-755: r = exp(log_rho - max) / norm, zeros -> tiny,
+            // log_rho += log(1/norm)
+            const double norm_inv = 1. / s;
+            const double log_norm_inv = log(norm_inv);
+            double elq = 0.0;
+            for (int k = 0; k < K; ++k, pk += STRIDE) {
+                double lr = ut[(size_t)k * 64] - m;
+                double r = exp(lr);
+                r *= norm_inv;
+                if (r == 0.0) r = TINY;
+                lr += log_norm_inv;
+                elq += r * lr;                            // variational.pyx:1003-1013
+                ut[(size_t)k * 64] = valid ? sw * r : 0.0;
+                if (a.r != nullptr || a.log_rho != nullptr) {
+                    const long long col = ((cint64 *)pk)[D + T + 5];
+                    if (valid && a.r != nullptr) a.r[n * a.ld + col] = r;
+                    if (valid && a.log_rho != nullptr) a.log_rho[n * a.ld + col] = lr;
+                }
+            }
+            if (valid) sc[0] = sw * elq;
+        } else {
+            // pmc.pyx:36-41: rho = exp(log q_k) * w_k / (exp(log_denominator) + tiny)
+            const double lse = log(s) + m;
+            const double denom = exp(lse) + TINY;
+            const long long lat = (a.mode == PMC_RESP_PMC_LATENT && valid) ? a.latent[n] : -1;
+            for (int k = 0; k < K; ++k, pk += STRIDE) {
+                cdouble *c = pk + D + T;
+                const long long col = ((cint64 *)pk)[D + T + 5];
+                double rho;
+                if (a.mode == PMC_RESP_PMC_LATENT) {
+                    rho = (lat == col) ? 1. : 0.;         // pmc.pyx:49-50
+                } else {
+                    rho = exp(ut[(size_t)k * 64]) * c[4];
+                    rho /= denom;
+                }
+                if (valid && a.r != nullptr) a.r[n * a.ld + col] = rho;
+                const double wr = valid ? sw * rho : 0.0;
+                if constexpr (KIND == PMC_KIND_STUDENT_T) {
+                    const double maha = mt[(size_t)k * 64];
+                    const double nu = c[3];
+                    const double gamma = (nu + (double)a.dreal) / (nu + maha);   // pmc.pyx:610
+                    ut[(size_t)k * 64] = wr * gamma;
+                    // per-wavefront sums of sample_w*rho and sample_w*rho*log(.5(maha+nu)), the
+                    // N-sized parts of pmc.pyx:612 (alpha) and :669 (dof condition)
+                    const double s1 = wave_sum(wr);
+                    const double s2 = wave_sum(wr * log(.5 * (maha + nu)));
+                    if (lane == 0) {
+                        vp[2 * k] = s1;
+                        vp[2 * k + 1] = s2;
+                    }
+                } else {
+                    ut[(size_t)k * 64] = wr;
+                }
+            }
+            if (valid) sc[3] = sw * lse;
+        }
+    }
+    if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
+}
+
+template <int KIND> hipError_t launch_logpdf_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_logpdf<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    return hipGetLastError();
+}
+template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_resp<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_d, PMC_D, PMC_PADDED)(int kind, const PmcArgsA &a,
+                                                                             unsigned grid, hipStream_t st)
+{
+    switch (kind) {
+    case PMC_KIND_GAUSS: return launch_logpdf_k<PMC_KIND_GAUSS>(a, grid, st);
+    case PMC_KIND_STUDENT_T: return launch_logpdf_k<PMC_KIND_STUDENT_T>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_resp_d, PMC_D, PMC_PADDED)(int kind, const PmcArgsA &a,
+                                                                           unsigned grid, hipStream_t st)
+{
+    switch (kind) {
+    case PMC_KIND_GAUSS: return launch_resp_k<PMC_KIND_GAUSS>(a, grid, st);
+    case PMC_KIND_STUDENT_T: return launch_resp_k<PMC_KIND_STUDENT_T>(a, grid, st);
+    case PMC_KIND_VB: return launch_resp_k<PMC_KIND_VB>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+}

@@ -14,11 +14,11 @@ def regularize(x):
 
 
 def split_stats(flat, K, D):
-    """flat = [scalars(NSCALARS) | K x (1 + D + D(D+1)/2 + 2)] (host array) ->
+    """flat = [scalars(NSCALARS) | K x (1 + D + D(D+1)/2) | K x 2] (host array) ->
     scalars, S0 (K), M1 (K,D), M2 (K,D,D symmetric), V1 (K), V2 (K)."""
     flat = np.asarray(flat, dtype=np.float64)
     T = D * (D + 1) // 2
-    ps = 1 + D + T + 2
+    ps = 1 + D + T
     scalars = flat[:NSCALARS].copy()
     body = flat[NSCALARS:NSCALARS + K * ps].reshape(K, ps)
     S0 = body[:, 0].copy()
@@ -27,9 +27,8 @@ def split_stats(flat, K, D):
     il, jl = np.tril_indices(D)          # row-major (i, j<=i): the kernel's packing order
     M2[:, il, jl] = body[:, 1 + D:1 + D + T]
     M2[:, jl, il] = body[:, 1 + D:1 + D + T]
-    V1 = body[:, 1 + D + T].copy()
-    V2 = body[:, 2 + D + T].copy()
-    return scalars, S0, M1, M2, V1, V2
+    vs = flat[NSCALARS + K * ps:NSCALARS + K * ps + 2 * K].reshape(K, 2)
+    return scalars, S0, M1, M2, vs[:, 0].copy(), vs[:, 1].copy()
 
 
 def centred_moments(S0_mean, M1, M2, shift, S0_cov=None):

@@ -79,7 +79,7 @@ def main():
                          tflops=N * K * flops_pair / t * 1e-9)
     t, tm = timeit(lambda: be.logpdf(x, cs, pack=pack, log_target=lt, want_scalars=True))
     res["logpdf+is"] = dict(ms=t, ms_median=tm, samples_per_s=N / t * 1e3)
-    out = be.zeros(8 + K * be.stats_stride(D))
+    out = be.zeros(be.stats_len(K, D))
     t, tm = timeit(lambda: be.estep(x, vb, 0, pack=vpack, out=out))
     fl_vb = K * (D * D + 4 * D) + K * (1 + 2 * D + D * (D + 1)) + K * 40
     res["vb_estep"] = dict(ms=t, ms_median=tm, samples_per_s=N / t * 1e3, tflops=N * fl_vb / t * 1e-9)
@@ -93,8 +93,8 @@ def main():
                                                     P(None), P(None), P(None), P(None), P(None), K, P(out), P(ws),
                                                     be._stream()))
     res["vb_resp_only"] = dict(ms=t, ms_median=tm)
-    t, tm = timeit(lambda: lib.pmc_sufficient_stats(P(x), N, D, P(vpack), K, P(u), P(None), P(None), P(out[8:]),
-                                                    P(ws), be._stream()))
+    t, tm = timeit(lambda: lib.pmc_sufficient_stats(P(x), N, D, P(vpack), K, P(u), P(out[8:]), P(ws),
+                                                    be._stream()))
     res["vb_stats_only"] = dict(ms=t, ms_median=tm)
     print(json.dumps(dict(N=N, K=K, D=D, student=args.student, **res), indent=1))
 
