@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): IS samples/s + VB E-step samples/s at N=1e7, K=32, D=20.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the hot path over one batch of N synthetic samples per GPU, resident
+in HBM before the clock starts:
+  IS  : log P (K_t=4 Gaussian target mixture) -> log q (K=32 Gaussian proposal) -> w = exp(log P -
+        log q) + the perplexity/ESS sums                                   (2 x pmc_mixture_logpdf)
+  VB  : responsibilities of the K=32 variational posterior -> N_k, sum r d, sum r d d^T, E[log q(Z)]
+        -> RCCL all-reduce of the statistics vector -> copy to the host   (pmc_responsibilities +
+        pmc_sufficient_stats + all_reduce)
+Samples are sharded over ranks (weak scaling, N per GPU fixed); the only collective is the
+all-reduce of K x (1 + D + D(D+1)/2) + 8 doubles.  `value` = samples of all ranks / step time.
+
+The line also carries the roofline of the dominant kernel (HIP events on the launch stream) and
+a CPU baseline: the C oracle (a bit-exact restatement of the reference's Cython loops, the
+reference itself cannot run on the GPU box) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K, D, K_T = 32, 20, 4
+FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (spec)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md
+
+
+def mk(K, D, seed):
+    """mu_k ~ N(0, 9 I), Sigma_k = A A^T / D + 0.5 I, w ~ U(0.5, 1.5)."""
+    rs = np.random.RandomState(seed)
+    mu = rs.normal(0, 3, size=(K, D))
+    cov = np.empty((K, D, D))
+    for k in range(K):
+        A = rs.normal(0, 1, size=(D, D))
+        cov[k] = A.dot(A.T) / D + 0.5 * np.eye(D)
+    w = rs.uniform(0.5, 1.5, size=K)
+    return mu, cov, w / w.sum()
+
+
+def gauss_params(mu, cov):
+    inv = np.linalg.inv(cov)
+    inv = 0.5 * (inv + inv.transpose(0, 2, 1))
+    ln = -0.5 * mu.shape[1] * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(cov)[1]
+    return inv, ln
+
+
+def vb_params(mu, cov, w, N):
+    """posterior start values as GaussianInference derives them from a mixture guess
+    (variational.pyx:646-673) with the default priors"""
+    from scipy.special import digamma
+    K, D = mu.shape
+    alpha0, beta0, nu0 = 1e-5, 1e-5, D - 1. + 1e-5
+    alpha = w * (K * alpha0 + N - K) + 1
+    beta = beta0 + N * w
+    nu = nu0 + N * w
+    W = np.linalg.inv(cov * (nu - D)[:, None, None])
+    W = 0.5 * (W + W.transpose(0, 2, 1))
+    ln_lambda = sum(digamma(0.5 * (nu + 1. - i)) for i in range(1, D + 1)) + D * np.log(2.) + \
+        np.linalg.slogdet(W)[1]
+    ln_pi = digamma(alpha) - digamma(alpha.sum())
+    return W, beta, nu, ln_pi, ln_lambda
+
+
+def flops_logpdf(K, D):       # K (D^2 + 4D) + K c_tr, c_tr = 40
+    return K * (D * D + 4 * D) + K * 40
+
+
+def flops_stats(K, D):        # K (1 + 2D + D(D+1))
+    return K * (1 + 2 * D + D * (D + 1))
+
+
+def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
+    """Oracle on the host: same step on a bounded sample, single thread (the reference is single
+    threaded) and -- as an extra -- OpenMP over all cores."""
+    from oracle import oracle as orc
+    orc.build()
+    rs = np.random.RandomState(7)
+    inv, ln = gauss_params(mu, cov)
+    tinv, tln = gauss_params(tmu, tcov)
+    W, beta, nu, ln_pi, ln_lambda = vbp
+    L = np.linalg.cholesky(cov)
+
+    def draw(n):
+        k = rs.choice(len(w), size=n, p=w)
+        return mu[k] + np.einsum('nij,nj->ni', L[k], rs.normal(size=(n, D)))
+
+    def step(x, mt):
+        lt, _ = orc.mixture_multi_evaluate(0, x, tw, tmu, tinv, tln, mt=mt)
+        lq, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln, mt=mt)
+        wts = orc.is_weights(lt, lq)
+        orc.perp(wts), orc.ess(wts)
+        orc.vb_estep(x, None, mu, W, beta, nu, ln_pi, ln_lambda, mt=mt)
+
+    out = {}
+    for mt, label in ((False, "single"), (True, "all")):
+        x = draw(2000)
+        t0 = time.perf_counter()
+        step(x, mt)
+        rate = 2000 / (time.perf_counter() - t0)
+        n = int(max(2000, min(rate * seconds_target, 4_000_000)))
+        x = draw(n)
+        t0 = time.perf_counter()
+        step(x, mt)
+        dt = time.perf_counter() - t0
+        out[label] = dict(value=n / dt, n=n, seconds=dt, cores=orc.num_threads() if mt else 1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000, help="samples per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per variant")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+
+    from pypmc_amd.backend import HipBackend, ComponentSet
+    from pypmc_amd import parallel
+    be = HipBackend(local_rank)
+    dev = be.device
+    N = args.n
+
+    mu, cov, w = mk(K, D, 1)
+    tmu, tcov, tw = mk(K_T, D, 11)
+    inv, ln = gauss_params(mu, cov)
+    tinv, tln = gauss_params(tmu, tcov)
+    vbp = vb_params(mu, cov, w, N * world)
+    W, beta, nu, ln_pi, ln_lambda = vbp
+    proposal = ComponentSet(0, mu, inv, c0=ln, weight=w)
+    target = ComponentSet(0, tmu, tinv, c0=tln, weight=tw)
+    posterior = ComponentSet(2, mu, W, c0=D / beta, c1=nu, c2=ln_pi, c3=ln_lambda - D * np.log(2. * np.pi))
+    p_prop, p_tgt, p_vb = be.pack(proposal), be.pack(target), be.pack(posterior)
+
+    # synthetic samples drawn from the proposal on the device: x = mu_k + L_k z
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    comp = torch.multinomial(torch.tensor(w, device=dev), N, replacement=True, generator=gen)
+    comp, _ = torch.sort(comp)                       # ordered by component, as propose(trace) does
+    counts = torch.bincount(comp, minlength=K).tolist()
+    x = torch.randn(N, D, dtype=torch.float64, device=dev, generator=gen)
+    Lc = torch.tensor(np.linalg.cholesky(cov), device=dev)
+    mu_d = torch.tensor(mu, device=dev)
+    start = 0
+    for k in range(K):
+        seg = x[start:start + counts[k]]
+        seg.copy_(seg @ Lc[k].T + mu_d[k])
+        start += counts[k]
+    del comp
+    x = x[torch.randperm(N, device=dev, generator=gen)].contiguous()
+
+    stats = be.zeros(be.stats_len(K, D))
+    be.profile = None
+
+    def step():
+        lt = be.logpdf(x, target, pack=p_tgt)["out"]
+        r = be.logpdf(x, proposal, want_out=False, log_target=lt, want_scalars=True, pack=p_prop)
+        e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
+        flat = parallel.all_reduce_sum(e["stats"])
+        return r["scalars"], flat.cpu()              # K-sized results reach the host every step
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    be.profile = []
+    phase = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a, b, c = ev(), ev(), ev()
+        a.record()
+        lt = be.logpdf(x, target, pack=p_tgt)["out"]
+        r = be.logpdf(x, proposal, want_out=False, log_target=lt, want_scalars=True, pack=p_prop)
+        b.record()
+        e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
+        flat = parallel.all_reduce_sum(e["stats"])
+        host = flat.cpu()
+        c.record()
+        phase.append((a, b, c))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    is_ms = float(np.mean([a.elapsed_time(b) for a, b, c in phase]))
+    vb_ms = float(np.mean([b.elapsed_time(c) for a, b, c in phase]))
+    kern = {}
+    for name, s, e_ in be.profile:
+        kern.setdefault(name, []).append(s.elapsed_time(e_))
+    kern = {k_: float(np.mean(v)) for k_, v in kern.items()}
+    be.profile = None
+
+    # sanity of the numbers that came back (cheap, outside the timed region)
+    sc = r["scalars"].cpu().numpy()
+    perp = float(np.exp(-(sc[1] / sc[0] - np.log(sc[0]))) / N)
+    n_k_sum = float(host.numpy()[8:8 + K * be.stats_stride(D)].reshape(K, -1)[:, 0].sum())
+    assert abs(n_k_sum / (N * world) - 1) < 1e-9, "sum_k N_k != N"
+
+    if rank == 0:
+        flops = {"pmc_mixture_logpdf[K=32]": N * flops_logpdf(K, D),
+                 "pmc_mixture_logpdf[K=4]": N * flops_logpdf(K_T, D),
+                 "pmc_responsibilities": N * flops_logpdf(K, D),
+                 "pmc_sufficient_stats": N * flops_stats(K, D)}
+        dominant = max(kern, key=kern.get)
+        achieved = flops[dominant] / (kern[dominant] * 1e-3) * 1e-12
+        alg_bytes = {"pmc_mixture_logpdf[K=32]": N * 8 * (D + 3), "pmc_mixture_logpdf[K=4]": N * 8 * (D + 1),
+                     "pmc_responsibilities": N * 8 * (D + K), "pmc_sufficient_stats": N * 8 * (D + K)}
+        line = {
+            "metric": "IS samples/sec + VB E-step samples/sec at N=1e7, K=32, D=20",
+            "value": N * world / (ms_per_step * 1e-3),
+            "unit": "samples/s through one IS weighting pass plus one VB E-step",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "IS weights (K=32 Gauss proposal, K_t=4 Gauss target, perplexity/ESS sums) "
+                                   "+ VB E-step (r_nk, N_k, x_k, S_k, E[log q(Z)], all-reduce)",
+                       "N_per_gpu": N, "K": K, "D": D, "K_target": K_T, "parallelism": "samples sharded x%d" % world},
+            "is_samples_per_s": N * world / (is_ms * 1e-3),
+            "vb_estep_samples_per_s": N * world / (vb_ms * 1e-3),
+            "mixture_logpdf_evals_per_s": N / (kern["pmc_mixture_logpdf[K=32]"] * 1e-3),
+            "kernel_ms": kern,
+            "perplexity": perp,
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "note": "fp64 VALU (v_fma_f64) kernel priced against the fp64 matrix peak, which equals "
+                                 "the fp64 vector peak on MI355X; flops = SURVEY 8(d) per-sample figure x N",
+                         "per_kernel_tflops": {k_: flops[k_] / (v * 1e-3) * 1e-12 for k_, v in kern.items()},
+                         "hbm": {"achieved": alg_bytes[dominant] / (kern[dominant] * 1e-3) * 1e-9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg_bytes[dominant] / (kern[dominant] * 1e-3) * 1e-9 / HBM_PEAK_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.cpu_seconds, mu, cov, w, tmu, tcov, tw, vbp)
+            line["cpu_baseline"] = {"value": cb["single"]["value"], "unit": line["unit"], "cores": 1, "kind": "port",
+                                    "sample": "same step on %d samples drawn from the proposal (%.1f s), C oracle = "
+                                              "restatement of the reference's single-threaded Cython loops"
+                                              % (cb["single"]["n"], cb["single"]["seconds"]),
+                                    "all_cores": {"value": cb["all"]["value"], "cores": cb["all"]["cores"],
+                                                  "sample": "%d samples, %.1f s, OpenMP over samples"
+                                                            % (cb["all"]["n"], cb["all"]["seconds"])}}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,14 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
 int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_workspace,
                     void *stream);
 
+/*
+ * logsumexp2D of an existing N x K row-major matrix (pypmc/tools/_regularize.pyx:57-84), used by
+ * combine_weights (importance_sampling.py:362) and by mixtures of foreign component types:
+ * d_out[n] = max_k a[n,k] + log sum_k w_k exp(a[n,k] - max).
+ */
+int pmc_logsumexp2d(const double *d_a, const double *d_w, int64_t N, int K, double *d_out,
+                    void *stream);
+
 /* ---- responsibilities ------------------------------------------------------------------------ */
 /*
  * The N x K responsibility matrix of the VB E-step (variational.pyx:774-798 exponent,

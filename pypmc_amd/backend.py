@@ -78,8 +78,30 @@ class HipBackend(object):
         self.tile = self.lib.pmc_tile()
         self._ws = None
         self._bufs = {}
+        self.profile = None      # set to a list to collect (entry point, start, end) event triples
+
+    # Densities keep a reference to their backend and are deep-copied / pickled by the front-end
+    # (MixtureDensity copies its components, ImportanceSampler its proposal): a backend is a
+    # process-wide handle, never duplicated, and re-created from the default when unpickled.
+    def __deepcopy__(self, memo):
+        return self
+
+    def __reduce__(self):
+        return (get_backend, ())
 
     # ------------------------------------------------------------------ plumbing
+    def _timed(self, name, fn, *args):
+        """Call a C-ABI entry point, bracketed by events on the launch stream when profiling."""
+        if self.profile is None:
+            return fn(*args)
+        start = self.torch.cuda.Event(enable_timing=True)
+        end = self.torch.cuda.Event(enable_timing=True)
+        start.record()
+        rc = fn(*args)
+        end.record()
+        self.profile.append((name, start, end))
+        return rc
+
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -153,7 +175,8 @@ class HipBackend(object):
         sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
         scalars = self.zeros(NSCALARS) if want_scalars else None
         ws = self._workspace(N, comps.K, D) if want_scalars else None
-        _lib.check(self.lib.pmc_mixture_logpdf(
+        _lib.check(self._timed(
+            "pmc_mixture_logpdf[K=%d]" % comps.K, self.lib.pmc_mixture_logpdf,
             self._p(x), N, D, self._p(pack), comps.K, comps.kind, int(bool(max_init_zero)),
             self._p(out), self._p(individual), comps.ld, self._p(lt), self._p(weights), self._p(sw),
             self._p(scalars), self._p(ws), self._stream()), "pmc_mixture_logpdf")
@@ -168,6 +191,17 @@ class HipBackend(object):
         _lib.check(self.lib.pmc_weight_sums(self._p(w), N, self._p(scalars), self._p(ws),
                                             self._stream()), "pmc_weight_sums")
         return scalars
+
+    def logsumexp2d(self, a, w):
+        """row-wise log sum_k w_k exp(a_nk) of an N x K matrix (device tensor result)."""
+        a = self.asdevice(a)
+        w = self.asdevice(w).reshape(-1)
+        N, K = a.shape
+        assert w.shape[0] == K
+        out = self.empty(N)
+        _lib.check(self.lib.pmc_logsumexp2d(self._p(a), self._p(w), N, K, self._p(out),
+                                            self._stream()), "pmc_logsumexp2d")
+        return out
 
     def estep(self, x, comps, mode, max_init_zero=False, sample_w=None, latent=None,
               want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None):
@@ -198,12 +232,14 @@ class HipBackend(object):
         assert flat.numel() == nflat
         vsums = flat[NSCALARS + K * ps:] if student else None
         ws = self._workspace(N, K, D)
-        _lib.check(self.lib.pmc_responsibilities(
+        _lib.check(self._timed(
+            "pmc_responsibilities", self.lib.pmc_responsibilities,
             self._p(x), N, D, self._p(pack), K, comps.kind, int(mode), int(bool(max_init_zero)),
             self._p(sw), self._p(lat), self._p(u), self._p(scratch), self._p(vsums), self._p(r),
             self._p(log_rho), self._p(expo), comps.ld, self._p(flat), self._p(ws), self._stream()),
             "pmc_responsibilities")
-        _lib.check(self.lib.pmc_sufficient_stats(
+        _lib.check(self._timed(
+            "pmc_sufficient_stats", self.lib.pmc_sufficient_stats,
             self._p(x), N, D, self._p(pack), K, self._p(u), self._p(flat[NSCALARS:]), self._p(ws),
             self._stream()), "pmc_sufficient_stats")
         return dict(stats=flat, r=r, log_rho=log_rho, exponent=expo)

@@ -154,6 +154,23 @@ __global__ __launch_bounds__(256) void k_weight_sums(const double *__restrict__ 
     }
 }
 
+// logsumexp2D (pypmc/tools/_regularize.pyx:57-84) of an existing row-major N x K matrix:
+// out[n] = max_k a[n,k] + log sum_k w_k exp(a[n,k] - max), max initialised to -DBL_MAX.
+__global__ __launch_bounds__(256) void k_logsumexp2d(const double *__restrict__ a,
+                                                     const double *__restrict__ w, long long N,
+                                                     int K, double *__restrict__ out)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double *row = a + n * K;
+    double mx = -1.7976931348623157e308;
+    for (int k = 0; k < K; ++k)
+        if (row[k] > mx) mx = row[k];
+    double res = 0.0;
+    for (int k = 0; k < K; ++k) res += w[k] * exp(row[k] - mx);
+    out[n] = log(res) + mx;
+}
+
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 
 // statistics launch geometry
@@ -355,6 +372,18 @@ int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_wor
         if (e != hipSuccess) return hipfail(e, "k_weight_sums launch");
     }
     return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+}
+
+int pmc_logsumexp2d(const double *d_a, const double *d_w, int64_t N, int K, double *d_out, void *stream)
+{
+    if (N < 0 || K < 1 || !d_w || (N > 0 && (!d_a || !d_out)))
+        return fail(PMC_EINVAL, "pmc_logsumexp2d: bad argument");
+    if (N == 0) return PMC_OK;
+    hipLaunchKernelGGL(k_logsumexp2d, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_a, d_w, (long long)N, K, d_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_logsumexp2d launch");
+    return PMC_OK;
 }
 
 int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,

@@ -1,0 +1,77 @@
+"""Gaussian density with its log-pdf on the GPU (reference: pypmc/density/gauss.pyx)."""
+import numpy as np
+
+from .base import ProbabilityDensity
+from ..tools._linalg import chol_inv_det
+from ..backend import ComponentSet, get_backend
+from .._lib import PMC_KIND_GAUSS
+
+
+def _as_matrix(sigma):
+    """scalar / nested list / array -> fresh 2-D float array (1 x 1 for a scalar)."""
+    s = np.array(sigma, dtype=float)
+    if s.ndim == 0:
+        s = s.reshape(1, 1)
+    elif s.ndim == 1:
+        s = s.reshape(1, -1) if s.size == 1 else np.atleast_2d(s)
+    return s
+
+
+class Gauss(ProbabilityDensity):
+    r"""N(mu, sigma).  Usable as a MixtureDensity component.
+
+    Host state (authoritative, picklable): ``mu, sigma, inv_sigma, cholesky_sigma,
+    log_det_sigma, log_normalization, dim``.  ``evaluate``/``multi_evaluate`` run the HIP
+    mixture kernel with a single component."""
+
+    def __init__(self, mu, sigma, backend=None):
+        self._backend = backend
+        self.update(mu, sigma)
+
+    def update(self, mu, sigma):
+        """Replace mean and covariance.  A ``LinAlgError`` (asymmetric / not positive definite /
+        non-finite covariance) leaves the object untouched (reference: gauss.pyx:40-48, :86-116)."""
+        sigma = _as_matrix(sigma)
+        cholesky_sigma, inv_sigma, log_det_sigma = chol_inv_det(sigma)   # may raise LinAlgError
+        mu = np.array(mu, dtype=float).reshape(-1)
+        assert len(mu) == sigma.shape[0], \
+            "Dimensions of mean (%d) and covariance matrix (%d) do not match!" % (len(mu), sigma.shape[0])
+        self.mu, self.sigma, self.dim = mu, sigma, len(mu)
+        self.cholesky_sigma, self.inv_sigma, self.log_det_sigma = cholesky_sigma, inv_sigma, log_det_sigma
+        # gauss.pyx:56
+        self.log_normalization = -0.5 * self.dim * np.log(2 * np.pi) - 0.5 * self.log_det_sigma
+
+    # -- kernel description ------------------------------------------------------------------
+    kind = PMC_KIND_GAUSS
+
+    def _kernel_constants(self):
+        """(c0, c1, c2, c3) of ``enum pmc_kind`` for this component."""
+        return self.log_normalization, 0., 0., 0.
+
+    def _component_set(self):
+        return ComponentSet(self.kind, self.mu[None], self.inv_sigma[None],
+                            *[np.array([c]) for c in self._kernel_constants()])
+
+    # -- evaluation ---------------------------------------------------------------------------
+    def evaluate(self, x):
+        x = np.asarray(x, dtype=np.float64).reshape(1, -1)
+        return float(self.multi_evaluate(x)[0])
+
+    def multi_evaluate(self, x, out=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.ndim == 2 and x.shape[1] == self.dim
+        if out is None:
+            out = np.empty(len(x))
+        else:
+            assert len(out) == len(x)
+        be = get_backend(self._backend)
+        out[:] = be.tohost(be.logpdf(x, self._component_set())["out"])
+        return out
+
+    # -- sampling (host; the generator stream is consumed exactly as the reference does) ---------
+    def propose(self, N=1, rng=np.random.mtrand):
+        """mu + L z with z ~ N(0, 1)^D drawn sample by sample (reference: gauss.pyx:50-52,
+        :159-163); one (N, D) draw consumes the legacy generator stream identically."""
+        z = rng.normal(0, 1, (int(N), self.dim)) if N else np.empty((0, self.dim))
+        z = np.asarray(z, dtype=float).reshape(int(N), self.dim)
+        return self.mu + z.dot(self.cholesky_sigma.T)

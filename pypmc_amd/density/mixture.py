@@ -1,0 +1,177 @@
+"""Mixture densities with the fused log-pdf / log-sum-exp kernel behind them
+(reference: pypmc/density/mixture.pyx)."""
+from copy import deepcopy
+
+import numpy as np
+
+from .base import ProbabilityDensity
+from .gauss import Gauss
+from .student_t import StudentT
+from ..backend import ComponentSet, get_backend
+
+
+def component_set(components, weights, columns=None, ld=None):
+    """ComponentSet of homogeneous Gauss / StudentT ``components`` (None if they are of another
+    or of mixed type).  ``columns`` selects a subset, ``ld`` is the total component count."""
+    comps = list(components)
+    if not comps:
+        return None
+    first = type(comps[0])
+    if first not in (Gauss, StudentT) or any(type(c) is not first for c in comps):
+        return None
+    idx = list(range(len(comps))) if columns is None else list(columns)
+    sel = [comps[k] for k in idx]
+    consts = np.array([c._kernel_constants() for c in sel], dtype=np.float64).reshape(len(sel), 4)
+    return ComponentSet(first.kind,
+                        np.array([c.mu for c in sel], dtype=np.float64).reshape(len(sel), -1),
+                        np.array([c.inv_sigma for c in sel], dtype=np.float64),
+                        consts[:, 0], consts[:, 1], consts[:, 2], consts[:, 3],
+                        weight=np.asarray(weights, dtype=np.float64)[idx], column=idx,
+                        ld=len(comps) if ld is None else ld)
+
+
+class MixtureDensity(ProbabilityDensity):
+    """sum_k w_k q_k(x) over component densities q_k (reference: mixture.pyx:21-59).
+
+    ``components`` are deep-copied, ``weights`` normalised.  Host state is authoritative; the
+    device parameter pack is rebuilt from it for every evaluation."""
+
+    def __init__(self, components, weights=None, backend=None):
+        self._backend = backend
+        self.components = [deepcopy(c) for c in components]
+        assert self.components, "Must have at least one component!"
+        self.dim = self.components[0].dim
+        np.testing.assert_equal([c.dim for c in self.components], [self.dim] * len(self.components))
+        if weights is None:
+            self.weights = np.ones(len(self.components))
+        else:
+            self.weights = np.array(weights, dtype=float)
+            assert len(self.weights) == len(self.components)
+        self.normalize()
+
+    def __len__(self):
+        K = len(self.components)
+        assert K == len(self.weights)
+        return K
+
+    def normalize(self):
+        """Scale the weights to sum to one (in place)."""
+        self.weights /= self.weights.sum()
+
+    def normalized(self):
+        return bool(np.allclose(self.weights.sum(), 1.0))
+
+    def prune(self, threshold=0.0):
+        """Drop components with weight <= ``threshold``; returns [(index, component, weight), ...]
+        from the highest index down (reference: mixture.pyx:66-94)."""
+        removed = []
+        for k in range(len(self.weights) - 1, -1, -1):
+            if self.weights[k] <= threshold:
+                removed.append((k, self.components.pop(k), self.weights[k]))
+        self.weights = np.delete(self.weights, [r[0] for r in removed])
+        return removed
+
+    # -- evaluation ---------------------------------------------------------------------------
+    def evaluate(self, x, individual=False):
+        """log q(x) of one point [and the component log-densities] (reference: mixture.pyx:101-110)."""
+        x = np.asarray(x, dtype=np.float64).reshape(1, -1)
+        ind = np.empty((1, len(self)))
+        res = self.multi_evaluate(x, individual=ind)
+        return (float(res[0]), ind[0]) if individual else float(res[0])
+
+    def multi_evaluate(self, x, out=None, individual=None, components=None):
+        """log q(x_n) for all rows of ``x`` (N x D); optionally the N x K matrix of component
+        log-densities in ``individual``; with ``components`` only those columns of ``individual``
+        are computed and nothing is returned (reference: mixture.pyx:112-156, same assertions)."""
+        assert x.shape[1] == self.dim, \
+            "The points in ``x`` have the wrong dimension (%i instead of %i)" % (x.shape[1], self.dim)
+        N, K = len(x), len(self)
+        if individual is not None:
+            assert len(x) == len(individual), \
+                "For the provided ``x``, ``individual`` must have shape %s" % ((N, K),)
+            assert individual.shape[1] == K, \
+                "For the provided ``x``, ``individual`` must have shape %s" % ((N, K),)
+        be = get_backend(self._backend)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+
+        if components is not None:
+            assert out is None, 'If ``components`` is not None, ``out`` must be None.'
+            components = list(components)
+            if individual is None:
+                individual = np.empty((N, K))       # reference allocates and discards it too
+            cs = component_set(self.components, self.weights, components, K)
+            if cs is not None and components:
+                dev = be.zeros((N, K))
+                be.logpdf(x, cs, want_out=False, individual=dev)
+                individual[:, components] = be.tohost(dev)[:, components]
+            else:
+                for k in components:
+                    self.components[k].multi_evaluate(x, individual[:, k])
+            return None
+
+        if out is not None:
+            assert len(out) == len(x), '``out`` must have length %i' % (len(x))
+        cs = component_set(self.components, self.weights)
+        if cs is not None:
+            res = be.logpdf(x, cs, want_out=True, want_individual=individual is not None)
+            if individual is not None:
+                individual[:] = be.tohost(res["individual"])
+            result = be.tohost(res["out"])
+        else:
+            # foreign component types: their own multi_evaluate, then the log-sum-exp kernel
+            ind = individual if individual is not None else np.empty((N, K))
+            for k, c in enumerate(self.components):
+                c.multi_evaluate(x, ind[:, k])
+            result = be.tohost(be.logsumexp2d(ind, self.weights))
+        if out is None:
+            return result
+        out[:] = result
+        return out
+
+    # -- sampling -------------------------------------------------------------------------------
+    def propose(self, N=1, rng=np.random.mtrand, trace=False, shuffle=True):
+        """N samples.  Component counts come from ``rng.multinomial(N, weights)``; with
+        ``trace`` the generating component of every sample is returned too (samples then stay
+        ordered by component).  Reference: mixture.pyx:159-212 -- including its quirk that the
+        components draw from their default generator, not from ``rng``."""
+        if trace and shuffle:
+            raise ValueError('Either ``shuffle`` or ``trace`` must be ``False``!')
+        counts = rng.multinomial(N, self.weights)
+        samples = np.empty((N, self.dim))
+        start = 0
+        for comp, n in zip(self.components, counts):
+            if n != 0:
+                samples[start:start + n] = comp.propose(n)
+            start += n
+        if trace:
+            return samples, np.repeat(np.arange(len(self.components)), counts)
+        if shuffle:
+            rng.shuffle(samples)
+        return samples
+
+
+def create_gaussian_mixture(means, covs, weights=None):
+    """MixtureDensity of Gauss components (reference: mixture.pyx:214-250)."""
+    assert len(means) == len(covs), \
+        'Number of means (%i) does not match number of covariances (%i)' % (len(means), len(covs))
+    return MixtureDensity([Gauss(m, c) for m, c in zip(means, covs)], weights)
+
+
+def recover_gaussian_mixture(mixture):
+    """(means, covs, weights) arrays of a Gaussian mixture (reference: mixture.pyx:252-282)."""
+    means = np.array([c.mu for c in mixture.components]).reshape(len(mixture), mixture.dim)
+    covs = np.array([c.sigma for c in mixture.components]).reshape(len(mixture), mixture.dim, mixture.dim)
+    return means, covs, np.array(mixture.weights)
+
+
+def create_t_mixture(means, covs, dofs, weights=None):
+    """MixtureDensity of StudentT components (reference: mixture.pyx:284-323)."""
+    assert (len(means) == len(covs)) and (len(means) == len(dofs)), \
+        'Number of ``means`` (%i), ``covs`` (%i) and ``dofs`` (%i) do not match.' % (len(means), len(covs), len(dofs))
+    return MixtureDensity([StudentT(m, c, d) for m, c, d in zip(means, covs, dofs)], weights)
+
+
+def recover_t_mixture(mixture):
+    """(means, covs, dofs, weights) arrays of a Student-t mixture (reference: mixture.pyx:325-350)."""
+    means, covs, weights = recover_gaussian_mixture(mixture)
+    return means, covs, np.array([c.dof for c in mixture.components], dtype=float), weights

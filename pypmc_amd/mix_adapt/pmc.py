@@ -1,0 +1,289 @@
+"""(M-)PMC updates of Gaussian and Student-t mixture proposals [Cap+08, Kil+09, HOD12] with the
+responsibilities and all N-sized reductions on the GPU (reference: pypmc/mix_adapt/pmc.pyx).
+
+One kernel pass produces rho_nk (Rao-Blackwellised, pmc.pyx:23-43, or the latent one-hot form,
+:45-51) -- for Student-t also gamma_nk (:602-610) -- directly in the layout of the statistics
+kernel, which reduces  sum u | sum u d | sum u d d^T  with d = x - mu_k^old and u = w rho [gamma].
+The host turns these K-sized sums into the reference's alpha, mu, Sigma (and the constant of the
+degree-of-freedom condition), applies ``component.update`` with the LinAlgError fall-back, and
+does the root finding and pruning.  With torch.distributed initialised the sums are all-reduced
+(pypmc_amd.parallel) and every rank performs the same update.
+"""
+import logging
+from copy import deepcopy
+
+import numpy as np
+from scipy.optimize import brentq
+from scipy.special import digamma
+
+from .. import parallel
+from .._lib import PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT
+from ..backend import get_backend
+from ..density.gauss import Gauss
+from ..density.student_t import StudentT
+from ..density.mixture import MixtureDensity, component_set
+from ._stats import regularize, split_stats, centred_moments
+
+logger = logging.getLogger(__name__)
+
+
+def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend):
+    """Argument checks, live-component bookkeeping and the device pass
+    (reference: pmc.pyx:53-118).  Returns density, live_components (after ``mincount`` pruning),
+    the indices the statistics were computed for, the host statistics, the weight normalisation
+    and the renormalisation flag."""
+    need_renormalize = False
+    if copy:
+        density = deepcopy(density)
+    N_local = len(samples)
+    if weights is not None:
+        weights = np.asarray(weights)
+        assert len(weights.shape) == 1, 'Weights must be one-dimensional.'
+        assert len(weights) == N_local, \
+            "Number of weights (%s) does not match the number of samples (%s)." % (len(weights), N_local)
+        local_norm = weights.sum()
+    else:
+        local_norm = float(N_local)
+    K = len(density)
+
+    if latent is None:
+        if mincount > 0:
+            raise ValueError('`mincount` must be 0 if `latent` is not provided!')
+        if not rb:
+            raise ValueError('`rb` must be True if `latent` is not provided!')
+        count = None
+    else:
+        latent = np.asarray(latent)
+        count = np.histogram(latent, bins=K, range=(0, K))[0].astype(np.float64)
+
+    live_components = [k for k in range(K) if density.weights[k] != 0]
+    stat_components = list(live_components)
+
+    be = get_backend(backend)
+    D = density.dim
+    if live_components:
+        cs = component_set(density.components, density.weights, live_components, K)
+        if cs is None:
+            raise TypeError('``density`` must have only Gauss or only StudentT components')
+        mode = PMC_RESP_PMC_RB if rb else PMC_RESP_PMC_LATENT
+        # dead components' all-zero columns take part in the row maximum (pmc.pyx:24-34)
+        res = be.estep(samples, cs, mode, max_init_zero=len(live_components) < K,
+                       sample_w=weights, latent=None if rb else latent)
+        flat = res["stats"]
+        nlive = len(live_components)
+    else:
+        flat, nlive = be.zeros(be.stats_len(1, D)), 0
+
+    # one exchange: statistics | weight normalisation | latent histogram
+    tail = np.concatenate(([local_norm], count if count is not None else np.zeros(0)))
+    if parallel.world_size() > 1:
+        flat = be.tohost(parallel.all_reduce_sum(flat))
+        tail = parallel.all_reduce_sum(tail)
+    else:
+        flat = be.tohost(flat)
+    weight_normalization = float(tail[0])
+    stats = split_stats(flat, max(nlive, 1), D)
+
+    if count is not None:
+        count = tail[1:]
+        # prune components that generated fewer than ``mincount`` samples -- AFTER rho was
+        # computed; the list is edited while it is iterated exactly as in pmc.pyx:110-116, which
+        # skips the element following a removed one
+        for k in live_components:
+            if count[k] < mincount:
+                live_components.remove(k)
+                density.weights[k] = 0.
+                need_renormalize = True
+                logger.warning("Component %i died because of too few (%i) samples." % (k, count[k]))
+
+    return density, live_components, stat_components, stats, weight_normalization, need_renormalize
+
+
+def _apply_updates(density, live_components, new_params, need_renormalize):
+    """``component.update`` with the reference's fall-back: a LinAlgError restores the old
+    parameters and zeroes the component's weight (pmc.pyx:227-244, :713-737)."""
+    for k in live_components:
+        component = density.components[k]
+        alpha_k, args = new_params[k]
+        density.weights[k] = alpha_k
+        old = (component.mu, component.sigma) + ((component.dof,) if len(args) == 3 else ())
+        try:
+            component.update(*args)
+        except np.linalg.LinAlgError:
+            logger.warning("Could not update component %i --> weight is set to zero." % k)
+            component.update(*old)
+            density.weights[k] = 0.
+            need_renormalize = True
+    if need_renormalize:
+        density.normalize()
+    return density
+
+
+def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=0, copy=True,
+                 backend=None):
+    """Adapt a Gaussian mixture ``density`` to the (weighted) ``samples`` it proposed
+    (reference: pmc.pyx:120-246, same signature and semantics)."""
+    assert samples is not None
+    if isinstance(samples, np.ndarray):          # device-resident tensors pass through untouched
+        samples = np.ascontiguousarray(samples, dtype=np.float64)
+    density, live, stat_comps, stats, norm, renorm = \
+        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend)
+    _, S0, M1, M2, _, _ = stats
+    if stat_comps:
+        shift = np.array([density.components[k].mu for k in stat_comps])
+        mu, cov = centred_moments(S0, M1, M2, shift)             # pmc.pyx:194-204 / :213-222
+        alpha = S0 / norm                                         # :191-193
+        pos = {k: i for i, k in enumerate(stat_comps)}
+        new = {k: (alpha[pos[k]], (mu[pos[k]], cov[pos[k]])) for k in live}
+    else:
+        new = {}
+    return _apply_updates(density, live, new, renorm)
+
+
+def _dof_condition(const):
+    """First-order condition for nu, [HOD12] eq. (16): const + log(nu/2) - psi(nu/2) = 0
+    (reference: pmc.pyx:478-497)."""
+    return lambda nu: const + np.log(.5 * nu) - digamma(.5 * nu)
+
+
+def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solver_steps=100,
+                  mindof=1e-5, maxdof=1e3, mincount=0, copy=True, backend=None):
+    """Adapt a Student-t mixture ``density`` (means, covariances and -- unless
+    ``dof_solver_steps`` is 0 -- degrees of freedom) to the (weighted) ``samples`` it proposed
+    (reference: pmc.pyx:499-739, same signature and semantics)."""
+    assert samples is not None
+    if isinstance(samples, np.ndarray):
+        samples = np.ascontiguousarray(samples, dtype=np.float64)
+    density, live, stat_comps, stats, norm, renorm = \
+        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend)
+    _, S0g, M1, M2, V1, V2 = stats        # S0g = sum w rho gamma, V1 = sum w rho
+    D = density.dim
+    new = {}
+    if stat_comps:
+        shift = np.array([density.components[k].mu for k in stat_comps])
+        old_dof = np.array([density.components[k].dof for k in stat_comps])
+        # mean: normalised by sum w rho gamma; covariance: by sum w rho   (pmc.pyx:620-630)
+        mu, cov = centred_moments(S0g, M1, M2, shift, S0_cov=V1)
+        alpha = V1 / norm
+        if dof_solver_steps:
+            # sum_n w_n (xi + delta)_nk of pmc.pyx:659-679 assembled from the device sums:
+            #   rho (log(.5(b+nu)) - psi(.5(D+nu)))      -> V2 - psi(.5(D+nu)) V1
+            #   (1-rho)(log(.5 nu) - psi(.5 nu))          -> (W - V1)(log(.5 nu) - psi(.5 nu))
+            #   rho (D+nu)/(b+nu)                         -> S0g
+            #   (1-rho)                                   -> W - V1
+            total = V2 - digamma(.5 * (D + old_dof)) * V1 \
+                + (norm - V1) * (np.log(.5 * old_dof) - digamma(.5 * old_dof)) + S0g + (norm - V1)
+            const = 1. - total / norm
+        pos = {k: i for i, k in enumerate(stat_comps)}
+        for k in live:
+            i = pos[k]
+            if dof_solver_steps:
+                condition = _dof_condition(const[i])
+                try:
+                    dof = brentq(condition, mindof, maxdof, maxiter=dof_solver_steps)
+                except RuntimeError:                      # not converged
+                    logger.warning("``dof`` solver for component %i did not converge." % k)
+                    dof = density.components[k].dof
+                except ValueError as error:
+                    # same sign at both ends; the condition decreases with nu (pmc.pyx:700-710)
+                    if condition(mindof) < 0.:
+                        dof = mindof
+                    elif condition(maxdof) > 0.:
+                        dof = maxdof
+                    else:
+                        raise RuntimeError('``dof`` adaptation for component %i raised an error.' % k, error)
+            else:
+                dof = density.components[k].dof
+            new[k] = (alpha[i], (mu[i], cov[i], dof))
+    return _apply_updates(density, live, new, renorm)
+
+
+class PMC(object):
+    """EM driver: repeated PMC updates on the same samples until the log-likelihood converges
+    (reference: pmc.pyx:248-476, same constructor and ``run``)."""
+
+    def __init__(self, samples, density, weights=None, latent=None, rb=True, mincount=0,
+                 backend=None, **kwargs):
+        assert samples is not None
+        self._backend = backend
+        if weights is not None:
+            self.weights = np.asarray(weights)
+            assert len(self.weights.shape) == 1, 'Weights must be one-dimensional.'
+            assert len(self.weights) == len(samples), \
+                "Number of weights (%s) does not match the number of samples (%s)." % (len(weights), len(samples))
+        else:
+            self.weights = None
+        if latent is None:
+            if mincount > 0:
+                raise ValueError('`mincount` must be 0 if `latent` is not provided!')
+            if not rb:
+                raise ValueError('`rb` must be True if `latent` is not provided!')
+        wrong = '``density`` must be a ``pypmc_amd.density.mixture.MixtureDensity`` with ' \
+                '``pypmc_amd.density.gauss.Gauss`` or ``pypmc_amd.density.student_t.StudentT`` components'
+        if not isinstance(density, MixtureDensity):
+            raise TypeError(wrong)
+        first = type(density.components[0])
+        if issubclass(first, StudentT):
+            self.pmc, required = student_t_pmc, StudentT
+        elif issubclass(first, Gauss):
+            self.pmc, required = gaussian_pmc, Gauss
+        else:
+            raise TypeError(wrong)
+        for c in density.components:
+            if not isinstance(c, required) or (required is Gauss and isinstance(c, StudentT)):
+                raise TypeError(wrong)
+        self.density = deepcopy(density)
+        self.samples = np.ascontiguousarray(samples, dtype=np.float64)
+        self.latent = latent
+        self.rb = rb
+        self.mincount = mincount
+        self.additional_args = kwargs
+        # global normalisation of the importance weights (sum over all ranks)
+        local = self.weights.sum() if self.weights is not None else float(len(self.samples))
+        self._norm = parallel.all_reduce_scalars(local)[0]
+        if self.weights is not None:
+            self.normalized_weights = self.weights / self._norm
+        be = get_backend(self._backend)
+        self._samples_dev = be.asdevice(self.samples)
+
+    def log_likelihood(self):
+        """sum_n wbar_n log q(x_n), eq. (5) of [Cap+08] (reference: pmc.pyx:367-391); the sum is
+        reduced on the device by the log-pdf kernel."""
+        be = get_backend(self._backend)
+        cs = component_set(self.density.components, self.density.weights)
+        res = be.logpdf(self._samples_dev, cs, want_out=False, sample_w=self.weights, want_scalars=True)
+        total = be.tohost(parallel.all_reduce_sum(res["scalars"]))[3]
+        return float(total / self._norm)
+
+    def run(self, iterations=1000, prune=0., rel_tol=1e-10, abs_tol=1e-5, verbose=False):
+        """Iterate updates until the log-likelihood converges; returns the iteration count or
+        None (reference: pmc.pyx:393-476 -- same convergence rules)."""
+        old_K = None
+        bound = None
+        for i in range(1, iterations + 1):
+            if old_K == len(self.density):
+                old_bound = bound
+            else:
+                old_bound = self.log_likelihood()
+                logger.info('New bound=%g, K=%i' % (old_bound, len(self.density)))
+            self.pmc(self._samples_dev, self.density,
+                     self.weights, self.latent, self.rb, mincount=self.mincount, copy=False,
+                     backend=self._backend, **self.additional_args)
+            bound = self.log_likelihood()
+            logger.info('After update %d: bound=%.15g, K=%i, component_weights=%s'
+                        % (i, bound, len(self.density), self.density.weights))
+            if bound < old_bound:
+                logger.warning('Bound decreased from %g to %g' % (old_bound, bound))
+            if bound == old_bound:
+                return i
+            diff = bound - old_bound
+            if diff > 0:
+                if abs(bound) < abs_tol:
+                    if abs(diff) < abs_tol:
+                        return i
+                elif abs(diff / bound) < rel_tol:
+                    return i
+            old_K = len(self.density)                       # K *before* pruning
+            self.density.prune(prune)
+            self.density.normalize()
+        return None

@@ -1,0 +1,454 @@
+"""Variational-Bayes Gaussian mixture fit [Bis06, ch. 10.2] with the N-sized E-step on the GPU
+(reference: pypmc/mix_adapt/variational.pyx, class GaussianInference).
+
+Division of labour
+  device (pmc_responsibilities + pmc_sufficient_stats, one pass each over the resident samples):
+      E[gauss exponent] (10.64) -> log rho (10.46) -> r (10.49) -> N_k, x-bar_k, S_k (10.51-53)
+      and the bound term E[log q(Z)] (10.75).  The N x K matrices are never materialised unless
+      the attributes ``r``, ``log_rho`` or ``expectation_gauss_exponent`` are read.
+  host   (K-sized, replicated on every rank): digamma expectations (10.65-66), M-step (10.58-62),
+      the other six bound terms (10.71-77), pruning, convergence control.
+With torch.distributed initialised each rank holds a shard of the data; the statistics vector is
+all-reduced once per E-step (pypmc_amd.parallel).
+"""
+import logging
+
+import numpy as np
+from scipy.special import digamma, gammaln
+
+from .. import parallel
+from .._lib import PMC_KIND_VB, PMC_RESP_VB
+from ..backend import ComponentSet, get_backend
+from ..density.gauss import Gauss
+from ..density.mixture import MixtureDensity, recover_gaussian_mixture
+from ..tools._linalg import chol_inv_det
+from ._stats import regularize, split_stats, centred_moments
+
+logger = logging.getLogger(__name__)
+
+
+class GaussianInference(object):
+    """Approximate the density behind ``data`` (N x D; optionally weighted) by a K-component
+    Gaussian mixture with a Gauss-Wishart / Dirichlet variational posterior.
+
+    Same constructor, methods and public attributes as the reference class
+    (variational.pyx:27-114): ``GaussianInference(data, components=0, weights=None,
+    initial_guess="first", **variational_parameters)``."""
+
+    def __init__(self, data, components=0, weights=None, initial_guess="first", backend=None, **kwargs):
+        self._backend = backend
+        data = np.asarray(data, dtype=np.float64)
+        self.N_local = data.shape[0]
+        self.data = data.reshape(self.N_local, 1) if data.ndim == 1 else data
+        self.dim = self.data.shape[1]
+        self.weights = None
+        sum_w_local = 0.0
+        if weights is not None:
+            weights = np.asarray(weights, dtype=np.float64)
+            assert weights.shape == (self.N_local,), \
+                "The number of samples (%s) does not match the number of weights (%s)" % (self.N_local, weights.shape[0])
+            assert np.isfinite(weights).all(), 'Some weights are not finite; i.e., inf or nan\n' + str(weights)
+            sum_w_local = weights.sum()
+        # global sample count / weight sum (identical to the local ones for a single process)
+        n_glob, sum_w = parallel.all_reduce_scalars(self.N_local, sum_w_local)
+        self.N = int(round(n_glob))
+        if weights is not None:
+            assert sum_w > 0, 'Sum of weights <= 0 (%g)' % sum_w
+            self.weights = self.N * (weights / sum_w)          # normalised to N (variational.pyx:94)
+
+        self._initialize_K(initial_guess, components, kwargs)
+        self.set_variational_parameters(initial_guess=initial_guess, **kwargs)
+        if not isinstance(initial_guess, str):
+            self._parse_initial_guess(initial_guess)
+        self._initialize_intermediate()
+
+        be = get_backend(self._backend)
+        self._data_dev = be.asdevice(np.ascontiguousarray(self.data))
+        self._weights_dev = be.asdevice(self.weights) if self.weights is not None else None
+        self.E_step()
+
+    # ------------------------------------------------------------------------- E / M steps
+    def E_step(self):
+        """Expectation values and summary statistics (reference: variational.pyx:116-127)."""
+        self._update_expectation_det_ln_lambda()        # first: catches an invalid W early
+        self._update_expectation_ln_pi()
+        D = self.dim
+        cs = ComponentSet(PMC_KIND_VB, self.m, self.W, c0=D / self.beta, c1=self.nu,
+                          c2=self.expectation_ln_pi,
+                          c3=self.expectation_det_ln_lambda - D * np.log(2. * np.pi))
+        be = get_backend(self._backend)
+        res = be.estep(self._data_dev, cs, PMC_RESP_VB, sample_w=self._weights_dev)
+        flat = be.tohost(parallel.all_reduce_sum(res["stats"]))
+        scalars, S0, M1, M2, _, _ = split_stats(flat, self.K, D)
+        if not np.isfinite(S0).any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(S0))
+        self.N_comp = regularize(S0)
+        self.inv_N_comp = 1. / self.N_comp
+        self.x_mean_comp, self.S = centred_moments(self.N_comp, M1, M2, self.m)
+        if not np.isfinite(self.S).any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of sample covariance\n' + str(self.S))
+        self._expectation_log_q_Z = float(scalars[0])
+        self._estep_set = cs            # parameters the current r / log_rho belong to
+        self._nk_cache = {}
+
+    def M_step(self):
+        """Update the Gauss-Wishart / Dirichlet parameters (reference: variational.pyx:129-136)."""
+        self.nu = self.nu0 + self.N_comp
+        self.alpha = self.alpha0 + self.N_comp
+        self.beta = self.beta0 + self.N_comp
+        # (10.61)
+        self.m = (self.beta0[:, None] * self.m0 + self.N_comp[:, None] * self.x_mean_comp) / self.beta[:, None]
+        # (10.62): W_k^-1 = W0_k^-1 + N_k S_k + beta0 N_k / (beta0 + N_k) (xbar - m0)(xbar - m0)^T
+        self.W = np.array(self.W)
+        for k in range(self.K):
+            dx = self.x_mean_comp[k] - self.m0[k]
+            inv_w = np.outer(dx, dx) * (self.beta0[k] / (self.beta0[k] + self.N_comp[k]))
+            inv_w += self.S[k]
+            inv_w *= self.N_comp[k]
+            inv_w += self.inv_W0[k]
+            self.W[k], log_det = chol_inv_det(inv_w)[1:]
+            self.log_det_W[k] = -log_det
+
+    def update(self):
+        """One M-step followed by one E-step (reference: variational.pyx:571-578)."""
+        self.M_step()
+        self.E_step()
+
+    # ------------------------------------------------------------------------- N x K attributes
+    def _nk(self, name):
+        """r / log_rho / expectation_gauss_exponent of the latest E-step, computed on demand for
+        this rank's shard (the reference keeps all three resident: variational.pyx:636-638)."""
+        if name not in self._nk_cache:
+            be = get_backend(self._backend)
+            res = be.estep(self._data_dev, self._estep_set, PMC_RESP_VB, sample_w=self._weights_dev,
+                           want_r=True, want_log_rho=True, want_exponent=True)
+            self._nk_cache = dict(r=be.tohost(res["r"]), log_rho=be.tohost(res["log_rho"]),
+                                  expectation_gauss_exponent=be.tohost(res["exponent"]))
+        return self._nk_cache[name]
+
+    r = property(lambda self: self._nk("r"))
+    log_rho = property(lambda self: self._nk("log_rho"))
+    expectation_gauss_exponent = property(lambda self: self._nk("expectation_gauss_exponent"))
+
+    # ------------------------------------------------------------------------- K-sized expectations
+    def _update_expectation_det_ln_lambda(self):
+        # (10.65): sum_{i=1..D} psi((nu + 1 - i)/2) + D ln 2 + ln|W|
+        i = np.arange(1, self.dim + 1)
+        self.expectation_det_ln_lambda = digamma(0.5 * (self.nu[:, None] + 1. - i[None, :])).sum(axis=1) \
+            + self.dim * np.log(2.) + self.log_det_W
+
+    def _update_expectation_ln_pi(self):
+        # (10.66)
+        self.expectation_ln_pi = digamma(self.alpha) - digamma(self.alpha.sum())
+
+    # ------------------------------------------------------------------------- results
+    def make_mixture(self):
+        """Gaussian mixture at the mode of the variational posterior; components whose mode is
+        undefined are skipped (reference: variational.pyx:138-192)."""
+        components, weights, skipped = [], [], []
+        for k in range(self.K):
+            pi = self.alpha[k] - 1.                       # un-normalised Dirichlet mode
+            if pi <= 0:
+                logger.warning("Skipped component %i because of zero weight" % k)
+                skipped.append(k)
+                continue
+            if self.nu[k] <= self.dim:                    # Gauss-Wishart mode needs nu > D
+                logger.warning("Gauss-Wishart mode of component %i is not defined" % k)
+                skipped.append(k)
+                continue
+            try:
+                cov = chol_inv_det((self.nu[k] - self.dim) * self.W[k])[1]
+                components.append(Gauss(self.m[k], cov, backend=self._backend))
+            except Exception as error:
+                logger.error("Could not create component %i. The error was: %s" % (k, repr(error)))
+                skipped.append(k)
+                continue
+            weights.append(pi)
+        if skipped:
+            logger.warning("The following components have been skipped: %s" % skipped)
+        return MixtureDensity(components, weights, backend=self._backend)
+
+    def likelihood_bound(self):
+        """Lower bound L(Q) on the log marginal likelihood (reference: variational.pyx:194-209)."""
+        bound = self._update_expectation_log_p_X()
+        bound += self._update_expectation_log_p_Z()
+        bound += self._update_expectation_log_p_pi()
+        bound += self._update_expectation_log_p_mu_lambda()
+        bound -= self._update_expectation_log_q_Z()
+        bound -= self._update_expectation_log_q_pi()
+        bound -= self._update_expectation_log_q_mu_lambda()
+        return bound
+
+    def posterior2prior(self):
+        """Posterior hyper-parameters in the form the constructor accepts as a prior."""
+        return dict(alpha0=self.alpha.copy(), beta0=self.beta.copy(), nu0=self.nu.copy(),
+                    m0=self.m.copy(), W0=self.W.copy(), components=self.K)
+
+    def prior_posterior(self):
+        """Copies of all prior and posterior hyper-parameters."""
+        return dict(alpha0=self.alpha0.copy(), beta0=self.beta0.copy(), m0=self.m0.copy(),
+                    nu0=self.nu0.copy(), W0=self.W0.copy(), alpha=self.alpha.copy(),
+                    beta=self.beta.copy(), m=self.m.copy(), nu=self.nu.copy(), W=self.W.copy(),
+                    components=self.K)
+
+    def prune(self, threshold=1.):
+        """Remove components with fewer than ``threshold`` effective samples and redo the E-step
+        (reference: variational.pyx:233-281)."""
+        if not threshold:
+            return
+        keep = np.where(self.N_comp >= threshold)[0]
+        if len(keep) == 0:
+            raise ValueError("Prune threshold %g too large, would remove all components" % threshold)
+        self.K = len(keep)
+        for name in ('alpha0', 'alpha', 'beta0', 'beta', 'expectation_det_ln_lambda',
+                     'expectation_ln_pi', 'N_comp', 'nu0', 'nu', 'm0', 'm', 'S', 'W0', 'inv_W0', 'W',
+                     'log_det_W', 'log_det_W0', 'x_mean_comp'):
+            setattr(self, name, np.array(getattr(self, name))[keep])
+        self.E_step()
+
+    def run(self, iterations=1000, prune=1., rel_tol=1e-10, abs_tol=1e-5, verbose=False):
+        """Iterate ``update`` until the bound converges; returns the iteration count or None
+        (reference: variational.pyx:283-359 -- same convergence rules)."""
+        old_K = None
+        bound = None
+        for i in range(1, iterations + 1):
+            if self.K == old_K:
+                old_bound = bound
+            else:
+                old_bound = self.likelihood_bound()
+                logger.info('New bound=%g, K=%d, N_k=%s' % (old_bound, self.K, self.N_comp))
+            self.update()
+            bound = self.likelihood_bound()
+            logger.info('After update %d: bound=%.15g, K=%d, N_k=%s' % (i, bound, self.K, self.N_comp))
+            if bound < old_bound:
+                logger.warning('Bound decreased from %g to %g' % (old_bound, bound))
+            if bound == old_bound:
+                return i
+            diff = bound - old_bound
+            if diff > 0:
+                if abs(bound) < abs_tol:
+                    if abs(diff) < abs_tol:
+                        return i
+                elif abs(diff / bound) < rel_tol:
+                    return i
+            old_K = self.K                                  # K *before* pruning
+            self.prune(prune)
+        return None
+
+    # ------------------------------------------------------------------------- parameters
+    def set_variational_parameters(self, *args, **kwargs):
+        """(Re)set prior (``alpha0, beta0, nu0, m0, W0``) and initial posterior (``alpha, beta, nu,
+        m, W``) hyper-parameters; scalars are promoted to K-vectors, ``m0`` (D) and ``W0`` (D x D)
+        to one copy per component.  Defaults and validation as in the reference
+        (variational.pyx:361-569)."""
+        if args:
+            raise TypeError('keyword args only')
+        K, D = self.K, self.dim
+
+        def k_vector(name, default, minimum=0.0):
+            v = kwargs.pop(name, default)
+            v = v * np.ones(K) if not np.iterable(v) else np.array(v, dtype=float)
+            setattr(self, name, v)
+            self._check_K_vector(name, min=minimum)
+            return v
+
+        k_vector('alpha0', 1e-5)
+        k_vector('alpha', np.ones(K) * self.alpha0)
+        k_vector('beta0', 1e-5)
+        k_vector('beta', np.ones(K) * self.beta0)
+        nu_min = D - 1.
+        k_vector('nu0', nu_min + 1e-5, nu_min)
+        k_vector('nu', self.nu0 * np.ones(K), nu_min)
+
+        self.m0 = np.array(kwargs.pop('m0', np.zeros(D)), dtype=float)
+        if len(self.m0) == D and self.m0.ndim == 1:
+            self.m0 = np.vstack([self.m0] * K)
+        initial_guess = kwargs.pop('initial_guess')
+        m = kwargs.pop('m', None)
+        if m is not None:
+            self.m = np.array(m, dtype=float)
+        elif isinstance(initial_guess, str):
+            self.m = self._initialize_m(initial_guess)
+        else:
+            self.m = np.linspace(-1., 1., K * D).reshape((K, D))      # overwritten by the guess
+        for name in ('m0', 'm'):
+            if getattr(self, name).shape != (K, D):
+                raise ValueError('Shape of %s %s does not match (K,d)=%s' % (name, getattr(self, name).shape, (K, D)))
+
+        W0 = kwargs.pop('W0', None)
+        if W0 is None:
+            self.W0 = np.array([np.eye(D)] * K)
+            self.inv_W0 = self.W0.copy()
+            self.log_det_W0 = np.zeros(K)
+        else:
+            W0 = np.array(W0, dtype=float)
+            if W0.shape == (D, D):
+                inv, log_det = chol_inv_det(W0)[1:]
+                self.W0 = np.array([W0] * K)
+                self.inv_W0 = np.array([inv] * K)
+                self.log_det_W0 = np.array([log_det] * K)
+            elif W0.shape == (K, D, D):
+                self.W0 = W0
+                self.inv_W0 = np.empty_like(W0)
+                self.log_det_W0 = np.empty(K)
+                for k in range(K):
+                    self.inv_W0[k], self.log_det_W0[k] = chol_inv_det(W0[k])[1:]
+            else:
+                raise ValueError('W0 is neither None, nor a %s array, nor a %s array.' % ((D, D), (K, D, D)))
+        self.W = np.array(kwargs.pop('W', self.W0.copy()), dtype=float)
+        if self.W.shape != (K, D, D):
+            raise ValueError('Shape of W %s does not match (K, d, d)=%s' % (self.W.shape, (K, D, D)))
+        self.log_det_W = np.array([chol_inv_det(W)[2] for W in self.W])     # also validates W
+        if kwargs:
+            raise TypeError('unexpected keyword(s): ' + str(kwargs.keys()))
+
+    def _check_initial_guess(self, initial_guess, other_args):
+        for name in ('m', 'W', 'alpha', 'beta', 'nu'):
+            if name in other_args:
+                raise ValueError('Specify EITHER ``%s`` OR ``initial_guess``' % name)
+
+    def _initialize_K(self, initial_guess, components, kwargs):
+        if not isinstance(initial_guess, str):
+            self.K = len(initial_guess)
+            self._check_initial_guess(initial_guess, kwargs)
+        elif components > 0:
+            self.K = components
+        else:
+            raise ValueError('Specify either `components` or a mixture density as `initial_guess` to set the initial values')
+
+    def _check_K_vector(self, name, min=0.0):
+        v = getattr(self, name)
+        if len(v.shape) != 1:
+            raise ValueError('%s is not a vector but has shape %s' % (name, v.shape))
+        if len(v) != self.K:
+            raise ValueError('len(%s)=%d does not match K=%d' % (name, len(v), self.K))
+        if not (v > min).all():
+            raise ValueError('All elements of %s must exceed %g. %s=%s' % (name, min, name, v))
+
+    def _initialize_m(self, initial_guess):
+        """Initial means from the data: the first K points, or K random ones."""
+        if self.K > self.N_local:
+            raise ValueError("Can't auto-initialize ``m`` with more output components than samples."
+                             " Specify ``m`` explicitly.")
+        if initial_guess == 'first':
+            return self.data[:self.K].copy()
+        if initial_guess == 'random':
+            return self.data[np.random.choice(self.N_local, size=self.K, replace=False)].copy()
+        raise ValueError('Invalid ``initial_guess``: ' + str(initial_guess))
+
+    def _initialize_intermediate(self):
+        self.x_mean_comp = np.zeros((self.K, self.dim))
+        self.S = np.empty_like(self.W)
+        self.N_comp = np.zeros(self.K)
+        self.expectation_det_ln_lambda = np.zeros(self.K)
+        self.expectation_ln_pi = np.zeros(self.K)
+        self._nk_cache = {}
+
+    def _parse_initial_guess(self, initial_guess):
+        """Posterior start values from a Gaussian mixture (reference: variational.pyx:646-673)."""
+        means, covs, component_weights = recover_gaussian_mixture(initial_guess)
+        N, K = self.N, self.K
+        self.alpha = component_weights * (self.alpha0.sum() + N - K) + 1     # Dirichlet mode solved for alpha
+        self.beta = self.beta0 + N * component_weights
+        self.nu = self.nu0 + N * component_weights
+        assert (self.alpha > 0.0).all()
+        assert (self.beta > 0.0).all()
+        assert (self.nu > self.dim - 1).all()
+        self.m = means
+        self.W = np.empty_like(covs)
+        for k in range(K):
+            self.W[k], self.log_det_W[k] = chol_inv_det(covs[k] * (self.nu[k] - self.dim))[1:]
+        self.log_det_W *= -1          # det W = 1 / det(scaled covariance)
+
+    # ------------------------------------------------------------------------- bound terms
+    def _quad(self, v, M):
+        """v_k^T M_k v_k for every component"""
+        return np.einsum('ki,kij,kj->k', v, M, v)
+
+    def _update_expectation_log_p_X(self):
+        # (10.71)
+        D = self.dim
+        dx = self.x_mean_comp - self.m
+        tr_SW = np.einsum('kij,kji->k', self.S, self.W)
+        per_k = self.expectation_det_ln_lambda - D / self.beta \
+            - self.nu * (tr_SW + self._quad(dx, self.W)) - D * np.log(2 * np.pi)
+        self._expectation_log_p_X = 0.5 * float(np.dot(self.N_comp, per_k))
+        return self._expectation_log_p_X
+
+    def _update_expectation_log_p_Z(self):
+        # (10.72) with N_k = sum_n r_nk
+        self._expectation_log_p_Z = float(np.dot(self.N_comp, self.expectation_ln_pi))
+        return self._expectation_log_p_Z
+
+    def _update_expectation_log_p_pi(self):
+        # (10.73)
+        self._expectation_log_p_pi = Dirichlet_log_C(self.alpha0) + \
+            float(np.dot(self.alpha0 - 1, self.expectation_ln_pi))
+        return self._expectation_log_p_pi
+
+    def _update_expectation_log_p_mu_lambda(self):
+        # (10.74)
+        D = self.dim
+        dm = self.m - self.m0
+        res = 0.
+        for k in range(self.K):
+            res += D * np.log(self.beta0[k] / (2. * np.pi))
+            res += self.expectation_det_ln_lambda[k] - D * self.beta0[k] / self.beta[k] \
+                - self.beta0[k] * self.nu[k] * dm[k].dot(self.W[k]).dot(dm[k])
+            res += 2 * Wishart_log_B(D, self.nu0[k], self.log_det_W0[k])
+            res += (self.nu0[k] - D - 1) * self.expectation_det_ln_lambda[k]
+            res -= self.nu[k] * np.trace(self.inv_W0[k].dot(self.W[k]))
+        self._expectation_log_p_mu_lambda = 0.5 * res
+        return self._expectation_log_p_mu_lambda
+
+    def _update_expectation_log_q_Z(self):
+        # (10.75): the only N-sized bound term, reduced on the device during the E-step
+        return self._expectation_log_q_Z
+
+    def _update_expectation_log_q_pi(self):
+        # (10.76)
+        self._expectation_log_q_pi = float(np.dot(self.alpha - 1, self.expectation_ln_pi)) + \
+            Dirichlet_log_C(self.alpha)
+        return self._expectation_log_q_pi
+
+    def _update_expectation_log_q_mu_lambda(self):
+        # (10.77)
+        D = self.dim
+        res = -0.5 * self.K * D
+        for k in range(self.K):
+            res += 0.5 * (self.expectation_det_ln_lambda[k] + D * np.log(self.beta[k] / (2 * np.pi)))
+            res -= Wishart_H(D, self.nu[k], self.log_det_W[k])
+        self._expectation_log_q_mu_lambda = res
+        return self._expectation_log_q_mu_lambda
+
+
+# ----------------------------------------------------------------------------- Wishart / Dirichlet
+def Wishart_log_B(D, nu, log_det):
+    """log of the Wishart normalisation B(W, nu), [Bis06] (B.79); ``log_det`` = log|W|."""
+    assert D > 0, 'Invalid dimension: %s' % D
+    assert nu > D - 1, 'Invalid degree of freedom: %s' % nu
+    assert np.isfinite(log_det), 'Non-finite log(det): %s' % log_det
+    i = np.arange(1, D + 1)
+    return -0.5 * nu * log_det - 0.5 * nu * D * np.log(2) - 0.25 * D * (D - 1) * np.log(np.pi) \
+        - gammaln(0.5 * (nu + 1 - i)).sum()
+
+
+def Wishart_expect_log_lambda(D, nu, log_det):
+    """E[log|Lambda|] under a Wishart, [Bis06] (B.81)."""
+    assert D > 0, 'Invalid dimension: %s' % D
+    assert nu > D - 1, 'Invalid degree of freedom: %s' % nu
+    assert np.isfinite(log_det), 'Non-finite log(det): %s' % log_det
+    i = np.arange(1, D + 1)
+    return digamma(0.5 * (nu + 1 - i)).sum() + D * np.log(2.) + log_det
+
+
+def Wishart_H(D, nu, log_det):
+    """Entropy of the Wishart distribution, [Bis06] (B.82)."""
+    return -Wishart_log_B(D, nu, log_det) \
+        - 0.5 * (nu - D - 1) * Wishart_expect_log_lambda(D, nu, log_det) + 0.5 * nu * D
+
+
+def Dirichlet_log_C(alpha):
+    """log of the Dirichlet normalisation C(alpha), [Bis06] (B.23)."""
+    alpha = np.asarray(alpha, dtype=float)
+    return float(gammaln(alpha.sum()) - gammaln(alpha).sum())

@@ -1,0 +1,183 @@
+"""Importance sampling with the proposal density and the weights evaluated on the GPU
+(reference: pypmc/sampler/importance_sampling.py)."""
+from copy import deepcopy
+
+import numpy as np
+
+from ..backend import get_backend
+from ..tools._history import History
+from ..tools.indicator import merge_function_with_indicator
+
+
+def calculate_expectation(samples, weights, f):
+    """sum_n w_n f(x_n) / sum_n w_n  (reference: importance_sampling.py:13-44); host loop over
+    the user's callable."""
+    assert len(samples) == len(weights), \
+        "The number of samples (got %i) must equal the number of weights (got %i)." % (len(samples), len(weights))
+    total, norm = 0., 0.
+    for w, x in zip(weights, samples):
+        norm += w
+        total += w * f(x)
+    return total / norm
+
+
+def calculate_mean(samples, weights):
+    """Weighted sample mean (reference: importance_sampling.py:46-61)."""
+    assert len(samples) == len(weights), \
+        "The number of samples (got %i) must equal the number of weights (got %i)." % (len(samples), len(weights))
+    return np.average(samples, axis=0, weights=weights)
+
+
+def calculate_covariance(samples, weights):
+    """Weighted sample covariance with the (sum w)^2 / ((sum w)^2 - sum w^2) correction
+    (reference: importance_sampling.py:63-83)."""
+    assert len(samples) == len(weights), \
+        "The number of samples (got %i) must equal the number of weights (got %i)." % (len(samples), len(weights))
+    samples, weights = np.asarray(samples), np.asarray(weights)
+    s1sq, s2 = weights.sum() ** 2, (weights ** 2).sum()
+    d = samples - calculate_mean(samples, weights)
+    return s1sq / (s1sq - s2) * np.einsum('n,ni,nj->ij', weights, d, d) / weights.sum()
+
+
+class ImportanceSampler(object):
+    """Weighted samples of ``target`` (a callable returning log P(x)) drawn from ``proposal``
+    (reference: importance_sampling.py:132-236; same constructor, attributes and ``run``).
+
+    Per run the proposal's log-density, w = exp(log P - log q) and the three sums behind
+    perplexity / ESS come from one fused kernel launch; the user's ``target`` stays a host
+    callable evaluated per sample (or per batch, if it is the ``evaluate`` method of a density
+    offering ``multi_evaluate``)."""
+
+    def __init__(self, target, proposal, indicator=None, prealloc=0, save_target_values=False,
+                 rng=np.random.mtrand, backend=None):
+        self._backend = backend
+        self.proposal = deepcopy(proposal)
+        self.rng = rng
+        self._batch_target = None
+        owner = getattr(target, '__self__', None)
+        if indicator is None and owner is not None and getattr(target, '__name__', '') == 'evaluate' \
+                and hasattr(owner, 'multi_evaluate'):
+            self._batch_target = owner.multi_evaluate
+        self.target = merge_function_with_indicator(target, indicator, -np.inf)
+        self.target_values = History(1, prealloc) if save_target_values else None
+        self.weights = History(1, prealloc)
+        self.samples = History(proposal.dim, prealloc)
+        self.last_weight_sums = None      # (sum w, sum w log w, sum w^2) of the latest run
+
+    def clear(self):
+        """Forget samples, weights and target values; the proposal is untouched."""
+        self.samples.clear()
+        self.weights.clear()
+        if self.target_values is not None:
+            self.target_values.clear()
+
+    def run(self, N=1, trace_sort=False):
+        """Draw N samples and weight them.  With ``trace_sort`` (mixture proposals) the samples
+        are ordered by generating component and that component index is returned per sample."""
+        if N == 0:
+            return 0
+        if trace_sort:
+            this_samples, origin = self._get_samples(N, trace_sort=True)
+            self._calculate_weights(this_samples, N)
+            return origin
+        this_samples = self._get_samples(N, trace_sort=False)
+        self._calculate_weights(this_samples, N)
+
+    def _get_samples(self, N, trace_sort):
+        this_run = self.samples.append(N)
+        if trace_sort:
+            this_run[:], origin = self.proposal.propose(N, self.rng, trace=True, shuffle=False)
+            return this_run, origin
+        this_run[:] = self.proposal.propose(N, self.rng)
+        return this_run
+
+    def _target_values(self, x, N):
+        if self._batch_target is not None:
+            return np.asarray(self._batch_target(x), dtype=np.float64).reshape(N)
+        t = np.empty(N)
+        for i in range(N):
+            v = self.target(x[i])
+            t[i] = v.item() if np.ndim(v) != 0 else v
+        return t
+
+    def _calculate_weights(self, this_samples, N):
+        """w_n = exp(log P(x_n) - log q(x_n))  (reference: importance_sampling.py:197-215)."""
+        this_weights = self.weights.append(N)[:, 0]
+        log_target = self._target_values(this_samples, N)
+        if self.target_values is not None:
+            self.target_values.append(N)[:, 0] = log_target
+        be = get_backend(self._backend)
+        from ..density.mixture import MixtureDensity, component_set
+        cs = None
+        if isinstance(self.proposal, MixtureDensity):
+            cs = component_set(self.proposal.components, self.proposal.weights)
+        elif hasattr(self.proposal, '_component_set'):
+            cs = self.proposal._component_set()
+        if cs is not None:
+            res = be.logpdf(np.ascontiguousarray(this_samples), cs, want_out=False,
+                            log_target=log_target, want_scalars=True)
+            sc = be.tohost(res["scalars"])
+            if sc[4] > 0:
+                raise OverflowError('math range error')      # math.exp, importance_sampling.py:207
+            this_weights[:] = be.tohost(res["weights"])
+            self.last_weight_sums = (float(sc[0]), float(sc[1]), float(sc[2]))
+        else:
+            # foreign proposal type: its own multi_evaluate, exponentiation on the host
+            log_q = self.proposal.multi_evaluate(this_samples)
+            with np.errstate(over='raise'):
+                try:
+                    this_weights[:] = np.exp(log_target - log_q)
+                except FloatingPointError:
+                    raise OverflowError('math range error')
+            self.last_weight_sums = None
+
+
+def combine_weights(samples, weights, proposals, backend=None):
+    """Deterministic-mixture weights [Cor+12] of T importance-sampling runs with different
+    proposals (reference: importance_sampling.py:238-371).  Every q_l(x^t_n) comes from the
+    log-pdf kernel; the log-scale branch (all weights positive) reduces them with the
+    log-sum-exp kernel, the linear branch on the host.  Returns a History with one run per
+    proposal."""
+    samples, weights = list(samples), list(weights)
+    assert len(samples) == len(weights), \
+        "Got %i importance-sampling runs but %i weights" % (len(samples), len(weights))
+    assert len(samples) == len(proposals), \
+        "Got %i importance-sampling runs but %i proposal densities" % (len(samples), len(proposals))
+    T = len(proposals)
+    counts = np.empty(T)
+    for t in range(T):
+        samples[t] = np.asarray(samples[t])
+        assert samples[t].ndim == 2, '``samples[%i]`` is not matrix like.' % t
+        dim = samples[0].shape[-1]
+        assert samples[t].shape[-1] == dim, \
+            "Dimension of samples[0] (%i) does not match the dimension of samples[%i] (%i)" \
+            % (dim, t, samples[t].shape[-1])
+        counts[t] = len(samples[t])
+        weights[t] = np.asarray(weights[t])
+        assert counts[t] == len(weights[t]), \
+            'Length of weights[%i] (%i) does not match length of samples[%i] (%i)' \
+            % (t, len(weights[t]), t, counts[t])
+    n_total = int(counts.sum())
+    combined = History(1, n_total)
+    use_log = all((w > 0.0).all() for w in weights)
+    be = get_backend(backend)
+    for t in range(T):
+        x = np.ascontiguousarray(samples[t], dtype=np.float64)
+        q = np.empty((len(x), T))                 # log q_l(x^t_n), l = 0..T-1
+        for l, prop in enumerate(proposals):
+            q[:, l] = prop.multi_evaluate(x)
+        target_run = combined.append(len(x))[:, 0]
+        if use_log:
+            # log w = log omega + log q_t + log N_total - log sum_l N_l q_l   (:337-365)
+            log_w = np.log(weights[t]) + q[:, t] + np.log(n_total)
+            log_w -= be.tohost(be.logsumexp2d(q, counts))
+            target_run[:] = np.exp(log_w)
+        else:
+            # [Cor+12] eq. (3) on the linear scale (:316-333)
+            denominator = np.exp(q).dot(counts) / n_total
+            target_run[:] = np.exp(q[:, t]) * weights[t] / denominator
+    if use_log:
+        total = combined[:][:, 0].sum()
+        assert total > 0, 'Sum of weights <=0 (%g)' % total
+    assert np.isfinite(combined[:][:, 0]).all(), 'Encountered inf or nan mixture weights'
+    return combined

@@ -276,9 +276,9 @@ def main():
     for tag, K, D, N, seed in (("d2k3", 3, 2, 1000, 71), ("d5k4", 4, 5, 800, 72)):
         mu, cov, w = mk(K, D, seed)
         prop = create_gaussian_mixture(mu, cov, w)
-        tmu, tcov, tw = mk(2, D, 11)
-        tmu *= 0.5
-        target = create_gaussian_mixture(tmu, tcov, tw)
+        # target = a perturbed copy of the proposal, so the importance weights are healthy
+        rs = np.random.RandomState(seed + 7)
+        target = create_gaussian_mixture(mu + 0.4 * rs.normal(size=mu.shape), 1.3 * cov, w[::-1])
         np.random.seed(13)
         samples, latent = prop.propose(N, trace=True, shuffle=False)
         iw = np.exp(target.multi_evaluate(samples) - prop.multi_evaluate(samples))
@@ -314,9 +314,8 @@ def main():
         mu, cov, w = mk(K, D, seed)
         dofs = np.array([3.5, 6., 12.])[:K]
         prop = create_t_mixture(mu, cov, dofs, w)
-        tmu, tcov, tw = mk(2, D, 11)
-        tmu *= 0.5
-        target = create_gaussian_mixture(tmu, tcov, tw)
+        rs = np.random.RandomState(seed + 7)
+        target = create_gaussian_mixture(mu + 0.4 * rs.normal(size=mu.shape), 1.3 * cov, w[::-1])
         np.random.seed(17)
         samples, latent = prop.propose(N, trace=True, shuffle=False)
         iw = np.exp(target.multi_evaluate(samples) - prop.multi_evaluate(samples))

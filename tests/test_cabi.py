@@ -1,0 +1,96 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/pmc_hip.h
+declares, its host-only entry points work, and without a GPU the product path fails loudly
+instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pmc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pypmc_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), "libpmc_hip.so does not export " + name
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert lib.pmc_abi_version() == 1
+
+
+def test_host_side_entry_points():
+    from pypmc_amd import _lib
+    lib = _lib.load()
+    assert lib.pmc_max_dim() == 64 and lib.pmc_tile() == 64
+    assert lib.pmc_padded_dim(20) == 20 and lib.pmc_padded_dim(9) == 10 and lib.pmc_padded_dim(33) == 40
+    assert lib.pmc_padded_dim(65) < 0 and "not supported" in _lib.last_error()
+    assert lib.pmc_padded_dim(0) < 0
+    assert lib.pmc_stats_stride(20) == 1 + 20 + 210
+    assert lib.pmc_tile_buffer_len(65, 3) == 2 * 3 * 64
+    assert lib.pmc_workspace_bytes(10 ** 6, 32, 20) > 0
+    # pmc_pack_components: precision = R^T R, padding, constants, columns
+    rs = np.random.RandomState(0)
+    K, D = 3, 9
+    Dp = lib.pmc_padded_dim(D)
+    stride = lib.pmc_pack_stride(D)
+    assert stride % 8 == 0 and stride >= Dp + Dp * (Dp + 1) // 2 + 6
+    A = rs.normal(size=(K, D, D))
+    prec = np.einsum('kij,klj->kil', A, A) + 0.1 * np.eye(D)
+    mu = rs.normal(size=(K, D))
+    c = rs.normal(size=(4, K))
+    w = rs.uniform(size=K)
+    col = np.array([4, 0, 2], dtype=np.int32)
+    pack = np.empty(K * stride)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = lib.pmc_pack_components(K, D, dp(mu), dp(prec), dp(c[0].copy()), dp(c[1].copy()), dp(c[2].copy()),
+                                 dp(c[3].copy()), dp(w), col.ctypes.data_as(C.POINTER(C.c_int32)), dp(pack))
+    assert rc == 0
+    T = Dp * (Dp + 1) // 2
+    iu = np.triu_indices(Dp)
+    for k in range(K):
+        pk = pack[k * stride:(k + 1) * stride]
+        np.testing.assert_array_equal(pk[:D], mu[k])
+        assert (pk[D:Dp] == 0).all()
+        R = np.zeros((Dp, Dp))
+        R[iu] = pk[Dp:Dp + T]
+        np.testing.assert_allclose(R[:D, :D].T.dot(R[:D, :D]), prec[k], rtol=1e-12, atol=1e-13)
+        assert (R[D:, :] == 0).all() and (R[:, D:] == 0).all()
+        np.testing.assert_array_equal(pk[Dp + T:Dp + T + 4], c[:, k])
+        assert pk[Dp + T + 4] == w[k]
+        assert np.frombuffer(pk[Dp + T + 5:Dp + T + 6].tobytes(), dtype=np.int64)[0] == col[k]
+    bad = prec.copy()
+    bad[1] = -np.eye(D)
+    assert lib.pmc_pack_components(K, D, dp(mu), dp(bad), None, None, None, None, None, None, dp(pack)) == -2
+    assert "component 1" in _lib.last_error()
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pypmc_amd.backend import HipBackend, HipLibraryError, get_backend
+    with pytest.raises(HipLibraryError, match="no CPU fallback"):
+        HipBackend()
+    from pypmc_amd.density.gauss import Gauss
+    with pytest.raises(HipLibraryError):
+        Gauss([0.], [[1.]]).evaluate(np.array([0.]))
+
+
+def test_product_package_never_touches_the_oracle():
+    """pypmc_amd/ must not import, load or shell out to anything under oracle/."""
+    pkg = os.path.join(ROOT, "pypmc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower().replace("oraclebackend", ""), os.path.join(dirpath, f)
