@@ -71,24 +71,22 @@ const PmcKernelSet *kernels_for(int D)
 // ---------------------------------------------------------------------------------------------
 // finishing kernels (single workgroup, fixed summation order)
 // ---------------------------------------------------------------------------------------------
-// scalars[i] = sum_b partials[b*PMC_NSCALARS + i]
-__global__ __launch_bounds__(256) void k_finish_scalars(const double *__restrict__ partials,
-                                                        long long nblocks,
-                                                        double *__restrict__ scalars)
+// scalars[i] = sum_b partials[b*PMC_NSCALARS + i]; one workgroup per scalar, fixed order
+__global__ __launch_bounds__(1024) void k_finish_scalars(const double *__restrict__ partials,
+                                                         long long nblocks,
+                                                         double *__restrict__ scalars)
 {
-    __shared__ double red[256];
-    for (int i = 0; i < PMC_NSCALARS; ++i) {
-        double v = 0.0;
-        for (long long b = threadIdx.x; b < nblocks; b += 256) v += partials[b * PMC_NSCALARS + i];
-        red[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) scalars[i] = red[0];
+    __shared__ double red[1024];
+    const int i = blockIdx.x;
+    double v = 0.0;
+    for (long long b = threadIdx.x; b < nblocks; b += 1024) v += partials[b * PMC_NSCALARS + i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
+    if (threadIdx.x == 0) scalars[i] = red[0];
 }
 
 // stats[k][p] (real dimension D) = sum_chunk partials[chunk][k][p'] (compiled dimension Dc)
@@ -323,7 +321,7 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
 static int finish_scalars(const double *partials, long long nblocks, double *d_scalars,
                           hipStream_t st)
 {
-    hipLaunchKernelGGL(k_finish_scalars, dim3(1), dim3(256), 0, st, partials, nblocks, d_scalars);
+    hipLaunchKernelGGL(k_finish_scalars, dim3(PMC_NSCALARS), dim3(1024), 0, st, partials, nblocks, d_scalars);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_scalars launch");
     return PMC_OK;
