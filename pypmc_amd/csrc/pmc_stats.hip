@@ -63,7 +63,25 @@ template <int D, int S> struct Task {
 // Samples per pipeline step: NS tiles of 64 (LDS: 2 buffers of D x (NS*64+1) doubles, <= ~84 KB)
 template <int D> __host__ __device__ constexpr int stats_ns()
 {
+#ifdef PMC_STATS_NS
+    return PMC_STATS_NS;
+#else
     return D <= 20 ? 4 : (D <= 40 ? 2 : 1);
+#endif
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain the vector
+// memory counter too (s_waitcnt vmcnt(0) before every s_barrier), which would stall each step on
+// the global prefetch it has just issued; here only this wavefront's LDS operations are waited for
+// and the prefetch stays in flight across the barrier (the compiler still places counted vmcnt
+// waits before the first use of a loaded register).
+typedef double pmc_vec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double vec_get(double a, int) { return a; }
+__device__ __forceinline__ double vec_get(pmc_vec2 a, int v) { return v == 0 ? a.x : a.y; }
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int D, bool PADDED, int WAVES, int SUB>
@@ -74,7 +92,6 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     constexpr int NT = WAVES * 64;
     constexpr int NS = stats_ns<D>();
     constexpr int LDP = NS * 64 + 1;                      // row pitch: conflict-free b64 access
-    constexpr int NLD = (NS * 64 * D + NT - 1) / NT;      // staged doubles per thread and step
     constexpr bool ACTIVE = SUB >= 0;
     using TK = Task<D, ACTIVE ? SUB : 0>;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -97,86 +114,133 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
         __syncthreads();
     }
 
-    // software pipeline: while step s is consumed from LDS, the global loads of step s+1 are in
-    // flight into registers; they are written (transposed) to the other LDS buffer after the
-    // arithmetic, one barrier per step.
-    double xn[NLD];
+    // Software pipeline over steps of NS tiles (256 samples for D <= 20): while step s is consumed
+    // from one LDS buffer, the global loads of step s+1 are in flight into registers; they are
+    // written (transposed) into the other LDS buffer after the arithmetic; one LDS-only barrier per
+    // step.  Loads use "uniform base (SGPR pair) + loop-invariant 32-bit thread offset" addressing
+    // and are branch-free: offsets are clamped into the array instead of guarded (a clamped lane
+    // reads some other, finite sample, and its weight u is zero), so a load costs ~1 VALU op.
+    // Pairs of consecutive doubles (16-byte loads) when the row length is even: one
+    // global_load_dwordx4 per two elements (8-byte vector loads run at ~0.6x the rate).
+    constexpr int VW = (!PADDED && D % 2 == 0) ? 2 : 1;    // doubles per load
+    constexpr int NLV = (NS * 64 * D / VW + NT - 1) / NT;  // loads per thread and step
+    typedef double vec2_t __attribute__((ext_vector_type(2)));
+    typedef typename std::conditional<VW == 2, vec2_t, double>::type vec_t;
+    vec_t xn[NLV];
     double un[NS];
-    auto fetch = [&](long long t) {
-        const long long base = t * 64 * dreal;
+    unsigned xoff[NLV];
+    int lds_off[NLV][VW];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * NT;
-            const long long g = base + e;
-            xn[i] = (e < NS * 64 * dreal && g < total) ? b.x[g] : 0.0;
+    for (int i = 0; i < NLV; ++i) {
+        const int e = (tid + i * NT) * VW;                 // first element of the pair
+        xoff[i] = (unsigned)(tid + i * NT);                // in units of vec_t
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+            const int ee = e + v;
+            const int nloc = PADDED ? ee / dreal : ee / D;
+            const int j = PADDED ? ee % dreal : ee % D;
+            lds_off[i][v] = (ee < NS * 64 * dreal) ? j * LDP + nloc : -1;
+        }
+    }
+    // part `part` of `nparts` of the loads of the step starting at tile t: the loads are issued
+    // in NS slices, one per sub-step of the arithmetic, so that the texture addresser sees a steady
+    // trickle instead of 8 wavefronts x 9 loads right after every barrier
+    auto fetch = [&](long long t, int part, int nparts) {
+        const long long tt = t < t1 ? t : t0;                                   // keep addresses in range
+        const vec_t *__restrict__ xt = (const vec_t *)(b.x + tt * 64 * dreal);  // wave-uniform
+        const long long rem = (total - tt * 64 * dreal) / VW - 1;               // >= 0
+        const unsigned lim = rem > 0x7ffffff0ll ? 0x7ffffff0u : (unsigned)rem;
+#pragma unroll
+        for (int i = 0; i < NLV; ++i) {
+            if (i % nparts != part) continue;
+#ifdef PMC_EXP_NOFETCH
+            xn[i] = vec_t((double)(xoff[i] & 1023) * 1e-3);
+#else
+            xn[i] = xt[xoff[i] < lim ? xoff[i] : lim];
+#endif
         }
         if constexpr (ACTIVE) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                const bool in = t + q < t1;
-                const size_t uo = ((size_t)(t + q) * b.K + k) * 64 + lane;
-                un[q] = in ? b.u[uo] : 0.0;
+                if (q % nparts != part) continue;
+                const bool in = t + q < t1;                                     // wave-uniform
+                const double *__restrict__ uq = b.u + ((size_t)(in ? t + q : t0) * b.K + k) * 64;
+#ifdef PMC_EXP_NOU
+                un[q] = in ? (double)(lane & 255) * 1e-3 : 0.0;
+#else
+                const double v = uq[lane];
+                un[q] = in ? v : 0.0;
+#endif
             }
         }
     };
     auto stage = [&](double *xb) {
+#ifdef PMC_EXP_NOSTAGE
+        return;
+#endif
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = tid + i * NT;
-            if (e < NS * 64 * dreal) {
-                const int nloc = PADDED ? e / dreal : e / D;
-                const int j = PADDED ? e % dreal : e % D;
-                xb[j * LDP + nloc] = xn[i];
+        for (int i = 0; i < NLV; ++i) {
+#pragma unroll
+            for (int v = 0; v < VW; ++v) {
+                const double val = vec_get(xn[i], v);
+                if ((NS * 64 * D) % (NT * VW) == 0 && !PADDED) xb[lds_off[i][v]] = val;
+                else if (lds_off[i][v] >= 0) xb[lds_off[i][v]] = val;
             }
         }
     };
 
     int buf = 0;
-    if (t0 < t1) {
-        fetch(t0);
-        stage(xs);
-    }
-    __syncthreads();
+    fetch(t0, 0, 1);
+    stage(xs);
+    lds_barrier();
     for (long long t = t0; t < t1; t += NS, buf ^= 1) {
         const double *xb = xs + buf * (D * LDP);
         double uc[NS];
 #pragma unroll
         for (int q = 0; q < NS; ++q) uc[q] = un[q];
-        const bool more = t + NS < t1;
-        if (more) fetch(t + NS);
+        if constexpr (!ACTIVE) fetch(t + NS, 0, 1);
         if constexpr (ACTIVE) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
+                fetch(t + NS, q, NS);
+#ifndef PMC_EXP_NOSCHEDBARRIER
                 // keep the scheduler from overlapping the LDS reads of all NS sub-steps at once
                 // (it would need NS x (rows+cols) extra registers and spill)
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + q < t1) {
-                    const double u = uc[q];
-                    if constexpr (TK::zeroth) acc0 += u;
-                    const double *xl = xb + q * 64 + lane;
-                    double dr[TK::NR], dc[TK::NC];
+#endif
+                const double u = uc[q];                   // zero for tiles beyond the chunk
+                if constexpr (TK::zeroth) acc0 += u;
+                const double *xl = xb + q * 64 + lane;
+                double dr[TK::NR], dc[TK::NC];
 #pragma unroll
-                    for (int i = 0; i < TK::NR; ++i) dr[i] = xl[(TK::r0 + i) * LDP] - pk[TK::r0 + i];
-                    if constexpr (TK::diag) {
+#ifdef PMC_EXP_NOLDSREAD
+                for (int i = 0; i < TK::NR; ++i) dr[i] = (u + (double)i) - pk[TK::r0 + i];
+#else
+                for (int i = 0; i < TK::NR; ++i) dr[i] = xl[(TK::r0 + i) * LDP] - pk[TK::r0 + i];
+#endif
+                if constexpr (TK::diag) {
 #pragma unroll
-                        for (int j = 0; j < TK::NC; ++j) dc[j] = dr[j];
-                    } else {
+                    for (int j = 0; j < TK::NC; ++j) dc[j] = dr[j];
+                } else {
 #pragma unroll
-                        for (int j = 0; j < TK::NC; ++j) dc[j] = xl[(TK::c0 + j) * LDP] - pk[TK::c0 + j];
-                    }
+#ifdef PMC_EXP_NOLDSREAD
+                    for (int j = 0; j < TK::NC; ++j) dc[j] = (u - (double)j) - pk[TK::c0 + j];
+#else
+                    for (int j = 0; j < TK::NC; ++j) dc[j] = xl[(TK::c0 + j) * LDP] - pk[TK::c0 + j];
+#endif
+                }
 #pragma unroll
-                    for (int i = 0; i < TK::NR; ++i) {
-                        const double ud = u * dr[i];
-                        if constexpr (TK::first_moments) acc1[i] += ud;
+                for (int i = 0; i < TK::NR; ++i) {
+                    const double ud = u * dr[i];
+                    if constexpr (TK::first_moments) acc1[i] += ud;
 #pragma unroll
-                        for (int j = 0; j < TK::NC; ++j)
-                            if (!TK::diag || j <= i) acc2[i][j] = fma(ud, dc[j], acc2[i][j]);
-                    }
+                    for (int j = 0; j < TK::NC; ++j)
+                        if (!TK::diag || j <= i) acc2[i][j] = fma(ud, dc[j], acc2[i][j]);
                 }
             }
         }
-        if (more) stage(xs + (buf ^ 1) * (D * LDP));
-        __syncthreads();
+        stage(xs + (buf ^ 1) * (D * LDP));
+        lds_barrier();
     }
 
     if constexpr (ACTIVE) {

@@ -624,7 +624,37 @@ def case_student_t_pmc_golden(be):
         assert pmc.log_likelihood() >= l0
 
 
-ALL_CASES = [case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
+def case_example_pmc(be):
+    """BASELINE config 1: the reference's examples/pmc.py (:15-73), seeded, step by step."""
+    from pypmc_amd.density.gauss import Gauss
+    from pypmc_amd.density.mixture import MixtureDensity, create_gaussian_mixture
+    from pypmc_amd.sampler.importance_sampling import ImportanceSampler
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+    g = load_golden("example_pmc")
+    target = create_gaussian_mixture(g["target_means"], g["target_covs"], g["target_weights"])
+    target._backend = be
+    initial = MixtureDensity([Gauss(m, np.eye(2)) for m in g["prop_means"]], backend=be)
+    np.random.seed(int(g["seed"]))
+    sampler = ImportanceSampler(target.evaluate, initial, backend=be)
+    for i in range(int(g["steps"])):
+        origin = sampler.run(int(g["n_per_step"]), trace_sort=True)
+        np.testing.assert_array_equal(origin, g["origin_%d" % i], err_msg="origin step %d" % i)   # bit-exact
+        samples, weights = sampler.samples[-1], sampler.weights[-1][:, 0]
+        if i == 0:
+            np.testing.assert_allclose(samples, g["samples_0"], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(weights, g["weights_%d" % i], rtol=1e-7, atol=1e-300, err_msg="weights %d" % i)
+        gaussian_pmc(samples, sampler.proposal, weights, origin, mincount=20, rb=True, copy=False, backend=be)
+        np.testing.assert_allclose(sampler.proposal.weights, g["prop_weights_%d" % i], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose([c.mu for c in sampler.proposal.components], g["prop_mu_%d" % i],
+                                   rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose([c.sigma for c in sampler.proposal.components], g["prop_sigma_%d" % i],
+                                   rtol=1e-6, atol=1e-10)
+    # the adapted proposal has found both modes
+    w = sampler.proposal.weights
+    assert abs(w[0] - 0.3) < 0.05 and abs(w[1] - 0.7) < 0.05 and w[2] < 0.05
+
+
+ALL_CASES = [case_example_pmc, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,
              case_pmc_errors_and_fallback, case_student_t_pmc_golden]

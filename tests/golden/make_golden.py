@@ -344,6 +344,33 @@ def main():
     save("propose_trace", weights=np.array(mix.weights), mu=mu, sigma=cov, N=1000, seed=123,
          origin=origin, counts=counts, sample_mean=samples.mean(axis=0))
 
+    # ------------------------------------------------------------------ examples/pmc.py (BASELINE config 1)
+    # the reference's own example, seeded: bimodal 2-D Gaussian target, 3-component proposal,
+    # 10 x 1000 samples with a gaussian_pmc(mincount=20, rb=True) update after every run
+    tw = np.array([0.3, 0.7])
+    tmeans = [np.array([5.0, 0.01]), np.array([-4.0, 1.0])]
+    tcovs = [np.array([[0.01, 0.003], [0.003, 0.0025]]), np.array([[0.1, 0.], [0., 0.02]])]
+    target_mixture = create_gaussian_mixture(tmeans, tcovs, tw)
+    pmeans = [np.array([4.0, 0.0]), np.array([-5.0, 0.0]), np.array([0.0, 0.0])]
+    initial = MixtureDensity([Gauss(m, np.eye(2)) for m in pmeans])
+    np.random.seed(42)
+    sampler = ImportanceSampler(target_mixture.evaluate, initial)
+    out = dict(target_weights=tw, target_means=np.array(tmeans), target_covs=np.array(tcovs),
+               prop_means=np.array(pmeans), seed=42, steps=10, n_per_step=1000)
+    for i in range(10):
+        origin = sampler.run(10 ** 3, trace_sort=True)
+        samples = sampler.samples[-1]
+        weights = sampler.weights[-1][:, 0]
+        gaussian_pmc(samples, sampler.proposal, weights, origin, mincount=20, rb=True, copy=False)
+        out["origin_%d" % i] = origin
+        out["weights_%d" % i] = weights.copy()
+        if i == 0:
+            out["samples_0"] = samples.copy()
+        out["prop_weights_%d" % i] = np.array(sampler.proposal.weights)
+        out["prop_mu_%d" % i] = np.array([c.mu for c in sampler.proposal.components])
+        out["prop_sigma_%d" % i] = np.array([c.sigma for c in sampler.proposal.components])
+    save("example_pmc", **out)
+
     print("reference version", pypmc.__version__)
 
 
