@@ -79,6 +79,20 @@ def flops_stats(K, D):        # K (1 + 2D + D(D+1))
     return K * (1 + 2 * D + D * (D + 1))
 
 
+def measured_traffic(kernel, N):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 FETCH_SIZE x 2 +
+    WRITE_SIZE, separate passes; profiles/r*_traffic_n1.json), scaled to N samples.  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_n1.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1]))
+        return rec["kernels"][kernel]["hbm_bytes_per_launch"] * (N / float(rec["N"]))
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
     """Oracle on the host: same step on a bounded sample, single thread (the reference is single
     threaded) and -- as an extra -- OpenMP over all cores."""
@@ -251,9 +265,11 @@ def main():
             "kernel_ms": kern,
             "perplexity": perp,
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                         "traffic": measured_traffic(dominant, N),
                          "note": "fp64 VALU (v_fma_f64) kernel priced against the fp64 matrix peak, which equals "
                                  "the fp64 vector peak on MI355X; flops = SURVEY 8(d) per-sample figure x N",
+                         "algorithmic_bytes": alg_bytes[dominant],
                          "per_kernel_tflops": {k_: flops[k_] / (v * 1e-3) * 1e-12 for k_, v in kern.items()},
                          "hbm": {"achieved": alg_bytes[dominant] / (kern[dominant] * 1e-3) * 1e-9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
