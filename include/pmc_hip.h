@@ -153,6 +153,22 @@ int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_wor
 int pmc_logsumexp2d(const double *d_a, const double *d_w, int64_t N, int K, double *d_out,
                     void *stream);
 
+/* ---- proposing ------------------------------------------------------------------------------- */
+/*
+ * Device side of MixtureDensity.propose(N, rng, trace=True, shuffle=False)
+ * (pypmc/density/mixture.pyx:159-212; Gauss.propose gauss.pyx:159-163; StudentT.propose
+ * student_t.pyx:172-176).  The component counts come from the caller's generator on the host
+ * (rng.multinomial, mixture.pyx:192 -- counts and origin indices stay bit-exact); d_offsets holds
+ * their K+1 exclusive prefix sums.  Sample n (ordered by component) becomes
+ * mu_k + L_k z [* sqrt(nu_k / chi2)], L_k = lower Cholesky factor of sigma_k (row-major D x D),
+ * with Philox4x32-10 random numbers keyed by `seed` and counted by the GLOBAL sample index
+ * first_sample + n, so shards of one logical run on several GPUs draw disjoint streams.
+ * d_dof == NULL: Gaussian components.  d_origin (N int64, may be NULL) receives k per sample.
+ */
+int pmc_propose(const double *d_mu, const double *d_chol, const double *d_dof, const int64_t *d_offsets,
+                int K, int D, int64_t N, int64_t first_sample, uint64_t seed, double *d_x,
+                int64_t *d_origin, void *stream);
+
 /* ---- responsibilities ------------------------------------------------------------------------ */
 /*
  * The N x K responsibility matrix of the VB E-step (variational.pyx:774-798 exponent,

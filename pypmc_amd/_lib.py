@@ -43,6 +43,7 @@ SIGNATURES = {
     "pmc_mixture_logpdf": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _vp, _vp, _vp]),
     "pmc_weight_sums": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "pmc_propose": (_int, [_vp, _vp, _vp, _vp, _int, _int, _i64, _i64, C.c_uint64, _vp, _vp, _vp]),
     "pmc_logsumexp2d": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "pmc_responsibilities": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),

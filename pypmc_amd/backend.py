@@ -192,6 +192,28 @@ class HipBackend(object):
                                             self._stream()), "pmc_weight_sums")
         return scalars
 
+    def propose(self, mu, chol, dof, counts, seed, first_sample=0, want_origin=True):
+        """pmc_propose: samples of a Gauss / Student-t mixture for host-drawn component ``counts``.
+        mu K x D, chol K x D x D (lower Cholesky factors of the covariances), dof K or None.
+        Returns (x N x D, origin N int64 or None) as device tensors, ordered by component."""
+        torch = self.torch
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        K, D = mu.shape
+        counts = np.asarray(counts, dtype=np.int64).reshape(K)
+        offsets = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+        N = int(offsets[-1])
+        d_mu = self.asdevice(mu)
+        d_chol = self.asdevice(np.ascontiguousarray(chol, dtype=np.float64).reshape(K, D, D))
+        d_dof = self.asdevice(np.ascontiguousarray(dof, dtype=np.float64).reshape(K)) if dof is not None else None
+        d_off = self.asdevice(offsets, torch.int64)
+        x = self.empty((N, D))
+        origin = self.empty(N, torch.int64) if want_origin else None
+        _lib.check(self._timed(
+            "pmc_propose", self.lib.pmc_propose, self._p(d_mu), self._p(d_chol), self._p(d_dof),
+            self._p(d_off), K, D, N, int(first_sample), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+            self._p(x), self._p(origin), self._stream()), "pmc_propose")
+        return x, origin
+
     def logsumexp2d(self, a, w):
         """row-wise log sum_k w_k exp(a_nk) of an N x K matrix (device tensor result)."""
         a = self.asdevice(a)

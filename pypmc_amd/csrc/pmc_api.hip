@@ -18,7 +18,8 @@
     extern "C" hipError_t pmc_launch_logpdf_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t);   \
     extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t);       \
-    extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);
+    extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);                                        \
+    extern "C" hipError_t pmc_launch_propose_d##d##_p##p(const PmcArgsP &, unsigned, hipStream_t);
 #define PMC_DECL_X(d) PMC_DECL_UNIT(d, 0)
 #define PMC_DECL_XP(d) PMC_DECL_UNIT(d, 0) PMC_DECL_UNIT(d, 1)
 PMC_DIM_LIST(PMC_DECL_X, PMC_DECL_XP)
@@ -27,7 +28,7 @@ namespace {
 
 #define PMC_SET(d, p) \
     {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, \
-     &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p}
+     &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p}
 struct DimEntry {
     int dim;
     bool has_padded;
@@ -370,6 +371,25 @@ int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_wor
         if (e != hipSuccess) return hipfail(e, "k_weight_sums launch");
     }
     return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+}
+
+int pmc_propose(const double *d_mu, const double *d_chol, const double *d_dof, const int64_t *d_offsets,
+                int K, int D, int64_t N, int64_t first_sample, uint64_t seed, double *d_x,
+                int64_t *d_origin, void *stream)
+{
+    if (N < 0 || K < 1 || !d_mu || !d_chol || !d_offsets || (N > 0 && !d_x))
+        return fail(PMC_EINVAL, "pmc_propose: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (N == 0) return PMC_OK;
+    PmcArgsP a;
+    std::memset(&a, 0, sizeof(a));
+    a.mu = d_mu; a.chol = d_chol; a.dof = d_dof; a.offsets = (const long long *)d_offsets;
+    a.K = K; a.dreal = D; a.N = N; a.first_sample = first_sample; a.seed = seed;
+    a.x = d_x; a.origin = (long long *)d_origin;
+    hipError_t e = ks->propose(a, (unsigned)ceil_div(N, 256), (hipStream_t)stream);
+    if (e != hipSuccess) return hipfail(e, "k_propose launch");
+    return PMC_OK;
 }
 
 int pmc_logsumexp2d(const double *d_a, const double *d_w, int64_t N, int K, double *d_out, void *stream)

@@ -49,6 +49,19 @@ struct PmcArgsB {
     int ngroups;
 };
 
+// propose kernel
+struct PmcArgsP {
+    const double *mu;             // K x dreal
+    const double *chol;           // K x dreal x dreal, lower triangular
+    const double *dof;            // K or NULL
+    const long long *offsets;     // K + 1 exclusive prefix sums of the component counts
+    int K, dreal;
+    long long N, first_sample;
+    unsigned long long seed;
+    double *x;
+    long long *origin;
+};
+
 struct PmcKernelSet {
     int dim;              // compiled dimension
     int padded;           // 1: accepts dreal <= dim
@@ -58,4 +71,5 @@ struct PmcKernelSet {
     hipError_t (*resp)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
     hipError_t (*stats)(const PmcArgsB &, unsigned grid, hipStream_t);
     void (*config)(int *nsub, int *waves);
+    hipError_t (*propose)(const PmcArgsP &, unsigned grid, hipStream_t);
 };

@@ -1,0 +1,151 @@
+// pmc_propose.hip -- device side of MixtureDensity.propose (pypmc/density/mixture.pyx:159-212 with
+// Gauss.propose gauss.pyx:50-52,159-163 and LocalStudentT.propose student_t.pyx:49-55), compiled once
+// per sample dimension.
+//
+// The component counts are drawn on the HOST with the caller's generator (rng.multinomial -- they
+// and the derived origin indices stay bit-exact with the reference); the device fills the samples:
+// one lane = one sample n, its component k found from the exclusive prefix offsets of the counts,
+//     x_n = mu_k + L_k z            z ~ N(0,1)^D          (Gauss)
+//     x_n = mu_k + L_k z sqrt(nu_k / c),  c ~ chi^2(nu_k)  (Student-t)
+// Random numbers: Philox4x32-10, counter = (sample index, draw index), key = seed -- stateless, so
+// the stream of a sample does not depend on the launch geometry or on how samples are sharded over
+// GPUs (every rank passes its global sample offset).  Normals by Box-Muller from 53-bit uniforms;
+// chi-square(nu) = 2 Gamma(nu/2) by Marsaglia-Tsang rejection.  Sample values are statistically
+// (not bitwise) equivalent to numpy's MT19937 stream, as SURVEY section 7 ("RNG parity") states.
+#include "pmc_device.h"
+
+namespace {
+
+struct Philox {
+    unsigned k0, k1;
+    __device__ __forceinline__ static void round(unsigned (&c)[4], unsigned k0, unsigned k1)
+    {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    }
+    // 128 random bits for counter (n, draw)
+    __device__ __forceinline__ void operator()(unsigned long long n, unsigned draw, unsigned (&out)[4]) const
+    {
+        unsigned c[4] = {(unsigned)n, (unsigned)(n >> 32), draw, 0x9E3779B9u};
+        unsigned a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            round(c, a, b);
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = c[i];
+    }
+};
+
+// two uniforms: u1 in (0,1], u2 in [0,1), 53 bits each
+__device__ __forceinline__ void uniforms(const unsigned (&r)[4], double &u1, double &u2)
+{
+    const unsigned long long a = ((unsigned long long)r[0] << 32 | r[1]) >> 11;
+    const unsigned long long b = ((unsigned long long)r[2] << 32 | r[3]) >> 11;
+    u1 = ((double)a + 1.0) * (1.0 / 9007199254740992.0);
+    u2 = (double)b * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ void normal_pair(const Philox &g, unsigned long long n, unsigned draw, double &z0,
+                                            double &z1)
+{
+    unsigned r[4];
+    g(n, draw, r);
+    double u1, u2;
+    uniforms(r, u1, u2);
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(6.283185307179586476925286766559 * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+// chi^2(nu) = 2 * Gamma(nu/2): Marsaglia & Tsang (2000); draws start at index `draw0`
+__device__ __forceinline__ double chi_square(const Philox &g, unsigned long long n, unsigned draw0, double nu)
+{
+    double a = 0.5 * nu, boost = 1.0;
+    unsigned draw = draw0;
+    if (a < 1.0) {                                        // Gamma(a) = Gamma(a+1) U^(1/a)
+        unsigned r[4];
+        g(n, draw++, r);
+        double u1, u2;
+        uniforms(r, u1, u2);
+        boost = pow(u1, 1.0 / a);
+        a += 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double result = d;                                    // fallback after 64 rejections (p < 1e-60)
+    for (int it = 0; it < 64; ++it) {
+        double z, zz;
+        normal_pair(g, n, draw++, z, zz);
+        unsigned r[4];
+        g(n, draw++, r);
+        double u1, u2;
+        uniforms(r, u1, u2);
+        const double t = 1.0 + c * z;
+        if (t <= 0.0) continue;
+        const double v = t * t * t;
+        if (log(u1) < 0.5 * z * z + d - d * v + d * log(v)) {
+            result = d * v;
+            break;
+        }
+    }
+    return 2.0 * result * boost;
+}
+
+template <int D, bool PADDED>
+__global__ __launch_bounds__(256) void k_propose(const PmcArgsP a)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.N) return;
+    const int dreal = PADDED ? a.dreal : D;
+    // component of sample n: offsets[k] <= n < offsets[k+1]  (binary search, K+1 entries)
+    int lo = 0, hi = a.K;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.offsets[mid] <= n) lo = mid; else hi = mid;
+    }
+    const int k = lo;
+    const Philox g = {(unsigned)a.seed, (unsigned)(a.seed >> 32)};
+    const unsigned long long gn = (unsigned long long)(a.first_sample + n);   // global sample index
+
+    double z[D];
+#pragma unroll
+    for (int j = 0; j < D; j += 2) {
+        double z0, z1;
+        normal_pair(g, gn, (unsigned)(j >> 1), z0, z1);
+        z[j] = z0;
+        if (j + 1 < D) z[j + 1] = z1;
+    }
+    double scale = 1.0;
+    if (a.dof != nullptr) {
+        const double nu = a.dof[k];
+        scale = sqrt(nu / chi_square(g, gn, 0x10000u, nu));      // student_t.pyx:55
+    }
+    const double *__restrict__ L = a.chol + (size_t)k * dreal * dreal;   // lower triangular, row-major
+    const double *__restrict__ mu = a.mu + (size_t)k * dreal;
+    double *__restrict__ out = a.x + n * (long long)dreal;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        if (PADDED && i >= dreal) break;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) acc = fma(L[i * dreal + j], z[j], acc);
+        out[i] = mu[i] + acc * scale;
+    }
+    if (a.origin != nullptr) a.origin[n] = k;
+}
+
+}  // namespace
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_propose_d, PMC_D, PMC_PADDED)(const PmcArgsP &a, unsigned grid,
+                                                                              hipStream_t st)
+{
+    hipLaunchKernelGGL((k_propose<D_, P_>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

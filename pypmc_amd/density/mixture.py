@@ -129,14 +129,21 @@ class MixtureDensity(ProbabilityDensity):
         return out
 
     # -- sampling -------------------------------------------------------------------------------
-    def propose(self, N=1, rng=np.random.mtrand, trace=False, shuffle=True):
+    def propose(self, N=1, rng=np.random.mtrand, trace=False, shuffle=True, device=False):
         """N samples.  Component counts come from ``rng.multinomial(N, weights)``; with
         ``trace`` the generating component of every sample is returned too (samples then stay
         ordered by component).  Reference: mixture.pyx:159-212 -- including its quirk that the
-        components draw from their default generator, not from ``rng``."""
+        components draw from their default generator, not from ``rng``.
+
+        ``device=True`` (extension): the counts are still drawn on the host with ``rng`` (so counts
+        and origins are bit-exact for a given generator state), the samples are generated on the
+        GPU (pmc_propose, Philox stream seeded from ``rng``) and returned as device tensors --
+        nothing N-sized crosses PCIe."""
         if trace and shuffle:
             raise ValueError('Either ``shuffle`` or ``trace`` must be ``False``!')
         counts = rng.multinomial(N, self.weights)
+        if device:
+            return self._propose_device(counts, rng, trace, shuffle)
         samples = np.empty((N, self.dim))
         start = 0
         for comp, n in zip(self.components, counts):
@@ -148,6 +155,25 @@ class MixtureDensity(ProbabilityDensity):
         if shuffle:
             rng.shuffle(samples)
         return samples
+
+    def _propose_device(self, counts, rng, trace, shuffle, first_sample=0):
+        comps = self.components
+        first = type(comps[0])
+        if first not in (Gauss, StudentT) or any(type(c) is not first for c in comps):
+            raise TypeError('device-side propose needs only Gauss or only StudentT components')
+        be = get_backend(self._backend)
+        seed = int(rng.randint(0, 2 ** 31 - 1)) | (int(rng.randint(0, 2 ** 31 - 1)) << 32)
+        x, origin = be.propose(np.array([c.mu for c in comps]),
+                               np.array([c.cholesky_sigma for c in comps]),
+                               np.array([c.dof for c in comps]) if first is StudentT else None,
+                               counts, seed, first_sample=first_sample, want_origin=trace)
+        if trace:
+            return x, origin
+        if shuffle:
+            import torch
+            g = torch.Generator(device=x.device).manual_seed(seed & (2 ** 63 - 1))
+            x = x[torch.randperm(len(x), device=x.device, generator=g)].contiguous()
+        return x
 
 
 def create_gaussian_mixture(means, covs, weights=None):

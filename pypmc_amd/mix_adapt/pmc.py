@@ -36,12 +36,14 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
     if copy:
         density = deepcopy(density)
     N_local = len(samples)
+    on_device = lambda a: a is not None and not isinstance(a, (np.ndarray, list, tuple)) and hasattr(a, 'device')
     if weights is not None:
-        weights = np.asarray(weights)
+        if not on_device(weights):                  # device tensors (device-resident loops) pass through
+            weights = np.asarray(weights)
         assert len(weights.shape) == 1, 'Weights must be one-dimensional.'
         assert len(weights) == N_local, \
             "Number of weights (%s) does not match the number of samples (%s)." % (len(weights), N_local)
-        local_norm = weights.sum()
+        local_norm = float(weights.sum())
     else:
         local_norm = float(N_local)
     K = len(density)
@@ -52,6 +54,9 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
         if not rb:
             raise ValueError('`rb` must be True if `latent` is not provided!')
         count = None
+    elif on_device(latent):
+        import torch
+        count = torch.bincount(latent, minlength=K)[:K].cpu().numpy().astype(np.float64)
     else:
         latent = np.asarray(latent)
         count = np.histogram(latent, bins=K, range=(0, K))[0].astype(np.float64)

@@ -83,6 +83,31 @@ class ImportanceSampler(object):
         this_samples = self._get_samples(N, trace_sort=False)
         self._calculate_weights(this_samples, N)
 
+    def run_device(self, N, trace_sort=False, target_density=None):
+        """Extension for device-resident loops (BASELINE config 5): propose N samples ON THE GPU,
+        weight them there and return ``dict(samples, weights, origin, weight_sums)`` of device
+        tensors; nothing N-sized crosses PCIe and the History objects are not touched.
+        The target must be a density with GPU log-pdf (``target_density``, default: the object
+        whose ``evaluate`` was given as ``target``)."""
+        from ..density.mixture import MixtureDensity, component_set
+        be = get_backend(self._backend)
+        tgt = target_density if target_density is not None else getattr(self._batch_target, '__self__', None)
+        if not isinstance(tgt, MixtureDensity):
+            raise TypeError('run_device needs a MixtureDensity target (target_density=...)')
+        origin = None
+        if trace_sort:
+            x, origin = self.proposal.propose(N, self.rng, trace=True, shuffle=False, device=True)
+        else:
+            x = self.proposal.propose(N, self.rng, device=True)
+        log_target = be.logpdf(x, component_set(tgt.components, tgt.weights))["out"]
+        res = be.logpdf(x, component_set(self.proposal.components, self.proposal.weights), want_out=False,
+                        log_target=log_target, want_scalars=True)
+        sc = be.tohost(res["scalars"])
+        if sc[4] > 0:
+            raise OverflowError('math range error')
+        self.last_weight_sums = (float(sc[0]), float(sc[1]), float(sc[2]))
+        return dict(samples=x, weights=res["weights"], origin=origin, weight_sums=self.last_weight_sums)
+
     def _get_samples(self, N, trace_sort):
         this_run = self.samples.append(N)
         if trace_sort:
