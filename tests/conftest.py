@@ -23,3 +23,14 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """libpmc_hip.so is a build artefact (git-ignored): build it if this checkout has none yet
+    (hipcc cross-compiles for gfx950 without a GPU; objects are cached under pypmc_amd/csrc/build)."""
+    from pypmc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from pypmc_amd import build
+        build.build()
+    yield
