@@ -197,9 +197,11 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
             for (int q = 0; q < NS; ++q) {
                 dma(t + NS, xs + (buf ^ 1) * BUFD, q, NS);
                 dma_u(t + NS, us + (buf ^ 1) * (NS * UTILE), q, NS);
+#ifndef PMC_STATS_NOSCHEDBARRIER
                 // keep the scheduler from overlapping the LDS reads of all NS sub-steps at once
                 // (it would need NS x (rows+cols) extra registers and spill)
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 const double uraw = ub[q * UTILE];
                 const double u = (t + q < t1) ? uraw : 0.0;    // zero weight beyond the chunk
                 if constexpr (TK::zeroth) acc0 += u;

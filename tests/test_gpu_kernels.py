@@ -325,3 +325,47 @@ def test_edge_cases(be, orc):
     from pypmc_amd.backend import HipLibraryError
     with pytest.raises(HipLibraryError):
         be.logpdf(np.zeros((2, 65)), ComponentSet(0, np.zeros((1, 65)), np.eye(65)[None]))
+
+
+@pytest.mark.parametrize("cond", [1e4, 1e8, 1e10])
+def test_ill_conditioned_covariances(be, orc, cond):
+    """Whitened Mahalanobis form vs the reference's symmetric form when cond(Sigma) is large and the
+    components are far apart relative to their widths (the case a raw-moment / global-shift
+    formulation would lose digits on)."""
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    from pypmc_amd.tools._linalg import chol_inv_det
+    rs = np.random.RandomState(int(np.log10(cond)))
+    K, D, N = 3, 6, 3000
+    mu = rs.normal(0, 1e3, size=(K, D))                       # separation >> width
+    cov, inv, ln = np.empty((K, D, D)), np.empty((K, D, D)), np.empty(K)
+    for k in range(K):
+        Q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+        cov[k] = (Q * np.logspace(0, -np.log10(cond), D)).dot(Q.T)
+        cov[k] = 0.5 * (cov[k] + cov[k].T)
+        _, inv[k], logdet = chol_inv_det(cov[k])                # the reference's own inverse
+        ln[k] = -0.5 * D * np.log(2 * np.pi) - 0.5 * logdet
+    w = np.array([0.2, 0.5, 0.3])
+    x, comp = draw(mu, cov, w, N, 3)
+    cs = ComponentSet(0, mu, inv, c0=ln, weight=w)
+    ref_out, ref_ind = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    res = be.logpdf(x, cs, want_out=True, want_individual=True)
+    own = ref_ind[np.arange(N), comp]                           # each sample under its own component
+    got = be.tohost(res["individual"])[np.arange(N), comp]
+    # both forms carry the conditioning of inv_sigma itself: agree to ~cond * eps, relative
+    tol = max(1e-10, 50 * cond * 2.2e-16)
+    # (log densities cross zero here: relative to max(|value|, 1))
+    assert np.max(np.abs(got - own) / np.maximum(np.abs(own), 1.0)) < tol
+    assert np.max(np.abs(be.tohost(res["out"]) - ref_out) / np.maximum(np.abs(ref_out), 1.0)) < tol
+    # Rao-Blackwell statistics with per-component shift: means to ~1e-12 of the separation scale,
+    # covariances relative to their own (tiny) scale
+    e = be.estep(x, cs, 1)
+    _, S0, M1, M2, _, _ = split_stats(be.tohost(e["stats"]), K, D)
+    mean, sigma = centred_moments(S0, M1, M2, mu)
+    rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, [0, 1, 2])
+    _, mu_ref, cov_ref = orc.pmc_reductions(x, rho, None, None, [0, 1, 2])
+    np.testing.assert_allclose(mean, mu_ref, rtol=1e-13, atol=1e-10)
+    scale = np.abs(cov_ref).max(axis=(1, 2), keepdims=True)
+    # the oracle (like the reference) subtracts a mean of magnitude 1e3 from data of width <= 1:
+    # its own rounding is ~1e3 * eps / width; ours is bounded by the same quantity
+    assert np.max(np.abs(sigma - cov_ref) / scale) < 1e-9
