@@ -11,8 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (HipLibraryError, NotPositiveDefinite, PMC_KIND_GAUSS, PMC_KIND_STUDENT_T,
-                   PMC_KIND_VB, PMC_RESP_VB, PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT, NSCALARS)
+from ._lib import HipLibraryError, NotPositiveDefinite, PMC_KIND_STUDENT_T, NSCALARS  # noqa: F401
 
 __all__ = ["ComponentSet", "HipBackend", "get_backend", "set_default_backend", "HipLibraryError",
            "NotPositiveDefinite"]

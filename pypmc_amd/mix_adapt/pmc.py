@@ -22,7 +22,7 @@ from ..backend import get_backend
 from ..density.gauss import Gauss
 from ..density.student_t import StudentT
 from ..density.mixture import MixtureDensity, component_set
-from ._stats import regularize, split_stats, centred_moments
+from ._stats import split_stats, centred_moments
 
 logger = logging.getLogger(__name__)
 

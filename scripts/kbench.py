@@ -85,7 +85,6 @@ def main():
     res["vb_estep"] = dict(ms=t, ms_median=tm, samples_per_s=N / t * 1e3, tflops=N * fl_vb / t * 1e-9)
     # split: responsibilities alone
     lib = be.lib
-    import ctypes as C
     u = be._tilebuf("u", N, K)
     ws = be._workspace(N, K, D)
     P = be._p

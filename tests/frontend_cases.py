@@ -1,8 +1,6 @@
 """Front-end test cases, written against the reference's own tests and the
 golden vectors.  Every case takes the backend to use: the CPU suite runs them on the oracle-backed
 checker (host logic only), the GPU suite on the HIP backend (the product path)."""
-import re
-
 import numpy as np
 import pytest
 

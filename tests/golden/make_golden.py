@@ -85,7 +85,7 @@ def main():
     import logging
     logging.disable(logging.CRITICAL)
     import pypmc
-    from pypmc.tools._linalg import bilinear_sym, chol_inv_det
+    from pypmc.tools._linalg import bilinear_sym
     from pypmc.tools._regularize import logsumexp, logsumexp2D
     from pypmc.tools.convergence import perp, ess
     from pypmc.density.gauss import Gauss

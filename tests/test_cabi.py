@@ -78,7 +78,7 @@ def test_no_silent_cpu_fallback():
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
-    from pypmc_amd.backend import HipBackend, HipLibraryError, get_backend
+    from pypmc_amd.backend import HipBackend, HipLibraryError
     with pytest.raises(HipLibraryError, match="no CPU fallback"):
         HipBackend()
     from pypmc_amd.density.gauss import Gauss

@@ -133,7 +133,6 @@ def _gauss_lognorm(log_det, D):
 
 @pytest.mark.parametrize("tag", ["d2k3", "d5k4"])
 def test_gaussian_pmc_reductions(tag):
-    from scipy.linalg import cholesky
     g = load_golden("pmc_gauss_" + tag)
     x = g["samples"]
     N, D = x.shape
