@@ -460,8 +460,7 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
     if (N < 0 || K < 1 || !d_pack || !d_u || !d_stats || !d_workspace)
         return fail(PMC_EINVAL, "pmc_sufficient_stats: bad argument");
     if (N > 0 && !d_x) return fail(PMC_EINVAL, "pmc_sufficient_stats: d_x is NULL");
-    if (((uintptr_t)d_x & 15u) != 0)
-        return fail(PMC_EINVAL, "pmc_sufficient_stats: d_x must be 16-byte aligned (16-byte vector loads)");
+    if (((uintptr_t)d_x & 7u) != 0) return fail(PMC_EINVAL, "pmc_sufficient_stats: d_x must be 8-byte aligned");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
     hipStream_t st = (hipStream_t)stream;

@@ -66,7 +66,15 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
 
     be = get_backend(backend)
     D = density.dim
-    if live_components:
+    if live_components and not rb and count is not None and int(count.sum()) == N_local \
+            and _is_sorted(latent):
+        # non-Rao-Blackwell update of samples that arrive ordered by generating component (what
+        # propose(trace=True) / run(trace_sort=True) deliver): component k only sees its own
+        # contiguous block of samples, so the cost is N x D^2 instead of N x K x D^2 -- the
+        # "faster" variant of pmc.pyx:153 is actually faster here too
+        flat = _latent_blocks_estep(be, samples, weights, latent, density, live_components, count, K, D)
+        nlive = len(live_components)
+    elif live_components:
         cs = component_set(density.components, density.weights, live_components, K)
         if cs is None:
             raise TypeError('``density`` must have only Gauss or only StudentT components')
@@ -102,6 +110,39 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
                 logger.warning("Component %i died because of too few (%i) samples." % (k, count[k]))
 
     return density, live_components, stat_components, stats, weight_normalization, need_renormalize
+
+
+def _is_sorted(a):
+    """non-decreasing?  (numpy array or device tensor)"""
+    if len(a) < 2:
+        return True
+    return bool((a[1:] >= a[:-1]).all())
+
+
+def _latent_blocks_estep(be, samples, weights, latent, density, live_components, count, K, D):
+    """Statistics of the latent (one-hot) responsibilities when the samples are ordered by
+    component: one single-component pass per live component over its own block.  Returns the same
+    flat layout as ``backend.estep`` for the live components."""
+    from .._lib import NSCALARS
+    x = be.asdevice(samples)
+    lat = be.asdevice(latent, getattr(getattr(be, 'torch', None), 'int64', None))
+    w = be.asdevice(weights) if weights is not None else None
+    nlive = len(live_components)
+    ps = 1 + D + D * (D + 1) // 2
+    flat = be.zeros(be.stats_len(nlive, D))
+    offsets = np.concatenate(([0], np.cumsum(count))).astype(np.int64)
+    for i, k in enumerate(live_components):
+        a, b = int(offsets[k]), int(offsets[k + 1])
+        if a == b:
+            continue
+        cs = component_set(density.components, density.weights, [k], K)
+        if cs is None:
+            raise TypeError('``density`` must have only Gauss or only StudentT components')
+        one = be.estep(x[a:b], cs, PMC_RESP_PMC_LATENT, sample_w=None if w is None else w[a:b],
+                       latent=lat[a:b])["stats"]
+        flat[NSCALARS + i * ps:NSCALARS + (i + 1) * ps] = one[NSCALARS:NSCALARS + ps]
+        flat[NSCALARS + nlive * ps + 2 * i:NSCALARS + nlive * ps + 2 * i + 2] = one[NSCALARS + ps:NSCALARS + ps + 2]
+    return flat
 
 
 def _apply_updates(density, live_components, new_params, need_renormalize):
