@@ -100,6 +100,11 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     constexpr int BUFD = NS * 64 * ROWD;                  // doubles per LDS buffer
     constexpr int NDMA = NS * PITCH;                      // DMA instructions per step (64 slots each)
     constexpr int DMA_PER_WAVE = (NDMA + WAVES - 1) / WAVES;
+#ifdef PMC_STATS_DMA_SLICES
+    constexpr int DMA_SLICES = PMC_STATS_DMA_SLICES < NS ? PMC_STATS_DMA_SLICES : NS;
+#else
+    constexpr int DMA_SLICES = NS >= 4 ? NS / 2 : 1;
+#endif
     constexpr bool ACTIVE = SUB >= 0;
     using TK = Task<D, ACTIVE ? SUB : 0>;
     const int lane = threadIdx.x & 63;
@@ -195,15 +200,20 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
         if constexpr (ACTIVE) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                dma(t + NS, xs + (buf ^ 1) * BUFD, q, NS);
-                dma_u(t + NS, us + (buf ^ 1) * (NS * UTILE), q, NS);
-#ifndef PMC_STATS_NOSCHEDBARRIER
-                // keep the scheduler from overlapping the LDS reads of all NS sub-steps at once
-                // (it would need NS x (rows+cols) extra registers and spill)
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                // issue the next step's DMA in the first DMA_SLICES sub-steps only: the barrier at the
+                // end of the step waits for it (vmcnt(0)), so the last slice needs time to land
+                if (q < DMA_SLICES) {
+                    dma(t + NS, xs + (buf ^ 1) * BUFD, q, DMA_SLICES);
+                    dma_u(t + NS, us + (buf ^ 1) * (NS * UTILE), q, DMA_SLICES);
+                }
+
                 const double uraw = ub[q * UTILE];
-                const double u = (t + q < t1) ? uraw : 0.0;    // zero weight beyond the chunk
+                double u = (t + q < t1) ? uraw : 0.0;          // zero weight beyond the chunk
+                // Fence: the arithmetic of this sub-step depends on `u` and so stays behind this
+                // statement, and no LDS read of a LATER sub-step may move above it ("memory").
+                // Without it all NS sub-steps' reads are issued up front (NS x (rows+cols) live
+                // registers: spills and shuffling moves); with it at most two sub-steps overlap.
+                asm volatile("" : "+v"(u) : : "memory");
                 if constexpr (TK::zeroth) acc0 += u;
                 const pmc_vec2 *xl = (const pmc_vec2 *)(xb + (size_t)(q * 64 + lane) * ROWD);
                 // odd D: the pair holding coordinate D-1 of the array's LAST sample was fetched one
