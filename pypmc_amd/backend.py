@@ -11,7 +11,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import HipLibraryError, NotPositiveDefinite, PMC_KIND_STUDENT_T, NSCALARS  # noqa: F401
+from ._lib import (HipLibraryError, NotPositiveDefinite, PMC_KIND_GAUSS, PMC_KIND_STUDENT_T,  # noqa: F401
+                   NSCALARS)
 
 __all__ = ["ComponentSet", "HipBackend", "get_backend", "set_default_backend", "HipLibraryError",
            "NotPositiveDefinite"]
@@ -264,6 +265,33 @@ class HipBackend(object):
             self._p(x), N, D, self._p(pack), K, self._p(u), self._p(flat[NSCALARS:]), self._p(ws),
             self._stream()), "pmc_sufficient_stats")
         return dict(stats=flat, r=r, log_rho=log_rho, exponent=expo)
+
+    def weighted_moments(self, x, w):
+        """sum w | sum w (x - x_0) | sum w (x - x_0)(x - x_0)^T of weighted samples through the
+        statistics kernel (one "component" whose shift is the first sample).  Returns
+        (S0, M1 (D), M2 (D x D), shift (D), sum w^2) on the host."""
+        x = self.asdevice(x)
+        N, D = x.shape
+        w = self.asdevice(w).reshape(N)
+        shift = self.tohost(x[:1]).reshape(1, D) if N else np.zeros((1, D))
+        cs = ComponentSet(PMC_KIND_GAUSS, shift, np.eye(D)[None])
+        pack = self.pack(cs)
+        ntile = (N + self.tile - 1) // self.tile
+        u = self.zeros(max(ntile, 1) * self.tile)          # tile-major with K = 1: the weight vector
+        u[:N] = w
+        ps = int(self.lib.pmc_stats_stride(D))
+        stats = self.zeros(ps)
+        ws = self._workspace(max(N, 1), 1, D)
+        _lib.check(self._timed("pmc_sufficient_stats", self.lib.pmc_sufficient_stats,
+                               self._p(x), N, D, self._p(pack), 1, self._p(u), self._p(stats), self._p(ws),
+                               self._stream()), "pmc_sufficient_stats")
+        sums = self.tohost(self.weight_sums(w))
+        h = self.tohost(stats)
+        il, jl = np.tril_indices(D)
+        M2 = np.zeros((D, D))
+        M2[il, jl] = h[1 + D:]
+        M2[jl, il] = h[1 + D:]
+        return float(h[0]), h[1:1 + D].copy(), M2, shift[0], float(sums[2])
 
     def stats_len(self, K, D):
         """length of the flat statistics buffer of estep()"""

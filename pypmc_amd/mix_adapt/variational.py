@@ -452,3 +452,81 @@ def Dirichlet_log_C(alpha):
     """log of the Dirichlet normalisation C(alpha), [Bis06] (B.23)."""
     alpha = np.asarray(alpha, dtype=float)
     return float(gammaln(alpha.sum()) - gammaln(alpha).sum())
+
+
+class VBMerge(GaussianInference):
+    """Parsimonious reduction of a Gaussian mixture with variational Bayes [BGP10]: the L components
+    of ``input_mixture`` (standing for ``N`` virtual samples) are merged into at most ``components``
+    output components (reference: variational.pyx:1035-1218, same constructor and semantics).
+
+    Nothing here is N-sized: the "data" are the L input means.  The Mahalanobis part of the E-step
+    (E_lk = D/beta_k + nu_k (mu_l - m_k)^T W_k (mu_l - m_k), after eq. (40) of [BGP10]) runs through
+    the same GPU kernel as GaussianInference; the L x K soft-max and the K-sized sums stay on the host.
+    """
+    # plain attributes here (L x K, small), not the lazily computed properties of the base class
+    r = None
+    log_rho = None
+    expectation_gauss_exponent = None
+
+    def __init__(self, input_mixture, N, components=0, initial_guess='first', backend=None, **kwargs):
+        self._backend = backend
+        self.input = input_mixture                      # not copied: it is never modified
+        self.L = len(input_mixture.components)
+        self.mu = np.array([c.mu for c in self.input.components], dtype=np.float64)
+        self.sigma_in = np.array([c.sigma for c in self.input.components], dtype=np.float64)
+        self._initialize_K(initial_guess, components, kwargs)
+        self.dim = len(input_mixture.components[0].mu)
+        self.N = N
+        self.N_local = self.L
+        self.weights = None
+        self.Nomega = N * np.asarray(self.input.weights, dtype=np.float64)   # N omega' of [BGP10]
+        self.set_variational_parameters(initial_guess=initial_guess, **kwargs)
+        self._initialize_intermediate()
+        if not isinstance(initial_guess, str):
+            self._parse_initial_guess(initial_guess)
+        self._mu_dev = get_backend(self._backend).asdevice(self.mu)
+        self.E_step()
+
+    def _initialize_m(self, initial_guess):
+        if self.K > self.L:
+            raise ValueError("Can't auto-initialize ``m`` with more output components than input components."
+                             " Specify ``m`` explicitly.")
+        if initial_guess == 'first':
+            return self.mu[:self.K].copy()
+        if initial_guess == 'random':
+            return self.mu[np.random.choice(self.L, size=self.K, replace=False)].copy()
+        raise ValueError('Invalid ``initial_guess``: ' + str(initial_guess))
+
+    def E_step(self):
+        self._update_expectation_det_ln_lambda()
+        self._update_expectation_ln_pi()
+        D = self.dim
+        # after (40) in [BGP10]; variational.pyx:1117-1145
+        cs = ComponentSet(PMC_KIND_VB, self.m, self.W, c0=D / self.beta, c1=self.nu,
+                          c2=self.expectation_ln_pi,
+                          c3=self.expectation_det_ln_lambda - D * np.log(2. * np.pi))
+        be = get_backend(self._backend)
+        E = be.tohost(be.estep(self._mu_dev, cs, PMC_RESP_VB, want_exponent=True)["exponent"])
+        self.expectation_gauss_exponent = E
+        # (40): log rho_lk = N omega_l / 2 * (2 E[ln pi_k] + E[ln|Lambda_k|] - D ln 2 pi - E_lk)
+        tmp_k = 2. * self.expectation_ln_pi + self.expectation_det_ln_lambda - D * np.log(2. * np.pi)
+        log_rho = 0.5 * (self.Nomega[:, None] * tmp_k[None, :] - self.Nomega[:, None] * E)
+        # responsibilities: soft-max per input component, zeros -> tiny (variational.pyx:728-755)
+        log_rho -= log_rho.max(axis=1)[:, None]
+        r = np.exp(log_rho)
+        norm_inv = 1. / r.sum(axis=1)
+        r *= norm_inv[:, None]
+        r[r == 0.0] = np.finfo('d').tiny
+        log_rho += np.log(norm_inv)[:, None]
+        if not np.isfinite(r).any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(r))
+        self.r, self.log_rho = r, log_rho
+        # (41), (42), (43)+(44)
+        wr = self.Nomega[:, None] * r
+        self.N_comp = regularize(wr.sum(axis=0))
+        self.inv_N_comp = 1. / self.N_comp
+        self.x_mean_comp = wr.T.dot(self.mu) * self.inv_N_comp[:, None]
+        d = self.mu[:, None, :] - self.x_mean_comp[None, :, :]                     # L x K x D
+        self.S = (np.einsum('lk,lki,lkj->kij', wr, d, d) + np.einsum('lk,lij->kij', wr, self.sigma_in)) \
+            * self.inv_N_comp[:, None, None]
+        self._expectation_log_q_Z = float(np.einsum('lk,lk', r, log_rho))          # unweighted (10.75)

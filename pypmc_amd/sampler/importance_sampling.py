@@ -21,22 +21,28 @@ def calculate_expectation(samples, weights, f):
     return total / norm
 
 
-def calculate_mean(samples, weights):
-    """Weighted sample mean (reference: importance_sampling.py:46-61)."""
+def _moments(samples, weights, backend):
     assert len(samples) == len(weights), \
         "The number of samples (got %i) must equal the number of weights (got %i)." % (len(samples), len(weights))
-    return np.average(samples, axis=0, weights=weights)
+    be = get_backend(backend)
+    x = samples if hasattr(samples, 'device') and not isinstance(samples, np.ndarray) \
+        else np.ascontiguousarray(samples, dtype=np.float64)
+    return be.weighted_moments(x, weights)
 
 
-def calculate_covariance(samples, weights):
+def calculate_mean(samples, weights, backend=None):
+    """Weighted sample mean (reference: importance_sampling.py:46-61), reduced on the GPU by the
+    statistics kernel."""
+    S0, M1, _, shift, _ = _moments(samples, weights, backend)
+    return shift + M1 / S0
+
+
+def calculate_covariance(samples, weights, backend=None):
     """Weighted sample covariance with the (sum w)^2 / ((sum w)^2 - sum w^2) correction
-    (reference: importance_sampling.py:63-83)."""
-    assert len(samples) == len(weights), \
-        "The number of samples (got %i) must equal the number of weights (got %i)." % (len(samples), len(weights))
-    samples, weights = np.asarray(samples), np.asarray(weights)
-    s1sq, s2 = weights.sum() ** 2, (weights ** 2).sum()
-    d = samples - calculate_mean(samples, weights)
-    return s1sq / (s1sq - s2) * np.einsum('n,ni,nj->ij', weights, d, d) / weights.sum()
+    (reference: importance_sampling.py:63-83), reduced on the GPU by the statistics kernel."""
+    S0, M1, M2, _, Q = _moments(samples, weights, backend)
+    dbar = M1 / S0
+    return S0 * S0 / (S0 * S0 - Q) * (M2 / S0 - np.outer(dbar, dbar))
 
 
 class ImportanceSampler(object):

@@ -270,11 +270,12 @@ def case_importance_sampler(be):
         assert len(sampler.samples) == 0 and len(sampler.weights) == 0
         # moments helpers
         w = g["weights"]
-        np.testing.assert_allclose(calculate_mean(g["samples"], w), np.average(g["samples"], axis=0, weights=w))
-        mean = calculate_mean(g["samples"], w)
+        np.testing.assert_allclose(calculate_mean(g["samples"], w, backend=be),
+                                   np.average(g["samples"], axis=0, weights=w), rtol=1e-12)
+        mean = np.average(g["samples"], axis=0, weights=w)
         ref_cov = w.sum() ** 2 / (w.sum() ** 2 - (w ** 2).sum()) * \
             calculate_expectation(g["samples"], w, lambda x: np.outer(x - mean, x - mean))
-        np.testing.assert_allclose(calculate_covariance(g["samples"], w), ref_cov, rtol=1e-10)
+        np.testing.assert_allclose(calculate_covariance(g["samples"], w, backend=be), ref_cov, rtol=1e-9, atol=1e-13)
     # indicator: points outside get zero weight and the target is not called there
     g = load_golden("is_gauss_d2")
     prop = create_gaussian_mixture(g["prop_mu"], g["prop_sigma"], g["prop_weights"])
@@ -491,6 +492,40 @@ def case_vb_errors_and_prune(be):
     assert abs(Dirichlet_log_C(np.array([1., 2., 3.])) - np.log(60.)) < 1e-13
 
 
+def case_vbmerge_golden(be):
+    """VBMerge: reduction of an 18-component mixture (reference: variational.pyx:1035-1218)."""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.variational import VBMerge
+    g = load_golden("vbmerge")
+    big = create_gaussian_mixture(g["in_mu"], g["in_sigma"], g["in_weights"])
+    big._backend = be
+    merge = VBMerge(big, N=int(g["N"]), components=int(g["components"]), initial_guess='first', backend=be)
+    for stage in ("e0_", "u1_"):
+        if stage == "u1_":
+            merge.update()
+        p = lambda k: g[stage + k]
+        for name in ("alpha", "beta", "nu", "m", "W", "expectation_det_ln_lambda", "expectation_ln_pi"):
+            np.testing.assert_allclose(getattr(merge, name), p(name), rtol=1e-9, atol=1e-12, err_msg=stage + name)
+        assert_rel(merge.expectation_gauss_exponent, p("expectation_gauss_exponent"), what=stage + "exponent")
+        assert_rel(merge.r, p("r"), rtol=1e-9, what=stage + "r")
+        np.testing.assert_allclose(merge.N_comp, p("N_comp"), rtol=1e-9)
+        np.testing.assert_allclose(merge.x_mean_comp, p("x_mean_comp"), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(merge.S, p("S"), rtol=1e-8, atol=1e-10)
+        b, ref = merge.likelihood_bound(), float(g[stage + "bound"])
+        assert abs(b - ref) <= 1e-8 * abs(ref), (stage, b, ref)
+    merge2 = VBMerge(big, N=int(g["N"]), components=int(g["components"]), initial_guess='first', backend=be)
+    nit = merge2.run(100, prune=1.)
+    ref_it = int(g["run_iterations"])
+    assert (nit is None) == (ref_it < 0) and (nit is None or abs(nit - ref_it) <= 2)
+    assert merge2.K == int(g["run_K"])
+    mm = merge2.make_mixture()
+    np.testing.assert_allclose(mm.weights, g["run_mix_weights"], rtol=1e-6)
+    np.testing.assert_allclose([c.mu for c in mm.components], g["run_mix_mu"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose([c.sigma for c in mm.components], g["run_mix_sigma"], rtol=1e-6, atol=1e-8)
+    with pytest.raises(ValueError, match="more output components than input components"):
+        VBMerge(big, N=100, components=50, backend=be)
+
+
 # ------------------------------------------------------------------------------------------------
 def _mix_from(g, prefix, student, be):
     from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture
@@ -652,7 +687,7 @@ def case_example_pmc(be):
     assert abs(w[0] - 0.3) < 0.05 and abs(w[1] - 0.7) < 0.05 and w[2] < 0.05
 
 
-ALL_CASES = [case_example_pmc, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
+ALL_CASES = [case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,
              case_pmc_errors_and_fallback, case_student_t_pmc_golden]

@@ -93,7 +93,7 @@ def main():
     from pypmc.density.mixture import (MixtureDensity, create_gaussian_mixture,
                                        create_t_mixture)
     from pypmc.sampler.importance_sampling import ImportanceSampler, combine_weights
-    from pypmc.mix_adapt.variational import GaussianInference
+    from pypmc.mix_adapt.variational import GaussianInference, VBMerge
     from pypmc.mix_adapt.pmc import gaussian_pmc, student_t_pmc, PMC
 
     # ------------------------------------------------------------------ known-answer inputs
@@ -263,6 +263,32 @@ def main():
         out["run_mix_mu"] = np.array([c.mu for c in mm.components])
         out["run_mix_sigma"] = np.array([c.sigma for c in mm.components])
         save("vb_" + tag, **out)
+
+    # ------------------------------------------------------------------ VBMerge (mixture reduction)
+    rs = np.random.RandomState(17)
+    centres = np.array([[-4., 0.], [3., 3.], [2., -5.]])
+    L = 18
+    in_mu = centres[np.arange(L) % 3] + rs.normal(0, 0.6, (L, 2))
+    in_cov = np.array([np.eye(2) * rs.uniform(0.2, 0.6) + 0.05 * np.outer(v, v) for v in rs.normal(size=(L, 2))])
+    in_w = rs.uniform(0.5, 1.5, L)
+    in_w /= in_w.sum()
+    big = create_gaussian_mixture(in_mu, in_cov, in_w)
+    merge = VBMerge(big, N=5000, components=6, initial_guess='first')
+    out = dict(in_mu=in_mu, in_sigma=in_cov, in_weights=in_w, N=5000, components=6)
+    out.update(vb_state(merge, "e0_"))
+    out["e0_bound"] = merge.likelihood_bound()
+    merge.update()
+    out.update(vb_state(merge, "u1_"))
+    out["u1_bound"] = merge.likelihood_bound()
+    merge2 = VBMerge(big, N=5000, components=6, initial_guess='first')
+    nit = merge2.run(100, prune=1.)
+    out["run_iterations"] = -1 if nit is None else nit
+    out["run_K"] = merge2.K
+    mm = merge2.make_mixture()
+    out["run_mix_weights"] = np.array(mm.weights)
+    out["run_mix_mu"] = np.array([c.mu for c in mm.components])
+    out["run_mix_sigma"] = np.array([c.sigma for c in mm.components])
+    save("vbmerge", **out)
 
     # ------------------------------------------------------------------ PMC updates
     def mix_out(mix, prefix, student):

@@ -83,6 +83,12 @@ class OracleBackend(object):
         sc[0], sc[1], sc[2] = w.sum(), (w[nz] * np.log(w[nz])).sum(), (w ** 2).sum()
         return sc
 
+    def weighted_moments(self, x, w):
+        x, w = np.asarray(x, dtype=float), np.asarray(w, dtype=float).reshape(-1)
+        shift = x[0].copy()
+        d = x - shift
+        return float(w.sum()), w.dot(d), np.einsum('n,ni,nj->ij', w, d, d), shift, float((w ** 2).sum())
+
     def logsumexp2d(self, a, w):
         return orc.logsumexp2D(np.asarray(a, dtype=float), np.asarray(w, dtype=float))
 
