@@ -37,18 +37,22 @@ class GaussianInference(object):
 
     def __init__(self, data, components=0, weights=None, initial_guess="first", backend=None, **kwargs):
         self._backend = backend
-        data = np.asarray(data, dtype=np.float64)
+        on_device = hasattr(data, 'device') and not isinstance(data, np.ndarray)    # torch tensor: stays put
+        if not on_device:
+            data = np.asarray(data, dtype=np.float64)
         self.N_local = data.shape[0]
         self.data = data.reshape(self.N_local, 1) if data.ndim == 1 else data
         self.dim = self.data.shape[1]
         self.weights = None
         sum_w_local = 0.0
         if weights is not None:
-            weights = np.asarray(weights, dtype=np.float64)
-            assert weights.shape == (self.N_local,), \
+            if not (hasattr(weights, 'device') and not isinstance(weights, np.ndarray)):
+                weights = np.asarray(weights, dtype=np.float64)
+            assert tuple(weights.shape) == (self.N_local,), \
                 "The number of samples (%s) does not match the number of weights (%s)" % (self.N_local, weights.shape[0])
-            assert np.isfinite(weights).all(), 'Some weights are not finite; i.e., inf or nan\n' + str(weights)
-            sum_w_local = weights.sum()
+            assert bool(np.isfinite(weights).all() if isinstance(weights, np.ndarray) else weights.isfinite().all()), \
+                'Some weights are not finite; i.e., inf or nan\n' + str(weights)
+            sum_w_local = float(weights.sum())
         # global sample count / weight sum (identical to the local ones for a single process)
         n_glob, sum_w = parallel.all_reduce_scalars(self.N_local, sum_w_local)
         self.N = int(round(n_glob))
@@ -63,7 +67,7 @@ class GaussianInference(object):
         self._initialize_intermediate()
 
         be = get_backend(self._backend)
-        self._data_dev = be.asdevice(np.ascontiguousarray(self.data))
+        self._data_dev = be.asdevice(self.data if on_device else np.ascontiguousarray(self.data))
         self._weights_dev = be.asdevice(self.weights) if self.weights is not None else None
         self.E_step()
 
@@ -330,10 +334,12 @@ class GaussianInference(object):
         if self.K > self.N_local:
             raise ValueError("Can't auto-initialize ``m`` with more output components than samples."
                              " Specify ``m`` explicitly.")
+        host = (lambda rows: np.array(rows, dtype=np.float64)) if isinstance(self.data, np.ndarray) \
+            else (lambda rows: rows.detach().cpu().numpy().astype(np.float64))
         if initial_guess == 'first':
-            return self.data[:self.K].copy()
+            return host(self.data[:self.K])
         if initial_guess == 'random':
-            return self.data[np.random.choice(self.N_local, size=self.K, replace=False)].copy()
+            return host(self.data[np.random.choice(self.N_local, size=self.K, replace=False)])
         raise ValueError('Invalid ``initial_guess``: ' + str(initial_guess))
 
     def _initialize_intermediate(self):
