@@ -153,6 +153,21 @@ int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_wor
 int pmc_logsumexp2d(const double *d_a, const double *d_w, int64_t N, int K, double *d_out,
                     void *stream);
 
+/*
+ * Deterministic-mixture weights of run t out of T importance-sampling runs [Cor+12]
+ * (pypmc/sampler/importance_sampling.py:313-365).  d_q: T x N row-major, d_q[l*N + n] = log q_l(x^t_n)
+ * (row l is the d_out of pmc_mixture_logpdf for proposal l); d_counts[l] = N_l as double;
+ * d_omega[n] = ordinary importance weight of x^t_n; n_total = sum_l N_l.
+ *   log_scale != 0 (_combine_weights_log, :337-365; needs omega > 0):
+ *       d_out[n] = exp(log omega_n + q[t,n] + log n_total - logsumexp2D(q[:,n], counts))
+ *   log_scale == 0 (_combine_weights_linear, :313-333):
+ *       d_out[n] = exp(q[t,n]) * omega_n / ((sum_l N_l exp(q[l,n])) / n_total)
+ * d_flag (1 double, may be NULL) counts the non-finite results (the reference's final assert, :310).
+ */
+int pmc_combine_weights(const double *d_q, int64_t N, int T, const double *d_counts, int t,
+                        const double *d_omega, double n_total, int log_scale, double *d_out,
+                        double *d_flag, void *stream);
+
 /* ---- proposing ------------------------------------------------------------------------------- */
 /*
  * Device side of MixtureDensity.propose(N, rng, trace=True, shuffle=False)

@@ -159,6 +159,18 @@ def is_weights(log_target, log_proposal):
     return w
 
 
+def combine_weights_run(q, counts, t, omega, n_total, log_scale):
+    """Deterministic-mixture weights of run ``t``; q[n, l] = log q_l(x^t_n)."""
+    q, qp = _d(q)
+    c, cp = _d(counts)
+    o, op = _d(omega)
+    out = np.empty(len(q))
+    lib().orc_combine_weights(qp, _sz(q.shape[0]), _sz(q.shape[1]), cp, _sz(int(t)), op,
+                              C.c_double(float(n_total)), C.c_int(int(bool(log_scale))),
+                              out.ctypes.data_as(_dp))
+    return out
+
+
 def perp(weights):
     w, wp = _d(weights)
     return lib().orc_perp(wp, _sz(len(w)))

@@ -194,6 +194,37 @@ size_t orc_is_weights(const double *log_target, const double *log_proposal, size
     return overflow;
 }
 
+/*
+ * pypmc/sampler/importance_sampling.py:313-365  deterministic-mixture weights of run t
+ * (_combine_weights_linear :313-333, _combine_weights_log :335-371).  q: N x T row-major,
+ * q[n,l] = log q_l(x^t_n) (what proposals[l].multi_evaluate(samples[t]) returns); counts[l] = N_l.
+ */
+void orc_combine_weights(const double *q, size_t N, size_t T, const double *counts, size_t t,
+                         const double *omega, double n_total, int log_scale, double *out)
+{
+    size_t n, l;
+    if (log_scale) {
+        double *lse = (double *)malloc((N ? N : 1) * sizeof(double));
+        orc_logsumexp2D(q, counts, N, T, lse);                 /* :362 */
+        for (n = 0; n < N; ++n) {
+            double lw = log(omega[n]);                           /* :349 */
+            lw += q[n * T + t];                                  /* :350 */
+            lw += log(n_total);                                  /* :351 */
+            lw -= lse[n];                                        /* :362 */
+            out[n] = exp(lw);                                    /* :365 */
+        }
+        free(lse);
+    } else {
+        for (n = 0; n < N; ++n) {
+            double den = 0.0;
+            for (l = 0; l < T; ++l)
+                den += counts[l] * exp(q[n * T + l]);            /* :321-322 */
+            den /= n_total;                                      /* :323 */
+            out[n] = exp(q[n * T + t]) * omega[n] / den;         /* :325-327 */
+        }
+    }
+}
+
 /* pypmc/tools/convergence.py:31-39  perp */
 double orc_perp(const double *weights, size_t N)
 {

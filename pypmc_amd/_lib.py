@@ -45,6 +45,7 @@ SIGNATURES = {
     "pmc_weight_sums": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "pmc_propose": (_int, [_vp, _vp, _vp, _vp, _int, _int, _i64, _i64, C.c_uint64, _vp, _vp, _vp]),
     "pmc_logsumexp2d": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "pmc_combine_weights": (_int, [_vp, _i64, _int, _vp, _int, _vp, C.c_double, _int, _vp, _vp, _vp]),
     "pmc_responsibilities": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pmc_sufficient_stats": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),

@@ -112,7 +112,10 @@ class HipBackend(object):
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
         np_dtype = {torch.float64: np.float64, torch.int64: np.int64}[dtype]
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(self.device)
+        a = np.ascontiguousarray(a, dtype=np_dtype)
+        if not a.flags.writeable:                       # e.g. a DeviceHistory host copy
+            a = a.copy()
+        return torch.from_numpy(a).to(self.device)
 
     def tohost(self, t):
         return t.detach().cpu().numpy()
@@ -158,14 +161,19 @@ class HipBackend(object):
 
     # ------------------------------------------------------------------ operations
     def logpdf(self, x, comps, want_out=True, individual=None, want_individual=False,
-               max_init_zero=False, log_target=None, sample_w=None, want_scalars=False, pack=None):
+               max_init_zero=False, log_target=None, sample_w=None, want_scalars=False, pack=None,
+               out=None):
         """pmc_mixture_logpdf.  ``x`` N x D device tensor.  Returns dict(out, individual, weights,
-        scalars) of device tensors (None where not requested)."""
+        scalars) of device tensors (None where not requested).  ``out``: optional contiguous
+        N-vector on the device to receive log q (e.g. a row of combine_weights' q matrix)."""
         x = self.asdevice(x)
         N, D = x.shape
         assert D == comps.D, "sample dimension %d != component dimension %d" % (D, comps.D)
         pack = self.pack(comps) if pack is None else pack
-        out = self.empty(N) if want_out else None
+        if out is not None:
+            assert out.shape == (N,) and out.is_contiguous() and out.dtype == self.torch.float64
+        elif want_out:
+            out = self.empty(N)
         if individual is None and want_individual:
             individual = self.empty((N, comps.ld))
         if individual is not None:
@@ -192,7 +200,7 @@ class HipBackend(object):
                                             self._stream()), "pmc_weight_sums")
         return scalars
 
-    def propose(self, mu, chol, dof, counts, seed, first_sample=0, want_origin=True):
+    def propose(self, mu, chol, dof, counts, seed, first_sample=0, want_origin=True, out=None):
         """pmc_propose: samples of a Gauss / Student-t mixture for host-drawn component ``counts``.
         mu K x D, chol K x D x D (lower Cholesky factors of the covariances), dof K or None.
         Returns (x N x D, origin N int64 or None) as device tensors, ordered by component."""
@@ -206,7 +214,11 @@ class HipBackend(object):
         d_chol = self.asdevice(np.ascontiguousarray(chol, dtype=np.float64).reshape(K, D, D))
         d_dof = self.asdevice(np.ascontiguousarray(dof, dtype=np.float64).reshape(K)) if dof is not None else None
         d_off = self.asdevice(offsets, torch.int64)
-        x = self.empty((N, D))
+        if out is not None:
+            assert tuple(out.shape) == (N, D) and out.is_contiguous() and out.dtype == torch.float64
+            x = out
+        else:
+            x = self.empty((N, D))
         origin = self.empty(N, torch.int64) if want_origin else None
         _lib.check(self._timed(
             "pmc_propose", self.lib.pmc_propose, self._p(d_mu), self._p(d_chol), self._p(d_dof),
@@ -224,6 +236,20 @@ class HipBackend(object):
         _lib.check(self.lib.pmc_logsumexp2d(self._p(a), self._p(w), N, K, self._p(out),
                                             self._stream()), "pmc_logsumexp2d")
         return out
+
+    def combine_weights(self, q, counts, t, omega, n_total, log_scale):
+        """pmc_combine_weights: deterministic-mixture weights of run ``t``; ``q`` T x N with
+        q[l, n] = log q_l(x^t_n).  Returns (weights N, number of non-finite results) on the device."""
+        q = self.asdevice(q)
+        T, N = q.shape
+        counts = self.asdevice(np.asarray(counts, dtype=np.float64)).reshape(T)
+        omega = self.asdevice(omega).reshape(N)
+        out = self.empty(N)
+        flag = self.zeros(1)
+        _lib.check(self.lib.pmc_combine_weights(self._p(q), N, T, self._p(counts), int(t), self._p(omega),
+                                                float(n_total), int(bool(log_scale)), self._p(out),
+                                                self._p(flag), self._stream()), "pmc_combine_weights")
+        return out, flag
 
     def estep(self, x, comps, mode, max_init_zero=False, sample_w=None, latent=None,
               want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None):

@@ -170,6 +170,39 @@ __global__ __launch_bounds__(256) void k_logsumexp2d(const double *__restrict__ 
     out[n] = log(res) + mx;
 }
 
+// Deterministic-mixture weights of one run (pypmc/sampler/importance_sampling.py:313-365); the
+// operation order of both branches follows the reference statement by statement.
+__global__ __launch_bounds__(256) void k_combine_weights(const double *__restrict__ q, long long N, int T,
+                                                         const double *__restrict__ counts, int t,
+                                                         const double *__restrict__ omega, double n_total,
+                                                         int log_scale, double *__restrict__ out,
+                                                         double *__restrict__ flag)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double *col = q + n;                           // q[l, n] = col[l * N]
+    double w;
+    if (log_scale) {
+        double lw = log(omega[n]);                       // :349-351
+        lw += col[t * N];
+        lw += log(n_total);
+        double mx = -1.7976931348623157e308;             // logsumexp2D(q, N), _regularize.pyx:57-84
+        for (int l = 0; l < T; ++l)
+            if (col[l * N] > mx) mx = col[l * N];
+        double res = 0.0;
+        for (int l = 0; l < T; ++l) res += counts[l] * exp(col[l * N] - mx);
+        lw -= log(res) + mx;
+        w = exp(lw);                                     // :365
+    } else {
+        double den = 0.0;                                // :320-323
+        for (int l = 0; l < T; ++l) den += counts[l] * exp(col[l * N]);
+        den /= n_total;
+        w = exp(col[t * N]) * omega[n] / den;            // :325-327
+    }
+    out[n] = w;
+    if (flag && !(fabs(w) <= 1.7976931348623157e308)) atomicAdd(flag, 1.0);
+}
+
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 
 // statistics launch geometry
@@ -401,6 +434,20 @@ int pmc_logsumexp2d(const double *d_a, const double *d_w, int64_t N, int K, doub
                        d_a, d_w, (long long)N, K, d_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_logsumexp2d launch");
+    return PMC_OK;
+}
+
+int pmc_combine_weights(const double *d_q, int64_t N, int T, const double *d_counts, int t,
+                        const double *d_omega, double n_total, int log_scale, double *d_out,
+                        double *d_flag, void *stream)
+{
+    if (N < 0 || T < 1 || t < 0 || t >= T || !d_counts || !(n_total > 0) || (N > 0 && (!d_q || !d_omega || !d_out)))
+        return fail(PMC_EINVAL, "pmc_combine_weights: bad argument");
+    if (N == 0) return PMC_OK;
+    hipLaunchKernelGGL(k_combine_weights, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_q, (long long)N, T, d_counts, t, d_omega, n_total, log_scale, d_out, d_flag);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_combine_weights launch");
     return PMC_OK;
 }
 

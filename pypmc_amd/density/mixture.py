@@ -129,7 +129,7 @@ class MixtureDensity(ProbabilityDensity):
         return out
 
     # -- sampling -------------------------------------------------------------------------------
-    def propose(self, N=1, rng=np.random.mtrand, trace=False, shuffle=True, device=False):
+    def propose(self, N=1, rng=np.random.mtrand, trace=False, shuffle=True, device=False, out=None):
         """N samples.  Component counts come from ``rng.multinomial(N, weights)``; with
         ``trace`` the generating component of every sample is returned too (samples then stay
         ordered by component).  Reference: mixture.pyx:159-212 -- including its quirk that the
@@ -138,12 +138,13 @@ class MixtureDensity(ProbabilityDensity):
         ``device=True`` (extension): the counts are still drawn on the host with ``rng`` (so counts
         and origins are bit-exact for a given generator state), the samples are generated on the
         GPU (pmc_propose, Philox stream seeded from ``rng``) and returned as device tensors --
-        nothing N-sized crosses PCIe."""
+        nothing N-sized crosses PCIe.  ``out``: optional N x dim device buffer to generate into
+        (e.g. the run a DeviceHistory just opened)."""
         if trace and shuffle:
             raise ValueError('Either ``shuffle`` or ``trace`` must be ``False``!')
         counts = rng.multinomial(N, self.weights)
         if device:
-            return self._propose_device(counts, rng, trace, shuffle)
+            return self._propose_device(counts, rng, trace, shuffle, out=out)
         samples = np.empty((N, self.dim))
         start = 0
         for comp, n in zip(self.components, counts):
@@ -156,7 +157,7 @@ class MixtureDensity(ProbabilityDensity):
             rng.shuffle(samples)
         return samples
 
-    def _propose_device(self, counts, rng, trace, shuffle, first_sample=0):
+    def _propose_device(self, counts, rng, trace, shuffle, first_sample=0, out=None):
         comps = self.components
         first = type(comps[0])
         if first not in (Gauss, StudentT) or any(type(c) is not first for c in comps):
@@ -166,13 +167,15 @@ class MixtureDensity(ProbabilityDensity):
         x, origin = be.propose(np.array([c.mu for c in comps]),
                                np.array([c.cholesky_sigma for c in comps]),
                                np.array([c.dof for c in comps]) if first is StudentT else None,
-                               counts, seed, first_sample=first_sample, want_origin=trace)
+                               counts, seed, first_sample=first_sample, want_origin=trace,
+                               out=None if (shuffle and not trace) else out)
         if trace:
             return x, origin
         if shuffle:
             import torch
             g = torch.Generator(device=x.device).manual_seed(seed & (2 ** 63 - 1))
-            x = x[torch.randperm(len(x), device=x.device, generator=g)].contiguous()
+            perm = torch.randperm(len(x), device=x.device, generator=g)
+            x = torch.index_select(x, 0, perm, out=out) if out is not None else x[perm].contiguous()
         return x
 
 

@@ -5,7 +5,7 @@ from copy import deepcopy
 import numpy as np
 
 from ..backend import get_backend
-from ..tools._history import History
+from ..tools._history import History, DeviceHistory
 from ..tools.indicator import merge_function_with_indicator
 
 
@@ -21,12 +21,16 @@ def calculate_expectation(samples, weights, f):
     return total / norm
 
 
+def _on_device(a):
+    """True for a device tensor (anything array-like that is not a numpy array / sequence)."""
+    return hasattr(a, 'device') and not isinstance(a, np.ndarray)
+
+
 def _moments(samples, weights, backend):
     assert len(samples) == len(weights), \
         "The number of samples (got %i) must equal the number of weights (got %i)." % (len(samples), len(weights))
     be = get_backend(backend)
-    x = samples if hasattr(samples, 'device') and not isinstance(samples, np.ndarray) \
-        else np.ascontiguousarray(samples, dtype=np.float64)
+    x = samples if _on_device(samples) else np.ascontiguousarray(samples, dtype=np.float64)
     return be.weighted_moments(x, weights)
 
 
@@ -52,11 +56,17 @@ class ImportanceSampler(object):
     Per run the proposal's log-density, w = exp(log P - log q) and the three sums behind
     perplexity / ESS come from one fused kernel launch; the user's ``target`` stays a host
     callable evaluated per sample (or per batch, if it is the ``evaluate`` method of a density
-    offering ``multi_evaluate``)."""
+    offering ``multi_evaluate``).
+
+    ``device=True`` (extension): ``samples`` / ``weights`` / ``target_values`` are
+    :class:`DeviceHistory` objects — ``run`` proposes on the GPU straight into the store, weights
+    there, and only a target that is a host callable sees host copies of the samples.  Indexing
+    the histories still yields (lazy) host arrays, ``.device(i)`` the device views."""
 
     def __init__(self, target, proposal, indicator=None, prealloc=0, save_target_values=False,
-                 rng=np.random.mtrand, backend=None):
+                 rng=np.random.mtrand, backend=None, device=False):
         self._backend = backend
+        self.device = bool(device)
         self.proposal = deepcopy(proposal)
         self.rng = rng
         self._batch_target = None
@@ -65,9 +75,15 @@ class ImportanceSampler(object):
                 and hasattr(owner, 'multi_evaluate'):
             self._batch_target = owner.multi_evaluate
         self.target = merge_function_with_indicator(target, indicator, -np.inf)
-        self.target_values = History(1, prealloc) if save_target_values else None
-        self.weights = History(1, prealloc)
-        self.samples = History(proposal.dim, prealloc)
+        if self.device:
+            def store(dim):
+                return DeviceHistory(dim, prealloc, backend)
+        else:
+            def store(dim):
+                return History(dim, prealloc)
+        self.target_values = store(1) if save_target_values else None
+        self.weights = store(1)
+        self.samples = store(proposal.dim)
         self.last_weight_sums = None      # (sum w, sum w log w, sum w^2) of the latest run
 
     def clear(self):
@@ -82,6 +98,9 @@ class ImportanceSampler(object):
         are ordered by generating component and that component index is returned per sample."""
         if N == 0:
             return 0
+        if self.device:
+            res = self.run_device(N, trace_sort=trace_sort, store=True)
+            return get_backend(self._backend).tohost(res["origin"]) if trace_sort else None
         if trace_sort:
             this_samples, origin = self._get_samples(N, trace_sort=True)
             self._calculate_weights(this_samples, N)
@@ -89,29 +108,38 @@ class ImportanceSampler(object):
         this_samples = self._get_samples(N, trace_sort=False)
         self._calculate_weights(this_samples, N)
 
-    def run_device(self, N, trace_sort=False, target_density=None):
+    def run_device(self, N, trace_sort=False, target_density=None, store=False):
         """Extension for device-resident loops (BASELINE config 5): propose N samples ON THE GPU,
         weight them there and return ``dict(samples, weights, origin, weight_sums)`` of device
-        tensors; nothing N-sized crosses PCIe and the History objects are not touched.
-        The target must be a density with GPU log-pdf (``target_density``, default: the object
-        whose ``evaluate`` was given as ``target``)."""
+        tensors.  With a mixture target (``target_density``, default: the object whose ``evaluate``
+        was given as ``target``) nothing N-sized crosses PCIe; any other target is called on a host
+        copy of the samples and only its N log-values are uploaded.  ``store=True`` (needs
+        ``device=True`` at construction) generates into / records in the DeviceHistory objects."""
         from ..density.mixture import MixtureDensity, component_set
         be = get_backend(self._backend)
+        if store and not self.device:
+            raise ValueError('store=True needs ImportanceSampler(..., device=True)')
         tgt = target_density if target_density is not None else getattr(self._batch_target, '__self__', None)
-        if not isinstance(tgt, MixtureDensity):
-            raise TypeError('run_device needs a MixtureDensity target (target_density=...)')
+        out = self.samples.append(N) if store else None
         origin = None
         if trace_sort:
-            x, origin = self.proposal.propose(N, self.rng, trace=True, shuffle=False, device=True)
+            x, origin = self.proposal.propose(N, self.rng, trace=True, shuffle=False, device=True, out=out)
         else:
-            x = self.proposal.propose(N, self.rng, device=True)
-        log_target = be.logpdf(x, component_set(tgt.components, tgt.weights))["out"]
+            x = self.proposal.propose(N, self.rng, device=True, out=out)
+        if isinstance(tgt, MixtureDensity):
+            log_target = be.logpdf(x, component_set(tgt.components, tgt.weights))["out"]
+        else:
+            log_target = be.asdevice(self._target_values(be.tohost(x), N))
         res = be.logpdf(x, component_set(self.proposal.components, self.proposal.weights), want_out=False,
                         log_target=log_target, want_scalars=True)
         sc = be.tohost(res["scalars"])
         if sc[4] > 0:
             raise OverflowError('math range error')
         self.last_weight_sums = (float(sc[0]), float(sc[1]), float(sc[2]))
+        if store:
+            self.weights.append(N)[:, 0] = res["weights"]
+            if self.target_values is not None:
+                self.target_values.append(N)[:, 0] = log_target
         return dict(samples=x, weights=res["weights"], origin=origin, weight_sums=self.last_weight_sums)
 
     def _get_samples(self, N, trace_sort):
@@ -163,12 +191,23 @@ class ImportanceSampler(object):
             self.last_weight_sums = None
 
 
+def _proposal_component_set(prop):
+    from ..density.mixture import MixtureDensity, component_set
+    if isinstance(prop, MixtureDensity):
+        return component_set(prop.components, prop.weights)
+    if hasattr(prop, '_component_set'):
+        return prop._component_set()
+    return None
+
+
 def combine_weights(samples, weights, proposals, backend=None):
     """Deterministic-mixture weights [Cor+12] of T importance-sampling runs with different
-    proposals (reference: importance_sampling.py:238-371).  Every q_l(x^t_n) comes from the
-    log-pdf kernel; the log-scale branch (all weights positive) reduces them with the
-    log-sum-exp kernel, the linear branch on the host.  Returns a History with one run per
-    proposal."""
+    proposals (reference: importance_sampling.py:238-371).  Every log q_l(x^t_n) comes from the
+    log-pdf kernel straight into row l of a T x N_t device matrix, and one launch of
+    ``pmc_combine_weights`` per run turns it into the combined weights (log-scale branch if all
+    weights are positive, else the linear branch).  Returns a History with one run per proposal;
+    if any of the inputs is a device tensor (e.g. ``sampler.samples.device(i)``) everything stays
+    on the GPU and the result is a DeviceHistory."""
     samples, weights = list(samples), list(weights)
     assert len(samples) == len(weights), \
         "Got %i importance-sampling runs but %i weights" % (len(samples), len(weights))
@@ -176,39 +215,44 @@ def combine_weights(samples, weights, proposals, backend=None):
         "Got %i importance-sampling runs but %i proposal densities" % (len(samples), len(proposals))
     T = len(proposals)
     counts = np.empty(T)
+    on_device = any(_on_device(a) for a in samples + weights)
     for t in range(T):
-        samples[t] = np.asarray(samples[t])
+        if not _on_device(samples[t]):
+            samples[t] = np.asarray(samples[t])
         assert samples[t].ndim == 2, '``samples[%i]`` is not matrix like.' % t
         dim = samples[0].shape[-1]
         assert samples[t].shape[-1] == dim, \
             "Dimension of samples[0] (%i) does not match the dimension of samples[%i] (%i)" \
             % (dim, t, samples[t].shape[-1])
         counts[t] = len(samples[t])
-        weights[t] = np.asarray(weights[t])
+        if not _on_device(weights[t]):
+            weights[t] = np.asarray(weights[t])
         assert counts[t] == len(weights[t]), \
             'Length of weights[%i] (%i) does not match length of samples[%i] (%i)' \
             % (t, len(weights[t]), t, counts[t])
     n_total = int(counts.sum())
-    combined = History(1, n_total)
-    use_log = all((w > 0.0).all() for w in weights)
     be = get_backend(backend)
+    combined = DeviceHistory(1, n_total, backend) if on_device else History(1, n_total)
+    use_log = all(bool((w > 0.0).all()) for w in weights)
+    nonfinite, total = 0., 0.
     for t in range(T):
-        x = np.ascontiguousarray(samples[t], dtype=np.float64)
-        q = np.empty((len(x), T))                 # log q_l(x^t_n), l = 0..T-1
+        n_t = int(counts[t])
+        x = be.asdevice(samples[t])
+        q = be.empty((T, n_t))                    # q[l, n] = log q_l(x^t_n)
+        host_x = None
         for l, prop in enumerate(proposals):
-            q[:, l] = prop.multi_evaluate(x)
-        target_run = combined.append(len(x))[:, 0]
-        if use_log:
-            # log w = log omega + log q_t + log N_total - log sum_l N_l q_l   (:337-365)
-            log_w = np.log(weights[t]) + q[:, t] + np.log(n_total)
-            log_w -= be.tohost(be.logsumexp2d(q, counts))
-            target_run[:] = np.exp(log_w)
-        else:
-            # [Cor+12] eq. (3) on the linear scale (:316-333)
-            denominator = np.exp(q).dot(counts) / n_total
-            target_run[:] = np.exp(q[:, t]) * weights[t] / denominator
+            cs = _proposal_component_set(prop)
+            if cs is not None:
+                be.logpdf(x, cs, out=q[l])
+            else:                                 # foreign density type: its own multi_evaluate
+                host_x = be.tohost(x) if host_x is None else host_x
+                q[l] = be.asdevice(prop.multi_evaluate(host_x))
+        w, flag = be.combine_weights(q, counts, t, be.asdevice(weights[t]).reshape(n_t), n_total, use_log)
+        run = combined.append(n_t)
+        run[:, 0] = w if on_device else be.tohost(w)
+        nonfinite += float(be.tohost(flag)[0])
+        total += float(be.tohost(be.weight_sums(w))[0])
     if use_log:
-        total = combined[:][:, 0].sum()
         assert total > 0, 'Sum of weights <=0 (%g)' % total
-    assert np.isfinite(combined[:][:, 0]).all(), 'Encountered inf or nan mixture weights'
+    assert nonfinite == 0, 'Encountered inf or nan mixture weights'
     return combined

@@ -687,7 +687,59 @@ def case_example_pmc(be):
     assert abs(w[0] - 0.3) < 0.05 and abs(w[1] - 0.7) < 0.05 and w[2] < 0.05
 
 
+def case_device_history(be):
+    """DeviceHistory: History's run structure (reference tools/_history.py:7-116) over backend
+    storage; indexing gives read-only host copies, ``device()`` the stored views."""
+    from pypmc_amd.tools import DeviceHistory
+    h = DeviceHistory(2, prealloc=2, backend=be)
+    assert len(h) == 0 and h[:].size == 0 and h.device() is None
+    for i in range(3):                                 # third append outgrows the preallocation
+        a = h.append(i + 1)
+        assert tuple(a.shape) == (i + 1, 2)
+        a[:] = be.asdevice(np.full((i + 1, 2), i + 1.))
+    np.testing.assert_array_equal(h[0], [[1., 1.]])
+    np.testing.assert_array_equal(h[1], [[2., 2.], [2., 2.]])
+    np.testing.assert_array_equal(h[:], np.repeat([1., 2., 2., 3., 3., 3.], 2).reshape(6, 2))
+    np.testing.assert_array_equal(h[1:], h[:][1:])
+    np.testing.assert_array_equal(h[-1], be.tohost(h.device(-1)))
+    assert len(h) == 3 and h[0] is h[0]                # the host copy is cached
+    with pytest.raises(ValueError):
+        h[0][0, 0] = 7.                                # host copies are read-only
+    h.device(0)[0, 0] = 7.                             # the device view is the store
+    h.append(1)[:] = be.asdevice(np.zeros((1, 2)))     # any change of the store drops the host cache
+    assert h[0][0, 0] == 7. and len(h) == 4
+    with pytest.raises(NotImplementedError):
+        h[::2]
+    with pytest.raises(AssertionError):
+        h.append(0)
+    h.clear()
+    assert len(h) == 0 and h.memleft == 2
+
+
+def case_combine_weights_device_inputs(be):
+    """combine_weights on device-resident runs returns a DeviceHistory with the same numbers."""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.sampler.importance_sampling import combine_weights
+    from pypmc_amd.tools import DeviceHistory, History
+    g = load_golden("combine_weights")
+    p1 = create_gaussian_mixture(g["p1_mu"], g["p1_sigma"], g["p1_weights"])
+    p2 = create_gaussian_mixture(g["p2_mu"], g["p2_sigma"], g["p2_weights"])
+    p1._backend = p2._backend = be
+    hist = combine_weights([g["s1"], g["s2"]], [g["w1"], g["w2"]], [p1, p2], backend=be)
+    assert isinstance(hist, History)
+    if type(be).__name__ != "HipBackend":
+        return                                         # numpy "device" arrays are host inputs
+    dev = [be.asdevice(g[k]) for k in ("s1", "s2", "w1", "w2", "w1_zeros")]
+    hist = combine_weights(dev[:2], dev[2:4], [p1, p2], backend=be)
+    assert isinstance(hist, DeviceHistory) and len(hist) == 2
+    assert_rel(hist[:][:, 0], g["combined_log"], what="log branch, device inputs")
+    assert_rel(be.tohost(hist.device(1))[:, 0], g["combined_log"][len(g["s1"]):], what="device view")
+    hist = combine_weights(dev[:2], [dev[4], g["w2"]], [p1, p2], backend=be)      # mixed host / device
+    assert_rel(hist[:][:, 0], g["combined_linear"], what="linear branch, device inputs")
+
+
 ALL_CASES = [case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
+             case_device_history, case_combine_weights_device_inputs,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,
              case_pmc_errors_and_fallback, case_student_t_pmc_golden]

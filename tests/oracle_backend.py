@@ -50,11 +50,15 @@ class OracleBackend(object):
         return orc.logsumexp2D(ind, w)
 
     def logpdf(self, x, comps, want_out=True, individual=None, want_individual=False,
-               max_init_zero=False, log_target=None, sample_w=None, want_scalars=False, pack=None):
+               max_init_zero=False, log_target=None, sample_w=None, want_scalars=False, pack=None,
+               out=None):
         x = self.asdevice(x)
         N = len(x)
         ind = self._individual(x, comps)
         lse = self._lse(ind, comps.weight, max_init_zero)
+        if out is not None:
+            out[:] = lse
+            lse, want_out = out, True
         if individual is None and want_individual:
             individual = np.empty((N, comps.ld))
         if individual is not None:
@@ -91,6 +95,12 @@ class OracleBackend(object):
 
     def logsumexp2d(self, a, w):
         return orc.logsumexp2D(np.asarray(a, dtype=float), np.asarray(w, dtype=float))
+
+    def combine_weights(self, q, counts, t, omega, n_total, log_scale):
+        q = np.asarray(q, dtype=float)                       # T x N here, N x T in the reference
+        with np.errstate(all='ignore'):
+            out = orc.combine_weights_run(np.ascontiguousarray(q.T), counts, t, omega, n_total, log_scale)
+        return out, np.array([float(np.count_nonzero(~np.isfinite(out)))])
 
     def estep(self, x, comps, mode, max_init_zero=False, sample_w=None, latent=None,
               want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None):

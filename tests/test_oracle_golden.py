@@ -200,3 +200,26 @@ def test_student_t_pmc_reductions(tag):
             np.testing.assert_allclose(new, g[case + "_dof"], rtol=1e-9)
         else:
             np.testing.assert_array_equal(g[case + "_dof"], dof)
+
+
+def test_combine_weights_both_branches():
+    """importance_sampling.py:238-371 — deterministic-mixture weights, log and linear branch,
+    against the reference's own output.  Same statement order; the reference exponentiates with
+    numpy's SIMD exp/log, which differ from libm's by at most 1 ulp -> 4 ulp tolerance."""
+    g = load_golden("combine_weights")
+    samples = [g["s1"], g["s2"]]
+    counts = np.array([len(s) for s in samples], dtype=np.float64)
+    n_total = counts.sum()
+
+    def q_matrix(x):
+        q = np.empty((len(x), 2))
+        for l, p in enumerate(("p1_", "p2_")):
+            q[:, l], _ = orc.mixture_multi_evaluate(0, x, g[p + "weights"], g[p + "mu"], g[p + "inv_sigma"],
+                                                    g[p + "log_norm"])
+        return q
+
+    for omegas, key, log_scale in (([g["w1"], g["w2"]], "combined_log", True),
+                                   ([g["w1_zeros"], g["w2"]], "combined_linear", False)):
+        got = np.concatenate([orc.combine_weights_run(q_matrix(samples[t]), counts, t, omegas[t], n_total, log_scale)
+                              for t in range(2)])
+        np.testing.assert_allclose(got, g[key], rtol=9e-16, atol=0)
