@@ -4,87 +4,78 @@
 // Per component k, with d = x_n - mu_k and weight u_nk (tile-major, written by k_resp):
 //     sum u | sum u d (D) | sum u d d^T (lower triangle)
 //
-// Work decomposition.  The D rows are cut into G groups of <= 10 rows (even boundaries).  The
-// lower triangle of d d^T then consists of G diagonal blocks (b(b+1)/2 elements) and G(G-1)/2
-// off-diagonal blocks (b x b), each off-diagonal block split in two row halves: G^2 "block tasks"
-// of <= 55 per-lane fp64 accumulators that need only the <= 20 coordinates of their own rows and
-// columns.  One wavefront owns one (component, block task) and streams over its chunk of samples,
-// one sample per lane and sub-step; accumulators live in VGPRs for the whole chunk and are reduced
-// across the wavefront once at the end (fixed order => deterministic).
+// Arithmetic.  The second moments are rank-1 updates of a small symmetric matrix: the lower
+// triangle is cut into 4 x 4 blocks (coordinate groups of 4) and every block is accumulated by
+// v_mfma_f64_4x4x4_4b_f64, which multiplies four independent (4 coordinates x 4 samples) by
+// (4 samples x 4 coordinates) pairs per instruction, i.e. 16 samples:
+//     A[blk][i][s] = u * d_(4I+i)   lane 16 s + 4 blk + i      (layout probed on gfx950:
+//     B[blk][s][j] =     d_(4J+j)   lane 16 s + 4 blk + j       scripts/microbench/mfma_probe.hip)
+//     C[blk][i][j]                  lane 16 i + 4 blk + j
+// A and B share one lane layout, so ONE register per coordinate group holds d for both operands,
+// and the 16 accumulators of a block live in ONE register (4 batch blocks x 16 elements over the
+// 64 lanes; the batch blocks are summed once at the end).  At D = 20 a component needs 15 block
+// accumulators + 5 + 1 for the first moments and sum u = 42 VGPRs, against 462 for one fp64
+// accumulator per lane and matrix element -- this is what lets 4 wavefronts per SIMD run where
+// the per-lane (VALU) formulation was stuck at 2 and 57 % issue utilisation.  The fp64 matrix pipe
+// has the same peak as the fp64 vector pipe on this chip; the gain is register pressure, issue
+// slots (1 instruction per 256 FMAs) and LDS traffic, not a higher roof.  87.5 % of the MFMA slots
+// carry lower-triangle elements at D = 20 (210 of 240).
+//
+// Work decomposition.  One wavefront owns one (component, block-row range) -- a single range
+// unless D > 40 -- and streams over its chunk of samples, 16 samples per sub-step; the workgroup's
+// wavefronts (different components) share the sample tile in LDS.
 //
 // Data path.  The sample tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging
-// registers, no ds_write pass, no address arithmetic in the consumer loop), double buffered, one
-// step (NS tiles) ahead of the arithmetic.  LDS image: one row of PITCH 16-byte slots per sample,
-// slot p = coordinates (2p, 2p+1); PITCH is odd (pad slot if needed), so the per-lane
-// ds_read_b128 of a coordinate pair is bank-conflict free, and every DMA instruction covers 64
-// consecutive slots whose global sources are consecutive row pieces (fully coalesced).  The
-// workgroup's wavefronts share the tile; all task groups of a sample chunk run on one XCD and
-// share its L2 copy (measured HBM traffic = algorithmic).
+// registers, no ds_write pass), double buffered, one step (NS tiles) ahead of the arithmetic.
+// LDS image: one row of PITCH 16-byte slots per sample, slot p = coordinates (2p, 2p+1), PITCH odd.
+// A sub-step's ds_read_b64 of coordinate group I fetches, per 16 lanes, 4 coordinates of 4 samples
+// that are TWO rows apart: 32 * PITCH mod 128 is 32 or 96, so the four 32-byte pieces fall into
+// different bank octets (conflict free); the sample <-> lane assignment inside a sub-step is free
+// because all 16 (batch block, s) slots are summed in the end.  All task groups of a sample chunk
+// run on one XCD and share its L2 copy (measured HBM traffic = algorithmic).
 #include "pmc_device.h"
 
 namespace {
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
-typedef double pmc_vec2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
-// compile-time blocking of the lower triangle (in units of coordinate pairs)
+// compile-time blocking of the lower triangle
 // ---------------------------------------------------------------------------------------------
-#ifndef PMC_STATS_BMAX
-#define PMC_STATS_BMAX 10
-#endif
 template <int D> struct Blocking {
     static constexpr int NP = (D + 1) / 2;                // coordinate pairs per sample
     static constexpr int PITCH = NP | 1;                  // 16-byte slots per LDS row, odd
-    static constexpr int G = (D + PMC_STATS_BMAX - 1) / PMC_STATS_BMAX;   // row groups of <= BMAX
-    static constexpr int NSUB = G * G;                    // block tasks per component
-    __host__ __device__ static constexpr int pstart(int g) { return (int)(((long long)g * NP) / G); }
-    __host__ __device__ static constexpr int start(int g) { return 2 * pstart(g) < D ? 2 * pstart(g) : D; }
+    static constexpr int ROWD = 2 * PITCH;                // doubles per LDS row
+    static constexpr int G = (D + 3) / 4;                 // coordinate groups of 4
+    static constexpr int NBLK = G * (G + 1) / 2;          // 4 x 4 blocks of the lower triangle
+    // block-row ranges per component, one wavefront each (accumulator budget: <= ~60 blocks)
+    static constexpr int NSUB = NBLK <= 60 ? 1 : (NBLK <= 90 ? 2 : 4);
+    // first block row of range s: the row whose running block count is nearest to s/NSUB of all
+    __host__ __device__ static constexpr int row0(int s)
+    {
+        if (s <= 0) return 0;
+        if (s >= NSUB) return G;
+        const int target = s * NBLK;                      // compare I(I+1)/2 * NSUB with s * NBLK
+        int best = 0, bestdiff = target;
+        for (int I = 0; I <= G; ++I) {
+            int diff = I * (I + 1) / 2 * NSUB - target;
+            if (diff < 0) diff = -diff;
+            if (diff < bestdiff) { bestdiff = diff; best = I; }
+        }
+        return best;
+    }
 };
 
-// task s -> block: s < G: diagonal block (s,s); otherwise off-diagonal (g,h), g > h, row half
-template <int D, int S> struct Task {
-    using B = Blocking<D>;
-    static constexpr bool diag = S < B::G;
-    static constexpr int pair = diag ? 0 : (S - B::G) / 2;
-    static constexpr int half = diag ? 0 : (S - B::G) % 2;
-    __host__ __device__ static constexpr int pair_g()
-    {
-        int p = pair, g = 1;
-        while (p >= g) { p -= g; ++g; }
-        return g;
-    }
-    __host__ __device__ static constexpr int pair_h()
-    {
-        int p = pair, g = 1;
-        while (p >= g) { p -= g; ++g; }
-        return p;
-    }
-    static constexpr int g = diag ? S : pair_g();
-    static constexpr int h = diag ? S : pair_h();
-    static constexpr int gr0 = B::start(g), gr1 = B::start(g + 1);
-    static constexpr int pmid = (B::pstart(g) + B::pstart(g + 1)) / 2;
-    static constexpr int mid = 2 * pmid < gr1 ? 2 * pmid : gr1;             // even split point
-    static constexpr int r0 = diag ? gr0 : (half == 0 ? gr0 : mid);        // rows [r0, r1), r0 even
-    static constexpr int r1 = diag ? gr1 : (half == 0 ? mid : gr1);
-    static constexpr int c0 = B::start(h), c1 = B::start(h + 1);            // columns [c0, c1), c0 even
-    static constexpr int NR = r1 - r0, NC = c1 - c0;
-    // first moments sum u d_i: rows of group 0 by its diagonal block, rows of group g > 0 by the
-    // two halves of block (g, 0) -- this evens out the instruction count of the tasks
-    static constexpr bool first_moments = diag ? (S == 0) : (h == 0);
-    static constexpr bool zeroth = S == B::NSUB - 1;                        // sum u (lightest task)
-};
-
-// Samples per pipeline step: NS tiles of 64 (LDS: 2 buffers of NS*64 rows of PITCH*16 bytes)
-template <int D> __host__ __device__ constexpr int stats_ns()
+// Samples per pipeline step: NS tiles of 64
+template <int D, int WAVES> __host__ __device__ constexpr int stats_ns()
 {
 #ifdef PMC_STATS_NS
     return PMC_STATS_NS;
 #else
-    return (Blocking<D>::PITCH * 16 * 64 * 4 * 2 <= 96 * 1024)
-               ? 4
-               : ((Blocking<D>::PITCH * 16 * 64 * 2 * 2 <= 96 * 1024) ? 2 : 1);
+    // x rows + the u values of the workgroup's components, two buffers, within 128 KB
+    constexpr int per_tile = Blocking<D>::PITCH * 16 * 64 + (WAVES / Blocking<D>::NSUB) * 64 * 8;
+    return (per_tile * 4 * 2 <= 128 * 1024) ? 4 : ((per_tile * 2 * 2 <= 128 * 1024) ? 2 : 1);
 #endif
 }
 
@@ -94,9 +85,8 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
 {
     using BL = Blocking<D>;
     constexpr int STRIDE = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
-    constexpr int NS = stats_ns<D>();
-    constexpr int PITCH = BL::PITCH;
-    constexpr int ROWD = PITCH * 2;                       // doubles per LDS row
+    constexpr int NS = stats_ns<D, WAVES>();
+    constexpr int PITCH = BL::PITCH, ROWD = BL::ROWD, G = BL::G;
     constexpr int BUFD = NS * 64 * ROWD;                  // doubles per LDS buffer
     constexpr int NDMA = NS * PITCH;                      // DMA instructions per step (64 slots each)
     constexpr int DMA_PER_WAVE = (NDMA + WAVES - 1) / WAVES;
@@ -106,22 +96,57 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     constexpr int DMA_SLICES = NS >= 4 ? NS / 2 : 1;
 #endif
     constexpr bool ACTIVE = SUB >= 0;
-    using TK = Task<D, ACTIVE ? SUB : 0>;
+    constexpr int S_ = ACTIVE ? SUB : 0;
+    constexpr int I0 = BL::row0(S_), I1 = BL::row0(S_ + 1);   // block rows [I0, I1) of this task
+    constexpr int NROW = I1 - I0;
+    constexpr int NACC = I1 * (I1 + 1) / 2 - I0 * (I0 + 1) / 2;
+    static_assert(NROW >= 1, "empty block-row range");
+    // coordinate groups that may hold coordinates >= dreal (zero padding) or the array's very last
+    // element (odd dreal, see `dma`).  Exact units: the last group if D % 4 != 0.  Padded units serve
+    // prev < dreal < D with prev >= 3D/4: every group reaching beyond floor(3D/4).
+    constexpr int SPECIAL_FROM = PADDED ? (3 * D / 4) / 4 : (D % 4 != 0 ? G - 1 : G);
+    constexpr int NSPECIAL = I1 > SPECIAL_FROM ? I1 - SPECIAL_FROM : 0;
     const int lane = threadIdx.x & 63;
     const int dreal = PADDED ? b.dreal : D;
     const int npr = (dreal + 1) / 2;                      // pairs that carry data
     const long long total = b.N * (long long)dreal;
 
+    // lane -> (sample within the 16-sample sub-step, coordinate within the group)
+    const int ci = lane & 3, blk = (lane >> 2) & 3, ks = lane >> 4;
+    const int srow = 2 * blk + (ks & 1) + 8 * (ks >> 1);
+
     double acc0 = 0.0;
-    double acc1[TK::NR];
-    double acc2[TK::NR][TK::NC];
+    double acc1[NROW];
+    double acc2[NACC];
 #pragma unroll
-    for (int i = 0; i < TK::NR; ++i) {
-        acc1[i] = 0.0;
+    for (int i = 0; i < NROW; ++i) acc1[i] = 0.0;
 #pragma unroll
-        for (int j = 0; j < TK::NC; ++j) acc2[i][j] = 0.0;
+    for (int i = 0; i < NACC; ++i) acc2[i] = 0.0;
+
+    // this lane's slice of the component mean (ordinary global loads, once)
+    double mu[I1];
+    {
+        const double *pk = b.pack + (size_t)(ACTIVE ? k : 0) * STRIDE;
+#pragma unroll
+        for (int I = 0; I < I1; ++I) {
+            const int c = 4 * I + ci;
+            mu[I] = (ACTIVE && c < D) ? pk[c < D ? c : 0] : 0.0;
+        }
     }
-    cdouble *pk = (cdouble *)b.pack + (size_t)(ACTIVE ? k : 0) * STRIDE;
+    // special groups: per-lane column (clamped into the LDS row), validity, and the odd-dreal
+    // quirk of the array's very last sample: its last coordinate sits one element late in its slot,
+    // because that DMA piece was fetched one element early (see `dma`)
+    int scol[NSPECIAL > 0 ? NSPECIAL : 1], sfix[NSPECIAL > 0 ? NSPECIAL : 1];
+    double svalid[NSPECIAL > 0 ? NSPECIAL : 1];           // 1.0 / 0.0: coordinate < dreal
+    const long long lasttile = (b.N - 1) >> 6;            // wave-uniform position of sample N-1
+    const int lastss = (int)((b.N - 1) & 63) >> 4, lastrow = (int)((b.N - 1) & 15);
+#pragma unroll
+    for (int i = 0; i < NSPECIAL; ++i) {
+        const int c = 4 * (SPECIAL_FROM + i) + ci;
+        scol[i] = c < ROWD - 1 ? c : ROWD - 1;
+        svalid[i] = c < dreal ? 1.0 : 0.0;
+        sfix[i] = ((dreal % 2 == 1) && c == dreal - 1 && srow == lastrow) ? 1 : 0;
+    }
 
     // slot -> (sample row, pair) of this lane's DMA pieces: independent of the step
     unsigned dma_off[DMA_PER_WAVE];                       // double offset within the step's samples
@@ -134,9 +159,9 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     }
     // HBM -> LDS for the NS tiles starting at tile t (clamped into the array: a clamped slot belongs
     // to a sample whose weight is zero, except the odd-D last-row case handled by the consumer)
-    // (slice `part` of `nparts`: the instructions are spread over the sub-steps of the arithmetic --
-    // 8 wavefronts x 10 vector-memory instructions issued back to back after a barrier fill the
-    // memory pipeline's issue queue and stall every wavefront in front of its arithmetic)
+    // (slice `part` of `nparts`: the instructions are spread over the tiles of the arithmetic -- a
+    // workgroup's vector-memory instructions issued back to back after a barrier fill the memory
+    // pipeline's issue queue and stall every wavefront in front of its arithmetic)
     auto dma = [&](long long t, double *buf, int part, int nparts) {
         const long long tt = t < t1 ? t : t0;
         const double *__restrict__ xt = b.x + tt * 64 * dreal;               // wave-uniform
@@ -155,16 +180,16 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     };
 
     // The weights u of the workgroup's components (a contiguous range of k in the tile-major
-    // buffer) take the same route: one 1-KiB DMA piece covers two components of one tile, and the
-    // block tasks of a component share it instead of each loading its own copy.
+    // buffer) take the same route: one 1-KiB DMA piece covers two components of one tile.
     constexpr int NSUBC = BL::NSUB;
-    constexpr int UCOMP = (WAVES + NSUBC - 1) / NSUBC + 1;           // components a workgroup can touch
+    static_assert(WAVES % NSUBC == 0, "block-row ranges must divide the workgroup");
+    constexpr int UCOMP = WAVES / NSUBC;                              // components of a workgroup
     constexpr int UPIECES = (UCOMP * 64 * 8 + 1023) / 1024;          // 1-KiB pieces per tile
     constexpr int UTILE = UPIECES * 128;                              // doubles per tile in LDS
     constexpr int NUDMA = NS * UPIECES;
     constexpr int UDMA_PER_WAVE = (NUDMA + WAVES - 1) / WAVES;
     double *us = xs + 2 * BUFD;                                       // 2 buffers of NS * UTILE
-    const int kmin = (int)(((long long)blockIdx.x >> 3) % b.ngroups) * WAVES / NSUBC;   // first k of the group
+    const int kmin = (int)(((long long)blockIdx.x >> 3) % b.ngroups) * UCOMP;   // first k of the group
     const long long ulen = b.ntiles * (long long)b.K * 64;            // doubles in the u buffer
     auto dma_u = [&](long long t, double *ubuf, int part, int nparts) {
 #pragma unroll
@@ -191,8 +216,15 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     __syncthreads();
     int buf = 0;
     for (long long t = t0; t < t1; t += NS, buf ^= 1) {
-        const double *xb = xs + buf * BUFD;
-        const double *ub = us + buf * (NS * UTILE) + (size_t)(ACTIVE ? k - kmin : 0) * 64 + lane;
+        const double *xb = xs + buf * BUFD + (size_t)srow * ROWD;     // + this lane's sample row
+        // special groups: per-lane bases, so that every sub-step's read is base + immediate offset
+        const double *xsp[NSPECIAL > 0 ? NSPECIAL : 1], *xspfix[NSPECIAL > 0 ? NSPECIAL : 1];
+#pragma unroll
+        for (int i = 0; i < NSPECIAL; ++i) {
+            xsp[i] = xb + scol[i];
+            xspfix[i] = xsp[i] + sfix[i];
+        }
+        const double *ub = us + buf * (NS * UTILE) + (size_t)(ACTIVE ? k - kmin : 0) * 64 + srow;
         if constexpr (!ACTIVE) {
             dma(t + NS, xs + (buf ^ 1) * BUFD, 0, 1);
             dma_u(t + NS, us + (buf ^ 1) * (NS * UTILE), 0, 1);
@@ -200,52 +232,47 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
         if constexpr (ACTIVE) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                // issue the next step's DMA in the first DMA_SLICES sub-steps only: the barrier at the
+                // issue the next step's DMA in the first DMA_SLICES tiles only: the barrier at the
                 // end of the step waits for it (vmcnt(0)), so the last slice needs time to land
                 if (q < DMA_SLICES) {
                     dma(t + NS, xs + (buf ^ 1) * BUFD, q, DMA_SLICES);
                     dma_u(t + NS, us + (buf ^ 1) * (NS * UTILE), q, DMA_SLICES);
                 }
-
-                const double uraw = ub[q * UTILE];
-                double u = (t + q < t1) ? uraw : 0.0;          // zero weight beyond the chunk
-                // Fence: the arithmetic of this sub-step depends on `u` and so stays behind this
-                // statement, and no LDS read of a LATER sub-step may move above it ("memory").
-                // Without it all NS sub-steps' reads are issued up front (NS x (rows+cols) live
-                // registers: spills and shuffling moves); with it at most two sub-steps overlap.
-                asm volatile("" : "+v"(u) : : "memory");
-                if constexpr (TK::zeroth) acc0 += u;
-                const pmc_vec2 *xl = (const pmc_vec2 *)(xb + (size_t)(q * 64 + lane) * ROWD);
-                // odd D: the pair holding coordinate D-1 of the array's LAST sample was fetched one
-                // element early (its second half would lie outside the array)
-                const bool lastrow = (D % 2 == 1 || PADDED) && (dreal % 2 == 1) &&
-                                     ((t + q) * 64 + lane == b.N - 1);
-                auto coord = [&](int j) -> double {       // x_j of this lane's sample
-                    const pmc_vec2 v = xl[j / 2];
-                    double val = (j % 2 == 0) ? v.x : v.y;
-                    if ((D % 2 == 1 || PADDED) && j % 2 == 0) {
-                        if (lastrow && j == dreal - 1) val = v.y;
+                const bool live = t + q < t1;                  // tiles beyond the chunk carry no weight
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) {               // 16 samples per sub-step
+                    const double *xr = xb + (size_t)(q * 64 + ss * 16) * ROWD;
+                    const double uraw = ub[q * UTILE + ss * 16];
+                    double u = live ? uraw : 0.0;
+                    // Fence: the arithmetic of this sub-step depends on `u` and so stays behind this
+                    // statement, and no LDS read of a LATER sub-step may move above it ("memory").
+                    // Without it every sub-step's reads are issued up front (registers, spills).
+                    asm volatile("" : "+v"(u) : : "memory");
+                    const bool fixnow = (D % 2 == 1 || PADDED) && (t + q == lasttile) && (ss == lastss);
+                    double d[I1];
+#pragma unroll
+                    for (int I = 0; I < I1; ++I) {
+                        if (I < SPECIAL_FROM) {
+                            d[I] = xr[4 * I + ci] - mu[I];
+                        } else {
+                            const int i = I - SPECIAL_FROM;
+                            const double *xp = fixnow ? xspfix[i] : xsp[i];
+                            const double v = xp[(q * 64 + ss * 16) * ROWD];
+                            // padding coordinates: whatever finite value the slot holds, times 0
+                            // (a select here makes the compiler keep every sub-step's operands live)
+                            d[I] = (v - mu[I]) * svalid[i];
+                        }
                     }
-                    if (PADDED && j >= dreal) val = 0.0;
-                    return val;
-                };
-                double dr[TK::NR], dc[TK::NC];
+                    if constexpr (SUB == 0) acc0 += u;
+                    int a = 0;
 #pragma unroll
-                for (int i = 0; i < TK::NR; ++i) dr[i] = coord(TK::r0 + i) - pk[TK::r0 + i];
-                if constexpr (TK::diag) {
+                    for (int I = I0; I < I1; ++I) {
+                        const double ud = u * d[I];
+                        acc1[I - I0] += ud;
 #pragma unroll
-                    for (int j = 0; j < TK::NC; ++j) dc[j] = dr[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < TK::NC; ++j) dc[j] = coord(TK::c0 + j) - pk[TK::c0 + j];
-                }
-#pragma unroll
-                for (int i = 0; i < TK::NR; ++i) {
-                    const double ud = u * dr[i];
-                    if constexpr (TK::first_moments) acc1[i] += ud;
-#pragma unroll
-                    for (int j = 0; j < TK::NC; ++j)
-                        if (!TK::diag || j <= i) acc2[i][j] = fma(ud, dc[j], acc2[i][j]);
+                        for (int J = 0; J <= I; ++J, ++a)
+                            acc2[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(ud, d[J], acc2[a], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -253,25 +280,32 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     }
 
     if constexpr (ACTIVE) {
+        // accumulator lane layouts: acc2 -- lane 16 i + 4 blk + j; acc0 / acc1 -- per (sample, ci)
         double *out = b.partials + ((size_t)chunk * b.K + k) * PS;
-        if constexpr (TK::zeroth) {
-            const double s0 = wave_sum(acc0);
+        if constexpr (SUB == 0) {
+            double s0 = acc0;                              // every sample appears in 4 lanes (ci)
+            s0 += __shfl_xor(s0, 4, 64);
+            s0 += __shfl_xor(s0, 8, 64);
+            s0 += __shfl_xor(s0, 16, 64);
+            s0 += __shfl_xor(s0, 32, 64);
             if (lane == 0) out[0] = s0;
         }
+        int a = 0;
 #pragma unroll
-        for (int i = 0; i < TK::NR; ++i) {
-            const int gi = TK::r0 + i;
-            if constexpr (TK::first_moments) {
-                const double s = wave_sum(acc1[i]);
-                if (lane == 0) out[1 + gi] = s;
-            }
+        for (int I = I0; I < I1; ++I) {
+            double m = acc1[I - I0];
+            m += __shfl_xor(m, 4, 64);
+            m += __shfl_xor(m, 8, 64);
+            m += __shfl_xor(m, 16, 64);
+            m += __shfl_xor(m, 32, 64);
+            if (lane < 4 && 4 * I + lane < D) out[1 + 4 * I + lane] = m;
 #pragma unroll
-            for (int j = 0; j < TK::NC; ++j) {
-                if (!TK::diag || j <= i) {
-                    const int gj = TK::c0 + j;
-                    const double q = wave_sum(acc2[i][j]);
-                    if (lane == 0) out[1 + D + gi * (gi + 1) / 2 + gj] = q;
-                }
+            for (int J = 0; J <= I; ++J, ++a) {
+                double v = acc2[a];
+                v += __shfl_xor(v, 4, 64);                 // sum of the 4 batch blocks
+                v += __shfl_xor(v, 8, 64);
+                const int gi = 4 * I + (lane >> 4), gj = 4 * J + (lane & 3);
+                if (blk == 0 && gj <= gi && gi < D) out[1 + D + gi * (gi + 1) / 2 + gj] = v;
             }
         }
     }
@@ -313,7 +347,8 @@ constexpr int NSUB_ = Blocking<D_>::NSUB;
 #ifdef PMC_STATS_WAVES                                     // tuning override (scripts/tune_stats.sh)
 constexpr int SW_ = PMC_STATS_WAVES;
 #else
-constexpr int SW_ = 8;                                   // wavefronts per statistics workgroup
+// wavefronts per statistics workgroup: 4 per SIMD while a task's registers fit 128 VGPRs
+constexpr int SW_ = Blocking<D_>::G <= 6 ? 16 : 8;
 #endif
 
 }  // namespace
@@ -328,9 +363,10 @@ extern "C" void PMC_UNIT_NAME_X(pmc_stats_config_d, PMC_D, PMC_PADDED)(int *nsub
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_stats_d, PMC_D, PMC_PADDED)(const PmcArgsB &b, unsigned grid,
                                                                             hipStream_t st)
 {
-    constexpr int ucomp = (SW_ + NSUB_ - 1) / NSUB_ + 1;
-    constexpr size_t lds = sizeof(double) * 2 * stats_ns<D_>() *
+    constexpr int ucomp = SW_ / NSUB_;
+    constexpr size_t lds = sizeof(double) * 2 * stats_ns<D_, SW_>() *
                            (64 * Blocking<D_>::PITCH * 2 + ((ucomp * 64 * 8 + 1023) / 1024) * 128);
+    static_assert(lds <= 160 * 1024, "statistics tile buffers exceed the LDS");
     if constexpr (lds > 65536) {
         static const hipError_t once = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&k_stats<D_, P_, SW_>),
