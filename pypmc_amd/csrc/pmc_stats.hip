@@ -230,51 +230,71 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
             dma_u(t + NS, us + (buf ^ 1) * (NS * UTILE), 0, 1);
         }
         if constexpr (ACTIVE) {
+            // Sub-steps of 16 samples; the LDS reads of sub-step s+1 are issued before the arithmetic
+            // of sub-step s (register double buffer), so their latency hides behind ~15 MFMAs.  Only
+            // the first sub-step after the barrier waits for its operands.
+            constexpr int NSUBSTEP = NS * 4;
+            double xc[I1], xn[I1], uc, un = 0.0;
+            auto fetch = [&](auto S, double (&xx)[I1], double &uu) {
+                constexpr int s = decltype(S)::value, q = s / 4, ss = s % 4;
+                constexpr int ROW = (q * 64 + ss * 16) * ROWD;
+                uu = ub[q * UTILE + ss * 16];
+                const bool fixnow = (D % 2 == 1 || PADDED) && (t + q == lasttile) && (ss == lastss);
 #pragma unroll
-            for (int q = 0; q < NS; ++q) {
+                for (int I = 0; I < I1; ++I) {
+                    if (I < SPECIAL_FROM) {
+                        xx[I] = xb[ROW + 4 * I + ci];
+                    } else {
+                        const double *xp = fixnow ? xspfix[I - SPECIAL_FROM] : xsp[I - SPECIAL_FROM];
+                        xx[I] = xp[ROW];
+                    }
+                }
+            };
+            fetch(std::integral_constant<int, 0>{}, xc, uc);
+            static_for<0, NSUBSTEP>([&](auto S) {
+                constexpr int s = decltype(S)::value, q = s / 4;
                 // issue the next step's DMA in the first DMA_SLICES tiles only: the barrier at the
                 // end of the step waits for it (vmcnt(0)), so the last slice needs time to land
-                if (q < DMA_SLICES) {
+                if constexpr (s % 4 == 0 && q < DMA_SLICES) {
                     dma(t + NS, xs + (buf ^ 1) * BUFD, q, DMA_SLICES);
                     dma_u(t + NS, us + (buf ^ 1) * (NS * UTILE), q, DMA_SLICES);
                 }
-                const bool live = t + q < t1;                  // tiles beyond the chunk carry no weight
+                // Scheduling fences (no instructions).  The first pins this point behind the previous
+                // sub-step's arithmetic; the next ones make this sub-step's operands "appear" here, so
+                // nothing that consumes them is hoisted to right behind their loads (which would wait
+                // for the LDS in front of the previous sub-step's MFMAs); the last one -- on the weight
+                // every product below depends on -- keeps the prefetch of sub-step s+1 in front of the
+                // arithmetic of sub-step s.
 #pragma unroll
-                for (int ss = 0; ss < 4; ++ss) {               // 16 samples per sub-step
-                    const double *xr = xb + (size_t)(q * 64 + ss * 16) * ROWD;
-                    const double uraw = ub[q * UTILE + ss * 16];
-                    double u = live ? uraw : 0.0;
-                    // Fence: the arithmetic of this sub-step depends on `u` and so stays behind this
-                    // statement, and no LDS read of a LATER sub-step may move above it ("memory").
-                    // Without it every sub-step's reads are issued up front (registers, spills).
-                    asm volatile("" : "+v"(u) : : "memory");
-                    const bool fixnow = (D % 2 == 1 || PADDED) && (t + q == lasttile) && (ss == lastss);
-                    double d[I1];
+                for (int i = 0; i < NACC; ++i) asm volatile("" : "+v"(acc2[i]) : : "memory");
 #pragma unroll
-                    for (int I = 0; I < I1; ++I) {
-                        if (I < SPECIAL_FROM) {
-                            d[I] = xr[4 * I + ci] - mu[I];
-                        } else {
-                            const int i = I - SPECIAL_FROM;
-                            const double *xp = fixnow ? xspfix[i] : xsp[i];
-                            const double v = xp[(q * 64 + ss * 16) * ROWD];
-                            // padding coordinates: whatever finite value the slot holds, times 0
-                            // (a select here makes the compiler keep every sub-step's operands live)
-                            d[I] = (v - mu[I]) * svalid[i];
-                        }
-                    }
-                    if constexpr (SUB == 0) acc0 += u;
-                    int a = 0;
+                for (int I = 0; I < I1; ++I) asm volatile("" : "+v"(xc[I]));
+                if constexpr (s + 1 < NSUBSTEP) fetch(std::integral_constant<int, s + 1>{}, xn, un);
+                asm volatile("" : "+v"(uc) : : "memory");       // every MFMA below depends on uc
+                const double u = (t + q < t1) ? uc : 0.0;       // tiles beyond the chunk: no weight
+                double d[I1];
 #pragma unroll
-                    for (int I = I0; I < I1; ++I) {
-                        const double ud = u * d[I];
-                        acc1[I - I0] += ud;
-#pragma unroll
-                        for (int J = 0; J <= I; ++J, ++a)
-                            acc2[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(ud, d[J], acc2[a], 0, 0, 0);
-                    }
+                for (int I = 0; I < I1; ++I) {
+                    // padding coordinates: whatever finite value the slot holds, times 0 (a select
+                    // here makes the compiler keep every sub-step's operands live)
+                    d[I] = I < SPECIAL_FROM ? xc[I] - mu[I] : (xc[I] - mu[I]) * svalid[I - SPECIAL_FROM];
                 }
-            }
+                if constexpr (SUB == 0) acc0 += u;
+                int a = 0;
+#pragma unroll
+                for (int I = I0; I < I1; ++I) {
+                    const double ud = u * d[I];
+                    acc1[I - I0] += ud;
+#pragma unroll
+                    for (int J = 0; J <= I; ++J, ++a)
+                        acc2[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(ud, d[J], acc2[a], 0, 0, 0);
+                }
+                if constexpr (s + 1 < NSUBSTEP) {
+#pragma unroll
+                    for (int I = 0; I < I1; ++I) xc[I] = xn[I];
+                    uc = un;
+                }
+            });
         }
         __syncthreads();
     }
