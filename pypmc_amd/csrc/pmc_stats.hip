@@ -50,7 +50,10 @@ template <int D> struct Blocking {
     static constexpr int G = (D + 3) / 4;                 // coordinate groups of 4
     static constexpr int NBLK = G * (G + 1) / 2;          // 4 x 4 blocks of the lower triangle
     // block-row ranges per component, one wavefront each (accumulator budget: <= ~60 blocks)
-    static constexpr int NSUB = NBLK <= 60 ? 1 : (NBLK <= 90 ? 2 : 4);
+#ifndef PMC_STATS_MAXBLK
+#define PMC_STATS_MAXBLK 50
+#endif
+    static constexpr int NSUB = NBLK <= PMC_STATS_MAXBLK ? 1 : (NBLK <= 90 ? 2 : 4);
     // first block row of range s: the row whose running block count is nearest to s/NSUB of all
     __host__ __device__ static constexpr int row0(int s)
     {
@@ -367,8 +370,10 @@ constexpr int NSUB_ = Blocking<D_>::NSUB;
 #ifdef PMC_STATS_WAVES                                     // tuning override (scripts/tune_stats.sh)
 constexpr int SW_ = PMC_STATS_WAVES;
 #else
-// wavefronts per statistics workgroup: 4 per SIMD while a task's registers fit 128 VGPRs
-constexpr int SW_ = Blocking<D_>::G <= 6 ? 16 : 8;
+// wavefronts per statistics workgroup: 16 (4 per SIMD) while a task fits 128 VGPRs under that
+// launch bound, else 8 -- two such workgroups still share a CU when registers and LDS allow
+// (measured at D = 24: 8 -> 1.68 ms, 12 -> 2.68 ms, 16 (spills) -> 2.47 ms per 4e6 samples, K = 32)
+constexpr int SW_ = Blocking<D_>::G <= 5 ? 16 : 8;
 #endif
 
 }  // namespace
