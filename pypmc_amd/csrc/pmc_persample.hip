@@ -68,9 +68,19 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_logpdf(const PmcArgsA a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_resp: responsibilities in tile-major layout.  Pass 1 = a_nk (+ streaming log-sum-exp),
-// parked in the output buffer itself; pass 2 = normalisation.  A lane re-reads only what it
-// wrote, so no synchronisation is needed between the passes.
+// k_resp: responsibilities in tile-major layout.  Pass 1 = a_nk + streaming log-sum-exp; pass 2 =
+// normalisation.  Between the passes one double per (sample, component) is parked in the output
+// buffer itself (a lane re-reads only what it wrote: no synchronisation).
+//
+// What is parked is the ONE exponential the streaming log-sum-exp computes per step anyway:
+//     a_k <= m:  e_k = exp(a_k - m)           (the term added to s)          parked as  +e_k
+//     a_k >  m:  f_k = exp(m - a_k), m := a_k (the factor rescaling s)       parked as  -f_k
+// so exp(a_k - m_final) = (e_k or 1) * prod_{j > k, j a new maximum} f_j, and pass 2 -- walking the
+// components downwards with the running product -- needs no second exp per pair: ~10 instead of
+// ~45 vector instructions.  sum_k r_k a_k for E[log q(Z)] is carried through pass 1 like s.
+// This is the VB E-step's path.  a_k itself is parked, and pass 2 evaluates the reference's
+// expressions literally, when the caller wants the N x K matrix log_rho (materialised on demand,
+// never in the E-step itself) and for the PMC kinds (see `literal` below).
 // ---------------------------------------------------------------------------------------------
 template <int D, bool PADDED, int KIND>
 __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
@@ -93,14 +103,18 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
         double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)tile * K * 2 : nullptr;
 
         // ---- pass 1
-        double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0;
+        // wave-uniform: park a_k itself.  The PMC kinds always do: the reference's rho =
+        // exp(log q_k) w_k / (exp(lse) + tiny) underflows to 0 where log q_k < -745 although the ratio
+        // is representable, and parity with it needs exp(a_k) itself; VB's r is relative to the row
+        // maximum in the reference too, so the product form agrees to rounding.
+        const bool literal = KIND != PMC_KIND_VB || a.log_rho != nullptr;
+        double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0, ta = 0.0;
         cdouble *pk = (cdouble *)a.pack;
         for (int k = 0; k < K; ++k, pk += STRIDE) {
             touch_component<D>(pk);
             const double maha = mahalanobis<D>(xv, pk);
             double expo = 0.0;
             const double v = component_value<D, KIND>(maha, pk + D + T, expo);
-            ut[(size_t)k * 64] = v;
             if constexpr (KIND == PMC_KIND_STUDENT_T) mt[(size_t)k * 64] = maha;
             if constexpr (KIND == PMC_KIND_VB) {
                 if (a.exponent != nullptr) {
@@ -108,31 +122,55 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
                     if (valid) a.exponent[n * a.ld + col] = expo;
                 }
             }
-            lse_step(v, pk[D + T + 4], m, s);
+            // streaming log-sum-exp (lse_step) with its exponential kept
+            const double e = exp(-fabs(v - m));
+            const bool gt = v > m;
+            const double w = pk[D + T + 4];
+            s = gt ? fma(s, e, w) : fma(w, e, s);
+            if constexpr (KIND == PMC_KIND_VB) ta = gt ? fma(ta, e, v) : fma(e, v, ta);   // sum e_k a_k
+            m = gt ? v : m;
+            ut[(size_t)k * 64] = literal ? v : (gt ? -e : e);
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
 
-        // ---- pass 2
-        pk = (cdouble *)a.pack;
+        // ---- pass 2, components in DESCENDING order: the values parked last are re-read first, while
+        // they are still in L2, and are overwritten there before their first write-back
+        pk = (cdouble *)a.pack + (size_t)(K - 1) * STRIDE;
         if constexpr (KIND == PMC_KIND_VB) {
             // variational.pyx:741-755: r = exp(log_rho - max) / norm, zeros -> tiny,
             // log_rho += log(1/norm)
             const double norm_inv = 1. / s;
             const double log_norm_inv = log(norm_inv);
             double elq = 0.0;
-            for (int k = 0; k < K; ++k, pk += STRIDE) {
-                double lr = ut[(size_t)k * 64] - m;
-                double r = exp(lr);
-                r *= norm_inv;
-                if (r == 0.0) r = TINY;
-                lr += log_norm_inv;
-                elq += r * lr;                            // variational.pyx:1003-1013
-                ut[(size_t)k * 64] = valid ? sw * r : 0.0;
-                if (a.r != nullptr || a.log_rho != nullptr) {
+            if (literal) {
+                for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
+                    double lr = ut[(size_t)k * 64] - m;
+                    double r = exp(lr);
+                    r *= norm_inv;
+                    if (r == 0.0) r = TINY;
+                    lr += log_norm_inv;
+                    elq += r * lr;                        // variational.pyx:1003-1013
+                    ut[(size_t)k * 64] = valid ? sw * r : 0.0;
                     const long long col = ((cint64 *)pk)[D + T + 5];
                     if (valid && a.r != nullptr) a.r[n * a.ld + col] = r;
-                    if (valid && a.log_rho != nullptr) a.log_rho[n * a.ld + col] = lr;
+                    if (valid) a.log_rho[n * a.ld + col] = lr;
                 }
+            } else {
+                double c = norm_inv;                      // norm_inv * prod of the f_j above k
+                for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
+                    const double p = ut[(size_t)k * 64];
+                    const bool newmax = __double2hiint(p) < 0;      // sign bit (f may be -0.0)
+                    double r = (newmax ? 1.0 : p) * c;
+                    c = newmax ? c * -p : c;
+                    if (r == 0.0) r = TINY;
+                    ut[(size_t)k * 64] = valid ? sw * r : 0.0;
+                    if (a.r != nullptr) {
+                        const long long col = ((cint64 *)pk)[D + T + 5];
+                        if (valid) a.r[n * a.ld + col] = r;
+                    }
+                }
+                // sum_k r_k (a_k - m + log norm_inv) with sum_k r_k = 1   (variational.pyx:1003-1013)
+                elq = ta * norm_inv - m + log_norm_inv;
             }
             if (valid) sc[0] = sw * elq;
         } else {
@@ -140,7 +178,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
             const double lse = log(s) + m;
             const double denom = exp(lse) + TINY;
             const long long lat = (a.mode == PMC_RESP_PMC_LATENT && valid) ? a.latent[n] : -1;
-            for (int k = 0; k < K; ++k, pk += STRIDE) {
+            for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
                 cdouble *c = pk + D + T;
                 const long long col = ((cint64 *)pk)[D + T + 5];
                 double rho;

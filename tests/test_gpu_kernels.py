@@ -232,9 +232,16 @@ def test_vb_estep_vs_oracle(be, orc, D, K, N, weighted):
     np.testing.assert_allclose(x_mean[live], ref["x_mean_comp"][live], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(S[live], ref["S"][live], rtol=1e-8, atol=1e-10)
     assert abs(sc[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-11
+    # the E-step proper (no N x K matrices requested) normalises with the product form of the
+    # streaming log-sum-exp instead of a second exp per pair: same statistics to rounding, the same r
+    res2 = be.estep(x, cs, 0, sample_w=sw, want_r=True)
+    assert_rel(be.tohost(res2["r"]), ref["r"], what="r (product form)")
+    np.testing.assert_allclose(be.tohost(res2["stats"]), be.tohost(res["stats"]), rtol=1e-12, atol=1e-13)
+    sc2 = split_stats(be.tohost(res2["stats"]), K, D)[0]
+    assert abs(sc2[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-11
     # determinism: a second launch gives bitwise the same statistics
-    res2 = be.estep(x, cs, 0, sample_w=sw)
-    np.testing.assert_array_equal(be.tohost(res2["stats"]), be.tohost(res["stats"]))
+    res3 = be.estep(x, cs, 0, sample_w=sw)
+    np.testing.assert_array_equal(be.tohost(res3["stats"]), be.tohost(res2["stats"]))
 
 
 @pytest.mark.parametrize("tag", ["d2k3", "d5k4"])
