@@ -267,8 +267,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": measured_traffic(dominant, N),
-                         "note": "fp64 VALU (v_fma_f64) kernel priced against the fp64 matrix peak, which equals "
-                                 "the fp64 vector peak on MI355X; flops = SURVEY 8(d) per-sample figure x N",
+                         "note": "fp64 kernel (v_fma_f64; pmc_sufficient_stats: v_mfma_f64_4x4x4) priced against "
+                                 "the fp64 matrix peak, which equals the fp64 vector peak on MI355X; flops = "
+                                 "SURVEY 8(d) per-sample figure x N",
                          "algorithmic_bytes": alg_bytes[dominant],
                          "per_kernel_tflops": {k_: flops[k_] / (v * 1e-3) * 1e-12 for k_, v in kern.items()},
                          "hbm": {"achieved": alg_bytes[dominant] / (kern[dominant] * 1e-3) * 1e-9,
