@@ -6,6 +6,9 @@
 constexpr int PMC_TILE = 64;       // samples per tile = one wavefront
 constexpr int PMC_NSCALARS = 8;    // per-launch scalar reductions
 constexpr int PMC_A_WAVES = 4;     // wavefronts (tiles) per workgroup in the per-sample kernels
+// k_resp parks the first min(K, 16) components in LDS between its passes: 8 KB per wavefront, so
+// 16 wavefronts per CU (4 per SIMD, the register-limited occupancy) still fit in 160 KB
+constexpr int PMC_RESP_KLDS = 16;
 
 __host__ __device__ constexpr int pmc_tri(int D) { return D * (D + 1) / 2; }
 __host__ __device__ constexpr int pmc_pack_stride_c(int D) { return (D + pmc_tri(D) + 6 + 7) & ~7; }
@@ -20,6 +23,7 @@ struct PmcArgsA {
     int K;
     int max_init_zero;
     int mode;             // pmc_resp_mode (responsibility kernels)
+    int klds;             // responsibility kernels: components parked in LDS between the passes
     long long ld;
     double *out;
     double *individual;

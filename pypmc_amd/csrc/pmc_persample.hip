@@ -82,6 +82,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_logpdf(const PmcArgsA a)
 // expressions literally, when the caller wants the N x K matrix log_rho (materialised on demand,
 // never in the E-step itself) and for the PMC kinds (see `literal` below).
 // ---------------------------------------------------------------------------------------------
+extern __shared__ double resp_park[];                     // PMC_A_WAVES x klds x 64 doubles
+
 template <int D, bool PADDED, int KIND>
 __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
 {
@@ -99,6 +101,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
         double xv[D];
         load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
         double *ut = a.u + (size_t)tile * K * 64 + lane;
+        // parking place between the passes: LDS for the first klds components (the ones pass 2, which
+        // walks downwards, would find evicted from L2), the output buffer itself for the rest
+        const int klds = a.klds;
+        double *pl = resp_park + (size_t)(threadIdx.x >> 6) * klds * 64 + lane;
         double *mt = (KIND == PMC_KIND_STUDENT_T) ? a.scratch + (size_t)tile * K * 64 + lane : nullptr;
         double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)tile * K * 2 : nullptr;
 
@@ -129,7 +135,9 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
             s = gt ? fma(s, e, w) : fma(w, e, s);
             if constexpr (KIND == PMC_KIND_VB) ta = gt ? fma(ta, e, v) : fma(e, v, ta);   // sum e_k a_k
             m = gt ? v : m;
-            ut[(size_t)k * 64] = literal ? v : (gt ? -e : e);
+            const double parked = literal ? v : (gt ? -e : e);
+            if (k < klds) pl[k * 64] = parked;            // wave-uniform branch
+            else ut[(size_t)k * 64] = parked;
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
 
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
             double elq = 0.0;
             if (literal) {
                 for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
-                    double lr = ut[(size_t)k * 64] - m;
+                    double lr = (k < klds ? pl[k * 64] : ut[(size_t)k * 64]) - m;
                     double r = exp(lr);
                     r *= norm_inv;
                     if (r == 0.0) r = TINY;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
             } else {
                 double c = norm_inv;                      // norm_inv * prod of the f_j above k
                 for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
-                    const double p = ut[(size_t)k * 64];
+                    const double p = k < klds ? pl[k * 64] : ut[(size_t)k * 64];
                     const bool newmax = __double2hiint(p) < 0;      // sign bit (f may be -0.0)
                     double r = (newmax ? 1.0 : p) * c;
                     c = newmax ? c * -p : c;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
                 if (a.mode == PMC_RESP_PMC_LATENT) {
                     rho = (lat == col) ? 1. : 0.;         // pmc.pyx:49-50
                 } else {
-                    rho = exp(ut[(size_t)k * 64]) * c[4];
+                    rho = exp(k < klds ? pl[k * 64] : ut[(size_t)k * 64]) * c[4];
                     rho /= denom;
                 }
                 if (valid && a.r != nullptr) a.r[n * a.ld + col] = rho;
@@ -220,7 +228,8 @@ template <int KIND> hipError_t launch_logpdf_k(const PmcArgsA &a, unsigned grid,
 }
 template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_resp<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    const size_t lds = (size_t)PMC_A_WAVES * a.klds * 64 * sizeof(double);
+    hipLaunchKernelGGL((k_resp<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
     return hipGetLastError();
 }
 
