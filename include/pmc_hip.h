@@ -139,6 +139,23 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
                        double *d_scalars, void *d_workspace, void *stream);
 
 /*
+ * ImportanceSampler._calculate_weights (pypmc/sampler/importance_sampling.py:197-215) when the target
+ * is itself a mixture density (`target = mixture.evaluate`, pypmc/examples/pmc.py:32-53): log P(x_n) from
+ * d_target_pack, log q(x_n) from d_pack, w_n = exp(log P - log q) and the sums of pmc_mixture_logpdf in
+ * ONE pass over the samples (mixtures of the same kind; different kinds fall back to two passes through
+ * d_log_target_out, which is then required).  Bitwise the same numbers as pmc_mixture_logpdf(target)
+ * followed by pmc_mixture_logpdf(proposal, d_log_target).
+ *   d_out             N, log q(x_n)   (NULL: not wanted)
+ *   d_log_target_out  N, log P(x_n)   (NULL: not wanted; ImportanceSampler's target_values)
+ *   d_weights         N
+ *   d_scalars, d_workspace, d_sample_w as for pmc_mixture_logpdf (workspace for max(K, K_target))
+ */
+int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                           const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                           double *d_log_target_out, double *d_weights, const double *d_sample_w,
+                           double *d_scalars, void *d_workspace, void *stream);
+
+/*
  * perp / ess sums over a weight vector (pypmc/tools/convergence.py:31-39, :67-72):
  * d_scalars[0..2] = sum w, sum w log w (zeros masked), sum w^2.
  */

@@ -42,6 +42,8 @@ SIGNATURES = {
     "pmc_stats_stride": (_i64, [_int]),
     "pmc_mixture_logpdf": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _vp, _vp, _vp]),
+    "pmc_importance_weights": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp]),
     "pmc_weight_sums": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "pmc_propose": (_int, [_vp, _vp, _vp, _vp, _int, _int, _i64, _i64, C.c_uint64, _vp, _vp, _vp]),
     "pmc_logsumexp2d": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),

@@ -190,6 +190,28 @@ class HipBackend(object):
             self._p(scalars), self._p(ws), self._stream()), "pmc_mixture_logpdf")
         return dict(out=out, individual=individual, weights=weights, scalars=scalars)
 
+    def importance_weights(self, x, comps, target, sample_w=None, want_out=False, want_log_target=False,
+                           pack=None, target_pack=None):
+        """pmc_importance_weights: w = exp(log P - log q) for a mixture target P (``target``) and proposal
+        q (``comps``) in one pass over ``x``.  Returns dict(weights, scalars, out, log_target)."""
+        x = self.asdevice(x)
+        N, D = x.shape
+        assert D == comps.D == target.D, "sample / proposal / target dimensions differ"
+        pack = self.pack(comps) if pack is None else pack
+        target_pack = self.pack(target) if target_pack is None else target_pack
+        out = self.empty(N) if want_out else None
+        lt = self.empty(N) if (want_log_target or comps.kind != target.kind) else None
+        weights = self.empty(N)
+        sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
+        scalars = self.zeros(NSCALARS)
+        ws = self._workspace(N, max(comps.K, target.K), D)
+        _lib.check(self._timed(
+            "pmc_importance_weights[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights,
+            self._p(x), N, D, self._p(pack), comps.K, comps.kind, self._p(target_pack), target.K, target.kind,
+            self._p(out), self._p(lt), self._p(weights), self._p(sw), self._p(scalars), self._p(ws),
+            self._stream()), "pmc_importance_weights")
+        return dict(weights=weights, scalars=scalars, out=out, log_target=lt)
+
     def weight_sums(self, w):
         """(sum w, sum w log w [zeros masked], sum w^2) as a device tensor of NSCALARS doubles."""
         w = self.asdevice(w).reshape(-1)

@@ -391,6 +391,46 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
     return PMC_OK;
 }
 
+int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                           const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                           double *d_log_target_out, double *d_weights, const double *d_sample_w,
+                           double *d_scalars, void *d_workspace, void *stream)
+{
+    if (N < 0 || K < 1 || K_target < 1 || !d_pack || !d_target_pack)
+        return fail(PMC_EINVAL, "pmc_importance_weights: bad N/K/pack");
+    if ((kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T) ||
+        (target_kind != PMC_KIND_GAUSS && target_kind != PMC_KIND_STUDENT_T))
+        return fail(PMC_EINVAL, "pmc_importance_weights: kinds must be GAUSS or STUDENT_T");
+    if (N > 0 && (!d_x || !d_weights)) return fail(PMC_EINVAL, "pmc_importance_weights: d_x / d_weights is NULL");
+    if (d_scalars && !d_workspace) return fail(PMC_EINVAL, "pmc_importance_weights: d_scalars needs d_workspace");
+    if (target_kind != kind) {
+        // different component families: two passes over the samples through the caller's buffer
+        if (!d_log_target_out)
+            return fail(PMC_EINVAL, "pmc_importance_weights: kinds differ, d_log_target_out is required");
+        int rc = pmc_mixture_logpdf(d_x, N, D, d_target_pack, K_target, target_kind, 0, d_log_target_out, nullptr,
+                                    K_target, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+        if (rc != PMC_OK) return rc;
+        return pmc_mixture_logpdf(d_x, N, D, d_pack, K, kind, 0, d_out, nullptr, K, d_log_target_out, d_weights,
+                                  d_sample_w, d_scalars, d_workspace, stream);
+    }
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    hipStream_t st = (hipStream_t)stream;
+    const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    if (nblocks > 0) {
+        PmcArgsA a;
+        std::memset(&a, 0, sizeof(a));
+        a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.ld = K;
+        a.pack2 = d_target_pack; a.K2 = K_target; a.log_target_out = d_log_target_out;
+        a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w;
+        a.partials = d_scalars ? (double *)d_workspace : nullptr;
+        hipError_t e = ks->logpdf(kind, a, (unsigned)nblocks, st);
+        if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
+    }
+    if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+    return PMC_OK;
+}
+
 int pmc_weight_sums(const double *d_w, int64_t N, double *d_scalars, void *d_workspace, void *stream)
 {
     if (N < 0 || !d_scalars || !d_workspace || (N > 0 && !d_w))

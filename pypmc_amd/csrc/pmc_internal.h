@@ -21,6 +21,9 @@ struct PmcArgsA {
     int dreal;            // real sample dimension (== compiled D unless padded)
     const double *pack;
     int K;
+    const double *pack2;  // k_logpdf: target mixture of the importance weights (or NULL)
+    int K2;
+    double *log_target_out;
     int max_init_zero;
     int mode;             // pmc_resp_mode (responsibility kernels)
     int klds;             // responsibility kernels: components parked in LDS between the passes

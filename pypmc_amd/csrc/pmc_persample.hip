@@ -35,27 +35,37 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_logpdf(const PmcArgsA a)
     double xv[D];
     load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
 
-    double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0;
-    cdouble *pk = (cdouble *)a.pack;
-    for (int k = 0; k < a.K; ++k, pk += STRIDE) {
-        touch_component<D>(pk);
-        const double maha = mahalanobis<D>(xv, pk);
-        double expo;
-        const double v = component_value<D, KIND>(maha, pk + D + T, expo);
-        if (a.individual != nullptr) {
-            const long long col = ((cint64 *)pk)[D + T + 5];
-            if (valid) a.individual[n * a.ld + col] = v;
+    // pass 0: the mixture itself; pass 1 (pmc_importance_weights only): the TARGET mixture of the
+    // importance weights, evaluated on the same registers -- the samples are read once
+    double lse = 0.0, lse_target = 0.0;
+    const int npass = a.pack2 != nullptr ? 2 : 1;
+    for (int which = 0; which < npass; ++which) {
+        double m = (which == 0 && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
+        cdouble *pk = (cdouble *)(which == 0 ? a.pack : a.pack2);
+        const int K = which == 0 ? a.K : a.K2;
+        for (int k = 0; k < K; ++k, pk += STRIDE) {
+            touch_component<D>(pk);
+            const double maha = mahalanobis<D>(xv, pk);
+            double expo;
+            const double v = component_value<D, KIND>(maha, pk + D + T, expo);
+            if (which == 0 && a.individual != nullptr) {
+                const long long col = ((cint64 *)pk)[D + T + 5];
+                if (valid) a.individual[n * a.ld + col] = v;
+            }
+            lse_step(v, pk[D + T + 4], m, s);
         }
-        lse_step(v, pk[D + T + 4], m, s);
+        const double l = log(s) + m;                     // _regularize.pyx:81
+        if (which == 0) lse = l;
+        else lse_target = l;
     }
-    const double lse = log(s) + m;                       // _regularize.pyx:81
     if (a.out != nullptr && valid) a.out[n] = lse;
+    if (a.log_target_out != nullptr && valid) a.log_target_out[n] = lse_target;
 
-    if (a.partials == nullptr && a.log_target == nullptr) return;
+    if (a.partials == nullptr && a.log_target == nullptr && a.pack2 == nullptr) return;
 
     double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (a.log_target != nullptr && valid) {
-        const double tmp = a.log_target[n] - lse;        // importance_sampling.py:204
+    if ((a.log_target != nullptr || a.pack2 != nullptr) && valid) {
+        const double tmp = (a.pack2 != nullptr ? lse_target : a.log_target[n]) - lse;   // importance_sampling.py:204
         const double w = exp(tmp);                        // :207
         a.weights[n] = w;
         sc[0] = w;

@@ -126,12 +126,15 @@ class ImportanceSampler(object):
             x, origin = self.proposal.propose(N, self.rng, trace=True, shuffle=False, device=True, out=out)
         else:
             x = self.proposal.propose(N, self.rng, device=True, out=out)
+        prop_set = component_set(self.proposal.components, self.proposal.weights)
         if isinstance(tgt, MixtureDensity):
-            log_target = be.logpdf(x, component_set(tgt.components, tgt.weights))["out"]
+            # mixture target: log P, log q, the weights and the perplexity sums in one pass over x
+            res = be.importance_weights(x, prop_set, component_set(tgt.components, tgt.weights),
+                                        want_log_target=store and self.target_values is not None)
+            log_target = res["log_target"]
         else:
             log_target = be.asdevice(self._target_values(be.tohost(x), N))
-        res = be.logpdf(x, component_set(self.proposal.components, self.proposal.weights), want_out=False,
-                        log_target=log_target, want_scalars=True)
+            res = be.logpdf(x, prop_set, want_out=False, log_target=log_target, want_scalars=True)
         sc = be.tohost(res["scalars"])
         if sc[4] > 0:
             raise OverflowError('math range error')

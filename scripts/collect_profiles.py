@@ -39,8 +39,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for row in csv.DictReader(open(f)):
         name, val = row["Kernel_Name"], float(row["Counter_Value"])
         if "k_logpdf" in name:
-            # two launches per step: K_t = 4 and K = 32; tell them apart by their traffic later
-            key = "k_logpdf"
+            key = "pmc_importance_weights[K=%d+%d]" % (cfg["K"], cfg["K_target"])
         elif "k_resp" in name:
             key = "pmc_responsibilities"
         elif "k_stats" in name:
@@ -51,12 +50,6 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         acc[key][row["Dispatch_Id"]] += val
     for key, d in acc.items():
         vals = sorted(d.values())
-        if key == "k_logpdf":
-            # both launches read x once (FETCH equal); the K=32 launch also reads log_target and
-            # writes the weights.  Dispatches alternate K_t=4, K=32: take every second one.
-            ids = sorted(d, key=int)
-            vals = [d[i] for i in ids[1::2]]
-            key = "pmc_mixture_logpdf[K=32]"
         per.setdefault(key, {})[counter + "_KiB"] = sum(vals) / len(vals)
 for key, d in per.items():
     d["hbm_bytes_per_launch"] = (2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024

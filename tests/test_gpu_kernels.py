@@ -376,3 +376,56 @@ def test_ill_conditioned_covariances(be, orc, cond):
     # the oracle (like the reference) subtracts a mean of magnitude 1e3 from data of width <= 1:
     # its own rounding is ~1e3 * eps / width; ours is bounded by the same quantity
     assert np.max(np.abs(sigma - cov_ref) / scale) < 1e-9
+
+
+@pytest.mark.parametrize("D,K,KT,N,kinds", [(2, 3, 2, 257, "gg"), (5, 4, 1, 64, "gg"), (20, 32, 4, 5000, "gg"),
+                                            (9, 5, 3, 1, "gg"), (30, 8, 4, 700, "tt"), (7, 3, 2, 333, "tg"),
+                                            (33, 2, 5, 129, "gt")])
+def test_importance_weights_against_a_mixture_target(be, orc, D, K, KT, N, kinds):
+    """pmc_importance_weights (proposal and target in one pass over the samples): bitwise the numbers
+    of the two-launch path, and the oracle's weights to 1e-10."""
+    def build(kind, K_, seed):
+        mu, cov, w = mk(K_, D, seed)
+        if kind == "g":
+            cs, inv, ln = gauss_set(mu, cov, w)
+            return cs, lambda x: orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)[0]
+        dof = np.full(K_, 5.0)
+        cs, inv, ln, pf, idf = student_set(mu, cov, w, dof)
+        return cs, lambda x: orc.mixture_multi_evaluate(1, x, w, mu, inv, ln, pf, idf)[0]
+    prop, ref_q = build(kinds[0], K, 70 + D)
+    tgt, ref_t = build(kinds[1], KT, 80 + D)
+    x, _ = draw(*mk(K, D, 70 + D), N, 3)
+    sw = np.random.RandomState(1).uniform(0.5, 1.5, N)
+    fused = be.importance_weights(x, prop, tgt, sample_w=sw, want_out=True, want_log_target=True)
+    lt = be.logpdf(x, tgt)["out"]
+    two = be.logpdf(x, prop, log_target=lt, sample_w=sw, want_scalars=True)
+    for key_f, ref in (("weights", two["weights"]), ("out", two["out"]), ("log_target", lt)):
+        np.testing.assert_array_equal(be.tohost(fused[key_f]), be.tohost(ref))
+    np.testing.assert_array_equal(be.tohost(fused["scalars"]), be.tohost(two["scalars"]))
+    assert_rel(be.tohost(fused["weights"]), orc.is_weights(ref_t(x), ref_q(x)), what="weights")
+    # nothing but the weights and the sums requested
+    lean = be.importance_weights(x, prop, tgt)
+    np.testing.assert_array_equal(be.tohost(lean["weights"]), be.tohost(two["weights"]))
+    assert lean["out"] is None and (lean["log_target"] is None or kinds[0] != kinds[1])
+
+
+def test_importance_weights_errors(be):
+    import ctypes as C
+    lib = be.lib
+    rc = lib.pmc_importance_weights(None, 10, 2, None, 1, 0, None, 1, 0, None, None, None, None, None, None, None)
+    assert rc == -1 and b"pmc_importance_weights" in lib.pmc_last_error()
+    mu, cov, w = mk(2, 2, 1)
+    g, _, _ = gauss_set(mu, cov, w)
+    t = student_set(mu, cov, w, np.full(2, 3.))[0]
+    pg, pt = be.pack(g), be.pack(t)
+    x = be.asdevice(np.zeros((4, 2)))
+    wts = be.empty(4)
+    # kinds differ and no buffer for the target values
+    rc = lib.pmc_importance_weights(C.c_void_p(x.data_ptr()), 4, 2, C.c_void_p(pg.data_ptr()), 2, 0,
+                                    C.c_void_p(pt.data_ptr()), 2, 1, None, None, C.c_void_p(wts.data_ptr()),
+                                    None, None, None, None)
+    assert rc == -1 and b"d_log_target_out" in lib.pmc_last_error()
+    # empty input is fine
+    rc = lib.pmc_importance_weights(None, 0, 2, C.c_void_p(pg.data_ptr()), 2, 0, C.c_void_p(pg.data_ptr()), 2, 0,
+                                    None, None, None, None, None, None, None)
+    assert rc == 0
