@@ -687,6 +687,48 @@ def case_example_pmc(be):
     assert abs(w[0] - 0.3) < 0.05 and abs(w[1] - 0.7) < 0.05 and w[2] < 0.05
 
 
+def case_reference_known_answers(be):
+    """Known-answer values held by the reference's own tests (Mathematica / MCMC numbers quoted in
+    pypmc/mix_adapt/variational_test.py:672-728)."""
+    from pypmc_amd.density.gauss import Gauss
+    from pypmc_amd.density.mixture import MixtureDensity
+    from pypmc_amd.mix_adapt.variational import VBMerge, Wishart_log_B, Wishart_H, Wishart_expect_log_lambda
+    W = np.array([[1, 0.3], [0.3, 11.2]])
+    nu = 8.3
+    ld = np.log(np.linalg.det(W))
+    assert abs(Wishart_log_B(3, 6, 0.0) - np.log(0.00013192862453429398)) < 1e-7        # :710-717
+    assert abs(Wishart_log_B(2, nu, ld) - (-19.6714760251454)) < 1e-7                    # :719-720
+    assert abs(Wishart_H(2, nu, ld) - 11.4262373965875) < 1e-7                           # :722-725
+    assert abs(Wishart_expect_log_lambda(2, nu, ld) - 6.24348627492751) < 1e-7           # :727-728
+    # weighted moments with hand-computed answers (pypmc/sampler/importance_sampling_test.py:176-208)
+    from pypmc_amd.sampler.importance_sampling import calculate_mean, calculate_covariance, calculate_expectation
+    samples = np.array([[0., 4.5], [4., 5.5], [2., 5.]])
+    wts = np.array([1., 2., 5.])
+    np.testing.assert_allclose(calculate_expectation(samples, wts, lambda x: x), [2.25, 5.0625], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(calculate_mean(samples, wts, backend=be), [2.25, 5.0625], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(calculate_covariance(samples, wts, backend=be),
+                               8. / 34. * np.array([[11.5, 2.875], [2.875, 0.71875]]), rtol=0, atol=1e-14)
+    for f in (calculate_mean, calculate_covariance):
+        with pytest.raises(AssertionError, match="number of samples.*must.*equal.*number of weights"):
+            f(samples, [1., 2., 3., 4.], backend=be)
+    # VBMerge on two nearly identical components: merges them in two steps (:672-702)
+    target_mean = np.array([4.3, 1.1])
+    target_sigma = np.array([[0.01, 0.003], [0.003, 0.0025]])
+    means = (np.array([4.30733653, 1.10121756]), np.array([4.29948, 1.09937727]))
+    cov = (np.array([[0.01382637, 0.00361037], [0.00361037, 0.0043224]]),
+           np.array([[0.00969403, 0.00292157], [0.00292157, 0.00247721]]))
+    weights = np.array([0.12644431, 0.87355569])
+    mix = MixtureDensity([Gauss(m, c) for m, c in zip(means, cov)], weights)
+    vb = VBMerge(mix, N=1e4, components=2, m=np.linspace(-1., 1., 4).reshape((2, 2)), backend=be)
+    S = np.array([[0.01022336, 0.00301026], [0.00301026, 0.00271089]])
+    np.testing.assert_allclose(vb.S[0], S, rtol=1e-5)
+    assert vb.run() == 2
+    assert vb.K == 1
+    res = vb.make_mixture()
+    np.testing.assert_allclose(res.components[0].mu, target_mean, rtol=1e-3)
+    np.testing.assert_allclose(res.components[0].sigma, target_sigma, rtol=0.15)
+
+
 def case_device_history(be):
     """DeviceHistory: History's run structure (reference tools/_history.py:7-116) over backend
     storage; indexing gives read-only host copies, ``device()`` the stored views."""
@@ -740,6 +782,6 @@ def case_combine_weights_device_inputs(be):
 
 ALL_CASES = [case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
-             case_device_history, case_combine_weights_device_inputs,
+             case_device_history, case_combine_weights_device_inputs, case_reference_known_answers,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,
              case_pmc_errors_and_fallback, case_student_t_pmc_golden]
