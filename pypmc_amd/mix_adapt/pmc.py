@@ -23,6 +23,7 @@ from ..density.gauss import Gauss
 from ..density.student_t import StudentT
 from ..density.mixture import MixtureDensity, component_set
 from ._stats import split_stats, centred_moments
+from ..tools._linalg import single_threaded_blas
 
 logger = logging.getLogger(__name__)
 
@@ -148,18 +149,19 @@ def _latent_blocks_estep(be, samples, weights, latent, density, live_components,
 def _apply_updates(density, live_components, new_params, need_renormalize):
     """``component.update`` with the reference's fall-back: a LinAlgError restores the old
     parameters and zeroes the component's weight (pmc.pyx:227-244, :713-737)."""
-    for k in live_components:
-        component = density.components[k]
-        alpha_k, args = new_params[k]
-        density.weights[k] = alpha_k
-        old = (component.mu, component.sigma) + ((component.dof,) if len(args) == 3 else ())
-        try:
-            component.update(*args)
-        except np.linalg.LinAlgError:
-            logger.warning("Could not update component %i --> weight is set to zero." % k)
-            component.update(*old)
-            density.weights[k] = 0.
-            need_renormalize = True
+    with single_threaded_blas():                  # K small factorisations: thread pool = overhead
+        for k in live_components:
+            component = density.components[k]
+            alpha_k, args = new_params[k]
+            density.weights[k] = alpha_k
+            old = (component.mu, component.sigma) + ((component.dof,) if len(args) == 3 else ())
+            try:
+                component.update(*args)
+            except np.linalg.LinAlgError:
+                logger.warning("Could not update component %i --> weight is set to zero." % k)
+                component.update(*old)
+                density.weights[k] = 0.
+                need_renormalize = True
     if need_renormalize:
         density.normalize()
     return density
