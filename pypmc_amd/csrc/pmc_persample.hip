@@ -88,9 +88,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_logpdf(const PmcArgsA a)
 // so exp(a_k - m_final) = (e_k or 1) * prod_{j > k, j a new maximum} f_j, and pass 2 -- walking the
 // components downwards with the running product -- needs no second exp per pair: ~10 instead of
 // ~45 vector instructions.  sum_k r_k a_k for E[log q(Z)] is carried through pass 1 like s.
-// This is the VB E-step's path.  a_k itself is parked, and pass 2 evaluates the reference's
-// expressions literally, when the caller wants the N x K matrix log_rho (materialised on demand,
-// never in the E-step itself) and for the PMC kinds (see `literal` below).
+// The PMC kinds multiply the product by exp(m_final) first, so that rho = exp(log q_k) w_k /
+// (exp(lse) + tiny) underflows where the reference's exp(log q_k) does.  a_k itself is parked, and
+// pass 2 evaluates the reference's expressions literally, only when the caller wants the N x K
+// matrix log_rho (materialised on demand, never in the E-step itself).
 // ---------------------------------------------------------------------------------------------
 extern __shared__ double resp_park[];                     // PMC_A_WAVES x klds x 64 doubles
 
@@ -119,11 +120,9 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
         double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)tile * K * 2 : nullptr;
 
         // ---- pass 1
-        // wave-uniform: park a_k itself.  The PMC kinds always do: the reference's rho =
-        // exp(log q_k) w_k / (exp(lse) + tiny) underflows to 0 where log q_k < -745 although the ratio
-        // is representable, and parity with it needs exp(a_k) itself; VB's r is relative to the row
-        // maximum in the reference too, so the product form agrees to rounding.
-        const bool literal = KIND != PMC_KIND_VB || a.log_rho != nullptr;
+        // wave-uniform: park a_k itself and evaluate the reference's expressions literally (only when
+        // the N x K matrix log_rho is wanted)
+        const bool literal = a.log_rho != nullptr;
         double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0, ta = 0.0;
         cdouble *pk = (cdouble *)a.pack;
         for (int k = 0; k < K; ++k, pk += STRIDE) {
@@ -193,8 +192,13 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
             if (valid) sc[0] = sw * elq;
         } else {
             // pmc.pyx:36-41: rho = exp(log q_k) * w_k / (exp(log_denominator) + tiny)
+            // product form: exp(log q_k) = g_k exp(m) with g_k = (e_k or 1) * prod of the f_j above k.
+            // exp(m) is applied to g_k before anything else, so where the reference's exp(log q_k)
+            // underflows (log q_k < -708) this product underflows with it.
             const double lse = log(s) + m;
             const double denom = exp(lse) + TINY;
+            const double em = exp(m);
+            double chain = 1.0;
             const long long lat = (a.mode == PMC_RESP_PMC_LATENT && valid) ? a.latent[n] : -1;
             for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
                 cdouble *c = pk + D + T;
@@ -202,8 +206,14 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
                 double rho;
                 if (a.mode == PMC_RESP_PMC_LATENT) {
                     rho = (lat == col) ? 1. : 0.;         // pmc.pyx:49-50
-                } else {
+                } else if (literal) {
                     rho = exp(k < klds ? pl[k * 64] : ut[(size_t)k * 64]) * c[4];
+                    rho /= denom;
+                } else {
+                    const double p = k < klds ? pl[k * 64] : ut[(size_t)k * 64];
+                    const bool newmax = __double2hiint(p) < 0;
+                    rho = (newmax ? 1.0 : p) * chain * em * c[4];
+                    chain = newmax ? chain * -p : chain;
                     rho /= denom;
                 }
                 if (valid && a.r != nullptr) a.r[n * a.ld + col] = rho;

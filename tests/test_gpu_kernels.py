@@ -429,3 +429,31 @@ def test_importance_weights_errors(be):
     rc = lib.pmc_importance_weights(None, 0, 2, C.c_void_p(pg.data_ptr()), 2, 0, C.c_void_p(pg.data_ptr()), 2, 0,
                                     None, None, None, None, None, None, None)
     assert rc == 0
+
+
+def test_rho_where_the_reference_underflows(be, orc):
+    """pmc.pyx:36-41 computes rho = exp(log q_k) w_k / (exp(lse) + tiny): for samples so far out that
+    log q_k < -708 the numerator is denormal or zero although the ratio is representable.  The
+    product-form normalisation of k_resp must follow the reference there, not the exact ratio."""
+    D, K = 5, 4
+    mu, cov, w = mk(K, D, 77)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    rs = np.random.RandomState(3)
+    v = rs.normal(size=D)
+    v /= np.sqrt(v.dot(inv[0]).dot(v))                      # unit Mahalanobis length w.r.t. component 0
+    # walk away from the mixture and keep the stretch where log q runs from -600 down to -800
+    # (numerator normal -> denormal -> zero)
+    x = mu[0] + np.linspace(20, 80, 6000)[:, None] * v[None, :]
+    lq = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)[0]
+    keep = (lq < -600) & (lq > -800)
+    x, lq = np.ascontiguousarray(x[keep]), lq[keep]
+    assert len(x) > 200 and lq.min() < -760 and lq.max() > -640
+    got = be.tohost(be.estep(x, cs, 1, want_r=True)["r"])
+    ref = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+    assert np.isfinite(got).all() and (got >= 0).all()
+    normal = lq > -700                                       # numerator and denominator normal numbers
+    np.testing.assert_allclose(got[normal], ref[normal], rtol=1e-10, atol=1e-300)
+    # below: the reference's own numerator has only a few bits left; agree to those and go to 0 with it
+    np.testing.assert_allclose(got[~normal], ref[~normal], rtol=1e-2, atol=1e-12)
+    gone = lq < -750
+    assert (ref[gone] == 0).all() and (got[gone] == 0).all()
