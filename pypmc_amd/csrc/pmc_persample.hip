@@ -21,6 +21,11 @@
 
 namespace {
 
+// Minimum wavefronts per SIMD the register allocator has to leave room for.  Beyond D = 48 the
+// kernels would otherwise take 256 VGPRs + AGPRs = one wavefront per SIMD; two with ~50 spilled
+// registers are 1.7x faster (D = 64: 9.3 -> 5.3 ms per 2e6 samples x 16 components).
+__host__ __device__ constexpr int pmc_min_waves(int D) { return D > 48 ? 2 : 1; }
+
 // The wavefronts of a workgroup walk the components in step: a barrier per component keeps them on
 // the same parameter lines, so that one wavefront's scalar-cache fill serves the other three
 // (D = 20: -3 % kernel time; neutral at D = 40).
@@ -36,7 +41,7 @@ __device__ __forceinline__ void component_sync()
 // (_regularize.pyx:57-84) [+ importance weights, importance_sampling.py:197-215] in one pass.
 // ---------------------------------------------------------------------------------------------
 template <int D, bool PADDED, int KIND>
-__global__ __launch_bounds__(PMC_A_WAVES * 64) void k_logpdf(const PmcArgsA a)
+__global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(const PmcArgsA a)
 {
     constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
     const long long n = ((long long)blockIdx.x * PMC_A_WAVES * 64) + threadIdx.x;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_logpdf(const PmcArgsA a)
 extern __shared__ double resp_park[];                     // PMC_A_WAVES x klds x 64 doubles
 
 template <int D, bool PADDED, int KIND>
-__global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp(const PmcArgsA a)
+__global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(const PmcArgsA a)
 {
     constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
     const int lane = threadIdx.x & 63;
