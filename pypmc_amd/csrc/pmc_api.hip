@@ -107,6 +107,21 @@ __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__
     stats[idx] = v;
 }
 
+// N = 1, D = 1: stats[k] = (u_k, u_k d, u_k d^2), d = x - mu_k   (u tile-major: one tile, lane 0)
+__global__ __launch_bounds__(256) void k_stats_single(const double *__restrict__ x,
+                                                      const double *__restrict__ pack, int stride, int K,
+                                                      const double *__restrict__ u,
+                                                      double *__restrict__ stats)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const double uk = u[(size_t)k * 64], d = x[0] - pack[(size_t)k * stride];
+    const double ud = uk * d;
+    stats[3 * k] = uk;
+    stats[3 * k + 1] = ud;
+    stats[3 * k + 2] = fma(ud, d, 0.0);
+}
+
 // vsums[k*2+c] = sum_tile vpartials[(tile*K + k)*2 + c]   (one workgroup per output, fixed order)
 __global__ __launch_bounds__(256) void k_finish_vsums(const double *__restrict__ vpartials,
                                                       long long ntiles, int K,
@@ -556,6 +571,14 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
     if (N == 0) {
         hipError_t e = hipMemsetAsync(d_stats, 0, sizeof(double) * (size_t)K * PS, st);
         if (e != hipSuccess) return hipfail(e, "hipMemsetAsync");
+        return PMC_OK;
+    }
+    if (N * (int64_t)D == 1) {
+        // a single scalar sample: the tile kernel moves 16-byte pieces, which do not fit into 8 bytes
+        hipLaunchKernelGGL(k_stats_single, dim3((unsigned)ceil_div(K, 256)), dim3(256), 0, st, d_x, d_pack,
+                           pmc_pack_stride_c(ks->dim), K, d_u, d_stats);
+        hipError_t e1 = hipGetLastError();
+        if (e1 != hipSuccess) return hipfail(e1, "k_stats_single launch");
         return PMC_OK;
     }
     const StatsGeom g = stats_geom(N, K, ks);

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 //     a_k >  m:  f_k = exp(m - a_k), m := a_k (the factor rescaling s)       parked as  -f_k
 // so exp(a_k - m_final) = (e_k or 1) * prod_{j > k, j a new maximum} f_j, and pass 2 -- walking the
 // components downwards with the running product -- needs no second exp per pair: ~10 instead of
-// ~45 vector instructions.  sum_k r_k a_k for E[log q(Z)] is carried through pass 1 like s.
+// ~45 vector instructions.  sum_k e_k (a_k - m) for E[log q(Z)] is carried through pass 1 like s.
 // The PMC kinds multiply the product by exp(m_final) first, so that rho = exp(log q_k) w_k /
 // (exp(lse) + tiny) underflows where the reference's exp(log q_k) does.  a_k itself is parked, and
 // pass 2 evaluates the reference's expressions literally, only when the caller wants the N x K
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
         // wave-uniform: park a_k itself and evaluate the reference's expressions literally (only when
         // the N x K matrix log_rho is wanted)
         const bool literal = a.log_rho != nullptr;
-        double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0, ta = 0.0;
+        // (VB starts the maximum at -1e300 instead of -DBL_MAX so that a_0 - m stays finite below)
+        double m = a.max_init_zero ? 0.0 : (KIND == PMC_KIND_VB ? -1e300 : -DBL_MAX), s = 0.0, tb = 0.0;
         cdouble *pk = (cdouble *)a.pack;
         for (int k = 0; k < K; ++k, pk += STRIDE) {
             component_sync();
@@ -160,8 +161,15 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
             const double e = exp(-fabs(v - m));
             const bool gt = v > m;
             const double w = pk[D + T + 4];
+            if constexpr (KIND == PMC_KIND_VB) {
+                // tb = sum_j e_j (a_j - m) relative to the running maximum (w = 1 for this kind): the
+                // dominant component contributes exactly 0, so E[log q(Z)] = tb / s - log s keeps its
+                // accuracy when the responsibilities are nearly one-hot.  New maximum m' = a_k:
+                // every old term becomes f (e_j (a_j - m) + e_j (m - m')).
+                const double dm = v - m;
+                tb = gt ? e * fma(-s, dm, tb) : fma(e, dm, tb);
+            }
             s = gt ? fma(s, e, w) : fma(w, e, s);
-            if constexpr (KIND == PMC_KIND_VB) ta = gt ? fma(ta, e, v) : fma(e, v, ta);   // sum e_k a_k
             m = gt ? v : m;
             const double parked = literal ? v : (gt ? -e : e);
             if (k < klds) pl[k * 64] = parked;            // wave-uniform branch
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
                     }
                 }
                 // sum_k r_k (a_k - m + log norm_inv) with sum_k r_k = 1   (variational.pyx:1003-1013)
-                elq = ta * norm_inv - m + log_norm_inv;
+                elq = fma(tb, norm_inv, log_norm_inv);
             }
             if (valid) sc[0] = sw * elq;
         } else {

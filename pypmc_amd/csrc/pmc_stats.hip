@@ -168,14 +168,17 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     auto dma = [&](long long t, double *buf, int part, int nparts) {
         const long long tt = t < t1 ? t : t0;
         const double *__restrict__ xt = b.x + tt * 64 * dreal;               // wave-uniform
-        const long long rem = total - tt * 64 * dreal - 2;                    // last legal pair start
-        const unsigned lim = rem < 0 ? 0u : (rem > 0xfffffff0ll ? 0xfffffff0u : (unsigned)rem);
+        // last legal pair start relative to xt; -1 if the step begins at the array's very last
+        // element (dreal = 1, N = 1 mod 64): that pair then starts one element in FRONT of xt
+        // (the launcher guarantees total >= 2)
+        const long long rem = total - tt * 64 * dreal - 2;
+        const int lim = rem > 0x7ffffff0ll ? 0x7ffffff0 : (int)rem;
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
             const int idx = wave + i * WAVES;
             if (i % nparts != part) continue;
             if (NDMA % WAVES == 0 || idx < NDMA) {        // wave-uniform
-                const unsigned o = dma_off[i] < lim ? dma_off[i] : lim;
+                const int o = (int)dma_off[i] < lim ? (int)dma_off[i] : lim;
                 __builtin_amdgcn_global_load_lds((gvoid_t *)(xt + o), (lvoid_t *)(buf + (size_t)idx * 128), 16,
                                                  0, 0);
             }

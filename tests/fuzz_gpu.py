@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the HIP path against the oracle over EVERY sample dimension 1..64 (exact and
+padded kernel units), ragged N and odd K -- a development aid, run by hand on the GPU box:
+
+    python tests/fuzz_gpu.py [seed] [rounds]
+"""
+import os
+import sys
+
+import numpy as np
+from scipy.special import digamma
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def mk(K, D, rs):
+    mu = rs.normal(0, 3, size=(K, D))
+    cov = np.empty((K, D, D))
+    for k in range(K):
+        A = rs.normal(0, 1, size=(D, D))
+        cov[k] = A.dot(A.T) / D + 0.5 * np.eye(D)
+    w = rs.uniform(0.5, 1.5, size=K)
+    return mu, cov, w / w.sum()
+
+
+def rel(a, b, floor=1e-300):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    from oracle import oracle as orc
+    from pypmc_amd.backend import HipBackend, ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    be = HipBackend()
+    rs = np.random.RandomState(seed)
+    worst = {}
+
+    def note(name, v, tol, ctx):
+        worst[name] = max(worst.get(name, 0.0), v)
+        assert v < tol, "%s: %.3g >= %.3g at %s" % (name, v, tol, ctx)
+
+    for rnd in range(rounds):
+        for D in range(1, 65):
+            K = int(rs.randint(1, 41))
+            N = int(rs.choice([1, 2, 63, 64, 65, 127, 129, rs.randint(1, 3000)]))
+            ctx = dict(D=D, K=K, N=N, seed=seed, round=rnd)
+            mu, cov, w = mk(K, D, rs)
+            k = rs.choice(K, size=N, p=w)
+            L = np.linalg.cholesky(cov)
+            x = mu[k] + np.einsum('nij,nj->ni', L[k], rs.normal(size=(N, D)))
+            inv = np.linalg.inv(cov)
+            inv = 0.5 * (inv + inv.transpose(0, 2, 1))
+            ln = -0.5 * D * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(cov)[1]
+            # log-pdf + importance weights against a second mixture
+            cs = ComponentSet(0, mu, inv, c0=ln, weight=w)
+            ref_q, ref_ind = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+            res = be.logpdf(x, cs, want_individual=True)
+            note("logpdf", rel(be.tohost(res["out"]), ref_q), 1e-10, ctx)
+            note("individual", rel(be.tohost(res["individual"]), ref_ind), 1e-10, ctx)
+            KT = int(rs.randint(1, 5))
+            tmu, tcov, tw = mk(KT, D, rs)
+            tinv = np.linalg.inv(tcov)
+            tinv = 0.5 * (tinv + tinv.transpose(0, 2, 1))
+            tln = -0.5 * D * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(tcov)[1]
+            ref_t = orc.mixture_multi_evaluate(0, x, tw, tmu, tinv, tln)[0]
+            iw = be.importance_weights(x, cs, ComponentSet(0, tmu, tinv, c0=tln, weight=tw))
+            with np.errstate(over='ignore'):
+                ref_w = np.exp(ref_t - ref_q)
+            fin = np.isfinite(ref_w)
+            note("weights", rel(be.tohost(iw["weights"])[fin], ref_w[fin]), 1e-9, ctx)
+            # Student-t mixture log-pdf
+            from scipy.special import gammaln
+            dof = rs.uniform(1.0, 12.0, K)
+            tln_ = gammaln(.5 * (dof + D)) - gammaln(.5 * dof) - 0.5 * D * np.log(dof * np.pi) - \
+                0.5 * np.linalg.slogdet(cov)[1]
+            scs = ComponentSet(1, mu, inv, c0=tln_, c1=-.5 * (dof + D), c2=1. / dof, c3=dof, weight=w)
+            ref_s = orc.mixture_multi_evaluate(1, x, w, mu, inv, tln_, -.5 * (dof + D), 1. / dof)[0]
+            note("student logpdf", rel(be.tohost(be.logpdf(x, scs)["out"]), ref_s), 1e-10, ctx)
+            # VB E-step
+            sw = rs.uniform(0.5, 1.5, N) if rs.rand() < 0.5 else None
+            nu = D + 2. + rs.uniform(0, 5, K)
+            beta = 1. + rs.uniform(0, 5, K)
+            alpha = 1. + rs.uniform(0, 5, K)
+            W = inv / nu[:, None, None]
+            m = mu + 0.1 * rs.normal(size=mu.shape)
+            ln_lambda = sum(digamma(0.5 * (nu + 1. - i)) for i in range(1, D + 1)) + D * np.log(2.) + \
+                np.linalg.slogdet(W)[1]
+            ln_pi = digamma(alpha) - digamma(alpha.sum())
+            ref = orc.vb_estep(x, sw, m, W, beta, nu, ln_pi, ln_lambda)
+            vcs = ComponentSet(2, m, W, c0=D / beta, c1=nu, c2=ln_pi, c3=ln_lambda - D * np.log(2. * np.pi))
+            out = be.estep(x, vcs, 0, sample_w=sw, want_r=True)
+            note("vb r", rel(be.tohost(out["r"]), ref["r"]), 1e-10, ctx)
+            sc, S0, M1, M2, _, _ = split_stats(be.tohost(out["stats"]), K, D)
+            note("vb N_comp", rel(S0, ref["N_comp"], 1e-30), 1e-10, ctx)
+            live = ref["N_comp"] > 1e-3
+            xm, S = centred_moments(S0, M1, M2, m)
+            if live.any():
+                note("vb x_mean", float(np.max(np.abs(xm[live] - ref["x_mean_comp"][live]))), 1e-9, ctx)
+                note("vb S", float(np.max(np.abs(S[live] - ref["S"][live]))), 1e-8, ctx)
+            note("vb elq", abs(sc[0] - ref["expectation_log_q_Z"]) / (abs(ref["expectation_log_q_Z"]) + 1e-6), 1e-9, ctx)
+            # PMC Rao-Blackwell responsibilities + statistics
+            iwts = rs.uniform(0.1, 2.0, N)
+            out = be.estep(x, cs, 1, sample_w=iwts, want_r=True)
+            rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+            got = be.tohost(out["r"])
+            normal = ref_ind > -690                          # exp(log q_k) a normal number in the reference
+            note("pmc rho", rel(got[normal], rho[normal]), 1e-9, ctx)
+            # below, the reference's numerator is denormal (a few bits) or zero: follow it loosely
+            note("pmc rho (denormal numerator)", rel(got[~normal], rho[~normal], 1e-200), 5e-2, ctx)
+            sc, S0, M1, M2, _, _ = split_stats(be.tohost(out["stats"]), K, D)
+            note("pmc alpha", rel(S0, (iwts[:, None] * rho).sum(axis=0), 1e-30), 1e-9, ctx)
+            d = x[:, None, :] - mu[None, :, :]
+            M2ref = np.einsum('n,nk,nki,nkj->kij', iwts, rho, d, d)
+            note("pmc M2", float(np.max(np.abs(M2 - M2ref) / (np.abs(M2ref) + 1e-6 * np.abs(M2ref).max()))), 1e-8, ctx)
+        print("round %d ok" % rnd, flush=True)
+    for k_, v in sorted(worst.items()):
+        print("worst %-12s %.3g" % (k_, v))
+
+
+if __name__ == "__main__":
+    main()

@@ -199,7 +199,8 @@ def test_vb_estep_golden(be, tag, stage):
     assert abs(sc[0] - float(g[stage + "log_q_Z"])) <= 1e-10 * abs(float(g[stage + "log_q_Z"])) + 1e-12
 
 
-@pytest.mark.parametrize("D,K,N,weighted", [(2, 2, 64, False), (4, 7, 1000, True), (20, 32, 5000, False),
+@pytest.mark.parametrize("D,K,N,weighted", [(1, 3, 65, True), (1, 2, 1, False), (3, 4, 129, True), (5, 2, 65, False),
+                                            (2, 2, 64, False), (4, 7, 1000, True), (20, 32, 5000, False),
                                             (6, 40, 777, True), (30, 5, 300, False), (12, 9, 64 * 9 + 1, True),
                                             (17, 3, 500, False), (40, 4, 400, True), (64, 2, 200, False)])
 def test_vb_estep_vs_oracle(be, orc, D, K, N, weighted):
@@ -457,3 +458,49 @@ def test_rho_where_the_reference_underflows(be, orc):
     np.testing.assert_allclose(got[~normal], ref[~normal], rtol=1e-2, atol=1e-12)
     gone = lq < -750
     assert (ref[gone] == 0).all() and (got[gone] == 0).all()
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 5, 7, 9, 13])
+def test_statistics_with_a_lonely_last_sample(be, D):
+    """Sufficient statistics against plain numpy sums when the array's last sample starts a tile of
+    its own (N = 1 mod 64) -- the 16-byte pieces of the LDS-DMA then begin at the very last element
+    (regression: D = 1 read 8 bytes past the end and picked up the wrong half of the piece)."""
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats
+    for K in (1, 17):
+        for N in (1, 2, 65, 257, 64 * 9 + 1):
+            rs = np.random.RandomState(N + K + D)
+            x = rs.normal(size=(N, D)) + 5
+            mu = rs.normal(size=(K, D))
+            w = rs.uniform(0.5, 1.5, N)
+            lat = rs.randint(0, K, N)                       # one-hot responsibilities: exact sums
+            cs = ComponentSet(0, mu, np.tile(np.eye(D), (K, 1, 1)), c0=np.zeros(K), weight=np.full(K, 1. / K))
+            out = be.estep(x, cs, 2, sample_w=w, latent=lat)
+            sc, S0, M1, M2, _, _ = split_stats(be.tohost(out["stats"]), K, D)
+            u = np.zeros((N, K))
+            u[np.arange(N), lat] = w
+            d = x[:, None, :] - mu[None]
+            np.testing.assert_allclose(S0, u.sum(0), rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(M1, np.einsum('nk,nki->ki', u, d), rtol=1e-12, atol=1e-11)
+            np.testing.assert_allclose(M2, np.einsum('nk,nki,nkj->kij', u, d, d), rtol=1e-12, atol=1e-10)
+
+
+def test_expected_log_q_Z_when_responsibilities_are_nearly_one_hot(be, orc):
+    """E[log q(Z)] = sum r log r is tiny when every sample belongs to one component; the streaming
+    form must not lose it in the cancellation of sum r a - lse (variational.pyx:1003-1013)."""
+    from pypmc_amd.backend import ComponentSet
+    D, K, N = 13, 24, 65
+    rs = np.random.RandomState(5)
+    mu = rs.normal(0, 30, size=(K, D))                       # far apart: r is one-hot to ~1e-10 or better
+    cov = np.tile(np.eye(D), (K, 1, 1))
+    x = mu[rs.randint(0, K, N)] + rs.normal(size=(N, D))
+    nu = D + 2. + rs.uniform(0, 5, K)
+    beta = 1. + rs.uniform(0, 5, K)
+    W = cov / nu[:, None, None]
+    ln_lambda = sum(digamma(0.5 * (nu + 1. - i)) for i in range(1, D + 1)) + D * np.log(2.) + np.linalg.slogdet(W)[1]
+    ln_pi = np.log(np.full(K, 1. / K))
+    ref = orc.vb_estep(x, None, mu, W, beta, nu, ln_pi, ln_lambda)
+    cs = ComponentSet(2, mu, W, c0=D / beta, c1=nu, c2=ln_pi, c3=ln_lambda - D * np.log(2. * np.pi))
+    sc = be.tohost(be.estep(x, cs, 0)["stats"])[:8]
+    assert -1e-3 < ref["expectation_log_q_Z"] <= 0
+    assert abs(sc[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-300
