@@ -202,3 +202,38 @@ def test_cfg5_pmc_update_d40_k128(be, orc):
     r = be.estep(x[:n_sub].contiguous(), cs, 1, want_r=True)["r"].cpu().numpy()
     ref = orc.rho_rb(0, x[:n_sub].cpu().numpy(), w, mu, inv, ln, None, None, list(range(K)))
     assert rel(r, ref) < 1e-9
+
+
+def test_offsets_beyond_32_bits(be):
+    """N x D = 2.4e9 elements (19 GB of samples, 7.7 GB of responsibilities): element and byte
+    offsets beyond 2^31 / 2^32 in every kernel of the path."""
+    import torch
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats
+    D, K, N = 20, 8, 120_000_000
+    rs = np.random.RandomState(0)
+    mu = rs.normal(0, 3, (K, D))
+    inv = np.tile(np.eye(D), (K, 1, 1))
+    ln = np.full(K, -0.5 * D * np.log(2 * np.pi))
+    w = np.full(K, 1. / K)
+    g = torch.Generator(device=be.device).manual_seed(1)
+    x = torch.randn(N, D, dtype=torch.float64, device=be.device, generator=g)
+    comp = torch.randint(0, K, (N,), device=be.device, generator=g)
+    x += torch.tensor(mu, device=be.device)[comp]
+    cs = ComponentSet(0, mu, inv, c0=ln, weight=w)
+    out = be.logpdf(x, cs)["out"]
+    for sl in (slice(0, 100), slice(N // 2, N // 2 + 100), slice(N - 100, N)):
+        d = x[sl].cpu().numpy()[:, None, :] - mu[None]
+        a = ln[None] - 0.5 * (d ** 2).sum(-1)
+        ref = np.log((w * np.exp(a - a.max(1, keepdims=True))).sum(1)) + a.max(1)
+        np.testing.assert_allclose(out[sl].cpu().numpy(), ref, rtol=1e-12)
+    del out
+    S0, M1, M2 = split_stats(be.estep(x, cs, 1)["stats"].cpu().numpy(), K, D)[1:4]
+    assert abs(S0.sum() / N - 1) < 1e-11
+    counts = torch.bincount(comp, minlength=K).cpu().numpy()
+    # components 3 sigma apart in 20 dimensions: rho is one-hot to ~1e-9
+    np.testing.assert_allclose(S0, counts, rtol=1e-6)
+    assert np.abs(M1 / S0[:, None]).max() < 5e-3                              # x - mu_k averages to 0
+    assert np.abs(np.array([np.diag(M2[k]) / S0[k] for k in range(K)]) - 1).max() < 5e-3
+    be.release()
+    torch.cuda.empty_cache()
