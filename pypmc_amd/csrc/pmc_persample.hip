@@ -24,7 +24,7 @@ namespace {
 // Minimum wavefronts per SIMD the register allocator has to leave room for.  Beyond D = 48 the
 // kernels would otherwise take 256 VGPRs + AGPRs = one wavefront per SIMD; two with ~50 spilled
 // registers are 1.7x faster (D = 64: 9.3 -> 5.3 ms per 2e6 samples x 16 components).
-__host__ __device__ constexpr int pmc_min_waves(int D) { return D > 48 ? 2 : 1; }
+__host__ __device__ constexpr int pmc_min_waves(int D) { return D >= 40 ? 2 : 1; }
 
 // The wavefronts of a workgroup walk the components in step: a barrier per component keeps them on
 // the same parameter lines, so that one wavefront's scalar-cache fill serves the other three
@@ -35,6 +35,183 @@ __device__ __forceinline__ void component_sync()
     __builtin_amdgcn_s_barrier();
 #endif
 }
+
+extern __shared__ double dyn_lds[];   // [MFMA engine: 2 parameter buffers] [k_resp: parked values]
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+// ---------------------------------------------------------------------------------------------
+// Mahalanobis engines: maha_nk = |R_k (x_n - mu_k)|^2 for the wavefront's 64 samples, lane = sample.
+// ---------------------------------------------------------------------------------------------
+// D < 40: the triangular product on the vector pipe with the parameters as SGPR operands (above).
+template <int D, bool PADDED, bool MFMA> struct MahaEngine {
+    static constexpr int LDS_DOUBLES = 0;
+    double xv[D];
+    __device__ __forceinline__ void load(const PmcArgsA &a, long long tile, int lane)
+    {
+        load_row<D, PADDED>(a.x, tile * 64 + lane, a.N, a.dreal, xv);
+    }
+    __device__ __forceinline__ void begin(const double *, int) {}
+    __device__ __forceinline__ double eval(cdouble *pk, int)
+    {
+        component_sync();
+        touch_component<D>(pk);
+        return mahalanobis<D>(xv, pk);
+    }
+    // a wavefront without samples keeps the workgroup's barrier count
+    __device__ static __forceinline__ void idle(const double *, int K)
+    {
+        for (int k = 0; k < K; ++k) component_sync();
+    }
+};
+
+// D >= 40: the scalar path cannot feed the vector pipe any more (6.9 KB = 108 cache lines per
+// component at D = 40, whose fill takes as long as the arithmetic; 54 % utilisation).  Here the
+// workgroup stages each component's parameters ONCE in LDS (LDS-DMA, double buffered, one barrier per
+// component) and the triangular product runs on the matrix pipe, 4 x 4 blocks of R against 16 samples
+// per v_mfma_f64_4x4x4_4b_f64 (lane layout: pmc_stats.hip):
+//     A[blk][i][c] = R[4I+i][4J+c]  lane 16c + 4blk + i   (the same block in all 4 batch slots)
+//     B[blk][c][j] = d[s][4J+c]     lane 16c + 4blk + j   (sample s = 4 blk + j of the sub-tile)
+//     C[blk][i][j] = y[s][4I+i]     lane 16i + 4blk + j
+// so a lane holds coordinate (lane >> 4) of sample (lane & 15) of each of the tile's four sub-tiles,
+// squares its y, and after the block rows two cross-lane additions give every lane the sub-tile's
+// |y|^2; lane l then keeps sub-tile (l >> 4): sample l of the tile, the layout the epilogues expect.
+template <int D, bool PADDED> struct MahaEngine<D, PADDED, true> {
+    static constexpr int G = D / 4, STRIDE = pmc_pack_stride_c(D);
+    static constexpr int PIECES = (STRIDE * 8 + 1023) / 1024;     // 1-KiB DMA pieces per component
+    static constexpr int PBUF = PIECES * 128;                      // doubles per parameter buffer
+    static constexpr int LDS_DOUBLES = 2 * PBUF;
+#ifdef PMC_MFMA_NT
+    static constexpr int NT = PMC_MFMA_NT;
+#else
+    static constexpr int NT = G <= 12 ? 2 : 1;                     // sub-tiles sharing an A block (registers)
+#endif
+    static_assert(D % 4 == 0, "MFMA engine needs whole coordinate groups");
+    double xm[4][G];             // x[16 s + (lane & 15)][4J + (lane >> 4)]
+    int rowbase[G];              // double index of R[4I + (lane & 3)][lane >> 4] in a component's pack
+    const double *pack;
+    int K, lane, wave;
+
+    __device__ __forceinline__ void load(const PmcArgsA &a, long long tile, int lane_)
+    {
+        lane = lane_;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int c = lane >> 4, s16 = lane & 15, i = lane & 3;
+        const int dreal = PADDED ? a.dreal : D;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long row = tile * 64 + s * 16 + s16;
+            const double *p = a.x + (row < a.N ? row : 0) * (long long)dreal;
+#pragma unroll
+            for (int J = 0; J < G; ++J) {
+                const int col = 4 * J + c;
+                double v = 0.0;
+                if (row < a.N && (!PADDED || col < dreal)) v = p[col];
+                xm[s][J] = v;
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < G; ++I) {
+            const int r = 4 * I + i;                      // row of R; element (r, col) sits at
+            rowbase[I] = D + r * D - r * (r - 1) / 2 - r + c;   // rowbase + 4 J   (col = 4J + c >= r)
+        }
+    }
+    // HBM/L2 -> LDS copy of component k's parameters into buffer (k & 1)
+    __device__ __forceinline__ void stage(int k)
+    {
+        const double *src = pack + (size_t)k * STRIDE;
+        double *dst = dyn_lds + (k & 1) * PBUF;
+#pragma unroll
+        for (int q = 0; q < (PIECES + PMC_A_WAVES - 1) / PMC_A_WAVES; ++q) {
+            const int piece = wave + q * PMC_A_WAVES;     // wave-uniform
+            if (piece < PIECES) {
+                int o = piece * 128 + 2 * lane;           // doubles
+                if (o > STRIDE - 2) o = STRIDE - 2;       // the last piece may be partial
+                __builtin_amdgcn_global_load_lds((gvoid_t *)(src + o), (lvoid_t *)(dst + piece * 128), 16, 0, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void begin(const double *pack_, int K_)
+    {
+        pack = pack_;
+        K = K_;
+        __syncthreads();                                  // nobody still reads buffer 0
+        stage(0);
+    }
+    __device__ __forceinline__ double eval(cdouble *, int k)
+    {
+        __syncthreads();                                  // component k has landed; k-1 is consumed
+        if (k + 1 < K) stage(k + 1);
+        const double *buf = dyn_lds + (k & 1) * PBUF;
+        const int c = lane >> 4, i = lane & 3;
+        // A operand of block (I, J); diagonal blocks hold zeros below the diagonal
+        auto block = [&](int I, int J) -> double {
+            const double A = buf[rowbase[I] + 4 * J];
+            return (J == I && c < i) ? 0.0 : A;
+        };
+        double total[4];
+        // NT sub-tiles of 16 samples at a time share every A block; two block rows per sweep: 2 NT
+        // independent accumulator chains for the matrix pipe
+#pragma unroll
+        for (int s0 = 0; s0 < 4; s0 += NT) {
+            double d[NT][G], q[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                q[t] = 0.0;
+#pragma unroll
+                for (int J = 0; J < G; ++J) d[t][J] = xm[s0 + t][J] - buf[4 * J + c];
+            }
+#pragma unroll
+            for (int I = 0; I < G; I += 2) {
+                // fence: the A blocks of this sweep are not read before the previous sweep is done
+                // (without it every ds_read of the unrolled component is hoisted to its top: spills)
+                asm volatile("" : "+v"(q[0]) : : "memory");
+                double ya[NT], yb[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ya[t] = yb[t] = 0.0;
+#pragma unroll
+                for (int J = I; J < G; ++J) {
+                    const double Aa = block(I, J);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ya[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(Aa, d[t][J], ya[t], 0, 0, 0);
+                    if (J > I && I + 1 < G) {
+                        const double Ab = block(I + 1, J);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            yb[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ab, d[t][J], yb[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    q[t] = fma(ya[t], ya[t], q[t]);
+                    q[t] = fma(yb[t], yb[t], q[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double v = q[t];
+                v += __shfl_xor(v, 16, 64);               // sum over the 4 coordinates of each group
+                v += __shfl_xor(v, 32, 64);
+                total[s0 + t] = v;
+            }
+        }
+        return c == 0 ? total[0] : (c == 1 ? total[1] : (c == 2 ? total[2] : total[3]));
+    }
+    __device__ static __forceinline__ void idle(const double *pack_, int K_)
+    {
+        MahaEngine e;
+        e.lane = threadIdx.x & 63;
+        e.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        e.begin(pack_, K_);
+        for (int k = 0; k < K_; ++k) {
+            __syncthreads();
+            if (k + 1 < K_) e.stage(k + 1);
+        }
+    }
+};
+
+template <int D> __host__ __device__ constexpr bool pmc_use_mfma() { return D >= 40 && D % 4 == 0; }
 
 // ---------------------------------------------------------------------------------------------
 // k_logpdf: MixtureDensity.multi_evaluate (mixture.pyx:112-156) + logsumexp2D
@@ -47,8 +224,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
     const long long n = ((long long)blockIdx.x * PMC_A_WAVES * 64) + threadIdx.x;
     const bool valid = n < a.N;
 
-    double xv[D];
-    load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
+    MahaEngine<D, PADDED, pmc_use_mfma<D>()> engine;
+    engine.load(a, (long long)blockIdx.x * PMC_A_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
 
     // pass 0: the mixture itself; pass 1 (pmc_importance_weights only): the TARGET mixture of the
     // importance weights, evaluated on the same registers -- the samples are read once
@@ -58,10 +235,9 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         double m = (which == 0 && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
         cdouble *pk = (cdouble *)(which == 0 ? a.pack : a.pack2);
         const int K = which == 0 ? a.K : a.K2;
+        engine.begin((const double *)pk, K);
         for (int k = 0; k < K; ++k, pk += STRIDE) {
-            component_sync();
-            touch_component<D>(pk);
-            const double maha = mahalanobis<D>(xv, pk);
+            const double maha = engine.eval(pk, k);
             double expo;
             const double v = component_value<D, KIND>(maha, pk + D + T, expo);
             if (which == 0 && a.individual != nullptr) {
@@ -109,8 +285,6 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 // pass 2 evaluates the reference's expressions literally, only when the caller wants the N x K
 // matrix log_rho (materialised on demand, never in the E-step itself).
 // ---------------------------------------------------------------------------------------------
-extern __shared__ double resp_park[];                     // PMC_A_WAVES x klds x 64 doubles
-
 template <int D, bool PADDED, int KIND>
 __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(const PmcArgsA a)
 {
@@ -124,16 +298,17 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
     const int K = a.K;
 
     double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    using Engine = MahaEngine<D, PADDED, pmc_use_mfma<D>()>;
     if (!tile_live) {
-        for (int k = 0; k < K; ++k) component_sync();     // keep the workgroup's barrier count
+        Engine::idle(a.pack, K);                          // keep the workgroup's barriers / staging
     } else {
-        double xv[D];
-        load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
+        Engine engine;
+        engine.load(a, tile, lane);
         double *ut = a.u + (size_t)tile * K * 64 + lane;
         // parking place between the passes: LDS for the first klds components (the ones pass 2, which
         // walks downwards, would find evicted from L2), the output buffer itself for the rest
         const int klds = a.klds;
-        double *pl = resp_park + (size_t)(threadIdx.x >> 6) * klds * 64 + lane;
+        double *pl = dyn_lds + Engine::LDS_DOUBLES + (size_t)(threadIdx.x >> 6) * klds * 64 + lane;
         double *mt = (KIND == PMC_KIND_STUDENT_T) ? a.scratch + (size_t)tile * K * 64 + lane : nullptr;
         double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)tile * K * 2 : nullptr;
 
@@ -144,10 +319,9 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
         // (VB starts the maximum at -1e300 instead of -DBL_MAX so that a_0 - m stays finite below)
         double m = a.max_init_zero ? 0.0 : (KIND == PMC_KIND_VB ? -1e300 : -DBL_MAX), s = 0.0, tb = 0.0;
         cdouble *pk = (cdouble *)a.pack;
+        engine.begin(a.pack, K);
         for (int k = 0; k < K; ++k, pk += STRIDE) {
-            component_sync();
-            touch_component<D>(pk);
-            const double maha = mahalanobis<D>(xv, pk);
+            const double maha = engine.eval(pk, k);
             double expo = 0.0;
             const double v = component_value<D, KIND>(maha, pk + D + T, expo);
             if constexpr (KIND == PMC_KIND_STUDENT_T) mt[(size_t)k * 64] = maha;
@@ -270,12 +444,21 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
 
 template <int KIND> hipError_t launch_logpdf_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_logpdf<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    constexpr size_t lds = sizeof(double) * MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES;
+    hipLaunchKernelGGL((k_logpdf<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
     return hipGetLastError();
 }
 template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = (size_t)PMC_A_WAVES * a.klds * 64 * sizeof(double);
+    const size_t lds = sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
+                                         (size_t)PMC_A_WAVES * a.klds * 64);
+    if (lds > 65536) {
+        static const hipError_t once = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&k_resp<D_, P_, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (int)(sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
+                                    (size_t)PMC_A_WAVES * PMC_RESP_KLDS * 64)));
+        if (once != hipSuccess) return once;
+    }
     hipLaunchKernelGGL((k_resp<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
     return hipGetLastError();
 }
