@@ -7,11 +7,10 @@
 //     whitening factor R_k, constants) is wave-uniform, so it is fetched with scalar loads
 //     (address space 4 -> s_load_dwordx16 through the scalar cache) and used as the SGPR operand of
 //     v_fma_f64: the triangular product y = R_k (x - mu_k) costs D(D+1)/2 v_fmac_f64 and no LDS or
-//     vector-memory traffic at all.  fp64 MFMA has the same peak as fp64 VALU on gfx950 and cannot
-//     exploit the triangular structure or D not a multiple of 16, so it is not used.
-//   * Statistics kernel (k_stats): one wavefront owns one (component, row-subset) task and streams
-//     over a chunk of samples with ~50 per-lane fp64 accumulators; the 64 x D sample tile is
-//     loaded coalesced and transposed through LDS once per workgroup and shared by its wavefronts.
+//     vector-memory traffic at all.  From D = 40 on the parameters outgrow the scalar cache and the
+//     product moves to the fp64 matrix pipe with the parameters staged in LDS (MahaEngine below).
+//   * Statistics kernel (k_stats, pmc_stats.hip): one wavefront owns one component and streams over
+//     a chunk of samples, accumulating 4 x 4 blocks of the second moments with the fp64 MFMA.
 //   * All reductions are fixed-order trees (per lane -> wavefront shuffle -> per-block partial ->
 //     one finishing kernel): bit-reproducible run to run, no fp64 atomics.
 //
@@ -85,7 +84,9 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, true> {
 #ifdef PMC_MFMA_NT
     static constexpr int NT = PMC_MFMA_NT;
 #else
-    static constexpr int NT = G <= 12 ? 2 : 1;                     // sub-tiles sharing an A block (registers)
+    // sub-tiles sharing an A block: as many as the registers hold (measured, ms per 2e6 samples:
+    // D=40 K=128: NT 1/2/4 = 11.1 / 9.0 / 8.4;  D=48 K=32: 2/4 = 3.37 / 2.99;  D=64 K=16: 1/2 = 3.48 / 3.23)
+    static constexpr int NT = G <= 12 ? 4 : 2;
 #endif
     static_assert(D % 4 == 0, "MFMA engine needs whole coordinate groups");
     double xm[4][G];             // x[16 s + (lane & 15)][4J + (lane >> 4)]
