@@ -43,7 +43,7 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 // ---------------------------------------------------------------------------------------------
 // Mahalanobis engines: maha_nk = |R_k (x_n - mu_k)|^2 for the wavefront's 64 samples, lane = sample.
 // ---------------------------------------------------------------------------------------------
-// D < 40: the triangular product on the vector pipe with the parameters as SGPR operands (above).
+// D < 32: the triangular product on the vector pipe with the parameters as SGPR operands (above).
 template <int D, bool PADDED, bool MFMA> struct MahaEngine {
     static constexpr int LDS_DOUBLES = 0;
     double xv[D];
@@ -65,7 +65,8 @@ template <int D, bool PADDED, bool MFMA> struct MahaEngine {
     }
 };
 
-// D >= 40: the scalar path cannot feed the vector pipe any more (6.9 KB = 108 cache lines per
+// D >= 32 (multiples of 4; measured break-even: D = 32 log-pdf -17 %, responsibilities +2 %;
+// D = 24 +15 %): the scalar path cannot feed the vector pipe any more (6.9 KB = 108 cache lines per
 // component at D = 40, whose fill takes as long as the arithmetic; 54 % utilisation).  Here the
 // workgroup stages each component's parameters ONCE in LDS (LDS-DMA, double buffered, one barrier per
 // component) and the triangular product runs on the matrix pipe, 4 x 4 blocks of R against 16 samples
@@ -212,7 +213,10 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, true> {
     }
 };
 
-template <int D> __host__ __device__ constexpr bool pmc_use_mfma() { return D >= 40 && D % 4 == 0; }
+#ifndef PMC_MFMA_FROM
+#define PMC_MFMA_FROM 32
+#endif
+template <int D> __host__ __device__ constexpr bool pmc_use_mfma() { return D >= PMC_MFMA_FROM && D % 4 == 0; }
 
 // ---------------------------------------------------------------------------------------------
 // k_logpdf: MixtureDensity.multi_evaluate (mixture.pyx:112-156) + logsumexp2D
