@@ -12,7 +12,7 @@
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------
-// kernel-set registry (one accessor per compiled dimension, defined in pmc_kernels.hip units)
+// kernel-set registry (launchers of the per-dimension units pmc_persample / pmc_stats / pmc_propose)
 // ---------------------------------------------------------------------------------------------
 #define PMC_DECL_UNIT(d, p) \
     extern "C" hipError_t pmc_launch_logpdf_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
