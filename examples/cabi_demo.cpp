@@ -1,0 +1,110 @@
+// The C ABI of libpmc_hip.so used from plain C++/HIP -- no Python, no PyTorch: device memory from
+// hipMalloc, the library only launches kernels on the stream it is given.
+//
+//   hipcc -O2 -I include examples/cabi_demo.cpp -L pypmc_amd/lib -lpmc_hip -Wl,-rpath,$PWD/pypmc_amd/lib -o cabi_demo
+//   ./cabi_demo [N]
+//
+// A 3-component Gaussian mixture in D = 4 (parameters fixed below), N samples on a lattice; prints
+// log q(x_n) of the first samples, the importance-weight sums against a second mixture, and the
+// Rao-Blackwell statistics N_k -- tests/test_gpu_cabi_demo.py compares them with the oracle.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "pmc_hip.h"
+
+#define HIP_OK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));               \
+            return 2;                                                                  \
+        }                                                                              \
+    } while (0)
+#define PMC_OK_(x)                                                                     \
+    do {                                                                               \
+        if ((x) != 0) {                                                                \
+            std::fprintf(stderr, "%s: %s\n", #x, pmc_last_error());                    \
+            return 3;                                                                  \
+        }                                                                              \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    const int64_t N = argc > 1 ? std::atoll(argv[1]) : 1000;
+    const int D = 4, K = 3;
+    // diagonal covariances: precision = diag(1 / var); log_norm = -D/2 log 2pi - 1/2 sum log var
+    const double mu[K * D] = {0, 0, 0, 0, 2, -1, 0.5, 1, -3, 2, 1, -1};
+    const double var[K * D] = {1, 2, 0.5, 1, 0.3, 0.7, 1.1, 2.0, 1.5, 0.4, 0.9, 1.2};
+    const double weight[K] = {0.5, 0.3, 0.2};
+    std::vector<double> prec(K * D * D, 0.0), log_norm(K);
+    for (int k = 0; k < K; ++k) {
+        double ld = 0.0;
+        for (int i = 0; i < D; ++i) {
+            prec[(k * D + i) * D + i] = 1.0 / var[k * D + i];
+            ld += std::log(var[k * D + i]);
+        }
+        log_norm[k] = -0.5 * D * std::log(2.0 * M_PI) - 0.5 * ld;
+    }
+    std::vector<double> x((size_t)N * D);
+    for (int64_t n = 0; n < N; ++n)
+        for (int i = 0; i < D; ++i) x[n * D + i] = std::sin(0.37 * (double)n + 1.3 * i) * 3.0;
+
+    // host: parameter packs (proposal = the mixture, target = the same means with unit variances)
+    const int64_t stride = pmc_pack_stride(D);
+    std::vector<double> pack(K * stride), tpack(K * stride), tprec(K * D * D, 0.0), tln(K);
+    for (int k = 0; k < K; ++k) {
+        for (int i = 0; i < D; ++i) tprec[(k * D + i) * D + i] = 1.0;
+        tln[k] = -0.5 * D * std::log(2.0 * M_PI);
+    }
+    PMC_OK_(pmc_pack_components(K, D, mu, prec.data(), log_norm.data(), nullptr, nullptr, nullptr, weight, nullptr,
+                                pack.data()));
+    PMC_OK_(pmc_pack_components(K, D, mu, tprec.data(), tln.data(), nullptr, nullptr, nullptr, weight, nullptr,
+                                tpack.data()));
+
+    // device buffers
+    double *d_x, *d_pack, *d_tpack, *d_out, *d_w, *d_scalars, *d_u, *d_stats;
+    void *d_ws;
+    const int64_t ws_bytes = pmc_workspace_bytes(N, K, D), ulen = pmc_tile_buffer_len(N, K);
+    const int64_t nstats = 8 + K * pmc_stats_stride(D) + 2 * K;
+    HIP_OK(hipMalloc(&d_x, sizeof(double) * N * D));
+    HIP_OK(hipMalloc(&d_pack, sizeof(double) * K * stride));
+    HIP_OK(hipMalloc(&d_tpack, sizeof(double) * K * stride));
+    HIP_OK(hipMalloc(&d_out, sizeof(double) * N));
+    HIP_OK(hipMalloc(&d_w, sizeof(double) * N));
+    HIP_OK(hipMalloc(&d_scalars, sizeof(double) * 8));
+    HIP_OK(hipMalloc(&d_u, sizeof(double) * ulen));
+    HIP_OK(hipMalloc(&d_stats, sizeof(double) * nstats));
+    HIP_OK(hipMalloc(&d_ws, (size_t)ws_bytes));
+    HIP_OK(hipMemcpy(d_x, x.data(), sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_pack, pack.data(), sizeof(double) * K * stride, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_tpack, tpack.data(), sizeof(double) * K * stride, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(d_stats, 0, sizeof(double) * nstats));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+
+    // log q, importance weights against the target mixture + their sums, one pass over x
+    PMC_OK_(pmc_importance_weights(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, d_tpack, K, PMC_KIND_GAUSS, d_out, nullptr,
+                                   d_w, nullptr, d_scalars, d_ws, stream));
+    // Rao-Blackwell responsibilities weighted by the importance weights, then N_k / sum u d / sum u d d^T
+    PMC_OK_(pmc_responsibilities(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, PMC_RESP_PMC_RB, 0, d_w, nullptr, d_u, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, K, d_stats, d_ws, stream));
+    PMC_OK_(pmc_sufficient_stats(d_x, N, D, d_pack, K, d_u, d_stats + 8, d_ws, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+
+    std::vector<double> out(N), scalars(8), stats(nstats);
+    HIP_OK(hipMemcpy(out.data(), d_out, sizeof(double) * N, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(scalars.data(), d_scalars, sizeof(double) * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(stats.data(), d_stats, sizeof(double) * nstats, hipMemcpyDeviceToHost));
+    std::printf("abi %d arch ", pmc_abi_version());
+    char arch[64];
+    pmc_device_arch(0, arch, sizeof(arch));
+    std::printf("%s N %lld\n", arch, (long long)N);
+    for (int n = 0; n < 5 && n < N; ++n) std::printf("logq %d %.17g\n", n, out[n]);
+    std::printf("sums %.17g %.17g %.17g\n", scalars[0], scalars[1], scalars[2]);
+    for (int k = 0; k < K; ++k) std::printf("N_k %d %.17g\n", k, stats[8 + k * pmc_stats_stride(D)]);
+    return 0;
+}

@@ -1,0 +1,44 @@
+"""The C ABI from plain C++/HIP (examples/cabi_demo.cpp): no Python, no PyTorch on the caller's side.
+Compiled with hipcc on the GPU box, its printed numbers are compared with the oracle."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_demo_matches_oracle(tmp_path):
+    from oracle import oracle as orc
+    import pypmc_amd.build as build
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = build.build()
+    exe = str(tmp_path / "cabi_demo")
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "cabi_demo.cpp"), "-L", os.path.dirname(lib), "-lpmc_hip",
+                    "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True)
+    N = 1237
+    res = subprocess.run([exe, str(N)], check=True, stdout=subprocess.PIPE, text=True).stdout.splitlines()
+    assert res[0].startswith("abi 1 arch gfx950")
+    D, K = 4, 3
+    mu = np.array([[0, 0, 0, 0], [2, -1, 0.5, 1], [-3, 2, 1, -1]], dtype=float)
+    var = np.array([[1, 2, 0.5, 1], [0.3, 0.7, 1.1, 2.0], [1.5, 0.4, 0.9, 1.2]])
+    w = np.array([0.5, 0.3, 0.2])
+    n = np.arange(N)[:, None]
+    x = np.sin(0.37 * n + 1.3 * np.arange(D)[None, :]) * 3.0
+    inv = np.array([np.diag(1. / v) for v in var])
+    ln = -0.5 * D * np.log(2 * np.pi) - 0.5 * np.log(var).sum(axis=1)
+    lq = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)[0]
+    lt = orc.mixture_multi_evaluate(0, x, w, mu, np.tile(np.eye(D), (K, 1, 1)), np.full(K, -0.5 * D * np.log(2 * np.pi)))[0]
+    wts = orc.is_weights(lt, lq)
+    got_lq = np.array([float(line.split()[2]) for line in res if line.startswith("logq")])
+    np.testing.assert_allclose(got_lq, lq[:5], rtol=1e-12)
+    sums = np.array([float(v) for v in [line for line in res if line.startswith("sums")][0].split()[1:]])
+    np.testing.assert_allclose(sums, [wts.sum(), (wts * np.log(wts)).sum(), (wts ** 2).sum()], rtol=1e-11)
+    rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+    got_nk = np.array([float(line.split()[2]) for line in res if line.startswith("N_k")])
+    np.testing.assert_allclose(got_nk, (wts[:, None] * rho).sum(axis=0), rtol=1e-11)
