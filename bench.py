@@ -226,10 +226,10 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1:                                    # MAX over ranks, on the device the backend reduces on
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
 
     is_ms = float(np.mean([a.elapsed_time(b) for a, b, c in phase]))

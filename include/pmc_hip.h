@@ -142,8 +142,8 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
  * ImportanceSampler._calculate_weights (pypmc/sampler/importance_sampling.py:197-215) when the target
  * is itself a mixture density (`target = mixture.evaluate`, pypmc/examples/pmc.py:32-53): log P(x_n) from
  * d_target_pack, log q(x_n) from d_pack, w_n = exp(log P - log q) and the sums of pmc_mixture_logpdf in
- * ONE pass over the samples (mixtures of the same kind; different kinds fall back to two passes through
- * d_log_target_out, which is then required).  Bitwise the same numbers as pmc_mixture_logpdf(target)
+ * ONE pass over the samples, for any combination of proposal and target families (kind / target_kind =
+ * PMC_KIND_GAUSS or PMC_KIND_STUDENT_T).  Bitwise the same numbers as pmc_mixture_logpdf(target)
  * followed by pmc_mixture_logpdf(proposal, d_log_target).
  *   d_out             N, log q(x_n)   (NULL: not wanted)
  *   d_log_target_out  N, log P(x_n)   (NULL: not wanted; ImportanceSampler's target_values)

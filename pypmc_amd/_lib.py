@@ -6,6 +6,8 @@ operation raises ``HipLibraryError`` with the reason.
 import ctypes as C
 import os
 
+import numpy as np
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpmc_hip.so")
 
@@ -13,14 +15,25 @@ PMC_KIND_GAUSS, PMC_KIND_STUDENT_T, PMC_KIND_VB = 0, 1, 2
 PMC_RESP_VB, PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT = 0, 1, 2
 PMC_OK, PMC_EINVAL, PMC_ENOTPOSDEF, PMC_EHIP, PMC_ENODEVICE = 0, -1, -2, -3, -4
 NSCALARS = 8
+MAX_DIM = 64      # largest sample dimension the kernels are compiled for (== pmc_max_dim(), tested)
+
+
+def check_dim(dim):
+    """Sample dimensions beyond the compiled kernels are refused where a density is built, not at
+    its first evaluation (the reference's loops take any length, pypmc/tools/_linalg.pyx:32-37)."""
+    if dim > MAX_DIM:
+        raise ValueError("pypmc_amd's gfx950 kernels are compiled for sample dimensions up to %d "
+                         "(got %d); there is no CPU fallback" % (MAX_DIM, dim))
 
 
 class HipLibraryError(RuntimeError):
     """libpmc_hip.so is missing / unloadable, or a call into it failed."""
 
 
-class NotPositiveDefinite(HipLibraryError):
-    """A precision matrix handed to pmc_pack_components is not positive definite."""
+class NotPositiveDefinite(HipLibraryError, np.linalg.LinAlgError):
+    """A precision matrix handed to pmc_pack_components is not positive definite.  Also a
+    ``numpy.linalg.LinAlgError``: callers written against the reference catch that
+    (pypmc/mix_adapt/pmc.pyx:227-244, pypmc/density/gauss.pyx:40-48)."""
 
 
 _vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int

@@ -200,7 +200,7 @@ class HipBackend(object):
         pack = self.pack(comps) if pack is None else pack
         target_pack = self.pack(target) if target_pack is None else target_pack
         out = self.empty(N) if want_out else None
-        lt = self.empty(N) if (want_log_target or comps.kind != target.kind) else None
+        lt = self.empty(N) if want_log_target else None
         weights = self.empty(N)
         sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
         scalars = self.zeros(NSCALARS)

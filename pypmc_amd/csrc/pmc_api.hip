@@ -15,7 +15,7 @@
 // kernel-set registry (launchers of the per-dimension units pmc_persample / pmc_stats / pmc_propose)
 // ---------------------------------------------------------------------------------------------
 #define PMC_DECL_UNIT(d, p) \
-    extern "C" hipError_t pmc_launch_logpdf_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
+    extern "C" hipError_t pmc_launch_logpdf_d##d##_p##p(int, int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t);   \
     extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t);       \
     extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);                                        \
@@ -399,7 +399,7 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
         a.ld = ld; a.out = d_out; a.individual = d_individual; a.log_target = d_log_target;
         a.weights = d_weights; a.sample_w = d_sample_w;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
-        hipError_t e = ks->logpdf(kind, a, (unsigned)nblocks, st);
+        hipError_t e = ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
@@ -418,16 +418,6 @@ int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_
         return fail(PMC_EINVAL, "pmc_importance_weights: kinds must be GAUSS or STUDENT_T");
     if (N > 0 && (!d_x || !d_weights)) return fail(PMC_EINVAL, "pmc_importance_weights: d_x / d_weights is NULL");
     if (d_scalars && !d_workspace) return fail(PMC_EINVAL, "pmc_importance_weights: d_scalars needs d_workspace");
-    if (target_kind != kind) {
-        // different component families: two passes over the samples through the caller's buffer
-        if (!d_log_target_out)
-            return fail(PMC_EINVAL, "pmc_importance_weights: kinds differ, d_log_target_out is required");
-        int rc = pmc_mixture_logpdf(d_x, N, D, d_target_pack, K_target, target_kind, 0, d_log_target_out, nullptr,
-                                    K_target, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
-        if (rc != PMC_OK) return rc;
-        return pmc_mixture_logpdf(d_x, N, D, d_pack, K, kind, 0, d_out, nullptr, K, d_log_target_out, d_weights,
-                                  d_sample_w, d_scalars, d_workspace, stream);
-    }
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
     hipStream_t st = (hipStream_t)stream;
@@ -439,7 +429,7 @@ int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_
         a.pack2 = d_target_pack; a.K2 = K_target; a.log_target_out = d_log_target_out;
         a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
-        hipError_t e = ks->logpdf(kind, a, (unsigned)nblocks, st);
+        hipError_t e = ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);

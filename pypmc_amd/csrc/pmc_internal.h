@@ -74,7 +74,7 @@ struct PmcKernelSet {
     int padded;           // 1: accepts dreal <= dim
     int stats_nsub;       // row subsets per component in the statistics kernel
     int stats_waves;      // wavefronts per workgroup in the statistics kernel
-    hipError_t (*logpdf)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
+    hipError_t (*logpdf)(int kind, int kind2, const PmcArgsA &, unsigned grid, hipStream_t);
     hipError_t (*resp)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
     hipError_t (*stats)(const PmcArgsB &, unsigned grid, hipStream_t);
     void (*config)(int *nsub, int *waves);

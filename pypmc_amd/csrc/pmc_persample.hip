@@ -222,7 +222,7 @@ template <int D> __host__ __device__ constexpr bool pmc_use_mfma() { return D >=
 // k_logpdf: MixtureDensity.multi_evaluate (mixture.pyx:112-156) + logsumexp2D
 // (_regularize.pyx:57-84) [+ importance weights, importance_sampling.py:197-215] in one pass.
 // ---------------------------------------------------------------------------------------------
-template <int D, bool PADDED, int KIND>
+template <int D, bool PADDED, int KIND, int KIND2>
 __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(const PmcArgsA a)
 {
     constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
@@ -232,29 +232,27 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
     MahaEngine<D, PADDED, pmc_use_mfma<D>()> engine;
     engine.load(a, (long long)blockIdx.x * PMC_A_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
 
-    // pass 0: the mixture itself; pass 1 (pmc_importance_weights only): the TARGET mixture of the
-    // importance weights, evaluated on the same registers -- the samples are read once
-    double lse = 0.0, lse_target = 0.0;
-    const int npass = a.pack2 != nullptr ? 2 : 1;
-    for (int which = 0; which < npass; ++which) {
-        double m = (which == 0 && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
-        cdouble *pk = (cdouble *)(which == 0 ? a.pack : a.pack2);
-        const int K = which == 0 ? a.K : a.K2;
+    // the mixture itself (kind KIND), then -- pmc_importance_weights only -- the TARGET mixture of the
+    // importance weights (kind KIND2), evaluated on the same registers: the samples are read once
+    auto mixture = [&](auto kind, cdouble *pk, const int K, const bool first) -> double {
+        constexpr int KD = decltype(kind)::value;
+        double m = (first && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
         engine.begin((const double *)pk, K);
         for (int k = 0; k < K; ++k, pk += STRIDE) {
             const double maha = engine.eval(pk, k);
             double expo;
-            const double v = component_value<D, KIND>(maha, pk + D + T, expo);
-            if (which == 0 && a.individual != nullptr) {
+            const double v = component_value<D, KD>(maha, pk + D + T, expo);
+            if (first && a.individual != nullptr) {
                 const long long col = ((cint64 *)pk)[D + T + 5];
                 if (valid) a.individual[n * a.ld + col] = v;
             }
             lse_step(v, pk[D + T + 4], m, s);
         }
-        const double l = log(s) + m;                     // _regularize.pyx:81
-        if (which == 0) lse = l;
-        else lse_target = l;
-    }
+        return log(s) + m;                               // _regularize.pyx:81
+    };
+    const double lse = mixture(ic<KIND>{}, (cdouble *)a.pack, a.K, true);
+    double lse_target = 0.0;
+    if (a.pack2 != nullptr) lse_target = mixture(ic<KIND2>{}, (cdouble *)a.pack2, a.K2, false);
     if (a.out != nullptr && valid) a.out[n] = lse;
     if (a.log_target_out != nullptr && valid) a.log_target_out[n] = lse_target;
 
@@ -447,10 +445,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
     if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
 }
 
-template <int KIND> hipError_t launch_logpdf_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
+template <int KIND, int KIND2> hipError_t launch_logpdf_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
 {
     constexpr size_t lds = sizeof(double) * MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES;
-    hipLaunchKernelGGL((k_logpdf<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((k_logpdf<D_, P_, KIND, KIND2>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
     return hipGetLastError();
 }
 template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
@@ -470,14 +468,19 @@ template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, h
 
 }  // namespace
 
-extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_d, PMC_D, PMC_PADDED)(int kind, const PmcArgsA &a,
+// kind2: component family of the second (target) mixture of pmc_importance_weights; ignored without one
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_d, PMC_D, PMC_PADDED)(int kind, int kind2, const PmcArgsA &a,
                                                                              unsigned grid, hipStream_t st)
 {
-    switch (kind) {
-    case PMC_KIND_GAUSS: return launch_logpdf_k<PMC_KIND_GAUSS>(a, grid, st);
-    case PMC_KIND_STUDENT_T: return launch_logpdf_k<PMC_KIND_STUDENT_T>(a, grid, st);
-    default: return hipErrorInvalidValue;
-    }
+    if (a.pack2 == nullptr) kind2 = kind;
+    if (kind == PMC_KIND_GAUSS && kind2 == PMC_KIND_GAUSS) return launch_logpdf_k<PMC_KIND_GAUSS, PMC_KIND_GAUSS>(a, grid, st);
+    if (kind == PMC_KIND_STUDENT_T && kind2 == PMC_KIND_STUDENT_T)
+        return launch_logpdf_k<PMC_KIND_STUDENT_T, PMC_KIND_STUDENT_T>(a, grid, st);
+    if (kind == PMC_KIND_GAUSS && kind2 == PMC_KIND_STUDENT_T)
+        return launch_logpdf_k<PMC_KIND_GAUSS, PMC_KIND_STUDENT_T>(a, grid, st);
+    if (kind == PMC_KIND_STUDENT_T && kind2 == PMC_KIND_GAUSS)
+        return launch_logpdf_k<PMC_KIND_STUDENT_T, PMC_KIND_GAUSS>(a, grid, st);
+    return hipErrorInvalidValue;
 }
 
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_resp_d, PMC_D, PMC_PADDED)(int kind, const PmcArgsA &a,

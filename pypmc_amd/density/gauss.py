@@ -4,7 +4,7 @@ import numpy as np
 from .base import ProbabilityDensity
 from ..tools._linalg import chol_inv_det
 from ..backend import ComponentSet, get_backend
-from .._lib import PMC_KIND_GAUSS
+from .._lib import PMC_KIND_GAUSS, check_dim
 
 
 def _as_matrix(sigma):
@@ -34,6 +34,7 @@ class Gauss(ProbabilityDensity):
         sigma = _as_matrix(sigma)
         cholesky_sigma, inv_sigma, log_det_sigma = chol_inv_det(sigma)   # may raise LinAlgError
         mu = np.array(mu, dtype=float).reshape(-1)
+        check_dim(len(mu))
         assert len(mu) == sigma.shape[0], \
             "Dimensions of mean (%d) and covariance matrix (%d) do not match!" % (len(mu), sigma.shape[0])
         self.mu, self.sigma, self.dim = mu, sigma, len(mu)

@@ -88,11 +88,16 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
     else:
         flat, nlive = be.zeros(be.stats_len(1, D)), 0
 
-    # one exchange: statistics | weight normalisation | latent histogram
+    # ONE exchange: statistics | weight normalisation | latent histogram travel in the same buffer
+    # (on the device when the statistics are, so RCCL reduces it in place)
     tail = np.concatenate(([local_norm], count if count is not None else np.zeros(0)))
+    nstat = int(flat.shape[0])
     if parallel.world_size() > 1:
-        flat = be.tohost(parallel.all_reduce_sum(flat))
-        tail = parallel.all_reduce_sum(tail)
+        joined = be.zeros(nstat + len(tail))
+        joined[:nstat] = flat
+        joined[nstat:] = be.asdevice(tail)
+        joined = be.tohost(parallel.all_reduce_sum(joined))
+        flat, tail = joined[:nstat], joined[nstat:]
     else:
         flat = be.tohost(flat)
     weight_normalization = float(tail[0])

@@ -17,7 +17,7 @@ import numpy as np
 from scipy.special import digamma, gammaln
 
 from .. import parallel
-from .._lib import PMC_KIND_VB, PMC_RESP_VB
+from .._lib import PMC_KIND_VB, PMC_RESP_VB, check_dim
 from ..backend import ComponentSet, get_backend
 from ..density.gauss import Gauss
 from ..density.mixture import MixtureDensity, recover_gaussian_mixture
@@ -43,6 +43,7 @@ class GaussianInference(object):
         self.N_local = data.shape[0]
         self.data = data.reshape(self.N_local, 1) if data.ndim == 1 else data
         self.dim = self.data.shape[1]
+        check_dim(self.dim)
         self.weights = None
         sum_w_local = 0.0
         if weights is not None:
@@ -330,17 +331,26 @@ class GaussianInference(object):
             raise ValueError('All elements of %s must exceed %g. %s=%s' % (name, min, name, v))
 
     def _initialize_m(self, initial_guess):
-        """Initial means from the data: the first K points, or K random ones."""
-        if self.K > self.N_local:
+        """Initial means from the data: the first K points, or K random ones
+        (reference: variational.pyx:610-626).  With sharded data the K points are taken from the
+        GLOBAL sample array (rank order = sample order) and reach every rank through one sum
+        all-reduce, so all ranks start from bitwise identical means; 'random' uses rank 0's draw."""
+        if self.K > self.N:
             raise ValueError("Can't auto-initialize ``m`` with more output components than samples."
                              " Specify ``m`` explicitly.")
         host = (lambda rows: np.array(rows, dtype=np.float64)) if isinstance(self.data, np.ndarray) \
             else (lambda rows: rows.detach().cpu().numpy().astype(np.float64))
         if initial_guess == 'first':
-            return host(self.data[:self.K])
-        if initial_guess == 'random':
-            return host(self.data[np.random.choice(self.N_local, size=self.K, replace=False)])
-        raise ValueError('Invalid ``initial_guess``: ' + str(initial_guess))
+            indices = np.arange(self.K)
+        elif initial_guess == 'random':
+            indices = np.random.choice(self.N, size=self.K, replace=False)
+            if parallel.world_size() > 1:
+                indices = np.rint(parallel.broadcast_from_rank0(indices)).astype(np.int64)
+        else:
+            raise ValueError('Invalid ``initial_guess``: ' + str(initial_guess))
+        if parallel.world_size() == 1:
+            return host(self.data[:self.K] if initial_guess == 'first' else self.data[indices])
+        return parallel.global_rows(indices, self.N_local, lambda loc: host(self.data[loc]), self.dim)
 
     def _initialize_intermediate(self):
         self.x_mean_comp = np.zeros((self.K, self.dim))

@@ -5,8 +5,13 @@ collective on the hot path -- a sum all-reduce of the K-sized statistics vector
 The reference's only distributed code gathers whole pickled sample histories to rank 0 with
 mpi4py (pypmc/tools/parallel_sampler.py:58-71) and broadcasts the adapted proposal back
 (examples/pmc_mpi.py:119-131).  Here samples never leave their GPU: every rank reduces its shard to
-[scalars | K x (1 + D + D(D+1)/2) | K x 2] doubles, the ranks all-reduce that buffer, and every rank
-runs the identical K-sized host update -- no broadcast is needed.
+[scalars | K x (1 + D + D(D+1)/2) | K x 2 | bookkeeping tail] doubles, the ranks all-reduce that
+buffer, and every rank runs the identical K-sized host update -- no broadcast is needed.
+
+Everything that must be identical on all ranks but is derived from data (the start means of
+GaussianInference(initial_guess='first'/'random'), the global sample count) goes through a sum
+all-reduce as well -- the owner contributes the value, everybody else zeros -- so the result is
+bitwise the same everywhere.
 """
 import numpy as np
 
@@ -38,29 +43,81 @@ def shard_bounds(N, r=None, world=None):
     return begin, begin + base + (1 if r < extra else 0)
 
 
+def _collective_device(d):
+    """device the default process group's backend reduces on"""
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if d.get_backend() == "nccl" else torch.device("cpu")
+
+
 def all_reduce_sum(buf):
-    """In-place sum over ranks of a float64 buffer (CUDA tensor -> RCCL, CPU tensor / numpy ->
-    gloo).  Returns ``buf``.  A no-op for a single process."""
+    """In-place sum over ranks of a float64 buffer; returns ``buf``.  A no-op for a single process.
+
+    The buffer is reduced where the process group's backend works -- RCCL ("nccl") on the GPU, gloo
+    on the host -- and staged through the other memory when it lives there: a numpy / CPU buffer
+    under nccl goes through a device copy, a device tensor under gloo (the CPU test-suite and
+    `PMC_DIST_BACKEND=gloo`, several ranks on one GPU) through a host copy."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return buf
     import torch
+    dev = _collective_device(d)
     if isinstance(buf, np.ndarray):
-        t = torch.from_numpy(buf)          # shares memory with buf
-        d.all_reduce(t, op=d.ReduceOp.SUM)
+        t = torch.from_numpy(buf)                       # shares memory with buf
+        if dev.type == "cpu":
+            d.all_reduce(t, op=d.ReduceOp.SUM)
+        else:
+            g = t.to(dev)
+            d.all_reduce(g, op=d.ReduceOp.SUM)
+            t.copy_(g)
         return buf
-    d.all_reduce(buf, op=d.ReduceOp.SUM)
+    if buf.device.type == dev.type:
+        d.all_reduce(buf, op=d.ReduceOp.SUM)
+    else:
+        g = buf.to(dev)
+        d.all_reduce(g, op=d.ReduceOp.SUM)
+        buf.copy_(g)
     return buf
 
 
 def all_reduce_scalars(*values):
-    """Sum a few python floats over ranks (setup-time bookkeeping: global N, global sum of weights).
-    Uses a tensor on the device the process group's backend expects."""
+    """Sum a few python floats over ranks (setup-time bookkeeping: global N, global sum of weights)."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return tuple(float(v) for v in values)
-    import torch
-    dev = "cuda" if d.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
-    d.all_reduce(t, op=d.ReduceOp.SUM)
-    return tuple(float(v) for v in t.cpu())
+    a = np.array([float(v) for v in values], dtype=np.float64)
+    all_reduce_sum(a)
+    return tuple(float(v) for v in a)
+
+
+def shard_offset(n_local):
+    """Global index of this rank's first sample when the ranks hold consecutive blocks of
+    ``n_local`` rows each (rank order = sample order), and the global row count."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return 0, int(n_local)
+    sizes = np.zeros(d.get_world_size(), dtype=np.float64)
+    sizes[d.get_rank()] = float(n_local)
+    all_reduce_sum(sizes)
+    sizes = np.rint(sizes).astype(np.int64)
+    return int(sizes[:d.get_rank()].sum()), int(sizes.sum())
+
+
+def global_rows(indices, n_local, fetch, dim):
+    """Rows ``indices`` (global sample numbers) of the sharded sample array, identical on every
+    rank: the owner of a row contributes it, everybody else zeros, one sum all-reduce.
+    ``fetch(local_indices)`` returns this rank's rows as a float64 array."""
+    indices = np.asarray(indices, dtype=np.int64)
+    offset, _ = shard_offset(n_local)
+    out = np.zeros((len(indices), dim), dtype=np.float64)
+    mine = (indices >= offset) & (indices < offset + n_local)
+    if mine.any():
+        out[mine] = np.asarray(fetch(indices[mine] - offset), dtype=np.float64).reshape(-1, dim)
+    return all_reduce_sum(out)
+
+
+def broadcast_from_rank0(values):
+    """A float64 vector as rank 0 holds it, on every rank (sum all-reduce of zeros elsewhere)."""
+    a = np.array(values, dtype=np.float64)
+    if rank() != 0:
+        a[...] = 0.0
+    return all_reduce_sum(a)

@@ -5,6 +5,7 @@ from copy import deepcopy
 import numpy as np
 
 from ..backend import get_backend
+from ..density.base import ProbabilityDensity
 from ..tools._history import History, DeviceHistory
 from ..tools.indicator import merge_function_with_indicator
 
@@ -70,9 +71,12 @@ class ImportanceSampler(object):
         self.proposal = deepcopy(proposal)
         self.rng = rng
         self._batch_target = None
+        # batch shortcut only for this package's own densities: a foreign class's multi_evaluate
+        # may mean something else, and the reference calls target(x) once per sample
         owner = getattr(target, '__self__', None)
-        if indicator is None and owner is not None and getattr(target, '__name__', '') == 'evaluate' \
-                and hasattr(owner, 'multi_evaluate'):
+        if indicator is None and isinstance(owner, ProbabilityDensity) \
+                and getattr(target, '__name__', '') == 'evaluate' \
+                and getattr(target, '__func__', None) is getattr(type(owner), 'evaluate', None):
             self._batch_target = owner.multi_evaluate
         self.target = merge_function_with_indicator(target, indicator, -np.inf)
         if self.device:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the HIP path against the oracle over EVERY sample dimension 1..64 (exact and
-padded kernel units), ragged N and odd K -- a development aid, run by hand on the GPU box:
+padded kernel units), ragged N and odd K.  tests/test_gpu_fuzz.py runs it with fixed seeds under
+`-m gpu`; by hand on the GPU box:
 
     python tests/fuzz_gpu.py [seed] [rounds]
 """
@@ -29,13 +30,12 @@ def rel(a, b, floor=1e-300):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
 
 
-def main():
-    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True):
+    """Returns {quantity: worst relative error}; raises AssertionError naming the failing shape."""
     from oracle import oracle as orc
     from pypmc_amd.backend import HipBackend, ComponentSet
     from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
-    be = HipBackend()
+    be = be or HipBackend()
     rs = np.random.RandomState(seed)
     worst = {}
 
@@ -44,7 +44,7 @@ def main():
         assert v < tol, "%s: %.3g >= %.3g at %s" % (name, v, tol, ctx)
 
     for rnd in range(rounds):
-        for D in range(1, 65):
+        for D in dims:
             K = int(rs.randint(1, 41))
             N = int(rs.choice([1, 2, 63, 64, 65, 127, 129, rs.randint(1, 3000)]))
             ctx = dict(D=D, K=K, N=N, seed=seed, round=rnd)
@@ -71,7 +71,7 @@ def main():
             with np.errstate(over='ignore'):
                 ref_w = np.exp(ref_t - ref_q)
             fin = np.isfinite(ref_w)
-            note("weights", rel(be.tohost(iw["weights"])[fin], ref_w[fin]), 1e-9, ctx)
+            note("weights", rel(be.tohost(iw["weights"])[fin], ref_w[fin]), 1e-10, ctx)
             # Student-t mixture log-pdf
             from scipy.special import gammaln
             dof = rs.uniform(1.0, 12.0, K)
@@ -108,7 +108,7 @@ def main():
             rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
             got = be.tohost(out["r"])
             normal = ref_ind > -690                          # exp(log q_k) a normal number in the reference
-            note("pmc rho", rel(got[normal], rho[normal]), 1e-9, ctx)
+            note("pmc rho", rel(got[normal], rho[normal]), 1e-10, ctx)
             # below, the reference's numerator is denormal (a few bits) or zero: follow it loosely
             note("pmc rho (denormal numerator)", rel(got[~normal], rho[~normal], 1e-200), 5e-2, ctx)
             sc, S0, M1, M2, _, _ = split_stats(be.tohost(out["stats"]), K, D)
@@ -116,8 +116,15 @@ def main():
             d = x[:, None, :] - mu[None, :, :]
             M2ref = np.einsum('n,nk,nki,nkj->kij', iwts, rho, d, d)
             note("pmc M2", float(np.max(np.abs(M2 - M2ref) / (np.abs(M2ref) + 1e-6 * np.abs(M2ref).max()))), 1e-8, ctx)
-        print("round %d ok" % rnd, flush=True)
-    for k_, v in sorted(worst.items()):
+        if verbose:
+            print("round %d ok" % rnd, flush=True)
+    return worst
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    for k_, v in sorted(sweep(seed, rounds).items()):
         print("worst %-12s %.3g" % (k_, v))
 
 

@@ -28,41 +28,60 @@ def test_shard_bounds():
         assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_vb_and_pmc_match_single_process():
-    import torch.multiprocessing as mp
-    from pypmc_amd.density.mixture import create_gaussian_mixture
-    from pypmc_amd.mix_adapt.variational import GaussianInference
-    from pypmc_amd.mix_adapt.pmc import gaussian_pmc, PMC
-    rs = np.random.RandomState(5)
-    K, D, N = 3, 4, 601
-    mu = rs.normal(0, 3, (K, D))
-    cov = np.array([np.eye(D) * (0.5 + k) for k in range(K)])
-    w = np.array([0.2, 0.5, 0.3])
-    latent = rs.choice(K, size=N, p=w)
-    data = mu[latent] + np.einsum('nij,nj->ni', np.linalg.cholesky(cov)[latent], rs.normal(size=(N, D)))
-    sw = rs.uniform(0.5, 1.5, N)
-    iw = rs.uniform(0.2, 2.0, N)
-    be = OracleBackend()
-    guess = create_gaussian_mixture(mu, cov, w)
-    vb = GaussianInference(data, initial_guess=guess, weights=sw, backend=be)
-    ref = dict(vb_N=vb.N, vb_N_comp0=vb.N_comp.copy(), vb_bound0=vb.likelihood_bound())
-    nit = vb.run(6, prune=1.)
-    ref.update(vb_nit=-1 if nit is None else nit, vb_m=vb.m, vb_W=vb.W, vb_alpha=vb.alpha,
-               vb_bound=vb.likelihood_bound())
-    prop = create_gaussian_mixture(mu, cov, w)
-    prop._backend = be
-    res = gaussian_pmc(data, prop, weights=iw, latent=latent, mincount=5, backend=be)
-    ref.update(pmc_w=res.weights, pmc_mu=np.array([c.mu for c in res.components]),
-               pmc_sigma=np.array([c.sigma for c in res.components]),
-               pmc_ll=PMC(data, prop, weights=iw, backend=be).log_likelihood())
-    with tempfile.TemporaryDirectory() as tmp:
-        np.savez(os.path.join(tmp, "inputs.npz"), data=data, mu=mu, cov=cov, w=w, sw=sw, iw=iw, latent=latent)
-        mp.spawn(dist_worker.run, args=(2, _free_port(), tmp), nprocs=2, join=True)
-        ranks = [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(2)]
+def check_two_ranks(single, ranks, N, rtol):
     assert sum(int(r["vb_r_rows"]) for r in ranks) == N        # r stays sharded
     for got in ranks:
-        for key, val in ref.items():
-            np.testing.assert_allclose(got[key], val, rtol=1e-10, atol=1e-12, err_msg=key)
-    # both ranks hold bitwise identical parameters (replicated update, no broadcast)
-    for key in ("vb_m", "vb_W", "pmc_mu", "pmc_sigma", "pmc_w"):
-        np.testing.assert_array_equal(ranks[0][key], ranks[1][key])
+        for key, val in single.items():
+            if key == "vb_r_rows":
+                continue
+            np.testing.assert_allclose(got[key], val, rtol=rtol, atol=1e-12, err_msg=key)
+    # the start means are rows of the data: exact, whatever the shard they came from
+    np.testing.assert_array_equal(ranks[0]["vbf_m0"], single["vbf_m0"])
+    np.testing.assert_array_equal(ranks[0]["vbr_m0"], single["vbr_m0"])
+    # all ranks hold bitwise identical parameters (replicated update, no broadcast)
+    for key in dist_worker.REPLICATED:
+        np.testing.assert_array_equal(ranks[0][key], ranks[1][key], err_msg=key)
+
+
+def spawn_two_ranks(z, backend_kind):
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "inputs.npz"), **z)
+        mp.spawn(dist_worker.run, args=(2, _free_port(), tmp, backend_kind), nprocs=2, join=True)
+        return [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(2)]
+
+
+def test_two_rank_vb_and_pmc_match_single_process():
+    z = dist_worker.make_inputs()
+    single = dist_worker.case(OracleBackend(), z, 0, len(z["data"]))
+    ranks = spawn_two_ranks(z, "oracle")
+    check_two_ranks(single, ranks, len(z["data"]), rtol=1e-10)
+
+
+def test_first_rows_spanning_ranks():
+    """initial_guess='first' with more start means than rank 0 holds rows"""
+    z = dist_worker.make_inputs(seed=8, N=9)
+    be = OracleBackend()
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    single = GaussianInference(z["data"], components=6, initial_guess="first", backend=be).m
+    np.testing.assert_array_equal(single, z["data"][:6])
+    with tempfile.TemporaryDirectory() as tmp:
+        import torch.multiprocessing as mp
+        np.savez(os.path.join(tmp, "inputs.npz"), **z)
+        mp.spawn(_first_rows_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        for r in range(2):
+            np.testing.assert_array_equal(np.load(os.path.join(tmp, "m%d.npy" % r)), single)
+
+
+def _first_rows_worker(rank, world, port, workdir):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from pypmc_amd import parallel
+        from pypmc_amd.mix_adapt.variational import GaussianInference
+        z = np.load(os.path.join(workdir, "inputs.npz"))
+        lo, hi = parallel.shard_bounds(len(z["data"]))             # 5 + 4 rows
+        vb = GaussianInference(z["data"][lo:hi], components=6, initial_guess="first", backend=OracleBackend())
+        np.save(os.path.join(workdir, "m%d.npy" % rank), vb.m)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,55 @@
+"""N > 1 path on the product backend: two ranks share the box's one GPU (process group "gloo",
+because RCCL refuses two ranks on one device), each runs the HIP kernels on its shard and the
+statistics buffer is all-reduced -- results must equal the single-process HIP run and be bitwise
+identical across ranks.  The driver's 8-GPU run uses the same code with backend "nccl"."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import dist_worker
+from test_distributed_cpu import check_two_ranks, spawn_two_ranks, _free_port
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_hip_backend_match_single_process():
+    from pypmc_amd.backend import HipBackend
+    z = dist_worker.make_inputs(N=5003)
+    single = dist_worker.case(HipBackend(), z, 0, len(z["data"]))
+    ranks = spawn_two_ranks(z, "hip")
+    assert all(str(r["backend"]) == "hip" for r in ranks)
+    # the two shards' statistics are summed in a different order than the single run's chunks
+    check_two_ranks(single, ranks, len(z["data"]), rtol=1e-9)
+
+
+def test_two_ranks_vs_oracle():
+    """the sharded HIP run against the single-process oracle run"""
+    from oracle_backend import OracleBackend
+    z = dist_worker.make_inputs(seed=11, N=1201)
+    single = dist_worker.case(OracleBackend(), z, 0, len(z["data"]))
+    ranks = spawn_two_ranks(z, "hip")
+    for got in ranks:
+        for key in ("vb_N_comp0", "vb_bound0", "vbf_m0", "vbf_N_comp0", "vbr_m0", "pmc_w", "pmc_mu", "pmc_sigma",
+                    "pmcl_mu", "pmc_ll", "tpmc_mu", "tpmc_sigma", "tpmc_dof"):
+            np.testing.assert_allclose(got[key], single[key], rtol=1e-9, atol=1e-11, err_msg=key)
+
+
+def test_bench_two_ranks_one_gpu():
+    """bench.py --gpus 2 end to end (torch.distributed.run, 2 ranks on the one GPU via gloo)"""
+    env = dict(os.environ, PMC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "300000"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "cpu_baseline" not in line                  # rank 0 at N=1 only
