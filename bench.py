@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000, help="samples per GPU")
+    ap.add_argument("--n", "--samples-per-gpu", dest="n", type=int, default=10_000_000, help="samples per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

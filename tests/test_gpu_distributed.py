@@ -45,7 +45,7 @@ def test_bench_two_ranks_one_gpu():
     env = dict(os.environ, PMC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--n", "300000"]
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples-per-gpu", "300000"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

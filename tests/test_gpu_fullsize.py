@@ -204,6 +204,67 @@ def test_cfg5_pmc_update_d40_k128(be, orc):
     assert rel(r, ref) < 1e-10
 
 
+def test_cfg5_full_loop_1p25e7_per_gpu(be, orc):
+    """BASELINE config 5 at its stated size: one GPU's share (1.25e7) of N=1e8 samples per iteration,
+    D=40, K=128, as the full propose -> weight -> Rao-Blackwell update loop with every N-sized array
+    resident on the device.  Checked through invariants and oracle parity on a subsample."""
+    import torch
+    import pypmc_amd as pypmc
+    from pypmc_amd.density.mixture import create_gaussian_mixture, component_set
+    from pypmc_amd.tools.convergence import perp_from_sums
+    K, D, K_T, N = 128, 40, 4, 12_500_000
+    tmu, tcov, tw = mk(K_T, D, 11)
+    tmu /= 3.0                                           # modes ~1 sigma apart per coordinate
+    target = create_gaussian_mixture(tmu, tcov, tw)
+    rs = np.random.RandomState(5)
+    which = np.arange(K) % K_T
+    proposal = create_gaussian_mixture(tmu[which] + rs.normal(0, 0.15, (K, D)), 1.5 * tcov[which])
+    sampler = pypmc.sampler.importance_sampling.ImportanceSampler(target.evaluate, proposal,
+                                                                  rng=np.random.RandomState(100))
+    perps = []
+    for it in range(2):
+        old = sampler.proposal
+        old_set = component_set(old.components, old.weights)
+        run = sampler.run_device(N, trace_sort=True)
+        x, wts, origin = run["samples"], run["weights"], run["origin"]
+        assert tuple(x.shape) == (N, D) and tuple(wts.shape) == (N,) and tuple(origin.shape) == (N,)
+        # counts / origins: exactly the host generator's multinomial draw, ordered by component
+        assert bool((origin[1:] >= origin[:-1]).all())
+        assert int(torch.bincount(origin, minlength=K).sum()) == N
+        S, L, Q = run["weight_sums"]
+        assert abs(S / float(wts.sum()) - 1) < 1e-12 and abs(Q / float((wts * wts).sum()) - 1) < 1e-12
+        perp = perp_from_sums(S, L, N)
+        ess = S * S / (N * Q)
+        assert 0 < ess <= perp <= 1
+        perps.append(perp)
+        # subsample parity of log q, log P and the weights with the oracle
+        rows = np.random.RandomState(it).choice(N, 256, replace=False)
+        xs = x[rows].cpu().numpy()
+        ref_q = orc.mixture_multi_evaluate(0, xs, old_set.weight, old_set.mu, old_set.precision, old_set.c0)[0]
+        tset = component_set(target.components, target.weights)
+        ref_p = orc.mixture_multi_evaluate(0, xs, tset.weight, tset.mu, tset.precision, tset.c0)[0]
+        assert rel(wts[rows].cpu().numpy(), orc.is_weights(ref_p, ref_q)) < 1e-10
+        # rho of the update on the first rows against the oracle
+        n_sub = 192
+        r = be.estep(x[:n_sub].contiguous(), old_set, 1, want_r=True)["r"].cpu().numpy()
+        ref = orc.rho_rb(0, x[:n_sub].cpu().numpy(), old_set.weight, old_set.mu, old_set.precision, old_set.c0,
+                         None, None, list(range(K)))
+        assert rel(r, ref) < 1e-10
+        old_mu = np.array([c.mu for c in old.components])
+        pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=False)
+        new = sampler.proposal
+        assert new.normalized() and (new.weights > 0).all() and len(new) == K
+        for c in new.components:
+            assert np.all(np.linalg.eigvalsh(c.sigma) > 0)
+        # the adapted means moved towards their target mode
+        new_mu = np.array([c.mu for c in new.components])
+        assert np.linalg.norm(new_mu - tmu[which]) < np.linalg.norm(old_mu - tmu[which])
+        del run, x, wts, origin
+    assert perps[1] > perps[0]                           # the adapted proposal is the better one
+    be.release()
+    torch.cuda.empty_cache()
+
+
 def test_offsets_beyond_32_bits(be):
     """N x D = 2.4e9 elements (19 GB of samples, 7.7 GB of responsibilities): element and byte
     offsets beyond 2^31 / 2^32 in every kernel of the path."""
