@@ -241,6 +241,24 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
 int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
                          const double *d_u, double *d_stats, void *d_workspace, void *stream);
 
+/* ---- the E-step in one call ---------------------------------------------------------------------- */
+/*
+ * GaussianInference.E_step (pypmc/mix_adapt/variational.pyx:116-127) / the N-sized part of gaussian_pmc
+ * and student_t_pmc (pypmc/mix_adapt/pmc.pyx:53-118, :188-222, :602-691): responsibilities AND
+ * sufficient statistics of the samples, d_stats as pmc_sufficient_stats and d_scalars / d_vsums as
+ * pmc_responsibilities produce them -- without the public N x K matrices.
+ *
+ * For small sample dimensions (pmc_estep_is_fused() != 0: compiled dimension <= 16, K <= 32, VB or
+ * Gaussian Rao-Blackwell PMC) ONE kernel does both and the N x K responsibilities never leave the
+ * compute units: d_u and d_scratch may then be NULL.  Otherwise the call is pmc_responsibilities
+ * followed by pmc_sufficient_stats through d_u (and d_scratch / d_vsums for Student-t).
+ */
+int pmc_estep_is_fused(int K, int D, int kind, int mode);
+int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, int mode,
+              int max_init_zero, const double *d_sample_w, const int64_t *d_latent, double *d_u,
+              double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
+              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,8 @@ SIGNATURES = {
     "pmc_responsibilities": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pmc_sufficient_stats": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
+    "pmc_estep_is_fused": (_int, [_int, _int, _int, _int]),
+    "pmc_estep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

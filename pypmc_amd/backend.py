@@ -291,8 +291,6 @@ class HipBackend(object):
         sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
         lat = self.asdevice(latent, torch.int64).reshape(N) if latent is not None else None
         student = comps.kind == PMC_KIND_STUDENT_T
-        u = self._tilebuf("u", N, K)
-        scratch = self._tilebuf("scratch", N, K) if student else None
         r = self.zeros((N, comps.ld)) if want_r else None
         log_rho = self.zeros((N, comps.ld)) if want_log_rho else None
         expo = self.zeros((N, comps.ld)) if want_exponent else None
@@ -302,6 +300,19 @@ class HipBackend(object):
         assert flat.numel() == nflat
         vsums = flat[NSCALARS + K * ps:] if student else None
         ws = self._workspace(N, K, D)
+        if r is None and log_rho is None and expo is None:
+            # the E-step proper: one call; for small D one kernel, the N x K matrix stays on chip
+            fused = bool(self.lib.pmc_estep_is_fused(K, D, comps.kind, int(mode)))
+            u = None if fused else self._tilebuf("u", N, K)
+            scratch = self._tilebuf("scratch", N, K) if student else None
+            _lib.check(self._timed(
+                "pmc_estep[fused]" if fused else "pmc_estep", self.lib.pmc_estep,
+                self._p(x), N, D, self._p(pack), K, comps.kind, int(mode), int(bool(max_init_zero)),
+                self._p(sw), self._p(lat), self._p(u), self._p(scratch), self._p(vsums),
+                self._p(flat[NSCALARS:]), self._p(flat), self._p(ws), self._stream()), "pmc_estep")
+            return dict(stats=flat, r=None, log_rho=None, exponent=None)
+        u = self._tilebuf("u", N, K)
+        scratch = self._tilebuf("scratch", N, K) if student else None
         _lib.check(self._timed(
             "pmc_responsibilities", self.lib.pmc_responsibilities,
             self._p(x), N, D, self._p(pack), K, comps.kind, int(mode), int(bool(max_init_zero)),

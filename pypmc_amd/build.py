@@ -73,7 +73,7 @@ def build(jobs=None, force=False, verbose=False):
     work = [(os.path.join(OBJ, "pmc_api.o"), asrc, [], [asrc] + headers, force)]
     for d, padded in dim_list():
         for p in ((0, 1) if padded else (0,)):
-            for unit in ("persample", "stats", "propose"):
+            for unit in ("persample", "stats", "propose", "fused"):
                 src = os.path.join(CSRC, "pmc_%s.hip" % unit)
                 work.append((os.path.join(OBJ, "pmc_%s_d%d_p%d.o" % (unit, d, p)), src,
                              ["-DPMC_D=%d" % d, "-DPMC_PADDED=%d" % p], [src] + headers, force))

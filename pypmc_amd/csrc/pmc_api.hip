@@ -19,7 +19,9 @@
     extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t);   \
     extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t);       \
     extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);                                        \
-    extern "C" hipError_t pmc_launch_propose_d##d##_p##p(const PmcArgsP &, unsigned, hipStream_t);
+    extern "C" hipError_t pmc_launch_propose_d##d##_p##p(const PmcArgsP &, unsigned, hipStream_t);         \
+    extern "C" hipError_t pmc_launch_fused_d##d##_p##p(int, int, const PmcArgsF &, unsigned, hipStream_t); \
+    extern "C" int pmc_fused_lds_bytes_d##d##_p##p(int, int);
 #define PMC_DECL_X(d) PMC_DECL_UNIT(d, 0)
 #define PMC_DECL_XP(d) PMC_DECL_UNIT(d, 0) PMC_DECL_UNIT(d, 1)
 PMC_DIM_LIST(PMC_DECL_X, PMC_DECL_XP)
@@ -28,7 +30,8 @@ namespace {
 
 #define PMC_SET(d, p) \
     {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, \
-     &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p}
+     &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p, \
+     &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p}
 struct DimEntry {
     int dim;
     bool has_padded;
@@ -90,21 +93,26 @@ __global__ __launch_bounds__(1024) void k_finish_scalars(const double *__restric
     if (threadIdx.x == 0) scalars[i] = red[0];
 }
 
-// stats[k][p] (real dimension D) = sum_chunk partials[chunk][k][p'] (compiled dimension Dc)
+// stats[k][p] (real dimension D) = sum_chunk partials[chunk][k][p'] (compiled dimension Dc).
+// One wavefront per output element: lane l sums the chunks l, l + 64, ... in ascending order, then a
+// fixed shuffle tree -- the same order on every launch (bit-reproducible), and the nchunks loads of an
+// element are 64 independent streams instead of one dependent chain.
 __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__ partials,
                                                       int nchunks, int K, int D, int Dc,
                                                       double *__restrict__ stats)
 {
     const int PS = pmc_stats_stride_c(D), PSc = pmc_stats_stride_c(Dc);
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (idx >= (long long)K * PS) return;
     const int k = (int)(idx / PS), p = (int)(idx % PS);
     int pc;
     if (p < 1 + D) pc = p;                                // sum u, first moments
     else pc = p - (1 + D) + (1 + Dc);                     // lower triangle: i(i+1)/2+j is D-free
     double v = 0.0;
-    for (int c = 0; c < nchunks; ++c) v += partials[((size_t)c * K + k) * PSc + pc];
-    stats[idx] = v;
+    for (int c = lane; c < nchunks; c += 64) v += partials[((size_t)c * K + k) * PSc + pc];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) stats[idx] = v;
 }
 
 // N = 1, D = 1: stats[k] = (u_k, u_k d, u_k d^2), d = x - mu_k   (u tile-major: one tile, lane 0)
@@ -242,6 +250,41 @@ StatsGeom stats_geom(long long N, int K, const PmcKernelSet *ks)
     return g;
 }
 
+// fused E-step launch geometry (pmc_fused.hip)
+struct FusedGeom {
+    int qs, kq, cw, tpr, rounds_per_wg;
+    long long ntiles, nrounds;
+    unsigned grid;
+    long long nchunks;        // partial statistics vectors: grid * (PMC_F_WAVES / cw)
+};
+bool fused_eligible(const PmcKernelSet *ks, int K, int kind, int mode)
+{
+    if (ks->dim > PMC_FUSED_MAX_DIM || K > PMC_FUSED_MAX_K) return false;
+    if (mode == PMC_RESP_VB) return kind == PMC_KIND_VB;
+    return mode == PMC_RESP_PMC_RB && kind == PMC_KIND_GAUSS;
+}
+FusedGeom fused_geom(long long N, int K)
+{
+    FusedGeom g;
+    g.qs = K <= PMC_F_KQMAX ? 1 : (K <= 2 * PMC_F_KQMAX ? 2 : 4);
+    g.kq = (K + g.qs - 1) / g.qs;
+    g.cw = PMC_F_WAVES;
+    if (g.qs == 1) {
+        g.cw = 1;
+        while (g.cw < K) g.cw *= 2;
+    }
+    g.tpr = PMC_F_WAVES / g.qs;
+    g.ntiles = ceil_div(N, PMC_TILE);
+    g.nrounds = ceil_div(g.ntiles, g.tpr);
+    long long wgs = 256LL * 3;                            // up to 3 workgroups per compute unit
+    if (wgs > g.nrounds) wgs = g.nrounds;
+    if (wgs < 1) wgs = 1;
+    g.rounds_per_wg = (int)ceil_div(g.nrounds > 0 ? g.nrounds : 1, wgs);
+    g.grid = (unsigned)ceil_div(g.nrounds > 0 ? g.nrounds : 1, g.rounds_per_wg);
+    g.nchunks = (long long)g.grid * (PMC_F_WAVES / g.cw);
+    return g;
+}
+
 size_t scalar_partials_bytes(long long N)
 {
     const long long blocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
@@ -317,6 +360,12 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     const size_t scal = scalar_partials_bytes(N) +
                         (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
     size_t total = stats > scal ? stats : scal;
+    if (ks->dim <= PMC_FUSED_MAX_DIM && K <= PMC_FUSED_MAX_K) {
+        const FusedGeom f = fused_geom(N > 0 ? N : 1, K);
+        const size_t fused = ((size_t)f.nchunks * K * pmc_stats_stride_c(ks->dim) + (size_t)f.grid * PMC_NSCALARS) *
+                             sizeof(double);
+        if (fused > total) total = fused;
+    }
     return (int64_t)((total + 255) & ~(size_t)255);
 }
 
@@ -580,11 +629,54 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
     hipError_t e = ks->stats(b, g.grid, st);
     if (e != hipSuccess) return hipfail(e, "k_stats launch");
     const long long total = (long long)K * PS;
-    hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
                        (const double *)d_workspace, g.nchunks, K, D, ks->dim, d_stats);
     e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
     return PMC_OK;
+}
+
+int pmc_estep_is_fused(int K, int D, int kind, int mode)
+{
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks || K < 1) return 0;
+    return fused_eligible(ks, K, kind, mode) ? 1 : 0;
+}
+
+int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, int mode,
+              int max_init_zero, const double *d_sample_w, const int64_t *d_latent, double *d_u,
+              double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
+              void *stream)
+{
+    if (N < 0 || K < 1 || !d_pack || !d_stats || !d_scalars || !d_workspace)
+        return fail(PMC_EINVAL, "pmc_estep: bad N/K/pack/stats/scalars/workspace");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (N == 0 || !fused_eligible(ks, K, kind, mode)) {
+        if (!d_u) return fail(PMC_EINVAL, "pmc_estep: d_u is required unless pmc_estep_is_fused()");
+        int rc = pmc_responsibilities(d_x, N, D, d_pack, K, kind, mode, max_init_zero, d_sample_w, d_latent, d_u,
+                                      d_scratch, d_vsums, nullptr, nullptr, nullptr, K, d_scalars, d_workspace, stream);
+        if (rc != PMC_OK) return rc;
+        return pmc_sufficient_stats(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream);
+    }
+    if (!d_x) return fail(PMC_EINVAL, "pmc_estep: d_x is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const FusedGeom g = fused_geom(N, K);
+    const int PSc = pmc_stats_stride_c(ks->dim);
+    PmcArgsF a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
+    a.qs = g.qs; a.kq = g.kq; a.cw = g.cw; a.sample_w = d_sample_w; a.ntiles = g.ntiles; a.rounds_per_wg = g.rounds_per_wg;
+    a.partials = (double *)d_workspace;
+    a.spartials = a.partials + (size_t)g.nchunks * K * PSc;
+    hipError_t e = ks->fused(kind, g.qs, a, g.grid, st);
+    if (e != hipSuccess) return hipfail(e, "k_estep_fused launch");
+    const long long total = (long long)K * pmc_stats_stride_c(D);
+    hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
+                       (const double *)a.partials, (int)g.nchunks, K, D, ks->dim, d_stats);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
+    return finish_scalars(a.spartials, g.grid, d_scalars, st);
 }
 
 }  // extern "C"

@@ -1,0 +1,343 @@
+// pmc_fused.hip -- the E-step in ONE kernel for small sample dimensions: responsibilities and
+// sufficient statistics of a block of samples without the N x K responsibility matrix ever leaving
+// the compute unit (the separate kernels write it tile-major to HBM and read it back: 16 K bytes per
+// sample against 8 D for the samples themselves -- at D <= 8 that round trip, not the arithmetic, is
+// what the E-step costs).  Compiled once per sample dimension D <= PMC_FUSED_MAX_DIM:
+//     hipcc -DPMC_D=<D> -DPMC_PADDED=<0|1> -c pmc_fused.hip
+//
+// Replaces, for the VB E-step, _update_expectation_gauss_exponent / _update_log_rho / _update_r /
+// _update_N_comp / _update_x_mean_comp / _update_S / _update_expectation_log_q_Z
+// (pypmc/mix_adapt/variational.pyx:675-932, :1003-1013) and, for the Gaussian PMC update,
+// calculate_rho_rb + the einsum reductions (pypmc/mix_adapt/pmc.pyx:23-43, :188-222).
+//
+// One workgroup = 8 wavefronts, persistent over its share of the samples, "rounds" of TPR = 8 / QS
+// tiles of 64 samples:
+//   phase A (lane = sample, parameters as SGPR operands exactly like k_logpdf): a tile's K components
+//     are split among QS wavefronts (<= 8 components each, a_nk parked in registers).  The soft-max
+//     is the reference's own two-pass form -- row maximum first, then ONE exp per pair -- with the
+//     maxima and partial sums of the QS wavefronts exchanged through LDS.  u_nk = w_n r_nk (VB) or
+//     w_n rho_nk (PMC) goes to an LDS buffer, tile-major like the HBM buffer it replaces.
+//   phase B (lane = (sample, coordinate) of a 16-sample sub-step): wavefront w owns components
+//     w, w + 8, ... of ALL tiles of the round and accumulates 4 x 4 blocks of sum u d d^T on the fp64
+//     matrix pipe (v_mfma_f64_4x4x4_4b_f64, lane layout of pmc_stats.hip).  If D is not a multiple
+//     of 4 the vector is augmented, d~ = (d, 1): sum u d and sum u then come out of the same blocks.
+// The accumulators stay in registers over all rounds; partial sums per workgroup are written in the
+// layout of k_stats' partials and summed by the same fixed-order finishing kernel.
+#include "pmc_device.h"
+
+#if PMC_D <= PMC_FUSED_MAX_DIM
+
+namespace {
+
+constexpr int FW = PMC_F_WAVES;          // wavefronts per workgroup
+
+template <int D> struct FusedGeom {
+    static constexpr int G = (D + 3) / 4;                         // coordinate groups of 4
+    static constexpr bool AUG = (D % 4) != 0;                     // room for the constant 1 in the last group
+    static constexpr int PIT = ((4 * G + 3) / 8) * 8 + 4;         // doubles per LDS sample row, = 4 mod 8:
+    static constexpr int NBLK = G * (G + 1) / 2;                  //   8 rows x 4 coordinates hit 32 bank pairs
+};
+
+// LDS doubles of a launch
+__host__ __device__ constexpr int fused_lds_doubles(int D, int QS, int K)
+{
+    const int G = (D + 3) / 4, PIT = ((4 * G + 3) / 8) * 8 + 4, TPR = FW / QS;
+    return TPR * 64 * PIT + TPR * K * 64 + (QS > 1 ? 3 * FW * 64 : 0);
+}
+
+template <int D, bool PADDED, int KIND, int NCH>
+__global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const PmcArgsF a)
+{
+    using GEO = FusedGeom<D>;
+    constexpr int G = GEO::G, PIT = GEO::PIT, NBLK = GEO::NBLK, T = pmc_tri(D);
+    constexpr bool AUG = GEO::AUG;
+    constexpr int STRIDE = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
+    extern __shared__ double lds[];
+    const int K = a.K;
+    const int QS = a.qs, TPR = FW / QS;                            // wavefronts per tile, tiles per round
+    double *xi = lds;                                              // [TPR][64][PIT]   sample rows
+    double *ub = xi + TPR * 64 * PIT;                              // [TPR][K][64]     a_nk, then u_nk, tile-major
+    double *red = ub + (size_t)TPR * K * 64;                       // [3][FW][64]      soft-max exchange
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // phase A role: tile slot ta, component range [k0, k1)
+    const int ta = w / QS, q = w % QS;
+    const int k0 = q * a.kq, k1 = (k0 + a.kq < K) ? k0 + a.kq : K;
+    // phase B role: components cb + CW j (j < NCH) of the tile slots ts0, ts0 + TS, ...
+    const int CW = a.cw, TS = FW / CW;
+    const int cb = w % CW, ts0 = w / CW;
+    const int ci = lane & 3, blk = (lane >> 2) & 3, ks = lane >> 4;
+    const int srow = 2 * blk + (ks & 1) + 8 * (ks >> 1);           // sample of the 16-sample sub-step
+
+    double acc2[NCH][NBLK], acc1[NCH][G], acc0[NCH], mu[NCH][G];
+    int coff[NCH];                                                 // component's offset in a tile of ub
+    double live[NCH];                                              // 0.0 for a slot beyond K
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = cb + CW * j;
+        const double *pk = a.pack + (size_t)(c < K ? c : 0) * STRIDE;
+        coff[j] = (c < K ? c : 0) * 64;
+        live[j] = c < K ? 1.0 : 0.0;
+        acc0[j] = 0.0;
+#pragma unroll
+        for (int I = 0; I < G; ++I) {
+            acc1[j][I] = 0.0;
+            mu[j][I] = (4 * I + ci < D) ? pk[4 * I + ci < D ? 4 * I + ci : 0] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc2[j][b] = 0.0;
+    }
+    double sc_a = 0.0;                                             // VB: E[log q(Z)] part; PMC: sum w log q
+
+    const long long nrounds = (a.ntiles + TPR - 1) / TPR;
+    const long long r0 = (long long)blockIdx.x * a.rounds_per_wg;
+    long long r1 = r0 + a.rounds_per_wg;
+    if (r1 > nrounds) r1 = nrounds;
+    for (long long round = r0; round < r1; ++round) {
+        // ------------------------------------------------------------------ phase A
+        const long long tile = round * TPR + ta;
+        const long long n = tile * 64 + lane;
+        const bool valid = n < a.N;
+        double *ut = ub + (size_t)ta * K * 64 + lane;
+        double M = a.max_init_zero ? 0.0 : -DBL_MAX;               // _regularize.pyx:73 / pmc.pyx:24-34
+        {
+            double xv[D];
+            load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
+            if (q == 0) {                                          // wave-uniform
+                double *row = xi + (size_t)(ta * 64 + lane) * PIT;
+#pragma unroll
+                for (int j = 0; j < 4 * G; ++j) row[j] = j < D ? xv[j] : ((AUG && j == D) ? 1.0 : 0.0);
+            }
+            cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
+#pragma unroll PMC_F_UNROLL_A
+            for (int k = k0; k < k1; ++k, pk += STRIDE) {          // a_nk parked in the u buffer
+                const double maha = mahalanobis<D>(xv, pk);
+                double expo;
+                const double v = component_value<D, KIND>(maha, pk + D + T, expo);
+                ut[(size_t)k * 64] = v;
+                if (v > M) M = v;
+            }
+        }
+        if (QS > 1) {
+            red[(size_t)w * 64 + lane] = M;
+            __syncthreads();
+            M = a.max_init_zero ? 0.0 : -DBL_MAX;
+            for (int qq = 0; qq < QS; ++qq) {
+                const double v = red[(size_t)(ta * QS + qq) * 64 + lane];
+                if (v > M) M = v;
+            }
+        }
+        double s = 0.0, tb = 0.0;
+        {
+            cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
+#pragma unroll PMC_F_UNROLL_A
+            for (int k = k0; k < k1; ++k, pk += STRIDE) {
+                const double lr = ut[(size_t)k * 64] - M;          // variational.pyx:741
+                const double e = exp(lr);                          // :742
+                if constexpr (KIND == PMC_KIND_VB) {
+                    s += e;                                        // :743
+                    tb = fma(e, lr, tb);                           // sum_k e_k (a_k - M), for E[log q(Z)]
+                    ut[(size_t)k * 64] = e;
+                } else {
+                    const double we = pk[D + T + 4] * e;           // _regularize.pyx:79
+                    s += we;
+                    ut[(size_t)k * 64] = we;                       // numerator of rho, up to exp(M)
+                }
+            }
+        }
+        if (QS > 1) {
+            red[(size_t)(FW + w) * 64 + lane] = s;
+            if constexpr (KIND == PMC_KIND_VB) red[(size_t)(2 * FW + w) * 64 + lane] = tb;
+            __syncthreads();
+            s = 0.0;
+            tb = 0.0;
+            for (int qq = 0; qq < QS; ++qq) {
+                s += red[(size_t)(FW + ta * QS + qq) * 64 + lane];
+                if constexpr (KIND == PMC_KIND_VB) tb += red[(size_t)(2 * FW + ta * QS + qq) * 64 + lane];
+            }
+        }
+        const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+        const double swv = valid ? sw : 0.0;
+        if constexpr (KIND == PMC_KIND_VB) {
+            const double norm_inv = 1. / s;                        // variational.pyx:748-755
+            for (int k = k0; k < k1; ++k) {
+                double r = ut[(size_t)k * 64] * norm_inv;
+                if (r == 0.0) r = TINY;
+                ut[(size_t)k * 64] = swv * r;
+            }
+            // sum_k r_k (a_k - M + log norm_inv) with sum_k r_k = 1   (variational.pyx:1003-1013)
+            if (q == 0) sc_a += swv * fma(tb, norm_inv, log(norm_inv));
+        } else {
+            const double lse = log(s) + M;                         // _regularize.pyx:81
+            const double denom = exp(lse) + TINY;                  // pmc.pyx:41
+            const double em = exp(M);
+            for (int k = k0; k < k1; ++k) {
+                double rho = ut[(size_t)k * 64] * em;              // exp(log q_k) w_k  (pmc.pyx:39)
+                rho /= denom;
+                ut[(size_t)k * 64] = swv * rho;
+            }
+            if (q == 0) sc_a += swv * lse;                         // pmc.pyx:388-391
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase B
+        for (int t = ts0; t < TPR; t += TS) {
+            const double *xt = xi + (size_t)(t * 64 + srow) * PIT + ci;
+            const double *utile = ub + (size_t)t * K * 64 + srow;
+            // operands of sub-step ss + 1 are read before the arithmetic of sub-step ss
+            double xc[G], uc[NCH], xn[G], un[NCH];
+            auto fetch = [&](int ss, double (&xx)[G], double (&uu)[NCH]) {
+#pragma unroll
+                for (int I = 0; I < G; ++I) xx[I] = xt[ss * 16 * PIT + 4 * I];
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) uu[j] = utile[coff[j] + ss * 16];
+            };
+            fetch(0, xc, uc);
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                // scheduling fences (no instructions): pin the prefetch behind the previous sub-step's
+                // arithmetic and in front of this one's
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(acc2[j][0]) : : "memory");
+                if (ss + 1 < 4) fetch(ss + 1, xn, un);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(uc[j]) : : "memory");
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const double u = uc[j] * live[j];
+                    double d[G];
+#pragma unroll
+                    for (int I = 0; I < G; ++I) d[I] = xc[I] - mu[j][I];
+                    if constexpr (!AUG) acc0[j] += u;
+                    int b = 0;
+#pragma unroll
+                    for (int I = 0; I < G; ++I) {
+                        const double ud = u * d[I];
+                        if constexpr (!AUG) acc1[j][I] += ud;
+#pragma unroll
+                        for (int J = 0; J <= I; ++J, ++b)
+                            acc2[j][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(ud, d[J], acc2[j][b], 0, 0, 0);
+                    }
+                }
+                if (ss + 1 < 4) {
+#pragma unroll
+                    for (int I = 0; I < G; ++I) xc[I] = xn[I];
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) uc[j] = un[j];
+                }
+            }
+        }
+        __syncthreads();                                           // LDS buffers are rewritten next round
+    }
+
+    // ---------------------------------------------------------------------- results
+    // accumulator lane layouts: acc2 -- lane 16 i + 4 blk + j; acc0 / acc1 -- per (sample, ci)
+    const long long chunk = (long long)blockIdx.x * TS + ts0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = cb + CW * j;
+        if (c >= K) continue;
+        double *out = a.partials + ((size_t)chunk * K + c) * PS;
+        if constexpr (!AUG) {
+            double s0 = acc0[j];                                   // every sample appears in 4 lanes (ci)
+            s0 += __shfl_xor(s0, 4, 64);
+            s0 += __shfl_xor(s0, 8, 64);
+            s0 += __shfl_xor(s0, 16, 64);
+            s0 += __shfl_xor(s0, 32, 64);
+            if (lane == 0) out[0] = s0;
+        }
+        int b = 0;
+#pragma unroll
+        for (int I = 0; I < G; ++I) {
+            if constexpr (!AUG) {
+                double m = acc1[j][I];
+                m += __shfl_xor(m, 4, 64);
+                m += __shfl_xor(m, 8, 64);
+                m += __shfl_xor(m, 16, 64);
+                m += __shfl_xor(m, 32, 64);
+                if (lane < 4 && 4 * I + lane < D) out[1 + 4 * I + lane] = m;
+            }
+#pragma unroll
+            for (int J = 0; J <= I; ++J, ++b) {
+                double v = acc2[j][b];
+                v += __shfl_xor(v, 4, 64);                         // sum of the 4 batch blocks
+                v += __shfl_xor(v, 8, 64);
+                const int gi = 4 * I + (lane >> 4), gj = 4 * J + (lane & 3);
+                if (blk == 0 && gj <= gi) {
+                    if (gi < D) out[1 + D + gi * (gi + 1) / 2 + gj] = v;
+                    else if (AUG && gi == D) out[gj < D ? 1 + gj : 0] = v;     // sum u d_gj / sum u
+                }
+            }
+        }
+    }
+    // scalars: one value per workgroup
+    __shared__ double sred[FW];
+    const double v = wave_sum(sc_a);
+    if (lane == 0) sred[w] = v;
+    __syncthreads();
+    if (threadIdx.x < PMC_NSCALARS) {
+        double tot = 0.0;
+        const int slot = (KIND == PMC_KIND_VB) ? 0 : 3;
+        if ((int)threadIdx.x == slot) {
+#pragma unroll
+            for (int i = 0; i < FW; ++i) tot += sred[i];
+        }
+        a.spartials[(size_t)blockIdx.x * PMC_NSCALARS + threadIdx.x] = tot;
+    }
+}
+
+template <int KIND, int NCH> hipError_t launch_fused_kq(const PmcArgsF &a, unsigned grid, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * fused_lds_doubles(D_, a.qs, a.K);
+    if (lds > 65536) {
+        static size_t configured = 0;                              // grows with K
+        if (lds > configured) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_estep_fused<D_, P_, KIND, NCH>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured = lds;
+        }
+    }
+    hipLaunchKernelGGL((k_estep_fused<D_, P_, KIND, NCH>), dim3(grid), dim3(FW * 64), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int KIND> hipError_t launch_fused_k(int nch, const PmcArgsF &a, unsigned grid, hipStream_t st)
+{
+    switch (nch) {
+    case 1: return launch_fused_kq<KIND, 1>(a, grid, st);
+    case 2: return launch_fused_kq<KIND, 2>(a, grid, st);
+    case 4: return launch_fused_kq<KIND, 4>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_fused_d, PMC_D, PMC_PADDED)(int kind, int nch, const PmcArgsF &a,
+                                                                            unsigned grid, hipStream_t st)
+{
+    switch (kind) {
+    case PMC_KIND_GAUSS: return launch_fused_k<PMC_KIND_GAUSS>(nch, a, grid, st);
+    case PMC_KIND_VB: return launch_fused_k<PMC_KIND_VB>(nch, a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+extern "C" int PMC_UNIT_NAME_X(pmc_fused_lds_bytes_d, PMC_D, PMC_PADDED)(int qs, int K)
+{
+    return (int)(sizeof(double) * fused_lds_doubles(D_, qs, K));
+}
+
+#else   // this dimension has no fused kernel
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_fused_d, PMC_D, PMC_PADDED)(int, int, const PmcArgsF &, unsigned,
+                                                                            hipStream_t)
+{
+    return hipErrorNotSupported;
+}
+
+extern "C" int PMC_UNIT_NAME_X(pmc_fused_lds_bytes_d, PMC_D, PMC_PADDED)(int, int) { return -1; }
+
+#endif

@@ -10,6 +10,19 @@ constexpr int PMC_A_WAVES = 4;     // wavefronts (tiles) per workgroup in the pe
 // 16 wavefronts per CU (4 per SIMD, the register-limited occupancy) still fit in 160 KB
 constexpr int PMC_RESP_KLDS = 16;
 
+// fused small-D E-step (pmc_fused.hip): wavefronts per workgroup, components per wavefront in its
+// responsibility phase (so K <= PMC_F_WAVES / 2 * PMC_F_KQMAX = 32), largest compiled dimension
+#define PMC_F_WAVES 8
+#define PMC_F_KQMAX 8
+#ifndef PMC_F_MIN_WAVES
+#define PMC_F_MIN_WAVES 4
+#endif
+#ifndef PMC_F_UNROLL_A
+#define PMC_F_UNROLL_A 1
+#endif
+#define PMC_FUSED_MAX_DIM 8
+#define PMC_FUSED_MAX_K 32
+
 __host__ __device__ constexpr int pmc_tri(int D) { return D * (D + 1) / 2; }
 __host__ __device__ constexpr int pmc_pack_stride_c(int D) { return (D + pmc_tri(D) + 6 + 7) & ~7; }
 __host__ __device__ constexpr int pmc_stats_stride_c(int D) { return 1 + D + pmc_tri(D); }
@@ -56,6 +69,24 @@ struct PmcArgsB {
     int ngroups;
 };
 
+// fused E-step kernel
+struct PmcArgsF {
+    const double *x;
+    long long N;
+    int dreal;
+    const double *pack;
+    int K;
+    int max_init_zero;
+    int qs;               // wavefronts that share a tile in the responsibility phase (1, 2, 4)
+    int kq;               // components per wavefront in the responsibility phase: ceil(K / qs)
+    int cw;               // wavefronts that own different components in the statistics phase (1, 2, 4, 8)
+    const double *sample_w;
+    double *partials;     // gridDim.x * (PMC_F_WAVES / cw) * K * pmc_stats_stride_c(Dcompiled)
+    double *spartials;    // gridDim.x * PMC_NSCALARS
+    long long ntiles;
+    int rounds_per_wg;
+};
+
 // propose kernel
 struct PmcArgsP {
     const double *mu;             // K x dreal
@@ -79,4 +110,6 @@ struct PmcKernelSet {
     hipError_t (*stats)(const PmcArgsB &, unsigned grid, hipStream_t);
     void (*config)(int *nsub, int *waves);
     hipError_t (*propose)(const PmcArgsP &, unsigned grid, hipStream_t);
+    hipError_t (*fused)(int kind, int qs, const PmcArgsF &, unsigned grid, hipStream_t);
+    int (*fused_lds_bytes)(int qs, int K);
 };

@@ -82,7 +82,8 @@ def main():
     out = be.zeros(be.stats_len(K, D))
     t, tm = timeit(lambda: be.estep(x, vb, 0, pack=vpack, out=out))
     fl_vb = K * (D * D + 4 * D) + K * (1 + 2 * D + D * (D + 1)) + K * 40
-    res["vb_estep"] = dict(ms=t, ms_median=tm, samples_per_s=N / t * 1e3, tflops=N * fl_vb / t * 1e-9)
+    res["vb_estep"] = dict(ms=t, ms_median=tm, samples_per_s=N / t * 1e3, tflops=N * fl_vb / t * 1e-9,
+                           fused=bool(be.lib.pmc_estep_is_fused(K, D, 2, 0)))
     # split: responsibilities alone
     lib = be.lib
     u = be._tilebuf("u", N, K)

@@ -240,9 +240,71 @@ def test_vb_estep_vs_oracle(be, orc, D, K, N, weighted):
     np.testing.assert_allclose(be.tohost(res2["stats"]), be.tohost(res["stats"]), rtol=1e-12, atol=1e-13)
     sc2 = split_stats(be.tohost(res2["stats"]), K, D)[0]
     assert abs(sc2[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-11
-    # determinism: a second launch gives bitwise the same statistics
-    res3 = be.estep(x, cs, 0, sample_w=sw)
-    np.testing.assert_array_equal(be.tohost(res3["stats"]), be.tohost(res2["stats"]))
+    # without N x K outputs the E-step is one call (one fused kernel for small D): same statistics
+    # to rounding, and a second launch gives them bitwise again
+    res3 = be.tohost(be.estep(x, cs, 0, sample_w=sw)["stats"]).copy()
+    np.testing.assert_allclose(res3, be.tohost(res2["stats"]), rtol=1e-11, atol=1e-12)
+    np.testing.assert_array_equal(be.tohost(be.estep(x, cs, 0, sample_w=sw)["stats"]), res3)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 16])
+@pytest.mark.parametrize("K,N,weighted", [(1, 70, False), (2, 1, True), (3, 257, True), (5, 64, False), (8, 1000, True),
+                                          (9, 65, False), (16, 3000, True), (17, 511, False), (24, 2000, True),
+                                          (31, 129, False), (32, 4097, True)])
+def test_fused_estep_vs_oracle(be, orc, D, K, N, weighted):
+    """pmc_estep on its one-kernel path (compiled dimension <= 16, K <= 32; every split of the components
+    among the wavefronts): VB statistics and E[log q(Z)], Gaussian PMC statistics and log-likelihood
+    against the restated reference loops, and against the two-kernel path."""
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    from pypmc_amd._lib import PMC_KIND_VB, PMC_KIND_GAUSS
+    fusable = int(be.lib.pmc_padded_dim(D) <= 8)          # beyond, pmc_estep is the two kernels (still tested here)
+    assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_VB, 0) == fusable
+    assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 1) == fusable
+    assert be.lib.pmc_estep_is_fused(K, D, 1, 1) == 0 and be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 2) == 0
+    mu, cov, w = mk(K, D, 900 + D + K)
+    x, _ = draw(mu, cov, w, N, 19)
+    rs = np.random.RandomState(D * K + N)
+    sw = rs.uniform(0.5, 1.5, N) if weighted else None
+    nu = D + 2. + rs.uniform(0, 5, K)
+    beta = 1. + rs.uniform(0, 5, K)
+    alpha = 1. + rs.uniform(0, 5, K)
+    W = np.linalg.inv(cov) / nu[:, None, None]
+    W = 0.5 * (W + W.transpose(0, 2, 1))
+    m = mu + 0.1 * rs.normal(size=mu.shape)
+    ln_lambda = sum(digamma(0.5 * (nu + 1. - i)) for i in range(1, D + 1)) + D * np.log(2.) + np.linalg.slogdet(W)[1]
+    ln_pi = digamma(alpha) - digamma(alpha.sum())
+    ref = orc.vb_estep(x, sw, m, W, beta, nu, ln_pi, ln_lambda)
+    cs = ComponentSet(2, m, W, c0=D / beta, c1=nu, c2=ln_pi, c3=ln_lambda - D * np.log(2. * np.pi))
+    fused = be.tohost(be.estep(x, cs, 0, sample_w=sw)["stats"]).copy()
+    two = be.tohost(be.estep(x, cs, 0, sample_w=sw, want_r=True)["stats"])
+    np.testing.assert_allclose(fused, two, rtol=1e-11, atol=1e-12)
+    sc, S0, M1, M2, _, _ = split_stats(fused, K, D)
+    assert_rel(S0, ref["N_comp"], rtol=1e-11, what="N_comp")
+    x_mean, S = centred_moments(S0, M1, M2, m)
+    live = ref["N_comp"] > 1e-6
+    np.testing.assert_allclose(x_mean[live], ref["x_mean_comp"][live], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(S[live], ref["S"][live], rtol=1e-8, atol=1e-10)
+    assert abs(sc[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-11
+    np.testing.assert_array_equal(be.tohost(be.estep(x, cs, 0, sample_w=sw)["stats"]), fused)     # deterministic
+    # Gaussian PMC, Rao-Blackwellised, with one dead component when there is more than one
+    _, inv, ln = gauss_set(mu, cov, w)
+    live_k = list(range(K)) if K == 1 else [k for k in range(K) if k != K // 2]
+    wl = w.copy()
+    if K > 1:
+        wl[K // 2] = 0.
+    gs = gauss_set(mu[live_k], cov[live_k], wl[live_k], columns=live_k, ld=K)[0]
+    fused = be.tohost(be.estep(x, gs, 1, max_init_zero=K > 1, sample_w=sw)["stats"]).copy()
+    two = be.tohost(be.estep(x, gs, 1, max_init_zero=K > 1, sample_w=sw, want_r=True)["stats"])
+    np.testing.assert_allclose(fused, two, rtol=1e-11, atol=1e-12)
+    rho = orc.rho_rb(0, x, wl, mu, inv, ln, None, None, live_k)[:, live_k]
+    swv = np.ones(N) if sw is None else sw
+    sc, S0, M1, M2, _, _ = split_stats(fused, len(live_k), D)
+    np.testing.assert_allclose(S0, (swv[:, None] * rho).sum(axis=0), rtol=1e-10, atol=1e-300)
+    d = x[:, None, :] - mu[None, live_k, :]
+    np.testing.assert_allclose(M1, np.einsum('n,nk,nki->ki', swv, rho, d), rtol=1e-9, atol=1e-10)
+    M2ref = np.einsum('n,nk,nki,nkj->kij', swv, rho, d, d)
+    np.testing.assert_allclose(M2, M2ref, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(M2ref).max()))
 
 
 @pytest.mark.parametrize("tag", ["d2k3", "d5k4"])
