@@ -42,11 +42,23 @@ template <int D> struct FusedGeom {
 __host__ __device__ constexpr int fused_lds_doubles(int D, int QS, int K)
 {
     const int G = (D + 3) / 4, PIT = ((4 * G + 3) / 8) * 8 + 4, TPR = FW / QS;
-    return TPR * 64 * PIT + TPR * K * 64 + (QS > 1 ? 3 * FW * 64 : 0);
+    return TPR * 64 * PIT + TPR * K * 64 + 64 + (QS > 1 ? 3 * FW * 64 : 0);
+}
+
+// wavefronts per SIMD the registers must leave room for: three workgroups per compute unit while the
+// Mahalanobis form is short (measured: D = 2 0.50 -> 0.47 ms per 4e6 samples x 32 components; from D = 5
+// on the allocator spills at 80 registers and 4 is faster)
+__host__ __device__ constexpr int fused_min_waves(int D)
+{
+#ifdef PMC_F_MIN_WAVES
+    return PMC_F_MIN_WAVES;
+#else
+    return D <= 4 ? 6 : 4;
+#endif
 }
 
 template <int D, bool PADDED, int KIND, int NCH>
-__global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const PmcArgsF a)
+__global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(const PmcArgsF a)
 {
     using GEO = FusedGeom<D>;
     constexpr int G = GEO::G, PIT = GEO::PIT, NBLK = GEO::NBLK, T = pmc_tri(D);
@@ -57,7 +69,8 @@ __global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const 
     const int QS = a.qs, TPR = FW / QS;                            // wavefronts per tile, tiles per round
     double *xi = lds;                                              // [TPR][64][PIT]   sample rows
     double *ub = xi + TPR * 64 * PIT;                              // [TPR][K][64]     a_nk, then u_nk, tile-major
-    double *red = ub + (size_t)TPR * K * 64;                       // [3][FW][64]      soft-max exchange
+    double *zero = ub + (size_t)TPR * K * 64;                      // [64]             u of a component slot beyond K
+    double *red = zero + 64;                                       // [3][FW][64]      soft-max exchange
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -71,14 +84,13 @@ __global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const 
     const int srow = 2 * blk + (ks & 1) + 8 * (ks >> 1);           // sample of the 16-sample sub-step
 
     double acc2[NCH][NBLK], acc1[NCH][G], acc0[NCH], mu[NCH][G];
-    int coff[NCH];                                                 // component's offset in a tile of ub
-    double live[NCH];                                              // 0.0 for a slot beyond K
+    int coff[NCH], toff[NCH];                                      // component's offset in a tile of ub, tile stride
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = cb + CW * j;
         const double *pk = a.pack + (size_t)(c < K ? c : 0) * STRIDE;
-        coff[j] = (c < K ? c : 0) * 64;
-        live[j] = c < K ? 1.0 : 0.0;
+        coff[j] = c < K ? c * 64 : TPR * K * 64 - srow;            // beyond K: the zero slot, for every tile
+        toff[j] = c < K ? K * 64 : 0;
         acc0[j] = 0.0;
 #pragma unroll
         for (int I = 0; I < G; ++I) {
@@ -88,6 +100,7 @@ __global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const 
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) acc2[j][b] = 0.0;
     }
+    if (threadIdx.x < 64) zero[threadIdx.x] = 0.0;                 // (the first barrier of a round orders it)
     double sc_a = 0.0;                                             // VB: E[log q(Z)] part; PMC: sum w log q
 
     const long long nrounds = (a.ntiles + TPR - 1) / TPR;
@@ -130,11 +143,13 @@ __global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const 
         }
         double s = 0.0, tb = 0.0;
         {
+            ExpConsts EC;
+            EC.load();
             cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
 #pragma unroll PMC_F_UNROLL_A
             for (int k = k0; k < k1; ++k, pk += STRIDE) {
                 const double lr = ut[(size_t)k * 64] - M;          // variational.pyx:741
-                const double e = exp(lr);                          // :742
+                const double e = exp_nonpos(lr, EC);               // :742
                 if constexpr (KIND == PMC_KIND_VB) {
                     s += e;                                        // :743
                     tb = fma(e, lr, tb);                           // sum_k e_k (a_k - M), for E[log q(Z)]
@@ -184,31 +199,31 @@ __global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const 
         // ------------------------------------------------------------------ phase B
         for (int t = ts0; t < TPR; t += TS) {
             const double *xt = xi + (size_t)(t * 64 + srow) * PIT + ci;
-            const double *utile = ub + (size_t)t * K * 64 + srow;
+            const double *utile = ub + srow;
             // operands of sub-step ss + 1 are read before the arithmetic of sub-step ss
-            double xc[G], uc[NCH], xn[G], un[NCH];
+            double xb[2][G], uq[2][NCH];                           // ping-pong operand registers
             auto fetch = [&](int ss, double (&xx)[G], double (&uu)[NCH]) {
 #pragma unroll
                 for (int I = 0; I < G; ++I) xx[I] = xt[ss * 16 * PIT + 4 * I];
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) uu[j] = utile[coff[j] + ss * 16];
+                for (int j = 0; j < NCH; ++j) uu[j] = utile[t * toff[j] + coff[j] + ss * 16];
             };
-            fetch(0, xc, uc);
-#pragma unroll
-            for (int ss = 0; ss < 4; ++ss) {
+            fetch(0, xb[0], uq[0]);
+            static_for<0, 4>([&](auto S_) {
+                constexpr int ss = decltype(S_)::value, cur = ss & 1, nxt = cur ^ 1;
                 // scheduling fences (no instructions): pin the prefetch behind the previous sub-step's
                 // arithmetic and in front of this one's
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(acc2[j][0]) : : "memory");
-                if (ss + 1 < 4) fetch(ss + 1, xn, un);
+                if constexpr (ss + 1 < 4) fetch(ss + 1, xb[nxt], uq[nxt]);
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(uc[j]) : : "memory");
+                for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(uq[cur][j]) : : "memory");
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
-                    const double u = uc[j] * live[j];
+                    const double u = uq[cur][j];
                     double d[G];
 #pragma unroll
-                    for (int I = 0; I < G; ++I) d[I] = xc[I] - mu[j][I];
+                    for (int I = 0; I < G; ++I) d[I] = xb[cur][I] - mu[j][I];
                     if constexpr (!AUG) acc0[j] += u;
                     int b = 0;
 #pragma unroll
@@ -220,13 +235,7 @@ __global__ __launch_bounds__(FW * 64, PMC_F_MIN_WAVES) void k_estep_fused(const 
                             acc2[j][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(ud, d[J], acc2[j][b], 0, 0, 0);
                     }
                 }
-                if (ss + 1 < 4) {
-#pragma unroll
-                    for (int I = 0; I < G; ++I) xc[I] = xn[I];
-#pragma unroll
-                    for (int j = 0; j < NCH; ++j) uc[j] = un[j];
-                }
-            }
+            });
         }
         __syncthreads();                                           // LDS buffers are rewritten next round
     }

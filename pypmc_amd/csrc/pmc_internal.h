@@ -14,11 +14,8 @@ constexpr int PMC_RESP_KLDS = 16;
 // responsibility phase (so K <= PMC_F_WAVES / 2 * PMC_F_KQMAX = 32), largest compiled dimension
 #define PMC_F_WAVES 8
 #define PMC_F_KQMAX 8
-#ifndef PMC_F_MIN_WAVES
-#define PMC_F_MIN_WAVES 4
-#endif
 #ifndef PMC_F_UNROLL_A
-#define PMC_F_UNROLL_A 1
+#define PMC_F_UNROLL_A 2
 #endif
 #define PMC_FUSED_MAX_DIM 8
 #define PMC_FUSED_MAX_K 32
