@@ -399,11 +399,31 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
                 }
             }
         }
-        // packed row-major (i, j>=i) for the compiled dimension; padding rows/cols are zero
         int idx = Dp;
-        for (int i = 0; i < Dp; ++i)
-            for (int j = i; j < Dp; ++j, ++idx)
-                pk[idx] = (i < D && j < D) ? R[(size_t)i * D + j] : 0.0;
+        if (pmc_engine(Dp) == PMC_ENG_DPP) {
+            // unit-diagonal form U_ij = R_ij / R_ii (j > i), s_i = R_ii^2, rows in pairs in the order the
+            // DPP engine consumes them:  U_i,i+1 | U_i+1,j U_i,j (j = i+2 ..) | s_i s_i+1 ; padding is zero
+            auto U = [&](int i, int j) { return (i < D && j < D) ? R[(size_t)i * D + j] / R[(size_t)i * D + i] : 0.0; };
+            auto S = [&](int i) { return i < D ? R[(size_t)i * D + i] * R[(size_t)i * D + i] : 0.0; };
+            for (int i = 0; i < Dp; i += 2) {
+                if (i + 1 < Dp) {
+                    pk[idx++] = U(i, i + 1);
+                    for (int j = i + 2; j < Dp; ++j) {
+                        pk[idx++] = U(i + 1, j);
+                        pk[idx++] = U(i, j);
+                    }
+                    pk[idx++] = S(i);
+                    pk[idx++] = S(i + 1);
+                } else {
+                    pk[idx++] = S(i);
+                }
+            }
+        } else {
+            // packed row-major (i, j>=i) for the compiled dimension; padding rows/cols are zero
+            for (int i = 0; i < Dp; ++i)
+                for (int j = i; j < Dp; ++j, ++idx)
+                    pk[idx] = (i < D && j < D) ? R[(size_t)i * D + j] : 0.0;
+        }
         double *c = pk + Dp + Tp;
         c[0] = c0 ? c0[k] : 0.0;
         c[1] = c1 ? c1[k] : 0.0;

@@ -101,6 +101,20 @@ template <int D> __device__ __forceinline__ double mahalanobis(const double (&xv
     return maha;
 }
 
+// acc += coef[lane N of this lane's 16-lane row] * d  -- v_fmac_f64 with a DPP row broadcast on its first
+// source: a coefficient held ONCE per row in a VGPR feeds the FMA of all 64 lanes like an SGPR operand
+// would, at the full fp64 rate (scripts/microbench/dpp_f64.hip: 73 TFLOP/s against 68 with plain VGPR
+// operands).  The broadcast operand must come from a vector load (no VALU -> DPP hazard to cover).
+template <int N> __device__ __forceinline__ void fmac_bcast(double &acc, double coef, double d)
+{
+    static_assert(N >= 0 && N < 16, "lane within a row");
+    // volatile + memory: the statements keep their order -- the order of the coefficients in the window --
+    // and the coefficient loads written between them stay between them in the instruction selector
+    // (MahaEngine's scheduling barriers do the same for the machine scheduler)
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(coef), "v"(d), "n"(N) : "memory");
+}
+
 // a_nk from maha_nk, in the reference's operation order (see enum pmc_kind).
 template <int D, int KIND>
 __device__ __forceinline__ double component_value(double maha, cdouble *c, double &expo)

@@ -20,6 +20,27 @@ constexpr int PMC_RESP_KLDS = 16;
 #define PMC_FUSED_MAX_DIM 8
 #define PMC_FUSED_MAX_K 32
 
+// Mahalanobis engines of the per-sample kernels (pmc_persample.hip) by compiled dimension, and with
+// them the layout of the triangular factor in the parameter pack (pmc_pack_components):
+//   SGPR  D <  PMC_DPP_FROM                      R row-major (i, j >= i), read through the scalar cache
+//   DPP   PMC_DPP_FROM <= D < PMC_MFMA_FROM      unit-diagonal rows in pairs, U_ij = R_ij / R_ii, s_i = R_ii^2,
+//                                                streamed through VGPRs (row broadcast)
+//   MFMA  D >= PMC_MFMA_FROM, D % 4 == 0         R row-major, staged in LDS
+// The DPP engine is a build-time alternative that is OFF by default: it removes every scalar-cache stall
+// (91 % instead of 86 % of the issue slots busy at D = 20) -- and the chip answers with a lower clock
+// (1.77 instead of 1.93 GHz, same box, profiles/r02_dpp_engine_ab.txt): these kernels are power-bound.
+#ifndef PMC_DPP_FROM
+#define PMC_DPP_FROM 1000
+#endif
+#ifndef PMC_MFMA_FROM
+#define PMC_MFMA_FROM 32
+#endif
+enum { PMC_ENG_SGPR = 0, PMC_ENG_DPP = 1, PMC_ENG_MFMA = 2 };
+__host__ __device__ constexpr int pmc_engine(int D)
+{
+    return (D >= PMC_MFMA_FROM && D % 4 == 0) ? PMC_ENG_MFMA : (D >= PMC_DPP_FROM ? PMC_ENG_DPP : PMC_ENG_SGPR);
+}
+
 __host__ __device__ constexpr int pmc_tri(int D) { return D * (D + 1) / 2; }
 __host__ __device__ constexpr int pmc_pack_stride_c(int D) { return (D + pmc_tri(D) + 6 + 7) & ~7; }
 __host__ __device__ constexpr int pmc_stats_stride_c(int D) { return 1 + D + pmc_tri(D); }

@@ -44,7 +44,7 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 // Mahalanobis engines: maha_nk = |R_k (x_n - mu_k)|^2 for the wavefront's 64 samples, lane = sample.
 // ---------------------------------------------------------------------------------------------
 // D < 32: the triangular product on the vector pipe with the parameters as SGPR operands (above).
-template <int D, bool PADDED, bool MFMA> struct MahaEngine {
+template <int D, bool PADDED, int ENGINE> struct MahaEngine {
     static constexpr int LDS_DOUBLES = 0;
     double xv[D];
     __device__ __forceinline__ void load(const PmcArgsA &a, long long tile, int lane)
@@ -65,6 +65,108 @@ template <int D, bool PADDED, bool MFMA> struct MahaEngine {
     }
 };
 
+// PMC_DPP_FROM <= D < 32: the triangular product on the vector pipe with the coefficients streamed
+// through a window of W VGPRs -- 16 consecutive coefficients per register, the same 16 in every 16-lane
+// row, loaded straight from the pack with ordinary vector loads (L2 / L1 hits) one window ahead of their
+// use, and consumed by v_fmac_f64 with a DPP row broadcast (fmac_bcast above).  Nothing but the mean
+// and the five constants of a component goes through the scalar cache any more (4 lines instead of
+// 30 at D = 20: a K = 32 pack stays resident), there is no touch prefetch, no wait for a scalar fill
+// and no barrier -- which is what kept the SGPR form at 87-89 % of the issue slots.
+// The factor is stored with a unit diagonal, maha = sum_i s_i (d_i + sum_{j>i} U_ij d_j)^2: row i
+// accumulates IN PLACE in d_i (row i is the last reader of d_i), so no accumulator has to be zeroed
+// and the instruction count equals the SGPR form's (D subtractions, T - D + 2 D multiply-adds).
+template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_DPP> {
+    static constexpr int LDS_DOUBLES = 0;
+    static constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
+    static constexpr int NPR = (T + 15) / 16;                     // registers' worth of coefficients
+    // window: a divisor of the (possibly padded by one) register count, so that the register of a
+    // coefficient is the same for every component
+    static constexpr int pick_w(int np)
+    {
+#ifdef PMC_DPP_W
+        for (int w = PMC_DPP_W; w >= 2; --w) if (np % w == 0) return w;
+#else
+        for (int w = 8; w >= 5; --w) if (np % w == 0) return w;
+#endif
+        return 0;
+    }
+    static constexpr int NP = pick_w(NPR) ? NPR : NPR + 1;
+    static constexpr int W = pick_w(NP) ? pick_w(NP) : NP;
+    static_assert(NP % W == 0, "window must divide the register count");
+    double xv[D];
+    double rb[W];
+    const double *lanebase;      // pack + D + (lane & 15): this lane's coefficient of register 0, component 0
+    int lastrel;                 // offset of the last (partial) register's coefficient, clamped into the factor
+    int K;
+
+    __device__ __forceinline__ void load(const PmcArgsA &a, long long tile, int lane)
+    {
+        load_row<D, PADDED>(a.x, tile * 64 + lane, a.N, a.dreal, xv);
+        const int n = lane & 15;
+        lastrel = (16 * (NPR - 1) + n < T ? 16 * (NPR - 1) + n : T - 1) - n;
+    }
+    // register v of component k (clamped to the pack's last component)
+    template <int V> __device__ __forceinline__ double fetch(int k) const
+    {
+        const double *p = lanebase + (size_t)(k < K ? k : K - 1) * STRIDE;
+        if constexpr (V < NPR - 1) return p[16 * V];
+        else return p[lastrel];                                      // the partial register / window padding
+    }
+    __device__ __forceinline__ void begin(const double *pack, int K_)
+    {
+        K = K_;
+        lanebase = pack + D + (threadIdx.x & 15);
+        static_for<0, W>([&](auto V) { rb[decltype(V)::value] = fetch<decltype(V)::value>(0); });
+    }
+    // coefficient c of the stream: multiply-add it into acc, then -- if it was its register's last one --
+    // refill the register with the one a window further on (the scheduling barrier keeps the load HERE:
+    // left alone the scheduler sinks it to just in front of its first use)
+    template <int C> __device__ __forceinline__ void use(double &acc, double operand, int k)
+    {
+        constexpr int v = C / 16, n = C % 16;
+        fmac_bcast<n>(acc, rb[v % W], operand);
+        if constexpr (n == 15 || C == T - 1) refill<v>(k);
+    }
+    template <int V> __device__ __forceinline__ void refill(int k)
+    {
+        if constexpr (V + W < NP) rb[V % W] = fetch<V + W>(k);
+        else rb[V % W] = fetch<V + W - NP>(k + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ double eval(cdouble *pk, int k)
+    {
+        double d[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) d[j] = xv[j] - pk[j];
+        double ma = 0.0, mb = 0.0;
+        // Rows in pairs (i, i + 1), their multiply-adds alternating so that no instruction depends on its
+        // predecessor; the coefficients sit in the pack in exactly this order (pmc_pack_components):
+        //   U_i,i+1 | U_i+1,j  U_i,j  (j = i+2 .. D-1) | s_i  s_i+1
+        static_for<0, (D + 1) / 2>([&](auto Q_) {
+            constexpr int i = 2 * decltype(Q_)::value;
+            constexpr int c0 = i * D - i * (i - 1) / 2;             // coefficients in front of row i
+            if constexpr (i + 1 < D) {
+                use<c0>(d[i], d[i + 1], k);
+                static_for<0, D - 2 - i>([&](auto T_) {
+                    constexpr int t = decltype(T_)::value, j = i + 2 + t;
+                    use<c0 + 1 + 2 * t>(d[i + 1], d[j], k);
+                    use<c0 + 2 + 2 * t>(d[i], d[j], k);
+                });
+                const double ta = d[i] * d[i], tb = d[i + 1] * d[i + 1];
+                use<c0 + 2 * D - 3 - 2 * i>(ma, ta, k);
+                use<c0 + 2 * D - 2 - 2 * i>(mb, tb, k);
+            } else {
+                const double ta = d[i] * d[i];
+                use<c0>(ma, ta, k);
+            }
+        });
+        // (window padding beyond the last coefficient is refilled like a register)
+        static_for<NPR, NP>([&](auto V_) { refill<decltype(V_)::value>(k); });
+        return ma + mb;
+    }
+    __device__ static __forceinline__ void idle(const double *, int) {}
+};
+
 // D >= 32 (multiples of 4; measured break-even: D = 32 log-pdf -17 %, responsibilities +2 %;
 // D = 24 +15 %): the scalar path cannot feed the vector pipe any more (6.9 KB = 108 cache lines per
 // component at D = 40, whose fill takes as long as the arithmetic; 54 % utilisation).  Here the
@@ -77,7 +179,7 @@ template <int D, bool PADDED, bool MFMA> struct MahaEngine {
 // so a lane holds coordinate (lane >> 4) of sample (lane & 15) of each of the tile's four sub-tiles,
 // squares its y, and after the block rows two cross-lane additions give every lane the sub-tile's
 // |y|^2; lane l then keeps sub-tile (l >> 4): sample l of the tile, the layout the epilogues expect.
-template <int D, bool PADDED> struct MahaEngine<D, PADDED, true> {
+template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_MFMA> {
     static constexpr int G = D / 4, STRIDE = pmc_pack_stride_c(D);
     static constexpr int PIECES = (STRIDE * 8 + 1023) / 1024;     // 1-KiB DMA pieces per component
     static constexpr int PBUF = PIECES * 128;                      // doubles per parameter buffer
@@ -213,10 +315,7 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, true> {
     }
 };
 
-#ifndef PMC_MFMA_FROM
-#define PMC_MFMA_FROM 32
-#endif
-template <int D> __host__ __device__ constexpr bool pmc_use_mfma() { return D >= PMC_MFMA_FROM && D % 4 == 0; }
+template <int D> __host__ __device__ constexpr int pmc_use_mfma() { return pmc_engine(D); }
 
 // ---------------------------------------------------------------------------------------------
 // k_logpdf: MixtureDensity.multi_evaluate (mixture.pyx:112-156) + logsumexp2D
@@ -234,10 +333,11 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 
     // the mixture itself (kind KIND), then -- pmc_importance_weights only -- the TARGET mixture of the
     // importance weights (kind KIND2), evaluated on the same registers: the samples are read once
-    auto mixture = [&](auto kind, cdouble *pk, const int K, const bool first) -> double {
+    auto mixture = [&](auto kind, const double *gpack, const int K, const bool first) -> double {
         constexpr int KD = decltype(kind)::value;
         double m = (first && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
-        engine.begin((const double *)pk, K);
+        cdouble *pk = (cdouble *)gpack;
+        engine.begin(gpack, K);                          // (the global pointer: vector loads of the DPP engine)
         for (int k = 0; k < K; ++k, pk += STRIDE) {
             const double maha = engine.eval(pk, k);
             double expo;
@@ -250,9 +350,9 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         }
         return log(s) + m;                               // _regularize.pyx:81
     };
-    const double lse = mixture(ic<KIND>{}, (cdouble *)a.pack, a.K, true);
+    const double lse = mixture(ic<KIND>{}, a.pack, a.K, true);
     double lse_target = 0.0;
-    if (a.pack2 != nullptr) lse_target = mixture(ic<KIND2>{}, (cdouble *)a.pack2, a.K2, false);
+    if (a.pack2 != nullptr) lse_target = mixture(ic<KIND2>{}, a.pack2, a.K2, false);
     if (a.out != nullptr && valid) a.out[n] = lse;
     if (a.log_target_out != nullptr && valid) a.log_target_out[n] = lse_target;
 
