@@ -80,16 +80,31 @@ def flops_stats(K, D):        # K (1 + 2D + D(D+1))
 
 
 def measured_traffic(kernel, N):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 FETCH_SIZE x 2 +
-    WRITE_SIZE, separate passes; profiles/r*_traffic_n1.json), scaled to N samples.  None if absent."""
+    """(HBM bytes per launch of `kernel`, source file) from the newest committed PMC summary (rocprofv3
+    FETCH_SIZE x 2 + WRITE_SIZE in separate passes: profiles/r*_traffic_n1.json, scripts/profile_bench.sh),
+    scaled to N samples -- NOT measured in this run.  (None, None) if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_n1.json")))
-    if not files:
-        return None
+    for f in reversed(files):
+        try:
+            rec = json.load(open(f))
+            old = {"k_logpdf": "pmc_importance_weights[K=%d+%d]" % (K, K_T), "k_resp": "pmc_responsibilities",
+                   "k_stats": "pmc_sufficient_stats"}          # names of the round-1 summary
+            ent = rec["kernels"].get(kernel) or rec["kernels"][old[kernel]]
+            return ent["hbm_bytes_per_launch"] * (N / float(rec["N"])), os.path.relpath(f, ROOT)
+        except (KeyError, ValueError, OSError):
+            continue
+    return None, None
+
+
+def reference_ratio():
+    """oracle speed / reference speed on the bench step, timed in the build container where the reference
+    runs (scripts/cpu_ratio.py -> profiles/r02_cpu_ratio.json); None if absent"""
     try:
-        rec = json.load(open(files[-1]))
-        return rec["kernels"][kernel]["hbm_bytes_per_launch"] * (N / float(rec["N"]))
-    except (KeyError, ValueError, OSError):
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_ratio.json")))
+        row = [r for r in rec["rows"] if r["case"].startswith("bench step")][0]
+        return float(row["oracle_over_reference"])
+    except (OSError, KeyError, IndexError, ValueError):
         return None
 
 
@@ -193,7 +208,6 @@ def main():
     x = x[torch.randperm(N, device=dev, generator=gen)].contiguous()
 
     stats = be.zeros(be.stats_len(K, D))
-    be.profile = None
 
     def step():
         r = be.importance_weights(x, proposal, target, pack=p_prop, target_pack=p_tgt)
@@ -209,7 +223,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    be.profile = []
+    be.kernel_timings()                              # clear the library's record
+    be.kernel_timing(True)                           # HIP events on the launch stream around every hot kernel
     phase = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -226,6 +241,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    be.kernel_timing(False)
     if world > 1:                                    # MAX over ranks, on the device the backend reduces on
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -234,11 +250,8 @@ def main():
 
     is_ms = float(np.mean([a.elapsed_time(b) for a, b, c in phase]))
     vb_ms = float(np.mean([b.elapsed_time(c) for a, b, c in phase]))
-    kern = {}
-    for name, s, e_ in be.profile:
-        kern.setdefault(name, []).append(s.elapsed_time(e_))
-    kern = {k_: float(np.mean(v)) for k_, v in kern.items()}
-    be.profile = None
+    timings = be.kernel_timings()                    # pmc_get_timings: per kernel launches, ms, algorithmic work
+    kern = {k_: v["ms"] / v["calls"] for k_, v in timings.items()}
 
     # sanity of the numbers that came back (cheap, outside the timed region)
     sc = r["scalars"].cpu().numpy()
@@ -247,14 +260,13 @@ def main():
     assert abs(n_k_sum / (N * world) - 1) < 1e-9, "sum_k N_k != N"
 
     if rank == 0:
-        IS_KERNEL = "pmc_importance_weights[K=%d+%d]" % (K, K_T)     # proposal and target in one pass
-        flops = {IS_KERNEL: N * flops_logpdf(K + K_T, D),
-                 "pmc_responsibilities": N * flops_logpdf(K, D),
-                 "pmc_sufficient_stats": N * flops_stats(K, D)}
-        dominant = max(kern, key=kern.get)
-        achieved = flops[dominant] / (kern[dominant] * 1e-3) * 1e-12
-        alg_bytes = {IS_KERNEL: N * 8 * (D + 1),
-                     "pmc_responsibilities": N * 8 * (D + K), "pmc_sufficient_stats": N * 8 * (D + K)}
+        hot = {k_: v for k_, v in timings.items() if k_ in ("k_logpdf", "k_resp", "k_stats", "k_estep_fused")}
+        dominant = max(hot, key=lambda k_: hot[k_]["ms"])
+        per_launch = {k_: dict(ms=v["ms"] / v["calls"], flops=v["flops"] / v["calls"], bytes=v["bytes"] / v["calls"])
+                      for k_, v in hot.items()}
+        dom = per_launch[dominant]
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) * 1e-12
+        traffic, traffic_src = measured_traffic(dominant, N)
         line = {
             "metric": "IS samples/sec + VB E-step samples/sec at N=1e7, K=32, D=20",
             "value": N * world / (ms_per_step * 1e-3),
@@ -268,20 +280,25 @@ def main():
             "is_samples_per_s": N * world / (is_ms * 1e-3),
             "vb_estep_samples_per_s": N * world / (vb_ms * 1e-3),
             # lower bound: the launch evaluates the K=32 proposal AND the K_t=4 target per sample
-            "mixture_logpdf_evals_per_s": N / (kern[IS_KERNEL] * 1e-3),
+            "mixture_logpdf_evals_per_s": N / (per_launch["k_logpdf"]["ms"] * 1e-3),
             "kernel_ms": kern,
             "perplexity": perp,
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": measured_traffic(dominant, N),
-                         "note": "fp64 kernel (v_fma_f64; pmc_sufficient_stats: v_mfma_f64_4x4x4) priced against "
-                                 "the fp64 matrix peak, which equals the fp64 vector peak on MI355X; flops = "
-                                 "SURVEY 8(d) per-sample figure x N",
-                         "algorithmic_bytes": alg_bytes[dominant],
-                         "per_kernel_tflops": {k_: flops[k_] / (v * 1e-3) * 1e-12 for k_, v in kern.items()},
-                         "hbm": {"achieved": alg_bytes[dominant] / (kern[dominant] * 1e-3) * 1e-9,
+                         "traffic": traffic,
+                         "traffic_source": ("%s (rocprofv3 PMC passes of an earlier run of this command, scaled to N; "
+                                            "not measured in this run)" % traffic_src) if traffic_src else None,
+                         "timing_source": "pmc_get_timings: HIP events on the launch stream around each kernel, "
+                                          "mean over the timed steps",
+                         "note": "fp64 kernels (v_fma_f64; k_stats: v_mfma_f64_4x4x4) priced against the fp64 matrix "
+                                 "peak, which equals the fp64 vector peak on MI355X; flops = SURVEY 8(d) per-sample "
+                                 "figure x N.  The kernels are power-bound: the chip holds 1.9-2.1 of its 2.4 GHz "
+                                 "under this load (profiles/r02_dpp_engine_ab.txt)",
+                         "algorithmic_bytes": dom["bytes"],
+                         "per_kernel_tflops": {k_: v["flops"] / (v["ms"] * 1e-3) * 1e-12 for k_, v in per_launch.items()},
+                         "hbm": {"achieved": dom["bytes"] / (dom["ms"] * 1e-3) * 1e-9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": alg_bytes[dominant] / (kern[dominant] * 1e-3) * 1e-9 / HBM_PEAK_GBS}},
+                                 "frac": dom["bytes"] / (dom["ms"] * 1e-3) * 1e-9 / HBM_PEAK_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.cpu_seconds, mu, cov, w, tmu, tcov, tw, vbp)
@@ -289,6 +306,11 @@ def main():
                                     "sample": "same step on %d samples drawn from the proposal (%.1f s), C oracle = "
                                               "restatement of the reference's single-threaded Cython loops"
                                               % (cb["single"]["n"], cb["single"]["seconds"]),
+                                    "oracle_over_reference": reference_ratio(),
+                                    "note": "the reference itself (Cython, single-threaded) cannot run on the GPU box; in the "
+                                            "build container the oracle runs this step oracle_over_reference times as fast "
+                                            "as the reference (profiles/r02_cpu_ratio.json), i.e. the reference-equivalent "
+                                            "rate is value / oracle_over_reference",
                                     "all_cores": {"value": cb["all"]["value"], "cores": cb["all"]["cores"],
                                                   "sample": "%d samples, %.1f s, OpenMP over samples"
                                                             % (cb["all"]["n"], cb["all"]["seconds"])}}

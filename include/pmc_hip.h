@@ -259,6 +259,27 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
               double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
               void *stream);
 
+/* ---- kernel timing ----------------------------------------------------------------------------- */
+/*
+ * Roofline numbers for callers without a profiler.  While timing is enabled every launch of a hot kernel
+ * is bracketed by HIP events on the caller's stream (the stream it is launched on).  pmc_get_timings
+ * waits for the recorded events, returns one entry per kernel that ran since the last call -- launches,
+ * summed milliseconds, and the ALGORITHMIC work of those launches: flops per sample K (D^2 + 4 D + 40) for
+ * the log-pdf / responsibility kernels, K (1 + 2 D + D (D + 1)) for the statistics kernel; bytes 8 (D + 1)
+ * per sample for the log-pdf, 8 (D + K) for responsibilities and statistics, 8 D for the fused E-step --
+ * and clears the record.  Names: "k_logpdf", "k_resp", "k_stats", "k_estep_fused", "k_propose",
+ * "finishing reductions".  Writes at most max_entries entries, *n_entries is the number available.
+ */
+typedef struct pmc_timing {
+    char name[48];
+    int calls;
+    double ms;
+    double flops;
+    double bytes;
+} pmc_timing;
+int pmc_timing_enable(int on);
+int pmc_get_timings(pmc_timing *h_out, int max_entries, int *n_entries);
+
 #ifdef __cplusplus
 }
 #endif

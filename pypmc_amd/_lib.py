@@ -64,9 +64,19 @@ SIGNATURES = {
     "pmc_responsibilities": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pmc_sufficient_stats": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
+    "pmc_timing_enable": (_int, [_int]),
+    "pmc_get_timings": (_int, [_vp, _int, C.POINTER(C.c_int)]),
     "pmc_estep_is_fused": (_int, [_int, _int, _int, _int]),
     "pmc_estep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+
+class Timing(C.Structure):
+    """struct pmc_timing (include/pmc_hip.h)"""
+    _fields_ = [("name", C.c_char * 48), ("calls", C.c_int), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
 
 _lib = None
 _load_error = None

@@ -105,6 +105,19 @@ class HipBackend(object):
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    def kernel_timing(self, on=True):
+        """Switch the library's own kernel timing on / off (pmc_timing_enable: HIP events on the launch
+        stream around every hot kernel)."""
+        _lib.check(self.lib.pmc_timing_enable(int(bool(on))), "pmc_timing_enable")
+
+    def kernel_timings(self):
+        """{kernel: dict(calls, ms, flops, bytes)} since the last call (pmc_get_timings; synchronises)."""
+        buf = (_lib.Timing * 16)()
+        n = C.c_int(0)
+        _lib.check(self.lib.pmc_get_timings(C.cast(buf, C.c_void_p), 16, C.byref(n)), "pmc_get_timings")
+        return {buf[i].name.decode(): dict(calls=buf[i].calls, ms=buf[i].ms, flops=buf[i].flops, bytes=buf[i].bytes)
+                for i in range(min(n.value, 16))}
+
     def asdevice(self, a, dtype=None):
         """numpy array / torch tensor -> contiguous tensor on this device."""
         torch = self.torch

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------
@@ -57,6 +58,64 @@ int hipfail(hipError_t e, const char *what)
 {
     return fail(PMC_EHIP, "%s: %s", what, hipGetErrorString(e));
 }
+
+// ---------------------------------------------------------------------------------------------
+// kernel timing through the ABI (pmc_timing_enable / pmc_get_timings): every launch of a hot kernel is
+// bracketed by HIP events on the caller's stream while timing is on
+// ---------------------------------------------------------------------------------------------
+enum { T_LOGPDF = 0, T_RESP, T_STATS, T_FUSED, T_PROPOSE, T_FINISH, T_COUNT };
+const char *const g_timing_names[T_COUNT] = {"k_logpdf", "k_resp", "k_stats", "k_estep_fused", "k_propose",
+                                             "finishing reductions"};
+struct TimingRec {
+    int id;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+std::mutex g_timing_mutex;
+bool g_timing_on = false;
+std::vector<TimingRec> g_timing_recs;
+std::vector<hipEvent_t> g_timing_pool;
+constexpr size_t PMC_TIMING_MAX_RECORDS = 1 << 16;
+
+hipEvent_t timing_event()
+{
+    if (!g_timing_pool.empty()) {
+        hipEvent_t e = g_timing_pool.back();
+        g_timing_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// RAII bracket: records the start event now and the stop event when it goes out of scope
+struct Timed {
+    TimingRec rec;
+    hipStream_t st;
+    bool on;
+    Timed(int id, hipStream_t st_, double flops, double bytes) : st(st_), on(false)
+    {
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        if (!g_timing_on || g_timing_recs.size() >= PMC_TIMING_MAX_RECORDS) return;
+        rec.id = id; rec.flops = flops; rec.bytes = bytes;
+        rec.a = timing_event();
+        rec.b = timing_event();
+        if (!rec.a || !rec.b) return;
+        on = hipEventRecord(rec.a, st) == hipSuccess;
+    }
+    ~Timed()
+    {
+        if (!on) return;
+        hipEventRecord(rec.b, st);
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        g_timing_recs.push_back(rec);
+    }
+};
+
+// algorithmic work per launch
+double flops_pairs(double N, int K, int D) { return N * K * ((double)D * D + 4.0 * D + 40.0); }
+double flops_stats(double N, int K, int D) { return N * K * (1.0 + 2.0 * D + (double)D * (D + 1)); }
 
 // kernel set (and with it the compiled dimension) for a sample dimension D
 const PmcKernelSet *kernels_for(int D)
@@ -439,6 +498,7 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
 static int finish_scalars(const double *partials, long long nblocks, double *d_scalars,
                           hipStream_t st)
 {
+    Timed t(T_FINISH, st, 0.0, 8.0 * PMC_NSCALARS * (double)nblocks);
     hipLaunchKernelGGL(k_finish_scalars, dim3(PMC_NSCALARS), dim3(1024), 0, st, partials, nblocks, d_scalars);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_scalars launch");
@@ -468,6 +528,7 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
         a.ld = ld; a.out = d_out; a.individual = d_individual; a.log_target = d_log_target;
         a.weights = d_weights; a.sample_w = d_sample_w;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
+        Timed t(T_LOGPDF, st, flops_pairs((double)N, K, D), 8.0 * N * (D + 1 + (d_individual ? K : 0)));
         hipError_t e = ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
@@ -498,6 +559,7 @@ int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_
         a.pack2 = d_target_pack; a.K2 = K_target; a.log_target_out = d_log_target_out;
         a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
+        Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D), 8.0 * N * (D + 1));
         hipError_t e = ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
@@ -534,6 +596,7 @@ int pmc_propose(const double *d_mu, const double *d_chol, const double *d_dof, c
     a.mu = d_mu; a.chol = d_chol; a.dof = d_dof; a.offsets = (const long long *)d_offsets;
     a.K = K; a.dreal = D; a.N = N; a.first_sample = first_sample; a.seed = seed;
     a.x = d_x; a.origin = (long long *)d_origin;
+    Timed t(T_PROPOSE, (hipStream_t)stream, (double)N * D * (D + 1), 8.0 * N * (D + 1));
     hipError_t e = ks->propose(a, (unsigned)ceil_div(N, 256), (hipStream_t)stream);
     if (e != hipSuccess) return hipfail(e, "k_propose launch");
     return PMC_OK;
@@ -603,6 +666,7 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
         a.klds = K < PMC_RESP_KLDS ? K : PMC_RESP_KLDS;
         a.r = d_r; a.log_rho = d_log_rho; a.exponent = d_exponent;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
+        Timed t(T_RESP, st, flops_pairs((double)N, K, D), 8.0 * N * (D + K));
         hipError_t e = ks->resp(kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_resp launch");
     }
@@ -646,14 +710,67 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
     b.x = d_x; b.N = N; b.dreal = D; b.pack = d_pack; b.K = K; b.u = d_u;
     b.partials = (double *)d_workspace; b.ntiles = g.ntiles; b.nchunks = g.nchunks;
     b.tiles_per_chunk = g.tiles_per_chunk; b.ngroups = g.ngroups;
-    hipError_t e = ks->stats(b, g.grid, st);
+    hipError_t e;
+    {
+        Timed t(T_STATS, st, flops_stats((double)N, K, D), 8.0 * N * (D + K));
+        e = ks->stats(b, g.grid, st);
+    }
     if (e != hipSuccess) return hipfail(e, "k_stats launch");
     const long long total = (long long)K * PS;
+    Timed tf(T_FINISH, st, 0.0, 8.0 * g.nchunks * K * pmc_stats_stride_c(ks->dim));
     hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
                        (const double *)d_workspace, g.nchunks, K, D, ks->dim, d_stats);
     e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
     return PMC_OK;
+}
+
+int pmc_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    g_timing_on = on != 0;
+    return PMC_OK;
+}
+
+int pmc_get_timings(pmc_timing *h_out, int max_entries, int *n_entries)
+{
+    if (!n_entries || (max_entries > 0 && !h_out)) return fail(PMC_EINVAL, "pmc_get_timings: bad argument");
+    std::vector<TimingRec> recs;
+    {
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        recs.swap(g_timing_recs);
+    }
+    pmc_timing acc[T_COUNT];
+    std::memset(acc, 0, sizeof(acc));
+    for (int i = 0; i < T_COUNT; ++i) snprintf(acc[i].name, sizeof(acc[i].name), "%s", g_timing_names[i]);
+    int rc = PMC_OK;
+    for (const TimingRec &r : recs) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) rc = hipfail(e, "pmc_get_timings: event");
+        else {
+            acc[r.id].calls += 1;
+            acc[r.id].ms += ms;
+            acc[r.id].flops += r.flops;
+            acc[r.id].bytes += r.bytes;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        for (const TimingRec &r : recs) {
+            g_timing_pool.push_back(r.a);
+            g_timing_pool.push_back(r.b);
+        }
+    }
+    int n = 0;
+    for (int i = 0; i < T_COUNT; ++i) {
+        if (acc[i].calls == 0) continue;
+        if (n < max_entries) h_out[n] = acc[i];
+        ++n;
+    }
+    *n_entries = n;
+    return rc;
 }
 
 int pmc_estep_is_fused(int K, int D, int kind, int mode)
@@ -689,9 +806,14 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     a.qs = g.qs; a.kq = g.kq; a.cw = g.cw; a.sample_w = d_sample_w; a.ntiles = g.ntiles; a.rounds_per_wg = g.rounds_per_wg;
     a.partials = (double *)d_workspace;
     a.spartials = a.partials + (size_t)g.nchunks * K * PSc;
-    hipError_t e = ks->fused(kind, g.qs, a, g.grid, st);
+    hipError_t e;
+    {
+        Timed t(T_FUSED, st, flops_pairs((double)N, K, D) + flops_stats((double)N, K, D), 8.0 * N * D);
+        e = ks->fused(kind, g.qs, a, g.grid, st);
+    }
     if (e != hipSuccess) return hipfail(e, "k_estep_fused launch");
     const long long total = (long long)K * pmc_stats_stride_c(D);
+    Timed tf(T_FINISH, st, 0.0, 8.0 * g.nchunks * K * PSc);
     hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
                        (const double *)a.partials, (int)g.nchunks, K, D, ks->dim, d_stats);
     e = hipGetLastError();

@@ -82,6 +82,17 @@ template <int D> __device__ __forceinline__ void touch_component(cdouble *pk)
     static_for<0, (LINES + 15) / 16>([&](auto B) { touch16<LINES, decltype(B)::value * 16>(pk); });
 }
 
+// Workgroup barrier behind LDS-DMA (global_load_lds): every wavefront first waits for ITS OWN pieces to have
+// landed (vmcnt), then the barrier orders them against the other wavefronts' reads.  The wait is explicit:
+// __syncthreads() alone does not always get one from the compiler -- in the component loop of the D >= 32
+// per-sample kernels the s_barrier came out bare and a component was occasionally (1 run in ~10, shortest
+// with a 1-4 component target mixture) read before its copy had arrived.
+__device__ __forceinline__ void dma_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // maha = |R (x - mu)|^2 ; R upper triangular, packed row-major in consumption order.
 // Replaces bilinear_sym(inv_sigma, x - mu) (pypmc/tools/_linalg.pyx:10-39).
 template <int D> __device__ __forceinline__ double mahalanobis(const double (&xv)[D], cdouble *pk)
@@ -137,49 +148,15 @@ __device__ __forceinline__ double component_value(double maha, cdouble *c, doubl
 
 // One step of the streaming log-sum-exp  log sum_k w_k exp(a_k) = m + log s  with
 // m = running max, s = sum_k w_k exp(a_k - m)   (one exp per step).
+// (Measured and dropped, round 2: an own exp for non-positive arguments -- degree-13 Taylor polynomial
+// with its constants as SGPR operands, 23 instead of the library's 32 vector instructions, within 1 ulp --
+// was 4-7 % SLOWER in k_logpdf at D = 2 ... 8 and neutral in the fused E-step kernel.)
 __device__ __forceinline__ void lse_step(double a, double w, double &m, double &s)
 {
     const double e = exp(-fabs(a - m));
     const bool gt = a > m;
     s = gt ? fma(s, e, w) : fma(w, e, s);
     m = gt ? a : m;
-}
-
-// exp(x) for x <= 0 (the only arguments a soft-max relative to the row maximum produces), with its
-// constants taken from a table in constant memory: loaded once through the scalar cache they are SGPR
-// operands of v_fma_f64 -- the library's exp re-materialises its 11 polynomial coefficients with
-// v_mov_b64 for every call (v_fmac_f64 overwrites its addend) and checks both overflow bounds.
-//   n = rint(x log2 e), r = x - n ln2 (two-step), p = Taylor polynomial of degree 13 in r
-//   (|r| <= 0.347: remainder 4e-18), exp(x) = ldexp(p, n) -- gradual underflow below -708, 0 below -745.
-// Within 1 ulp of the correctly rounded value (tests/test_gpu_kernels.py::test_exp_nonpos).
-__constant__ double pmc_exp_table[16] = {
-    1.4426950408889634,          // log2(e)
-    -6.93147180369123816490e-01, // -ln2 (high part: 32 significant bits)
-    -1.90821492927058770002e-10, // -ln2 (low part)
-    1. / 6227020800., 1. / 479001600., 1. / 39916800., 1. / 3628800., 1. / 362880., 1. / 40320.,
-    1. / 5040., 1. / 720., 1. / 120., 1. / 24., 1. / 6., 0.5, 1.0};
-
-struct ExpConsts {
-    double c[16];
-    __device__ __forceinline__ void load()
-    {
-        cdouble *t = (cdouble *)pmc_exp_table;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) c[i] = t[i];
-    }
-};
-
-__device__ __forceinline__ double exp_nonpos(double x, const ExpConsts &E)
-{
-    x = (x < -1000.0) ? -1000.0 : x;                     // -inf -> 0 below; a NaN stays a NaN
-    const double n = rint(x * E.c[0]);
-    double r = fma(E.c[1], n, x);
-    r = fma(E.c[2], n, r);
-    double p = E.c[3];
-#pragma unroll
-    for (int i = 4; i < 16; ++i) p = fma(p, r, E.c[i]);          // ... + r/1! (c[15] = 1/1!)
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
 }
 
 __device__ __forceinline__ double wave_sum(double v)

@@ -143,13 +143,11 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
         }
         double s = 0.0, tb = 0.0;
         {
-            ExpConsts EC;
-            EC.load();
             cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
 #pragma unroll PMC_F_UNROLL_A
             for (int k = k0; k < k1; ++k, pk += STRIDE) {
                 const double lr = ut[(size_t)k * 64] - M;          // variational.pyx:741
-                const double e = exp_nonpos(lr, EC);               // :742
+                const double e = exp(lr);                          // :742
                 if constexpr (KIND == PMC_KIND_VB) {
                     s += e;                                        // :743
                     tb = fma(e, lr, tb);                           // sum_k e_k (a_k - M), for E[log q(Z)]

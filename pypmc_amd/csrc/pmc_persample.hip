@@ -35,6 +35,10 @@ __device__ __forceinline__ void component_sync()
 #endif
 }
 
+#ifndef PMC_RESIDENT_MAX_DIM_RESP
+#define PMC_RESIDENT_MAX_DIM_RESP 8
+#endif
+
 extern __shared__ double dyn_lds[];   // [MFMA engine: 2 parameter buffers] [k_resp: parked values]
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
@@ -51,16 +55,39 @@ template <int D, bool PADDED, int ENGINE> struct MahaEngine {
     {
         load_row<D, PADDED>(a.x, tile * 64 + lane, a.N, a.dreal, xv);
     }
-    __device__ __forceinline__ void begin(const double *, int) {}
+    // A short pack needs neither the touch prefetch nor the barrier that keeps a workgroup on one
+    // component: with few lines per component they only add two scalar round trips to each.  Measured, ms per
+    // 4e6 samples x 32 components with / without: D = 2 0.224 / 0.192, D = 5 0.315 / 0.292, D = 8 0.453 /
+    // 0.425, D = 10 0.544 / 0.510, D = 12 (24.5 KB) 0.684 / 0.644 -- and D = 16 1.09 / 1.28, D = 20 1.38 / 2.24.
+#ifndef PMC_RESIDENT_BYTES
+#define PMC_RESIDENT_BYTES 26000
+#endif
+#ifndef PMC_RESIDENT_MAX_DIM
+#define PMC_RESIDENT_MAX_DIM 12
+#endif
+    // (the responsibility kernel, whose wavefronts also park their values, keeps both from D = 10 on:
+    //  D = 12 0.85 -> 1.18 ms without)
+    bool resident;
+    static __device__ __forceinline__ bool fits(int K, int maxdim = PMC_RESIDENT_MAX_DIM)
+    {
+        return D <= maxdim && K * pmc_pack_stride_c(D) * 8 <= PMC_RESIDENT_BYTES;
+    }
+    __device__ __forceinline__ void begin(const double *, int K, int maxdim = PMC_RESIDENT_MAX_DIM)
+    {
+        resident = fits(K, maxdim);
+    }
     __device__ __forceinline__ double eval(cdouble *pk, int)
     {
-        component_sync();
-        touch_component<D>(pk);
+        if (!resident) {                                  // workgroup-uniform
+            component_sync();
+            touch_component<D>(pk);
+        }
         return mahalanobis<D>(xv, pk);
     }
     // a wavefront without samples keeps the workgroup's barrier count
-    __device__ static __forceinline__ void idle(const double *, int K)
+    __device__ static __forceinline__ void idle(const double *, int K, int maxdim = PMC_RESIDENT_MAX_DIM)
     {
+        if (fits(K, maxdim)) return;
         for (int k = 0; k < K; ++k) component_sync();
     }
 };
@@ -112,7 +139,7 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_DPP> {
         if constexpr (V < NPR - 1) return p[16 * V];
         else return p[lastrel];                                      // the partial register / window padding
     }
-    __device__ __forceinline__ void begin(const double *pack, int K_)
+    __device__ __forceinline__ void begin(const double *pack, int K_, int = 0)
     {
         K = K_;
         lanebase = pack + D + (threadIdx.x & 15);
@@ -164,7 +191,7 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_DPP> {
         static_for<NPR, NP>([&](auto V_) { refill<decltype(V_)::value>(k); });
         return ma + mb;
     }
-    __device__ static __forceinline__ void idle(const double *, int) {}
+    __device__ static __forceinline__ void idle(const double *, int, int = 0) {}
 };
 
 // D >= 32 (multiples of 4; measured break-even: D = 32 log-pdf -17 %, responsibilities +2 %;
@@ -236,7 +263,7 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_MFMA> {
             }
         }
     }
-    __device__ __forceinline__ void begin(const double *pack_, int K_)
+    __device__ __forceinline__ void begin(const double *pack_, int K_, int = 0)
     {
         pack = pack_;
         K = K_;
@@ -245,7 +272,7 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_MFMA> {
     }
     __device__ __forceinline__ double eval(cdouble *, int k)
     {
-        __syncthreads();                                  // component k has landed; k-1 is consumed
+        dma_barrier();                                    // component k has landed; k-1 is consumed
         if (k + 1 < K) stage(k + 1);
         const double *buf = dyn_lds + (k & 1) * PBUF;
         const int c = lane >> 4, i = lane & 3;
@@ -302,14 +329,14 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_MFMA> {
         }
         return c == 0 ? total[0] : (c == 1 ? total[1] : (c == 2 ? total[2] : total[3]));
     }
-    __device__ static __forceinline__ void idle(const double *pack_, int K_)
+    __device__ static __forceinline__ void idle(const double *pack_, int K_, int = 0)
     {
         MahaEngine e;
         e.lane = threadIdx.x & 63;
         e.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         e.begin(pack_, K_);
         for (int k = 0; k < K_; ++k) {
-            __syncthreads();
+            dma_barrier();
             if (k + 1 < K_) e.stage(k + 1);
         }
     }
@@ -403,7 +430,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
     double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     using Engine = MahaEngine<D, PADDED, pmc_use_mfma<D>()>;
     if (!tile_live) {
-        Engine::idle(a.pack, K);                          // keep the workgroup's barriers / staging
+        Engine::idle(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);   // keep the workgroup's barriers / staging
     } else {
         Engine engine;
         engine.load(a, tile, lane);
@@ -422,7 +449,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(con
         // (VB starts the maximum at -1e300 instead of -DBL_MAX so that a_0 - m stays finite below)
         double m = a.max_init_zero ? 0.0 : (KIND == PMC_KIND_VB ? -1e300 : -DBL_MAX), s = 0.0, tb = 0.0;
         cdouble *pk = (cdouble *)a.pack;
-        engine.begin(a.pack, K);
+        engine.begin(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);
         for (int k = 0; k < K; ++k, pk += STRIDE) {
             const double maha = engine.eval(pk, k);
             double expo = 0.0;

@@ -219,7 +219,7 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
     // against every wavefront's reads.
     dma(t0, xs, 0, 1);
     dma_u(t0, us, 0, 1);
-    __syncthreads();
+    dma_barrier();
     int buf = 0;
     for (long long t = t0; t < t1; t += NS, buf ^= 1) {
         const double *xb = xs + buf * BUFD + (size_t)srow * ROWD;     // + this lane's sample row
@@ -302,7 +302,7 @@ __device__ __forceinline__ void stats_run(const PmcArgsB &b, double *xs, int k, 
                 }
             });
         }
-        __syncthreads();
+        dma_barrier();
     }
 
     if constexpr (ACTIVE) {

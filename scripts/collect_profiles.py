@@ -15,9 +15,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
-KERNELS = {"k_logpdf": None, "k_resp": "pmc_responsibilities", "k_stats": "pmc_sufficient_stats"}
 
 
 def one(pattern):
@@ -38,12 +37,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = {}
     for row in csv.DictReader(open(f)):
         name, val = row["Kernel_Name"], float(row["Counter_Value"])
-        if "k_logpdf" in name:
-            key = "pmc_importance_weights[K=%d+%d]" % (cfg["K"], cfg["K_target"])
-        elif "k_resp" in name:
-            key = "pmc_responsibilities"
-        elif "k_stats" in name:
-            key = "pmc_sufficient_stats"
+        for key in ("k_logpdf", "k_resp", "k_stats", "k_estep_fused"):     # pmc_get_timings' kernel names
+            if key in name:
+                break
         else:
             continue
         acc.setdefault(key, {}).setdefault(row["Dispatch_Id"], 0.0)

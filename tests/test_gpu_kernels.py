@@ -601,3 +601,4 @@ def test_student_t_pmc_vs_oracle(be, orc, D, K, N):
     W = iw.sum()
     total = V2 - digamma(.5 * (D + dof)) * V1 + (W - V1) * (np.log(.5 * dof) - digamma(.5 * dof)) + S0g + (W - V1)
     np.testing.assert_allclose(1. - total / W, c_ref, rtol=1e-9, atol=1e-11)
+
