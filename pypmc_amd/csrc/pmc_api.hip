@@ -134,22 +134,49 @@ const PmcKernelSet *kernels_for(int D)
 // ---------------------------------------------------------------------------------------------
 // finishing kernels (single workgroup, fixed summation order)
 // ---------------------------------------------------------------------------------------------
-// scalars[i] = sum_b partials[b*PMC_NSCALARS + i]; one workgroup per scalar, fixed order
-__global__ __launch_bounds__(1024) void k_finish_scalars(const double *__restrict__ partials,
-                                                         long long nblocks,
-                                                         double *__restrict__ scalars)
+// scalars[i] = sum_b partials[b*PMC_NSCALARS + i] in a fixed order, in one launch:
+// workgroup g sums its contiguous slice of the rows (thread t: scalar t % 8, rows t / 8, t / 8 + 32, ... --
+// every wavefront load covers 8 whole 64-byte rows; fixed LDS tree) into slices[g][8]; the workgroup that
+// takes the last ticket adds the slices in ascending g.  The ticket counter wraps to 0 by itself
+// (atomicInc), cross-workgroup visibility follows MI355X_MICROARCH.md: release fence + drained vmcnt before
+// the ticket, acquire fence after it.
+constexpr int FIN_GROUPS = 64;
+__global__ __launch_bounds__(256) void k_finish_scalars(const double *__restrict__ partials,
+                                                        long long nblocks, double *slices,
+                                                        unsigned *counter, double *__restrict__ scalars)
 {
-    __shared__ double red[1024];
-    const int i = blockIdx.x;
+    __shared__ double red[256];
+    __shared__ unsigned ticket;
+    const int i = threadIdx.x & (PMC_NSCALARS - 1), r = threadIdx.x >> 3;
+    const long long per = (nblocks + FIN_GROUPS - 1) / FIN_GROUPS;
+    const long long b0 = (long long)blockIdx.x * per;
+    long long b1 = b0 + per;
+    if (b1 > nblocks) b1 = nblocks;
     double v = 0.0;
-    for (long long b = threadIdx.x; b < nblocks; b += 1024) v += partials[b * PMC_NSCALARS + i];
+    for (long long b = b0 + r; b < b1; b += 256 / PMC_NSCALARS) v += partials[b * PMC_NSCALARS + i];
     red[threadIdx.x] = v;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s >= PMC_NSCALARS; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) scalars[i] = red[0];
+    if (threadIdx.x < PMC_NSCALARS) __hip_atomic_store(&slices[blockIdx.x * PMC_NSCALARS + threadIdx.x], red[threadIdx.x],
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = atomicInc(counter, FIN_GROUPS - 1);
+    }
+    __syncthreads();
+    if (ticket != FIN_GROUPS - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x < PMC_NSCALARS) {
+        double t = 0.0;
+        for (int g = 0; g < FIN_GROUPS; ++g)
+            t += __hip_atomic_load(&slices[g * PMC_NSCALARS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scalars[threadIdx.x] = t;
+    }
 }
 
 // stats[k][p] (real dimension D) = sum_chunk partials[chunk][k][p'] (compiled dimension Dc).
@@ -495,11 +522,41 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
     return PMC_OK;
 }
 
+// scratch of the scalar finishing kernel -- slices + ticket counter, zeroed once (the counter wraps) -- one per
+// (device, stream): launches on one stream are ordered, different streams never share it
+struct FinScratch {
+    int device;
+    hipStream_t stream;
+    double *slices;
+    unsigned *counter;
+};
+FinScratch *fin_scratch(hipStream_t st)
+{
+    static std::mutex m;
+    static std::vector<FinScratch> all;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(m);
+    for (FinScratch &f : all)
+        if (f.device == dev && f.stream == st) return &f;
+    void *p = nullptr;
+    const size_t bytes = sizeof(double) * FIN_GROUPS * PMC_NSCALARS + 256;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess) return nullptr;
+    all.reserve(256);                                       // (pointers handed out stay valid)
+    if (all.size() >= 256) return nullptr;
+    all.push_back(FinScratch{dev, st, (double *)p, (unsigned *)((char *)p + sizeof(double) * FIN_GROUPS * PMC_NSCALARS)});
+    return &all.back();
+}
+
 static int finish_scalars(const double *partials, long long nblocks, double *d_scalars,
                           hipStream_t st)
 {
+    FinScratch *f = fin_scratch(st);
+    if (!f) return fail(PMC_EHIP, "finishing scratch allocation failed");
     Timed t(T_FINISH, st, 0.0, 8.0 * PMC_NSCALARS * (double)nblocks);
-    hipLaunchKernelGGL(k_finish_scalars, dim3(PMC_NSCALARS), dim3(1024), 0, st, partials, nblocks, d_scalars);
+    hipLaunchKernelGGL(k_finish_scalars, dim3(FIN_GROUPS), dim3(256), 0, st, partials, nblocks, f->slices, f->counter,
+                       d_scalars);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_scalars launch");
     return PMC_OK;

@@ -10,7 +10,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out = {}
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", "sq", "pass*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}

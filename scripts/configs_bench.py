@@ -68,11 +68,12 @@ def main():
         "device_resident_s": t_dev, "evals_per_s": N / t_dev,
         "numpy_in_numpy_out_s": t_host, "numpy_evals_per_s": N / t_host}
 
-    # -- config 3: Student-t mixture (nu=8), D=30, K=32, N=1e7: importance weights + perplexity
+    # -- config 3: Student-t mixture (nu=8), D=30, K=32, N=1e7: importance weights + perplexity against the
+    #    SURVEY target (a K_t=4 Gaussian mixture, mk(4, D, 11)) -- proposal and target families differ: one pass
     D, K, N = 30, 32, 10_000_000
     mu, cov, w = mk(K, D, 2)
     prop = create_t_mixture(mu, cov, np.full(K, 8.), w)
-    target = create_gaussian_mixture(mu + 0.05, cov, w)
+    target = create_gaussian_mixture(*mk(4, D, 11))
     np.random.seed(8)
     sampler = ImportanceSampler(target.evaluate, prop)
     res = {}
@@ -84,9 +85,17 @@ def main():
     pcs, tcs = component_set(prop.components, prop.weights), component_set(target.components, target.weights)
     t_w = timed(lambda: be.importance_weights(x3, pcs, tcs), args.reps)
     S, L, Q = res["r"]["weight_sums"]
-    out["cfg3_student_t_IS_D30_K32_N1e7"] = {
+    flops = N * (36 * (D * D + 4 * D) + 32 * 80 + 4 * 40)     # c_tr = 40, +40 for Student-t's log
+    out["cfg3_student_t_IS_D30_K32_Kt4_N1e7"] = {
         "propose_plus_weights_s": t, "samples_per_s": N / t, "weights_only_s": t_w,
-        "weights_only_samples_per_s": N / t_w, "perplexity": perp_from_sums(S, L, N)}
+        "weights_only_samples_per_s": N / t_w, "weights_only_tflops": flops / t_w * 1e-12,
+        "fraction_of_fp64_bound_2.0e9_per_s": N / t_w / (78.6e12 / (flops / N)),
+        "perplexity": perp_from_sums(S, L, N)}
+    # the same with a target close to the proposal (healthy weights; K_t = 32)
+    target2 = create_gaussian_mixture(mu + 0.05, cov, w)
+    tcs2 = component_set(target2.components, target2.weights)
+    t_w2 = timed(lambda: be.importance_weights(x3, pcs, tcs2), args.reps)
+    out["cfg3_student_t_IS_D30_K32_Kt32_N1e7"] = {"weights_only_s": t_w2, "weights_only_samples_per_s": N / t_w2}
     del sampler, res, x3
 
     # -- config 4: GaussianInference E-step, D=20, K=64; N=1e7 on one GPU and one GPU's share of 8
@@ -101,8 +110,8 @@ def main():
         out["cfg4_vb_estep_D20_K64_" + label] = {"estep_s": t, "samples_per_s": N / t}
         del vb, x
 
-    # -- config 5: PMC adapt loop, D=40, K=128, N=1e8 over 8 GPUs -> one GPU's iteration on 1.25e7 / 5 chunks
-    D, K, KT, N = 40, 128, 4, 2_500_000
+    # -- config 5: PMC adapt loop, D=40, K=128, N=1e8 over 8 GPUs -> one GPU's share: 1.25e7 samples per iteration
+    D, K, KT, N = 40, 128, 4, 12_500_000
     tmu, tcov, tw = mk(KT, D, 11, spread=1.0)
     target = create_gaussian_mixture(tmu, tcov, tw)
     rs = np.random.RandomState(5)
@@ -123,7 +132,7 @@ def main():
         info["propose_weight_s"], info["update_s"] = t1 - t0, time.perf_counter() - t1
         info["perplexity"] = perp_from_sums(run["weight_sums"][0], run["weight_sums"][1], N)
     t = timed(iteration, 3)
-    out["cfg5_pmc_loop_D40_K128_N2.5e6_per_iteration"] = dict(iteration_s=t, samples_per_s=N / t, **info)
+    out["cfg5_pmc_loop_D40_K128_N1.25e7_per_iteration"] = dict(iteration_s=t, samples_per_s=N / t, **info)
 
     text = json.dumps(out, indent=1)
     print(text)
