@@ -64,10 +64,15 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
     constexpr int G = GEO::G, PIT = GEO::PIT, NBLK = GEO::NBLK, T = pmc_tri(D);
     constexpr bool AUG = GEO::AUG;
     constexpr int STRIDE = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
+    // D <= PMC_F_PERLANE_MAX: the statistics phase keeps lane = sample and accumulates the 1 + D + T moments
+    // of its components per lane with plain multiply-adds (D = 2: 10 vector instructions per tile and
+    // component against 8 + 4 MFMA = 24 slots' worth; measured 0.459 -> 0.430 ms per 4e6 samples x 32
+    // components).  From D = 3 on the NCH (1 + D + T) accumulators cost more occupancy than they save (0.49 -> 0.53)
+    constexpr bool PL = D <= PMC_F_PERLANE_MAX;
     extern __shared__ double lds[];
     const int K = a.K;
     const int QS = a.qs, TPR = FW / QS;                            // wavefronts per tile, tiles per round
-    double *xi = lds;                                              // [TPR][64][PIT]   sample rows
+    double *xi = lds;                                              // [TPR][64][PIT] sample rows  (PL: [TPR][PIT][64])
     double *ub = xi + TPR * 64 * PIT;                              // [TPR][K][64]     a_nk, then u_nk, tile-major
     double *zero = ub + (size_t)TPR * K * 64;                      // [64]             u of a component slot beyond K
     double *red = zero + 64;                                       // [3][FW][64]      soft-max exchange
@@ -100,6 +105,13 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) acc2[j][b] = 0.0;
     }
+    double pacc[PL ? NCH : 1][PL ? PS : 1];                        // per-lane moments: sum u | sum u d | sum u d d^T
+    if constexpr (PL) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int p = 0; p < PS; ++p) pacc[j][p] = 0.0;
+    }
     if (threadIdx.x < 64) zero[threadIdx.x] = 0.0;                 // (the first barrier of a round orders it)
     double sc_a = 0.0;                                             // VB: E[log q(Z)] part; PMC: sum w log q
 
@@ -118,9 +130,14 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
             double xv[D];
             load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
             if (q == 0) {                                          // wave-uniform
-                double *row = xi + (size_t)(ta * 64 + lane) * PIT;
+                if constexpr (PL) {
 #pragma unroll
-                for (int j = 0; j < 4 * G; ++j) row[j] = j < D ? xv[j] : ((AUG && j == D) ? 1.0 : 0.0);
+                    for (int j = 0; j < D; ++j) xi[(size_t)(ta * PIT + j) * 64 + lane] = xv[j];
+                } else {
+                    double *row = xi + (size_t)(ta * 64 + lane) * PIT;
+#pragma unroll
+                    for (int j = 0; j < 4 * G; ++j) row[j] = j < D ? xv[j] : ((AUG && j == D) ? 1.0 : 0.0);
+                }
             }
             cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
 #pragma unroll PMC_F_UNROLL_A
@@ -195,85 +212,125 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
         __syncthreads();
 
         // ------------------------------------------------------------------ phase B
-        for (int t = ts0; t < TPR; t += TS) {
-            const double *xt = xi + (size_t)(t * 64 + srow) * PIT + ci;
-            const double *utile = ub + srow;
-            // operands of sub-step ss + 1 are read before the arithmetic of sub-step ss
-            double xb[2][G], uq[2][NCH];                           // ping-pong operand registers
-            auto fetch = [&](int ss, double (&xx)[G], double (&uu)[NCH]) {
+        if constexpr (PL) {
+            for (int t = ts0; t < TPR; t += TS) {
+                double xr[D];
 #pragma unroll
-                for (int I = 0; I < G; ++I) xx[I] = xt[ss * 16 * PIT + 4 * I];
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) uu[j] = utile[t * toff[j] + coff[j] + ss * 16];
-            };
-            fetch(0, xb[0], uq[0]);
-            static_for<0, 4>([&](auto S_) {
-                constexpr int ss = decltype(S_)::value, cur = ss & 1, nxt = cur ^ 1;
-                // scheduling fences (no instructions): pin the prefetch behind the previous sub-step's
-                // arithmetic and in front of this one's
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(acc2[j][0]) : : "memory");
-                if constexpr (ss + 1 < 4) fetch(ss + 1, xb[nxt], uq[nxt]);
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(uq[cur][j]) : : "memory");
+                for (int i = 0; i < D; ++i) xr[i] = xi[(size_t)(t * PIT + i) * 64 + lane];
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
-                    const double u = uq[cur][j];
-                    double d[G];
+                    const int c = cb + CW * j;
+                    cdouble *pk = (cdouble *)a.pack + (size_t)(c < K ? c : 0) * STRIDE;
+                    const double u = c < K ? ub[((size_t)t * K + c) * 64 + lane] : 0.0;      // wave-uniform select
+                    double d[D];
 #pragma unroll
-                    for (int I = 0; I < G; ++I) d[I] = xb[cur][I] - mu[j][I];
-                    if constexpr (!AUG) acc0[j] += u;
-                    int b = 0;
+                    for (int i = 0; i < D; ++i) d[i] = xr[i] - pk[i];
+                    pacc[j][0] += u;
+                    int p = 1 + D;
 #pragma unroll
-                    for (int I = 0; I < G; ++I) {
-                        const double ud = u * d[I];
-                        if constexpr (!AUG) acc1[j][I] += ud;
+                    for (int i = 0; i < D; ++i) {
+                        const double ud = u * d[i];
+                        pacc[j][1 + i] += ud;
 #pragma unroll
-                        for (int J = 0; J <= I; ++J, ++b)
-                            acc2[j][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(ud, d[J], acc2[j][b], 0, 0, 0);
+                        for (int jj = 0; jj <= i; ++jj, ++p) pacc[j][p] = fma(ud, d[jj], pacc[j][p]);
                     }
                 }
-            });
+            }
+        } else {
+            for (int t = ts0; t < TPR; t += TS) {
+                const double *xt = xi + (size_t)(t * 64 + srow) * PIT + ci;
+                const double *utile = ub + srow;
+                // operands of sub-step ss + 1 are read before the arithmetic of sub-step ss
+                double xb[2][G], uq[2][NCH];                           // ping-pong operand registers
+                auto fetch = [&](int ss, double (&xx)[G], double (&uu)[NCH]) {
+    #pragma unroll
+                    for (int I = 0; I < G; ++I) xx[I] = xt[ss * 16 * PIT + 4 * I];
+    #pragma unroll
+                    for (int j = 0; j < NCH; ++j) uu[j] = utile[t * toff[j] + coff[j] + ss * 16];
+                };
+                fetch(0, xb[0], uq[0]);
+                static_for<0, 4>([&](auto S_) {
+                    constexpr int ss = decltype(S_)::value, cur = ss & 1, nxt = cur ^ 1;
+                    // scheduling fences (no instructions): pin the prefetch behind the previous sub-step's
+                    // arithmetic and in front of this one's
+    #pragma unroll
+                    for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(acc2[j][0]) : : "memory");
+                    if constexpr (ss + 1 < 4) fetch(ss + 1, xb[nxt], uq[nxt]);
+    #pragma unroll
+                    for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(uq[cur][j]) : : "memory");
+    #pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        const double u = uq[cur][j];
+                        double d[G];
+    #pragma unroll
+                        for (int I = 0; I < G; ++I) d[I] = xb[cur][I] - mu[j][I];
+                        if constexpr (!AUG) acc0[j] += u;
+                        int b = 0;
+    #pragma unroll
+                        for (int I = 0; I < G; ++I) {
+                            const double ud = u * d[I];
+                            if constexpr (!AUG) acc1[j][I] += ud;
+    #pragma unroll
+                            for (int J = 0; J <= I; ++J, ++b)
+                                acc2[j][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(ud, d[J], acc2[j][b], 0, 0, 0);
+                        }
+                    }
+                });
+            }
         }
         __syncthreads();                                           // LDS buffers are rewritten next round
     }
 
     // ---------------------------------------------------------------------- results
-    // accumulator lane layouts: acc2 -- lane 16 i + 4 blk + j; acc0 / acc1 -- per (sample, ci)
     const long long chunk = (long long)blockIdx.x * TS + ts0;
+    if constexpr (PL) {
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int c = cb + CW * j;
-        if (c >= K) continue;
-        double *out = a.partials + ((size_t)chunk * K + c) * PS;
-        if constexpr (!AUG) {
-            double s0 = acc0[j];                                   // every sample appears in 4 lanes (ci)
-            s0 += __shfl_xor(s0, 4, 64);
-            s0 += __shfl_xor(s0, 8, 64);
-            s0 += __shfl_xor(s0, 16, 64);
-            s0 += __shfl_xor(s0, 32, 64);
-            if (lane == 0) out[0] = s0;
-        }
-        int b = 0;
+        for (int j = 0; j < NCH; ++j) {
+            const int c = cb + CW * j;
+            if (c >= K) continue;
+            double *out = a.partials + ((size_t)chunk * K + c) * PS;
 #pragma unroll
-        for (int I = 0; I < G; ++I) {
-            if constexpr (!AUG) {
-                double m = acc1[j][I];
-                m += __shfl_xor(m, 4, 64);
-                m += __shfl_xor(m, 8, 64);
-                m += __shfl_xor(m, 16, 64);
-                m += __shfl_xor(m, 32, 64);
-                if (lane < 4 && 4 * I + lane < D) out[1 + 4 * I + lane] = m;
+            for (int p = 0; p < PS; ++p) {
+                const double v = wave_sum(pacc[j][p]);
+                if (lane == 0) out[p] = v;
             }
-#pragma unroll
-            for (int J = 0; J <= I; ++J, ++b) {
-                double v = acc2[j][b];
-                v += __shfl_xor(v, 4, 64);                         // sum of the 4 batch blocks
-                v += __shfl_xor(v, 8, 64);
-                const int gi = 4 * I + (lane >> 4), gj = 4 * J + (lane & 3);
-                if (blk == 0 && gj <= gi) {
-                    if (gi < D) out[1 + D + gi * (gi + 1) / 2 + gj] = v;
-                    else if (AUG && gi == D) out[gj < D ? 1 + gj : 0] = v;     // sum u d_gj / sum u
+        }
+    } else {
+        // accumulator lane layouts: acc2 -- lane 16 i + 4 blk + j; acc0 / acc1 -- per (sample, ci)
+    #pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = cb + CW * j;
+            if (c >= K) continue;
+            double *out = a.partials + ((size_t)chunk * K + c) * PS;
+            if constexpr (!AUG) {
+                double s0 = acc0[j];                                   // every sample appears in 4 lanes (ci)
+                s0 += __shfl_xor(s0, 4, 64);
+                s0 += __shfl_xor(s0, 8, 64);
+                s0 += __shfl_xor(s0, 16, 64);
+                s0 += __shfl_xor(s0, 32, 64);
+                if (lane == 0) out[0] = s0;
+            }
+            int b = 0;
+    #pragma unroll
+            for (int I = 0; I < G; ++I) {
+                if constexpr (!AUG) {
+                    double m = acc1[j][I];
+                    m += __shfl_xor(m, 4, 64);
+                    m += __shfl_xor(m, 8, 64);
+                    m += __shfl_xor(m, 16, 64);
+                    m += __shfl_xor(m, 32, 64);
+                    if (lane < 4 && 4 * I + lane < D) out[1 + 4 * I + lane] = m;
+                }
+    #pragma unroll
+                for (int J = 0; J <= I; ++J, ++b) {
+                    double v = acc2[j][b];
+                    v += __shfl_xor(v, 4, 64);                         // sum of the 4 batch blocks
+                    v += __shfl_xor(v, 8, 64);
+                    const int gi = 4 * I + (lane >> 4), gj = 4 * J + (lane & 3);
+                    if (blk == 0 && gj <= gi) {
+                        if (gi < D) out[1 + D + gi * (gi + 1) / 2 + gj] = v;
+                        else if (AUG && gi == D) out[gj < D ? 1 + gj : 0] = v;     // sum u d_gj / sum u
+                    }
                 }
             }
         }

@@ -14,6 +14,9 @@ constexpr int PMC_RESP_KLDS = 16;
 // responsibility phase (so K <= PMC_F_WAVES / 2 * PMC_F_KQMAX = 32), largest compiled dimension
 #define PMC_F_WAVES 8
 #define PMC_F_KQMAX 8
+#ifndef PMC_F_PERLANE_MAX
+#define PMC_F_PERLANE_MAX 2
+#endif
 #ifndef PMC_F_UNROLL_A
 #define PMC_F_UNROLL_A 2
 #endif

@@ -23,7 +23,16 @@ namespace {
 // Minimum wavefronts per SIMD the register allocator has to leave room for.  Beyond D = 48 the
 // kernels would otherwise take 256 VGPRs + AGPRs = one wavefront per SIMD; two with ~50 spilled
 // registers are 1.7x faster (D = 64: 9.3 -> 5.3 ms per 2e6 samples x 16 components).
-__host__ __device__ constexpr int pmc_min_waves(int D) { return D >= 40 ? 2 : 1; }
+// (RESP: the responsibility kernel.  Measured, ms per 4e6 samples x 32 components: log-pdf D = 16 with 1 / 4 / 5:
+// 1.13 / 1.08 / 1.05;  responsibilities D = 24 with 1 / 4: 2.02 / 1.90, D = 16 with 5: worse)
+__host__ __device__ constexpr int pmc_min_waves(int D, bool RESP = false)
+{
+#ifdef PMC_MIN_WAVES
+    return PMC_MIN_WAVES;
+#else
+    return D >= 40 ? 2 : ((!RESP && D == 16) ? 5 : ((RESP && D == 24) ? 4 : 1));
+#endif
+}
 
 // The wavefronts of a workgroup walk the components in step: a barrier per component keeps them on
 // the same parameter lines, so that one wavefront's scalar-cache fill serves the other three
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 // matrix log_rho (materialised on demand, never in the E-step itself).
 // ---------------------------------------------------------------------------------------------
 template <int D, bool PADDED, int KIND>
-__global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_resp(const PmcArgsA a)
+__global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_resp(const PmcArgsA a)
 {
     constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
     const int lane = threadIdx.x & 63;
