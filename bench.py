@@ -90,7 +90,7 @@ def measured_traffic(kernel, N):
             rec = json.load(open(f))
             old = {"k_logpdf": "pmc_importance_weights[K=%d+%d]" % (K, K_T), "k_resp": "pmc_responsibilities",
                    "k_stats": "pmc_sufficient_stats"}          # names of the round-1 summary
-            ent = rec["kernels"].get(kernel) or rec["kernels"][old[kernel]]
+            ent = rec["kernels"].get(kernel) or rec["kernels"][old.get(kernel, kernel)]
             return ent["hbm_bytes_per_launch"] * (N / float(rec["N"])), os.path.relpath(f, ROOT)
         except (KeyError, ValueError, OSError):
             continue

@@ -163,7 +163,15 @@ class HipBackend(object):
         self._bufs = {}
 
     def pack(self, comps):
-        """ComponentSet -> device parameter pack (host Cholesky in pmc_pack_components)."""
+        """ComponentSet -> device parameter pack (host Cholesky in pmc_pack_components).  A ComponentSet is
+        not modified after construction, so its pack is built and uploaded once and kept with it."""
+        cached = getattr(comps, "_pack", None)
+        if cached is not None and cached[0] is self:
+            return cached[1]
+        comps._pack = (self, self._build_pack(comps))
+        return comps._pack[1]
+
+    def _build_pack(self, comps):
         stride = _lib.check(self.lib.pmc_pack_stride(comps.D), "pmc_pack_stride")
         host = np.empty(comps.K * stride, dtype=np.float64)
         _lib.check(self.lib.pmc_pack_components(

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    path = os.path.join(ROOT, "profiles", "r01_bench_n1_with_cpu_baseline.json")
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_with_cpu_baseline.json")))[-1]
     return json.load(open(path))
 
 
@@ -39,6 +40,14 @@ def test_flop_and_traffic_helpers():
     # K (D^2 + 4D) + 40 K  and  K (1 + 2D + D(D+1))
     assert bench.flops_logpdf(32, 20) == 32 * 480 + 32 * 40
     assert bench.flops_stats(32, 20) == 32 * 461
-    t = bench.measured_traffic("pmc_sufficient_stats", 10_000_000)
-    assert t is None or 1e9 < t < 2e10
-    assert bench.measured_traffic("no_such_kernel", 1) is None
+    t, src = bench.measured_traffic("k_stats", 10_000_000)
+    assert t is None or (1e9 < t < 2e10 and src.startswith("profiles/"))
+    assert bench.measured_traffic("no_such_kernel", 1) == (None, None)
+    ratio = bench.reference_ratio()
+    assert ratio is None or 1.0 < ratio < 5.0
+
+
+def test_recorded_line_names_its_sources():
+    r = _line()["roofline"]
+    assert "timing_source" in r and "pmc_get_timings" in r["timing_source"]
+    assert r["traffic"] is None or "not measured in this run" in r["traffic_source"]

@@ -602,3 +602,38 @@ def test_student_t_pmc_vs_oracle(be, orc, D, K, N):
     total = V2 - digamma(.5 * (D + dof)) * V1 + (W - V1) * (np.log(.5 * dof) - digamma(.5 * dof)) + S0g + (W - V1)
     np.testing.assert_allclose(1. - total / W, c_ref, rtol=1e-9, atol=1e-11)
 
+
+
+def test_kernel_timings_through_the_abi(be):
+    """pmc_timing_enable / pmc_get_timings: launches, milliseconds and the algorithmic work per kernel"""
+    K, D, N = 5, 12, 20000
+    mu, cov, w = mk(K, D, 4)
+    x, _ = draw(mu, cov, w, N, 5)
+    cs = gauss_set(mu, cov, w)[0]
+    be.kernel_timings()                                   # clear
+    be.kernel_timing(True)
+    try:
+        be.logpdf(x, cs)
+        be.logpdf(x, cs, log_target=np.zeros(N), want_scalars=True)
+        be.estep(x, cs, 1)
+    finally:
+        be.kernel_timing(False)
+    t = be.kernel_timings()
+    assert t["k_logpdf"]["calls"] == 2 and t["k_resp"]["calls"] == 1 and t["k_stats"]["calls"] == 1
+    assert t["finishing reductions"]["calls"] == 3        # scalars of the weights call; scalars + statistics of the E-step
+    pair = D * D + 4 * D + 40
+    assert t["k_logpdf"]["flops"] == 2.0 * N * K * pair and t["k_resp"]["flops"] == 1.0 * N * K * pair
+    assert t["k_stats"]["flops"] == 1.0 * N * K * (1 + 2 * D + D * (D + 1))
+    assert t["k_logpdf"]["bytes"] == 2 * 8.0 * N * (D + 1) and t["k_stats"]["bytes"] == 8.0 * N * (D + K)
+    assert all(0 < v["ms"] < 50 for v in t.values())
+    assert be.kernel_timings() == {}                      # cleared by the read; nothing recorded while off
+    be.logpdf(x, cs)
+    assert be.kernel_timings() == {}
+    # the fused small-dimension E-step reports itself
+    mu, cov, w = mk(3, 2, 4)
+    x, _ = draw(mu, cov, w, 5000, 5)
+    be.kernel_timing(True)
+    be.estep(x, gauss_set(mu, cov, w)[0], 1)
+    be.kernel_timing(False)
+    t = be.kernel_timings()
+    assert t["k_estep_fused"]["calls"] == 1 and t["k_estep_fused"]["bytes"] == 8.0 * 5000 * 2 and "k_resp" not in t
