@@ -76,7 +76,7 @@ class HipBackend(object):
         if not self.arch.startswith("gfx950"):
             raise HipLibraryError("kernels are built for gfx950 (MI355X); device reports %r" % self.arch)
         self.tile = self.lib.pmc_tile()
-        self._ws = None
+        self._ws = {}            # launch stream -> scratch (calls on different streams may overlap)
         self._bufs = {}
         self.profile = None      # set to a list to collect (entry point, start, end) event triples
 
@@ -145,21 +145,24 @@ class HipBackend(object):
 
     def _workspace(self, N, K, D):
         need = _lib.check(self.lib.pmc_workspace_bytes(N, K, D), "pmc_workspace_bytes")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = self.torch.empty(int(need), dtype=self.torch.uint8, device=self.device)
-        return self._ws
+        key = self.torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = self.torch.empty(int(need), dtype=self.torch.uint8, device=self.device)
+        return ws
 
     def _tilebuf(self, name, N, K):
         need = _lib.check(self.lib.pmc_tile_buffer_len(N, K), "pmc_tile_buffer_len")
-        buf = self._bufs.get(name)
+        key = (name, self.torch.cuda.current_stream(self.device).cuda_stream)
+        buf = self._bufs.get(key)
         if buf is None or buf.numel() < need:
             buf = self.torch.empty(int(max(need, 1)), dtype=self.torch.float64, device=self.device)
-            self._bufs[name] = buf
+            self._bufs[key] = buf
         return buf
 
     def release(self):
         """Drop cached scratch buffers."""
-        self._ws = None
+        self._ws = {}
         self._bufs = {}
 
     def pack(self, comps):
