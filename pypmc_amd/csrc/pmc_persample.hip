@@ -424,6 +424,24 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 // pass 2 evaluates the reference's expressions literally, only when the caller wants the N x K
 // matrix log_rho (materialised on demand, never in the E-step itself).
 // ---------------------------------------------------------------------------------------------
+// Pass 2 of k_resp walks the parked values of components khi-1 ... klo downwards, four loads in flight.
+// (One loop over all components with `k < klds ? LDS : global` made the compiler select between the two
+// pointers and issue a flat load followed by s_waitcnt 0 in every iteration: a full memory round trip
+// per component and wavefront.)
+template <class Load, class Step>
+__device__ __forceinline__ void descend(int khi, int klo, Load load, Step step)
+{
+    int k = khi - 1;
+    for (; k - 3 >= klo; k -= 4) {
+        const double p0 = load(k), p1 = load(k - 1), p2 = load(k - 2), p3 = load(k - 3);
+        step(k, p0);
+        step(k - 1, p1);
+        step(k - 2, p2);
+        step(k - 3, p3);
+    }
+    for (; k >= klo; --k) step(k, load(k));
+}
+
 template <int D, bool PADDED, int KIND>
 __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_resp(const PmcArgsA a)
 {
@@ -514,18 +532,19 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 }
             } else {
                 double c = norm_inv;                      // norm_inv * prod of the f_j above k
-                for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
-                    const double p = k < klds ? pl[k * 64] : ut[(size_t)k * 64];
+                auto step = [&](int k, double p) {
                     const bool newmax = __double2hiint(p) < 0;      // sign bit (f may be -0.0)
                     double r = (newmax ? 1.0 : p) * c;
                     c = newmax ? c * -p : c;
                     if (r == 0.0) r = TINY;
                     ut[(size_t)k * 64] = valid ? sw * r : 0.0;
                     if (a.r != nullptr) {
-                        const long long col = ((cint64 *)pk)[D + T + 5];
+                        const long long col = ((cint64 *)((cdouble *)a.pack + (size_t)k * STRIDE))[D + T + 5];
                         if (valid) a.r[n * a.ld + col] = r;
                     }
-                }
+                };
+                descend(K, klds, [&](int k) { return ut[(size_t)k * 64]; }, step);
+                descend(klds, 0, [&](int k) { return pl[k * 64]; }, step);
                 // sum_k r_k (a_k - m + log norm_inv) with sum_k r_k = 1   (variational.pyx:1003-1013)
                 elq = fma(tb, norm_inv, log_norm_inv);
             }
@@ -540,22 +559,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             const double em = exp(m);
             double chain = 1.0;
             const long long lat = (a.mode == PMC_RESP_PMC_LATENT && valid) ? a.latent[n] : -1;
-            for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
-                cdouble *c = pk + D + T;
-                const long long col = ((cint64 *)pk)[D + T + 5];
-                double rho;
-                if (a.mode == PMC_RESP_PMC_LATENT) {
-                    rho = (lat == col) ? 1. : 0.;         // pmc.pyx:49-50
-                } else if (literal) {
-                    rho = exp(k < klds ? pl[k * 64] : ut[(size_t)k * 64]) * c[4];
-                    rho /= denom;
-                } else {
-                    const double p = k < klds ? pl[k * 64] : ut[(size_t)k * 64];
-                    const bool newmax = __double2hiint(p) < 0;
-                    rho = (newmax ? 1.0 : p) * chain * em * c[4];
-                    chain = newmax ? chain * -p : chain;
-                    rho /= denom;
-                }
+            // rho -> u (and the public matrix, gamma and the dof sums of the Student-t update)
+            auto emit = [&](int k, double rho, cdouble *c, long long col) {
                 if (valid && a.r != nullptr) a.r[n * a.ld + col] = rho;
                 const double wr = valid ? sw * rho : 0.0;
                 if constexpr (KIND == PMC_KIND_STUDENT_T) {
@@ -574,6 +579,33 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 } else {
                     ut[(size_t)k * 64] = wr;
                 }
+            };
+            if (a.mode == PMC_RESP_PMC_LATENT || literal) {
+                for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
+                    cdouble *c = pk + D + T;
+                    const long long col = ((cint64 *)pk)[D + T + 5];
+                    double rho;
+                    if (a.mode == PMC_RESP_PMC_LATENT) {
+                        rho = (lat == col) ? 1. : 0.;         // pmc.pyx:49-50
+                    } else {
+                        rho = exp(k < klds ? pl[k * 64] : ut[(size_t)k * 64]) * c[4];
+                        rho /= denom;
+                    }
+                    emit(k, rho, c, col);
+                }
+            } else {
+                auto step = [&](int k, double p) {
+                    cdouble *pkk = (cdouble *)a.pack + (size_t)k * STRIDE;
+                    cdouble *c = pkk + D + T;
+                    const long long col = ((cint64 *)pkk)[D + T + 5];
+                    const bool newmax = __double2hiint(p) < 0;
+                    double rho = (newmax ? 1.0 : p) * chain * em * c[4];
+                    chain = newmax ? chain * -p : chain;
+                    rho /= denom;
+                    emit(k, rho, c, col);
+                };
+                descend(K, klds, [&](int k) { return ut[(size_t)k * 64]; }, step);
+                descend(klds, 0, [&](int k) { return pl[k * 64]; }, step);
             }
             if (valid) sc[3] = sw * lse;
         }
