@@ -213,11 +213,34 @@ def main():
 
     stats = be.zeros(be.stats_len(K, D))
 
-    def step():
-        r = be.importance_weights(x, proposal, target, pack=p_prop, target_pack=p_tgt)
-        e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
+    s_is, s_vb = (torch.cuda.Stream(), torch.cuda.Stream()) if args.two_streams else (None, None)
+
+    def step(events=None):
+        """one pass of the hot path over the resident batch; K-sized results reach the host every step"""
+        if events:
+            events[0].record()
+        if args.two_streams:
+            cur = torch.cuda.current_stream()
+            s_is.wait_stream(cur)
+            s_vb.wait_stream(cur)
+            with torch.cuda.stream(s_is):
+                r = be.importance_weights(x, proposal, target, pack=p_prop, target_pack=p_tgt)
+            with torch.cuda.stream(s_vb):
+                e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
+            cur.wait_stream(s_is)
+            cur.wait_stream(s_vb)
+            if events:
+                events[1].record()
+        else:
+            r = be.importance_weights(x, proposal, target, pack=p_prop, target_pack=p_tgt)
+            if events:
+                events[1].record()
+            e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
         flat = parallel.all_reduce_sum(e["stats"])
-        return r["scalars"], flat.cpu()              # K-sized results reach the host every step
+        host = flat.cpu()
+        if events:
+            events[2].record()
+        return r, host
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
@@ -231,29 +254,10 @@ def main():
     be.kernel_timing(True)                           # HIP events on the launch stream around every hot kernel
     phase = []
     t0 = time.perf_counter()
-    s_is, s_vb = (torch.cuda.Stream(), torch.cuda.Stream()) if args.two_streams else (None, None)
     for _ in range(args.steps):
-        a, b, c = ev(), ev(), ev()
-        a.record()
-        if args.two_streams:
-            cur = torch.cuda.current_stream()
-            s_is.wait_stream(cur)
-            s_vb.wait_stream(cur)
-            with torch.cuda.stream(s_is):
-                r = be.importance_weights(x, proposal, target, pack=p_prop, target_pack=p_tgt)
-            with torch.cuda.stream(s_vb):
-                e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
-            cur.wait_stream(s_is)
-            cur.wait_stream(s_vb)
-            b.record()
-        else:
-            r = be.importance_weights(x, proposal, target, pack=p_prop, target_pack=p_tgt)
-            b.record()
-            e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
-        flat = parallel.all_reduce_sum(e["stats"])
-        host = flat.cpu()
-        c.record()
-        phase.append((a, b, c))
+        evs = (ev(), ev(), ev())
+        r, host = step(evs)
+        phase.append(evs)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
