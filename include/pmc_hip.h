@@ -248,7 +248,7 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  * sufficient statistics of the samples, d_stats as pmc_sufficient_stats and d_scalars / d_vsums as
  * pmc_responsibilities produce them -- without the public N x K matrices.
  *
- * For small sample dimensions (pmc_estep_is_fused() != 0: compiled dimension <= 16, K <= 32, VB or
+ * For small sample dimensions (pmc_estep_is_fused() != 0: compiled dimension <= 7, K <= 32, VB or
  * Gaussian Rao-Blackwell PMC) ONE kernel does both and the N x K responsibilities never leave the
  * compute units: d_u and d_scratch may then be NULL.  Otherwise the call is pmc_responsibilities
  * followed by pmc_sufficient_stats through d_u (and d_scratch / d_vsums for Student-t).

@@ -20,7 +20,7 @@ constexpr int PMC_RESP_KLDS = 16;
 #ifndef PMC_F_UNROLL_A
 #define PMC_F_UNROLL_A 2
 #endif
-#define PMC_FUSED_MAX_DIM 8
+#define PMC_FUSED_MAX_DIM 7
 #define PMC_FUSED_MAX_K 32
 
 // Mahalanobis engines of the per-sample kernels (pmc_persample.hip) by compiled dimension, and with

@@ -258,7 +258,7 @@ def test_fused_estep_vs_oracle(be, orc, D, K, N, weighted):
     from pypmc_amd.backend import ComponentSet
     from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
     from pypmc_amd._lib import PMC_KIND_VB, PMC_KIND_GAUSS
-    fusable = int(be.lib.pmc_padded_dim(D) <= 8)          # beyond, pmc_estep is the two kernels (still tested here)
+    fusable = int(be.lib.pmc_padded_dim(D) <= 7)          # beyond, pmc_estep is the two kernels (still tested here)
     assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_VB, 0) == fusable
     assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 1) == fusable
     assert be.lib.pmc_estep_is_fused(K, D, 1, 1) == 0 and be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 2) == 0
