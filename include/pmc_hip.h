@@ -13,6 +13,10 @@
  *     aborts; pmc_last_error() returns a thread-local message for the last failure.
  *   - launches are asynchronous on `stream`; outputs are valid after the stream is synchronised.
  *   - results are deterministic run-to-run (fixed reduction trees, no floating-point atomics).
+ *   - all N-sized and K-sized device memory is the caller's (pmc_workspace_bytes); the library keeps only a
+ *     few KB of device scratch per (device, stream) for its finishing reduction and a pool of HIP events
+ *     while timing is enabled.  Calls on different streams may run concurrently if they are given
+ *     different workspaces.
  *
  * Component parameter pack ("pack")
  *   The kernels read mixture parameters through the scalar cache from one flat fp64 array built on
