@@ -846,7 +846,14 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
         return fail(PMC_EINVAL, "pmc_estep: bad N/K/pack/stats/scalars/workspace");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
-    if (N == 0 || !fused_eligible(ks, K, kind, mode)) {
+    if (N == 0) {                                          // no samples: zero statistics, zero sums
+        hipStream_t st0 = (hipStream_t)stream;
+        hipError_t e0 = hipMemsetAsync(d_stats, 0, sizeof(double) * (size_t)K * pmc_stats_stride_c(D), st0);
+        if (e0 == hipSuccess && d_vsums) e0 = hipMemsetAsync(d_vsums, 0, sizeof(double) * 2 * (size_t)K, st0);
+        if (e0 != hipSuccess) return hipfail(e0, "hipMemsetAsync");
+        return finish_scalars((const double *)d_workspace, 0, d_scalars, st0);
+    }
+    if (!fused_eligible(ks, K, kind, mode)) {
         if (!d_u) return fail(PMC_EINVAL, "pmc_estep: d_u is required unless pmc_estep_is_fused()");
         int rc = pmc_responsibilities(d_x, N, D, d_pack, K, kind, mode, max_init_zero, d_sample_w, d_latent, d_u,
                                       d_scratch, d_vsums, nullptr, nullptr, nullptr, K, d_scalars, d_workspace, stream);

@@ -376,6 +376,14 @@ def test_edge_cases(be, orc):
     # empty input
     res = be.logpdf(np.zeros((0, 4)), cs)
     assert res["out"].shape[0] == 0
+    for kind_set, mode in ((cs, 1), (ComponentSet(2, mu, inv, c0=np.ones(3), c1=np.ones(3) * 6), 0)):
+        empty = be.tohost(be.estep(np.zeros((0, 4)), kind_set, mode)["stats"])      # fused path (D = 4)
+        assert empty.shape[0] == be.stats_len(3, 4) and not empty.any()
+    mu9, cov9, w9 = mk(3, 9, 1)                                                     # two-kernel path
+    empty = be.tohost(be.estep(np.zeros((0, 9)), gauss_set(mu9, cov9, w9)[0], 1)["stats"])
+    assert not empty.any()
+    # the LinAlgError a caller written against the reference catches (gauss.pyx:40-48, pmc.pyx:227-244)
+    assert issubclass(__import__("pypmc_amd").backend.NotPositiveDefinite, np.linalg.LinAlgError)
     # ragged tail: N = 1 and N = 65
     for N in (1, 63, 65):
         x, _ = draw(mu, cov, w, N, N)
