@@ -86,14 +86,18 @@ int main(int argc, char **argv)
     hipStream_t stream;
     HIP_OK(hipStreamCreate(&stream));
 
+    PMC_OK_(pmc_timing_enable(1));                        // HIP events around every hot kernel on `stream`
     // log q, importance weights against the target mixture + their sums, one pass over x
     PMC_OK_(pmc_importance_weights(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, d_tpack, K, PMC_KIND_GAUSS, d_out, nullptr,
                                    d_w, nullptr, d_scalars, d_ws, stream));
-    // Rao-Blackwell responsibilities weighted by the importance weights, then N_k / sum u d / sum u d d^T
-    PMC_OK_(pmc_responsibilities(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, PMC_RESP_PMC_RB, 0, d_w, nullptr, d_u, nullptr,
-                                 nullptr, nullptr, nullptr, nullptr, K, d_stats, d_ws, stream));
-    PMC_OK_(pmc_sufficient_stats(d_x, N, D, d_pack, K, d_u, d_stats + 8, d_ws, stream));
+    // Rao-Blackwell responsibilities weighted by the importance weights and N_k / sum u d / sum u d d^T in
+    // one call (at D = 4 one fused kernel: pmc_estep_is_fused() says d_u could be NULL)
+    PMC_OK_(pmc_estep(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, PMC_RESP_PMC_RB, 0, d_w, nullptr, d_u, nullptr, nullptr,
+                      d_stats + 8, d_stats, d_ws, stream));
     HIP_OK(hipStreamSynchronize(stream));
+    pmc_timing timings[8];
+    int ntimings = 0;
+    PMC_OK_(pmc_get_timings(timings, 8, &ntimings));
 
     std::vector<double> out(N), scalars(8), stats(nstats);
     HIP_OK(hipMemcpy(out.data(), d_out, sizeof(double) * N, hipMemcpyDeviceToHost));
@@ -106,5 +110,9 @@ int main(int argc, char **argv)
     for (int n = 0; n < 5 && n < N; ++n) std::printf("logq %d %.17g\n", n, out[n]);
     std::printf("sums %.17g %.17g %.17g\n", scalars[0], scalars[1], scalars[2]);
     for (int k = 0; k < K; ++k) std::printf("N_k %d %.17g\n", k, stats[8 + k * pmc_stats_stride(D)]);
+    std::printf("fused %d\n", pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, PMC_RESP_PMC_RB));
+    for (int i = 0; i < ntimings && i < 8; ++i)
+        std::printf("timing %s: %d launches, %.4f ms, %.3g flop, %.3g bytes\n", timings[i].name, timings[i].calls,
+                    timings[i].ms, timings[i].flops, timings[i].bytes);
     return 0;
 }

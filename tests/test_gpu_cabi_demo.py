@@ -42,3 +42,8 @@ def test_cabi_demo_matches_oracle(tmp_path):
     rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
     got_nk = np.array([float(line.split()[2]) for line in res if line.startswith("N_k")])
     np.testing.assert_allclose(got_nk, (wts[:, None] * rho).sum(axis=0), rtol=1e-11)
+    # the E-step went through the fused kernel, and the library's own timing reported it
+    assert "fused 1" in res
+    timing = [line for line in res if line.startswith("timing ")]
+    assert any(line.startswith("timing k_logpdf: 1 launches") for line in timing)
+    assert any(line.startswith("timing k_estep_fused: 1 launches") for line in timing)
