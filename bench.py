@@ -161,25 +161,14 @@ def main():
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # PMC_DIST_BACKEND=gloo: development aid -- several ranks on ONE GPU (RCCL refuses that) to
-        # exercise the sharded path end to end; the driver's runs use nccl (= RCCL), one GPU per rank
-        backend = os.environ.get("PMC_DIST_BACKEND", "nccl")
-        if backend != "nccl":
-            local_rank %= torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    sys.path.insert(0, ROOT)
+    from pypmc_amd import parallel
+    # torchrun: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; nccl (= RCCL), one GPU per rank.
+    # PMC_DIST_BACKEND=gloo is the development aid that lets several ranks share one GPU (tests).
+    rank, world, local_rank = parallel.init_from_env()
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
 
     from pypmc_amd.backend import HipBackend, ComponentSet
-    from pypmc_amd import parallel
     be = HipBackend(local_rank)
     dev = be.device
     N = args.n

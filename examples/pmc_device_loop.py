@@ -22,11 +22,7 @@ from pypmc_amd.tools.convergence import perp_from_sums   # noqa: E402
 
 import torch   # noqa: E402
 
-world = int(os.environ.get("WORLD_SIZE", "1"))
-if world > 1:
-    import torch.distributed as dist
-    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-    dist.init_process_group("nccl")
+rank, world, _ = parallel.init_from_env()        # torchrun: one process per GPU, RCCL; no-op for a single process
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -71,4 +67,5 @@ for it in range(iters):
               % (it, t1 - t0, t2 - t1, N / (t2 - t0), perp_from_sums(S, L, N),
                  int((sampler.proposal.weights > 0).sum())))
 if world > 1:
+    import torch.distributed as dist
     dist.destroy_process_group()

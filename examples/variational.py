@@ -16,12 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pypmc_amd as pypmc   # noqa: E402
 from pypmc_amd import parallel   # noqa: E402
 
-world = int(os.environ.get("WORLD_SIZE", "1"))
-if world > 1:
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-    dist.init_process_group("nccl")
+rank, world, _ = parallel.init_from_env()        # torchrun: one process per GPU, RCCL; no-op for a single process
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10 ** 6
 D = 5
@@ -45,4 +40,5 @@ if parallel.rank() == 0:
     for c in mix.components:
         print("mean:", np.round(c.mu, 3))
 if world > 1:
+    import torch.distributed as dist
     dist.destroy_process_group()

@@ -507,6 +507,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             else ut[(size_t)k * 64] = parked;
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+        const double swv = valid ? sw : 0.0;             // (one select per sample instead of one per pair)
 
         // ---- pass 2, components in DESCENDING order: the values parked last are re-read first, while
         // they are still in L2, and are overwritten there before their first write-back
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     if (r == 0.0) r = TINY;
                     lr += log_norm_inv;
                     elq += r * lr;                        // variational.pyx:1003-1013
-                    ut[(size_t)k * 64] = valid ? sw * r : 0.0;
+                    ut[(size_t)k * 64] = swv * r;
                     const long long col = ((cint64 *)pk)[D + T + 5];
                     if (valid && a.r != nullptr) a.r[n * a.ld + col] = r;
                     if (valid) a.log_rho[n * a.ld + col] = lr;
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     double r = (newmax ? 1.0 : p) * c;
                     c = newmax ? c * -p : c;
                     if (r == 0.0) r = TINY;
-                    ut[(size_t)k * 64] = valid ? sw * r : 0.0;
+                    ut[(size_t)k * 64] = swv * r;
                     if (a.r != nullptr) {
                         const long long col = ((cint64 *)((cdouble *)a.pack + (size_t)k * STRIDE))[D + T + 5];
                         if (valid) a.r[n * a.ld + col] = r;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             // rho -> u (and the public matrix, gamma and the dof sums of the Student-t update)
             auto emit = [&](int k, double rho, cdouble *c, long long col) {
                 if (valid && a.r != nullptr) a.r[n * a.ld + col] = rho;
-                const double wr = valid ? sw * rho : 0.0;
+                const double wr = swv * rho;
                 if constexpr (KIND == PMC_KIND_STUDENT_T) {
                     const double maha = mt[(size_t)k * 64];
                     const double nu = c[3];

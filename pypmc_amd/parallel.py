@@ -43,6 +43,31 @@ def shard_bounds(N, r=None, world=None):
     return begin, begin + base + (1 if r < extra else 0)
 
 
+def init_from_env():
+    """Join the process group ``torchrun`` set up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): one process per
+    GPU, backend "nccl" (= RCCL over xGMI).  ``PMC_DIST_BACKEND=gloo`` is the development aid used by the
+    tests: several ranks share the GPUs that exist (RCCL refuses two ranks on one device).
+    Returns (rank, world_size, local device index); a no-op (0, 1, current device) without WORLD_SIZE > 1."""
+    import os
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, torch.cuda.current_device() if torch.cuda.is_available() else 0
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("PMC_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size(), local
+
+
 def _collective_device(d):
     """device the default process group's backend reduces on"""
     import torch
