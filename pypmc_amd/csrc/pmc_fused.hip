@@ -170,9 +170,8 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
                     tb = fma(e, lr, tb);                           // sum_k e_k (a_k - M), for E[log q(Z)]
                     ut[(size_t)k * 64] = e;
                 } else {
-                    const double we = pk[D + T + 4] * e;           // _regularize.pyx:79
-                    s += we;
-                    ut[(size_t)k * 64] = we;                       // numerator of rho, up to exp(M)
+                    s += pk[D + T + 4] * e;                        // _regularize.pyx:79
+                    ut[(size_t)k * 64] = e;
                 }
             }
         }
@@ -202,8 +201,10 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
             const double lse = log(s) + M;                         // _regularize.pyx:81
             const double denom = exp(lse) + TINY;                  // pmc.pyx:41
             const double em = exp(M);
-            for (int k = k0; k < k1; ++k) {
-                double rho = ut[(size_t)k * 64] * em;              // exp(log q_k) w_k  (pmc.pyx:39)
+            cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
+            for (int k = k0; k < k1; ++k, pk += STRIDE) {
+                // exp(log q_k) = e exp(M) first: it underflows where the reference's does (pmc.pyx:39)
+                double rho = (ut[(size_t)k * 64] * em) * pk[D + T + 4];
                 rho /= denom;
                 ut[(size_t)k * 64] = swv * rho;
             }

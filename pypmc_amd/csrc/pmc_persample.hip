@@ -432,12 +432,22 @@ template <class Load, class Step>
 __device__ __forceinline__ void descend(int khi, int klo, Load load, Step step)
 {
     int k = khi - 1;
-    for (; k - 3 >= klo; k -= 4) {
-        const double p0 = load(k), p1 = load(k - 1), p2 = load(k - 2), p3 = load(k - 3);
+    if (k - 3 >= klo) {
+        // batches of four, the next batch's loads issued in front of the current batch's arithmetic
+        double p0 = load(k), p1 = load(k - 1), p2 = load(k - 2), p3 = load(k - 3);
+        for (; k - 7 >= klo; k -= 4) {
+            const double q0 = load(k - 4), q1 = load(k - 5), q2 = load(k - 6), q3 = load(k - 7);
+            step(k, p0);
+            step(k - 1, p1);
+            step(k - 2, p2);
+            step(k - 3, p3);
+            p0 = q0, p1 = q1, p2 = q2, p3 = q3;
+        }
         step(k, p0);
         step(k - 1, p1);
         step(k - 2, p2);
         step(k - 3, p3);
+        k -= 4;
     }
     for (; k >= klo; --k) step(k, load(k));
 }
@@ -469,12 +479,12 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
         double *mt = (KIND == PMC_KIND_STUDENT_T) ? a.scratch + (size_t)tile * K * 64 + lane : nullptr;
         double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)tile * K * 2 : nullptr;
 
-        // ---- pass 1
-        // wave-uniform: park a_k itself and evaluate the reference's expressions literally (only when
-        // the N x K matrix log_rho is wanted)
-        const bool literal = a.log_rho != nullptr;
-        // (VB starts the maximum at -1e300 instead of -DBL_MAX so that a_0 - m stays finite below)
-        double m = a.max_init_zero ? 0.0 : (KIND == PMC_KIND_VB ? -1e300 : -DBL_MAX), s = 0.0, tb = 0.0;
+        // ---- pass 1: a_nk, parked, and the row maximum M (variational.pyx:730-735 / _regularize.pyx:73-77).
+        // The soft-max is the reference's own two-pass form; the streaming log-sum-exp of k_logpdf would cost
+        // ~16 more vector instructions per pair here (its selects on the running maximum, the rescaled bound
+        // term, the product chain that undoes them in the normalisation pass).
+        const bool literal = a.log_rho != nullptr;       // wave-uniform: the N x K matrix log_rho is wanted
+        double M = a.max_init_zero ? 0.0 : -DBL_MAX;
         cdouble *pk = (cdouble *)a.pack;
         engine.begin(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);
         for (int k = 0; k < K; ++k, pk += STRIDE) {
@@ -488,39 +498,47 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     if (valid) a.exponent[n * a.ld + col] = expo;
                 }
             }
-            // streaming log-sum-exp (lse_step) with its exponential kept
-            const double e = exp(-fabs(v - m));
-            const bool gt = v > m;
-            const double w = pk[D + T + 4];
-            if constexpr (KIND == PMC_KIND_VB) {
-                // tb = sum_j e_j (a_j - m) relative to the running maximum (w = 1 for this kind): the
-                // dominant component contributes exactly 0, so E[log q(Z)] = tb / s - log s keeps its
-                // accuracy when the responsibilities are nearly one-hot.  New maximum m' = a_k:
-                // every old term becomes f (e_j (a_j - m) + e_j (m - m')).
-                const double dm = v - m;
-                tb = gt ? e * fma(-s, dm, tb) : fma(e, dm, tb);
-            }
-            s = gt ? fma(s, e, w) : fma(w, e, s);
-            m = gt ? v : m;
-            const double parked = literal ? v : (gt ? -e : e);
-            if (k < klds) pl[k * 64] = parked;            // wave-uniform branch
-            else ut[(size_t)k * 64] = parked;
+            M = fmax(v, M);                               // (a NaN value leaves M alone, like `if v > M`)
+            if (k < klds) pl[k * 64] = v;                 // wave-uniform branch
+            else ut[(size_t)k * 64] = v;
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
         const double swv = valid ? sw : 0.0;             // (one select per sample instead of one per pair)
+        auto parked_global = [&](int k) { return ut[(size_t)k * 64]; };
+        auto parked_lds = [&](int k) { return pl[k * 64]; };
 
-        // ---- pass 2, components in DESCENDING order: the values parked last are re-read first, while
-        // they are still in L2, and are overwritten there before their first write-back
-        pk = (cdouble *)a.pack + (size_t)(K - 1) * STRIDE;
+        // ---- pass 2: e = exp(a - M) [times the component weight], its sum, and -- unless the literal pass
+        // below needs a_nk again -- e parked in place of a.  Components in DESCENDING order: the values
+        // parked last are re-read first, while they are still in L2.
+        double s = 0.0, tb = 0.0;
+        auto expstep = [&](int k, double v) {
+            const double lr = v - M;                      // variational.pyx:741
+            const double e = exp(lr);                     // :742 / _regularize.pyx:79
+            if constexpr (KIND == PMC_KIND_VB) {
+                tb = fma(e, lr, tb);                      // sum_k e_k (a_k - M): the dominant component adds exactly 0
+                s += e;
+            } else {
+                s += ((cdouble *)a.pack + (size_t)k * STRIDE)[D + T + 4] * e;
+            }
+            if (!literal) {                               // wave-uniform
+                if (k < klds) pl[k * 64] = e;
+                else ut[(size_t)k * 64] = e;
+            }
+        };
+        descend(K, klds, parked_global, expstep);
+        descend(klds, 0, parked_lds, expstep);
+
+        // ---- pass 3: normalisation
         if constexpr (KIND == PMC_KIND_VB) {
-            // variational.pyx:741-755: r = exp(log_rho - max) / norm, zeros -> tiny,
-            // log_rho += log(1/norm)
+            // variational.pyx:748-755: r = exp(log_rho - max) / norm, zeros -> tiny, log_rho += log(1/norm)
             const double norm_inv = 1. / s;
             const double log_norm_inv = log(norm_inv);
-            double elq = 0.0;
+            double elq;
             if (literal) {
+                elq = 0.0;
+                pk = (cdouble *)a.pack + (size_t)(K - 1) * STRIDE;
                 for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
-                    double lr = (k < klds ? pl[k * 64] : ut[(size_t)k * 64]) - m;
+                    double lr = (k < klds ? pl[k * 64] : ut[(size_t)k * 64]) - M;
                     double r = exp(lr);
                     r *= norm_inv;
                     if (r == 0.0) r = TINY;
@@ -532,11 +550,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     if (valid) a.log_rho[n * a.ld + col] = lr;
                 }
             } else {
-                double c = norm_inv;                      // norm_inv * prod of the f_j above k
-                auto step = [&](int k, double p) {
-                    const bool newmax = __double2hiint(p) < 0;      // sign bit (f may be -0.0)
-                    double r = (newmax ? 1.0 : p) * c;
-                    c = newmax ? c * -p : c;
+                auto step = [&](int k, double e) {
+                    double r = e * norm_inv;
                     if (r == 0.0) r = TINY;
                     ut[(size_t)k * 64] = swv * r;
                     if (a.r != nullptr) {
@@ -544,21 +559,19 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                         if (valid) a.r[n * a.ld + col] = r;
                     }
                 };
-                descend(K, klds, [&](int k) { return ut[(size_t)k * 64]; }, step);
-                descend(klds, 0, [&](int k) { return pl[k * 64]; }, step);
-                // sum_k r_k (a_k - m + log norm_inv) with sum_k r_k = 1   (variational.pyx:1003-1013)
+                descend(K, klds, parked_global, step);
+                descend(klds, 0, parked_lds, step);
+                // sum_k r_k (a_k - M + log norm_inv) with sum_k r_k = 1   (variational.pyx:1003-1013)
                 elq = fma(tb, norm_inv, log_norm_inv);
             }
-            if (valid) sc[0] = sw * elq;
+            sc[0] = swv * elq;
         } else {
             // pmc.pyx:36-41: rho = exp(log q_k) * w_k / (exp(log_denominator) + tiny)
-            // product form: exp(log q_k) = g_k exp(m) with g_k = (e_k or 1) * prod of the f_j above k.
-            // exp(m) is applied to g_k before anything else, so where the reference's exp(log q_k)
-            // underflows (log q_k < -708) this product underflows with it.
-            const double lse = log(s) + m;
+            // product form: exp(log q_k) = e_k exp(M), formed BEFORE anything else touches it, so where the
+            // reference's exp(log q_k) underflows (log q_k < -708: denormal, then zero) this product does too.
+            const double lse = log(s) + M;                // _regularize.pyx:81
             const double denom = exp(lse) + TINY;
-            const double em = exp(m);
-            double chain = 1.0;
+            const double em = exp(M);
             const long long lat = (a.mode == PMC_RESP_PMC_LATENT && valid) ? a.latent[n] : -1;
             // rho -> u (and the public matrix, gamma and the dof sums of the Student-t update)
             auto emit = [&](int k, double rho, cdouble *c, long long col) {
@@ -582,6 +595,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 }
             };
             if (a.mode == PMC_RESP_PMC_LATENT || literal) {
+                pk = (cdouble *)a.pack + (size_t)(K - 1) * STRIDE;
                 for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
                     cdouble *c = pk + D + T;
                     const long long col = ((cint64 *)pk)[D + T + 5];
@@ -595,20 +609,16 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     emit(k, rho, c, col);
                 }
             } else {
-                auto step = [&](int k, double p) {
+                auto step = [&](int k, double e) {
                     cdouble *pkk = (cdouble *)a.pack + (size_t)k * STRIDE;
-                    cdouble *c = pkk + D + T;
-                    const long long col = ((cint64 *)pkk)[D + T + 5];
-                    const bool newmax = __double2hiint(p) < 0;
-                    double rho = (newmax ? 1.0 : p) * chain * em * c[4];
-                    chain = newmax ? chain * -p : chain;
+                    double rho = (e * em) * pkk[D + T + 4];
                     rho /= denom;
-                    emit(k, rho, c, col);
+                    emit(k, rho, pkk + D + T, ((cint64 *)pkk)[D + T + 5]);
                 };
-                descend(K, klds, [&](int k) { return ut[(size_t)k * 64]; }, step);
-                descend(klds, 0, [&](int k) { return pl[k * 64]; }, step);
+                descend(K, klds, parked_global, step);
+                descend(klds, 0, parked_lds, step);
             }
-            if (valid) sc[3] = sw * lse;
+            sc[3] = swv * lse;
         }
     }
     if (a.partials != nullptr) block_scalars<5>(sc, a.partials);

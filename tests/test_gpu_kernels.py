@@ -533,6 +533,10 @@ def test_rho_where_the_reference_underflows(be, orc):
     np.testing.assert_allclose(got[~normal], ref[~normal], rtol=1e-2, atol=1e-12)
     gone = lq < -750
     assert (ref[gone] == 0).all() and (got[gone] == 0).all()
+    # the one-kernel E-step (D = 5) forms rho the same way: its N_k against the matrix just checked
+    from pypmc_amd.mix_adapt._stats import split_stats
+    S0 = split_stats(be.tohost(be.estep(x, cs, 1)["stats"]), K, D)[1]
+    np.testing.assert_allclose(S0, got.sum(axis=0), rtol=1e-12, atol=1e-300)
 
 
 @pytest.mark.parametrize("D", [1, 2, 3, 5, 7, 9, 13])
