@@ -720,7 +720,7 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
         a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
         a.mode = mode; a.ld = ld; a.sample_w = d_sample_w; a.latent = (const long long *)d_latent;
         a.u = d_u; a.scratch = d_scratch; a.vpartials = vpartials;
-        a.klds = K < PMC_RESP_KLDS ? K : PMC_RESP_KLDS;
+        a.klds = K < pmc_resp_klds(ks->dim) ? K : pmc_resp_klds(ks->dim);
         a.r = d_r; a.log_rho = d_log_rho; a.exponent = d_exponent;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         Timed t(T_RESP, st, flops_pairs((double)N, K, D), 8.0 * N * (D + K));

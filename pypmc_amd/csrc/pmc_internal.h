@@ -6,10 +6,7 @@
 constexpr int PMC_TILE = 64;       // samples per tile = one wavefront
 constexpr int PMC_NSCALARS = 8;    // per-launch scalar reductions
 constexpr int PMC_A_WAVES = 4;     // wavefronts (tiles) per workgroup in the per-sample kernels
-// k_resp parks the first min(K, 16) components in LDS between its passes: 8 KB per wavefront, so
-// 16 wavefronts per CU (4 per SIMD, the register-limited occupancy) still fit in 160 KB
-constexpr int PMC_RESP_KLDS = 16;
-
+// k_resp parks its first components in LDS between its passes (pmc_resp_klds below) and the rest in the output buffer
 // fused small-D E-step (pmc_fused.hip): wavefronts per workgroup, components per wavefront in its
 // responsibility phase (so K <= PMC_F_WAVES / 2 * PMC_F_KQMAX = 32), largest compiled dimension
 #define PMC_F_WAVES 8
@@ -42,6 +39,16 @@ enum { PMC_ENG_SGPR = 0, PMC_ENG_DPP = 1, PMC_ENG_MFMA = 2 };
 __host__ __device__ constexpr int pmc_engine(int D)
 {
     return (D >= PMC_MFMA_FROM && D % 4 == 0) ? PMC_ENG_MFMA : (D >= PMC_DPP_FROM ? PMC_ENG_DPP : PMC_ENG_SGPR);
+}
+
+// Components k_resp parks in LDS: 19 x 512 B per wavefront is what 16 wavefronts per CU (4 per SIMD, the
+// register-limited occupancy) leave room for in 160 KB (19: 3.35-3.38 ms, 16: 3.40-3.44 ms at N = 1e7, K = 32,
+// D = 20); 16 where the MFMA engine needs LDS for its parameter buffers too.
+// Below D = 12 the registers allow a fifth wavefront per SIMD, which 16 leaves room for (D = 8: 0.56 against 0.62 ms
+// per 4e6 samples).
+__host__ __device__ constexpr int pmc_resp_klds(int D)
+{
+    return (pmc_engine(D) == PMC_ENG_MFMA || D < 12) ? 16 : 19;
 }
 
 __host__ __device__ constexpr int pmc_tri(int D) { return D * (D + 1) / 2; }

@@ -638,7 +638,7 @@ template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, h
         static const hipError_t once = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&k_resp<D_, P_, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize,
             (int)(sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
-                                    (size_t)PMC_A_WAVES * PMC_RESP_KLDS * 64)));
+                                    (size_t)PMC_A_WAVES * pmc_resp_klds(D_) * 64)));
         if (once != hipSuccess) return once;
     }
     hipLaunchKernelGGL((k_resp<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
