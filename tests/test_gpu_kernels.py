@@ -649,3 +649,22 @@ def test_kernel_timings_through_the_abi(be):
     be.kernel_timing(False)
     t = be.kernel_timings()
     assert t["k_estep_fused"]["calls"] == 1 and t["k_estep_fused"]["bytes"] == 8.0 * 5000 * 2 and "k_resp" not in t
+
+
+@pytest.mark.parametrize("D,K,N", [(2, 300, 500), (3, 1000, 130), (5, 33, 1000), (8, 129, 300), (20, 200, 257),
+                                   (40, 130, 100), (64, 70, 65), (1, 500, 64)])
+def test_many_components(be, orc, D, K, N):
+    """K far beyond the component counts the kernels are tuned for (and beyond the fused path's 32)"""
+    from pypmc_amd.mix_adapt._stats import split_stats
+    mu, cov, w = mk(K, D, 1200 + D)
+    x, _ = draw(mu, cov, w, N, 21)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    ref_q, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    assert_rel(be.tohost(be.logpdf(x, cs)["out"]), ref_q, what="log q")
+    iw = np.random.RandomState(K).uniform(0.1, 2, N)
+    rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+    got = be.tohost(be.estep(x, cs, 1, sample_w=iw, want_r=True)["r"])
+    normal = rho > 1e-280
+    assert_rel(got[normal], rho[normal], what="rho")
+    S0 = split_stats(be.tohost(be.estep(x, cs, 1, sample_w=iw)["stats"]), K, D)[1]
+    np.testing.assert_allclose(S0, (iw[:, None] * rho).sum(axis=0), rtol=1e-9, atol=1e-300)
