@@ -298,3 +298,28 @@ def test_offsets_beyond_32_bits(be):
     assert np.abs(np.array([np.diag(M2[k]) / S0[k] for k in range(K)]) - 1).max() < 5e-3
     be.release()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("D,K", [(2, 32), (3, 17), (4, 8), (5, 32), (7, 24), (2, 3)])
+def test_fused_estep_many_rounds(be, D, K):
+    """The one-kernel E-step where every workgroup loops over many rounds (LDS buffers reused behind barriers):
+    2e6 samples against the two-kernel path, VB (weighted) and Gaussian PMC, and bitwise reproducible."""
+    import torch
+    from pypmc_amd.backend import ComponentSet
+    N = 2_000_003
+    mu, cov, w = mk(K, D, 40 + D)
+    x, _ = device_samples(be, mu, cov, w, N, 11)
+    sw = torch.rand(N, dtype=torch.float64, device=be.device) + 0.5
+    inv = prec(cov)
+    ln = -0.5 * D * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(cov)[1]
+    vb, _ = _vb_set(mu, cov, w, N, D)
+    for cs, mode in ((vb, 0), (ComponentSet(0, mu, inv, c0=ln, weight=w), 1)):
+        assert be.lib.pmc_estep_is_fused(K, D, cs.kind, mode) == 1
+        fused = be.estep(x, cs, mode, sample_w=sw)["stats"].clone()
+        again = be.estep(x, cs, mode, sample_w=sw)["stats"]
+        assert bool((fused == again).all())
+        two = be.estep(x, cs, mode, sample_w=sw, want_r=True)["stats"]        # the two kernels (+ an N x K matrix)
+        np.testing.assert_allclose(fused.cpu().numpy(), two.cpu().numpy(), rtol=1e-10, atol=1e-9)
+        del two
+    be.release()
+    torch.cuda.empty_cache()
