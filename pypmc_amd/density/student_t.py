@@ -28,6 +28,14 @@ class StudentT(Gauss):
         self._eval_prefactor = -.5 * (self.dof + self.dim)      # student_t.pyx:116
         self._inv_dof = 1. / self.dof                           # :117
 
+    def _assign(self, mu, sigma, cholesky_sigma, inv_sigma, log_det_sigma, dof):
+        Gauss._assign(self, mu, sigma, cholesky_sigma, inv_sigma, log_det_sigma)
+        self.dof = float(dof)
+        self.log_normalization = gammaln(.5 * (self.dof + self.dim)) - gammaln(.5 * self.dof) \
+            - 0.5 * self.dim * np.log(self.dof * np.pi) - 0.5 * self.log_det_sigma
+        self._eval_prefactor = -.5 * (self.dof + self.dim)
+        self._inv_dof = 1. / self.dof
+
     def _kernel_constants(self):
         return self.log_normalization, self._eval_prefactor, self._inv_dof, self.dof
 

@@ -23,7 +23,7 @@ from ..density.gauss import Gauss
 from ..density.student_t import StudentT
 from ..density.mixture import MixtureDensity, component_set
 from ._stats import split_stats, centred_moments
-from ..tools._linalg import single_threaded_blas
+from ..tools._linalg import single_threaded_blas, chol_inv_det_batch
 
 logger = logging.getLogger(__name__)
 
@@ -153,12 +153,28 @@ def _latent_blocks_estep(be, samples, weights, latent, density, live_components,
 
 def _apply_updates(density, live_components, new_params, need_renormalize):
     """``component.update`` with the reference's fall-back: a LinAlgError restores the old
-    parameters and zeroes the component's weight (pmc.pyx:227-244, :713-737)."""
+    parameters and zeroes the component's weight (pmc.pyx:227-244, :713-737).
+
+    The K factorisations are done as one batch first (tools._linalg.chol_inv_det_batch); only if one of
+    them fails does the update go component by component, so that exactly the failing ones fall back."""
     with single_threaded_blas():                  # K small factorisations: thread pool = overhead
-        for k in live_components:
+        live = list(live_components)
+        batch = None
+        if len(live) > 1:
+            try:
+                sig = np.array([np.asarray(new_params[k][1][1], dtype=np.float64) for k in live])
+                if sig.ndim == 3 and all(float(new_params[k][1][2]) > 0. for k in live if len(new_params[k][1]) == 3):
+                    batch = (sig,) + chol_inv_det_batch(sig, check_symmetric=False)   # centred_moments mirrors
+            except np.linalg.LinAlgError:
+                batch = None
+        for i, k in enumerate(live):
             component = density.components[k]
             alpha_k, args = new_params[k]
             density.weights[k] = alpha_k
+            if batch is not None:
+                mu = np.array(args[0], dtype=float).reshape(-1)
+                component._assign(mu, batch[0][i].copy(), batch[1][i], batch[2][i], float(batch[3][i]), *args[2:])
+                continue
             old = (component.mu, component.sigma) + ((component.dof,) if len(args) == 3 else ())
             try:
                 component.update(*args)

@@ -21,7 +21,7 @@ from .._lib import PMC_KIND_VB, PMC_RESP_VB, check_dim
 from ..backend import ComponentSet, get_backend
 from ..density.gauss import Gauss
 from ..density.mixture import MixtureDensity, recover_gaussian_mixture
-from ..tools._linalg import chol_inv_det
+from ..tools._linalg import chol_inv_det, chol_inv_det_batch
 from ._stats import regularize, split_stats, centred_moments
 
 logger = logging.getLogger(__name__)
@@ -104,14 +104,23 @@ class GaussianInference(object):
         # (10.61)
         self.m = (self.beta0[:, None] * self.m0 + self.N_comp[:, None] * self.x_mean_comp) / self.beta[:, None]
         # (10.62): W_k^-1 = W0_k^-1 + N_k S_k + beta0 N_k / (beta0 + N_k) (xbar - m0)(xbar - m0)^T
+        # -- all K at once (the same operations in the same order per element as the loop below, which
+        #    takes over if a factorisation fails so that the error surfaces for the same component)
+        dx = self.x_mean_comp - self.m0
+        inv_w = np.einsum('ki,kj->kij', dx, dx) * (self.beta0 / (self.beta0 + self.N_comp))[:, None, None]
+        inv_w += self.S
+        inv_w *= self.N_comp[:, None, None]
+        inv_w += self.inv_W0
+        try:
+            _, W, log_det = chol_inv_det_batch(inv_w, check_symmetric=False)    # sums of symmetric terms
+            self.W = W
+            self.log_det_W = -log_det
+            return
+        except np.linalg.LinAlgError:
+            pass
         self.W = np.array(self.W)
         for k in range(self.K):
-            dx = self.x_mean_comp[k] - self.m0[k]
-            inv_w = np.outer(dx, dx) * (self.beta0[k] / (self.beta0[k] + self.N_comp[k]))
-            inv_w += self.S[k]
-            inv_w *= self.N_comp[k]
-            inv_w += self.inv_W0[k]
-            self.W[k], log_det = chol_inv_det(inv_w)[1:]
+            self.W[k], log_det = chol_inv_det(inv_w[k])[1:]
             self.log_det_W[k] = -log_det
 
     def update(self):
@@ -403,17 +412,20 @@ class GaussianInference(object):
         return self._expectation_log_p_pi
 
     def _update_expectation_log_p_mu_lambda(self):
-        # (10.74)
+        # (10.74) -- the K-sized pieces as array operations, the sum over components in the reference's order
         D = self.dim
         dm = self.m - self.m0
+        quad = self._quad(dm, self.W)
+        tr = np.einsum('kij,kji->k', self.inv_W0, self.W)
+        log_b = _wishart_log_B_vec(D, self.nu0, self.log_det_W0)
         res = 0.
         for k in range(self.K):
             res += D * np.log(self.beta0[k] / (2. * np.pi))
             res += self.expectation_det_ln_lambda[k] - D * self.beta0[k] / self.beta[k] \
-                - self.beta0[k] * self.nu[k] * dm[k].dot(self.W[k]).dot(dm[k])
-            res += 2 * Wishart_log_B(D, self.nu0[k], self.log_det_W0[k])
+                - self.beta0[k] * self.nu[k] * quad[k]
+            res += 2 * log_b[k]
             res += (self.nu0[k] - D - 1) * self.expectation_det_ln_lambda[k]
-            res -= self.nu[k] * np.trace(self.inv_W0[k].dot(self.W[k]))
+            res -= self.nu[k] * tr[k]
         self._expectation_log_p_mu_lambda = 0.5 * res
         return self._expectation_log_p_mu_lambda
 
@@ -430,15 +442,39 @@ class GaussianInference(object):
     def _update_expectation_log_q_mu_lambda(self):
         # (10.77)
         D = self.dim
+        entropy = -_wishart_log_B_vec(D, self.nu, self.log_det_W) \
+            - 0.5 * (self.nu - D - 1) * _wishart_expect_log_lambda_vec(D, self.nu, self.log_det_W) + 0.5 * self.nu * D
         res = -0.5 * self.K * D
         for k in range(self.K):
             res += 0.5 * (self.expectation_det_ln_lambda[k] + D * np.log(self.beta[k] / (2 * np.pi)))
-            res -= Wishart_H(D, self.nu[k], self.log_det_W[k])
+            res -= entropy[k]
         self._expectation_log_q_mu_lambda = res
         return self._expectation_log_q_mu_lambda
 
 
 # ----------------------------------------------------------------------------- Wishart / Dirichlet
+def _wishart_checks(D, nu, log_det):
+    assert D > 0, 'Invalid dimension: %s' % D
+    assert (nu > D - 1).all(), 'Invalid degree of freedom: %s' % nu
+    assert np.isfinite(log_det).all(), 'Non-finite log(det): %s' % log_det
+
+
+def _wishart_log_B_vec(D, nu, log_det):
+    """Wishart_log_B for K-vectors ``nu`` and ``log_det`` (same expression, one row per component)."""
+    nu, log_det = np.asarray(nu, dtype=float), np.asarray(log_det, dtype=float)
+    _wishart_checks(D, nu, log_det)
+    i = np.arange(1, D + 1)
+    return -0.5 * nu * log_det - 0.5 * nu * D * np.log(2) - 0.25 * D * (D - 1) * np.log(np.pi) \
+        - gammaln(0.5 * (nu[:, None] + 1 - i[None, :])).sum(axis=1)
+
+
+def _wishart_expect_log_lambda_vec(D, nu, log_det):
+    nu, log_det = np.asarray(nu, dtype=float), np.asarray(log_det, dtype=float)
+    _wishart_checks(D, nu, log_det)
+    i = np.arange(1, D + 1)
+    return digamma(0.5 * (nu[:, None] + 1 - i[None, :])).sum(axis=1) + D * np.log(2.) + log_det
+
+
 def Wishart_log_B(D, nu, log_det):
     """log of the Wishart normalisation B(W, nu), [Bis06] (B.79); ``log_det`` = log|W|."""
     assert D > 0, 'Invalid dimension: %s' % D

@@ -18,14 +18,21 @@ def _strict_lower(dim):
     return _TRIL[dim]
 
 
+_CONTROLLER = []                 # the process's threadpoolctl.ThreadpoolController, looked up once
+
+
 class single_threaded_blas(object):
     """Context for loops over many small factorisations: the BLAS thread pool only costs there
-    (D = 40: 93 -> 60 us per chol_inv_det).  No-op without threadpoolctl."""
+    (D = 40 on a 128-core host: 45 -> 8 us per potri).  The library scan behind
+    ``threadpoolctl.threadpool_limits`` takes a millisecond, so the controller is created once and only its
+    ``limit`` is entered per use.  No-op without threadpoolctl."""
 
     def __enter__(self):
         try:
-            from threadpoolctl import threadpool_limits
-            self._ctx = threadpool_limits(limits=1, user_api='blas')
+            if not _CONTROLLER:
+                from threadpoolctl import ThreadpoolController
+                _CONTROLLER.append(ThreadpoolController())
+            self._ctx = _CONTROLLER[0].limit(limits=1, user_api='blas')
             self._ctx.__enter__()
         except Exception:                                    # pragma: no cover
             self._ctx = None
@@ -59,6 +66,48 @@ def chol_inv_det(m):
     log_det *= 2.0
     if not np.isfinite(log_det):
         raise np.linalg.LinAlgError('Nonpositive eigenvalues lead to invalid determinant ' + repr(log_det))
+    return lower, inverse, log_det
+
+
+def chol_inv_det_batch(ms, check_symmetric=True):
+    """``chol_inv_det`` of a stack of K matrices in a handful of array operations: the K-sized host update of
+    a PMC / VB iteration is a Python loop over components otherwise, and at N <= 1e6 that loop -- not the
+    kernels -- is the iteration's wall time (K = 128, D = 40: 14 ms against 10 ms on the device).
+
+    Same checks and the same LAPACK factorisation as ``chol_inv_det`` (finite, symmetric to numpy.allclose's
+    tolerances, potrf, potri of the lower factor, mirrored inverse, log det summed left to right); raises
+    ``numpy.linalg.LinAlgError`` if ANY matrix fails, without saying which -- callers that need the
+    reference's per-component behaviour (object left unchanged, weight zeroed) fall back to the loop then.
+    ``check_symmetric=False`` is for callers whose matrices are symmetric by construction (mirrored by the
+    finishing kernel, or sums of x x^T): the comparison is a third of the whole call.
+    Returns lower (K, D, D), inverse (K, D, D), log_det (K)."""
+    ms = np.asarray(ms, dtype=np.float64)
+    if ms.ndim != 3 or ms.shape[1] != ms.shape[2]:
+        raise np.linalg.LinAlgError('expected a stack of square matrices, got shape %s' % (ms.shape,))
+    if not np.isfinite(ms).all():
+        raise np.linalg.LinAlgError('array must not contain infs or NaNs')
+    if check_symmetric:
+        mt = np.ascontiguousarray(ms.transpose(0, 2, 1))         # strided operands cost numpy 4x here
+        if not (np.abs(ms - mt) <= 1e-8 + 1e-5 * np.abs(mt)).all():
+            raise np.linalg.LinAlgError('matrix not symmetric')
+    K, D = ms.shape[0], ms.shape[1]
+    with single_threaded_blas():
+        lower = np.linalg.cholesky(ms)                           # batched potrf; LinAlgError if one is not PD
+        # potri has no batched form.  Each call gets its factor as a Fortran-ordered view of a transposed copy
+        # and works in place there (f2py copies and transposes a C-ordered argument: 27 -> 10 us per call)
+        work = np.ascontiguousarray(lower.transpose(0, 2, 1))
+        for k in range(K):
+            res = _POTRI(work[k].T, True, overwrite_c=True)[0]
+            if res.__array_interface__['data'][0] != work[k].__array_interface__['data'][0]:
+                work[k] = res.T                                  # f2py chose to copy after all
+    # potri filled the lower triangle of each work[k].T, i.e. the upper triangle of work[k]; mirror it.  Adding
+    # the zeros of the other triangle is exact
+    inverse = np.triu(work)
+    inverse += np.ascontiguousarray(np.triu(work, 1).transpose(0, 2, 1))
+    diag = np.log(np.diagonal(lower, axis1=1, axis2=2))
+    log_det = 2.0 * np.cumsum(diag, axis=1)[:, -1] if D else np.zeros(K)    # left-to-right, as the reference sums
+    if not np.isfinite(log_det).all():
+        raise np.linalg.LinAlgError('Nonpositive eigenvalues lead to invalid determinant')
     return lower, inverse, log_det
 
 
