@@ -338,36 +338,58 @@ StatsGeom stats_geom(long long N, int K, const PmcKernelSet *ks)
 
 // fused E-step launch geometry (pmc_fused.hip)
 struct FusedGeom {
-    int qs, kq, cw, tpr, rounds_per_wg;
+    int qs, kq, cw, tpr, rounds_per_wg, reg;
     long long ntiles, nrounds;
     unsigned grid;
-    long long nchunks;        // partial statistics vectors: grid * (PMC_F_WAVES / cw)
+    long long nchunks;        // partial statistics vectors: grid * (PMC_F_WAVES / cw), register form: grid * tpr
 };
+bool fused_reg(int dim, int K) { return pmc_freg_kqmax(dim) > 0 && K <= PMC_F_WAVES * pmc_freg_kqmax(dim); }
 bool fused_eligible(const PmcKernelSet *ks, int K, int kind, int mode)
 {
-    if (ks->dim > PMC_FUSED_MAX_DIM || K > PMC_FUSED_MAX_K) return false;
+    if (ks->dim > PMC_FUSED_MAX_DIM || (K > PMC_FUSED_MAX_K && !fused_reg(ks->dim, K))) return false;
+    if (ks->dim >= 5 && K < PMC_FUSED_MIN_K_FROM_D5) return false;
     if (mode == PMC_RESP_VB) return kind == PMC_KIND_VB;
     return mode == PMC_RESP_PMC_RB && kind == PMC_KIND_GAUSS;
 }
-FusedGeom fused_geom(long long N, int K)
+FusedGeom fused_geom(long long N, int K, int dim)
 {
     FusedGeom g;
-    g.qs = K <= PMC_F_KQMAX ? 1 : (K <= 2 * PMC_F_KQMAX ? 2 : 4);
-    g.kq = (K + g.qs - 1) / g.qs;
-    g.cw = PMC_F_WAVES;
-    if (g.qs == 1) {
+    g.reg = fused_reg(dim, K) ? 1 : 0;
+    long long wgs_per_cu = 3;
+    if (g.reg) {
+        // wavefronts per tile x components per wavefront: the split with the fewest idle component slots,
+        // the fewest wavefronts per tile among those (their soft-max exchange costs two barriers a round)
+        const int kqmax = pmc_freg_kqmax(dim);
+        int best = -1;
+        for (int qs = 1; qs <= PMC_F_WAVES; qs *= 2) {
+            const int kq = (K + qs - 1) / qs;
+            if (kq > kqmax) continue;
+            if (best < 0 || qs * kq - K < best) {
+                best = qs * kq - K;
+                g.qs = qs;
+                g.kq = kq;
+            }
+        }
         g.cw = 1;
-        while (g.cw < K) g.cw *= 2;
+        wgs_per_cu = 2;
+    } else {
+        g.qs = K <= PMC_F_KQMAX ? 1 : (K <= 2 * PMC_F_KQMAX ? 2 : 4);
+        g.kq = (K + g.qs - 1) / g.qs;
+        g.cw = PMC_F_WAVES;
+        if (g.qs == 1) {
+            g.cw = 1;
+            while (g.cw < K) g.cw *= 2;
+        }
     }
     g.tpr = PMC_F_WAVES / g.qs;
     g.ntiles = ceil_div(N, PMC_TILE);
     g.nrounds = ceil_div(g.ntiles, g.tpr);
-    long long wgs = 256LL * 3;                            // up to 3 workgroups per compute unit
+    long long wgs = 256LL * wgs_per_cu;                   // resident workgroups: each is persistent over its rounds
     if (wgs > g.nrounds) wgs = g.nrounds;
     if (wgs < 1) wgs = 1;
     g.rounds_per_wg = (int)ceil_div(g.nrounds > 0 ? g.nrounds : 1, wgs);
     g.grid = (unsigned)ceil_div(g.nrounds > 0 ? g.nrounds : 1, g.rounds_per_wg);
-    g.nchunks = (long long)g.grid * (PMC_F_WAVES / g.cw);
+    g.nchunks = g.reg ? (long long)g.grid * g.tpr : (long long)g.grid * (PMC_F_WAVES / g.cw);
     return g;
 }
 
@@ -446,8 +468,8 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     const size_t scal = scalar_partials_bytes(N) +
                         (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
     size_t total = stats > scal ? stats : scal;
-    if (ks->dim <= PMC_FUSED_MAX_DIM && K <= PMC_FUSED_MAX_K) {
-        const FusedGeom f = fused_geom(N > 0 ? N : 1, K);
+    if (ks->dim <= PMC_FUSED_MAX_DIM && (K <= PMC_FUSED_MAX_K || fused_reg(ks->dim, K))) {
+        const FusedGeom f = fused_geom(N > 0 ? N : 1, K, ks->dim);
         const size_t fused = ((size_t)f.nchunks * K * pmc_stats_stride_c(ks->dim) + (size_t)f.grid * PMC_NSCALARS) *
                              sizeof(double);
         if (fused > total) total = fused;
@@ -862,12 +884,12 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     }
     if (!d_x) return fail(PMC_EINVAL, "pmc_estep: d_x is NULL");
     hipStream_t st = (hipStream_t)stream;
-    const FusedGeom g = fused_geom(N, K);
+    const FusedGeom g = fused_geom(N, K, ks->dim);
     const int PSc = pmc_stats_stride_c(ks->dim);
     PmcArgsF a;
     std::memset(&a, 0, sizeof(a));
     a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
-    a.qs = g.qs; a.kq = g.kq; a.cw = g.cw; a.sample_w = d_sample_w; a.ntiles = g.ntiles; a.rounds_per_wg = g.rounds_per_wg;
+    a.qs = g.qs; a.kq = g.kq; a.cw = g.cw; a.sample_w = d_sample_w; a.ntiles = g.ntiles; a.rounds_per_wg = g.rounds_per_wg; a.reg = g.reg;
     a.partials = (double *)d_workspace;
     a.spartials = a.partials + (size_t)g.nchunks * K * PSc;
     hipError_t e;

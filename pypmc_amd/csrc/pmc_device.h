@@ -126,6 +126,26 @@ template <int N> __device__ __forceinline__ void fmac_bcast(double &acc, double 
                  : "+v"(acc) : "v"(coef), "v"(d), "n"(N) : "memory");
 }
 
+// max(a, b) as ONE v_max_f64: fmax() costs a second instruction (the compiler canonicalises an operand first),
+// "a > b ? a : b" a compare and two v_cndmask -- 1.6 and 6.8 issue slots against 0.8 on this chip
+// (scripts/microbench/fp64_oprates.hip).  A NaN operand loses, as it does against the reference's ">".
+__device__ __forceinline__ double max_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// r == 0 ? tiny : r for r >= +0 (variational.pyx:751-753) on the integer pipe: tiny = 0x0010000000000000 has a
+// zero low word, so only the high word is selected -- v_or, v_cmp_eq_u32, v_cndmask: 1.7 issue slots against 6.8
+// for the fp64 compare and its two selects.
+__device__ __forceinline__ double zero_to_tiny(double r)
+{
+    const unsigned lo = (unsigned)__double2loint(r), hi = (unsigned)__double2hiint(r);
+    const unsigned h2 = ((lo | hi) == 0u) ? 0x00100000u : hi;
+    return __hiloint2double((int)h2, (int)lo);
+}
+
 // a_nk from maha_nk, in the reference's operation order (see enum pmc_kind).
 template <int D, int KIND>
 __device__ __forceinline__ double component_value(double maha, cdouble *c, double &expo)

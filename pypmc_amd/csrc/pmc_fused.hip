@@ -10,6 +10,8 @@
 // (pypmc/mix_adapt/variational.pyx:675-932, :1003-1013) and, for the Gaussian PMC update,
 // calculate_rho_rb + the einsum reductions (pypmc/mix_adapt/pmc.pyx:23-43, :188-222).
 //
+// Two forms.  D <= PMC_F_REG_MAX_DIM: k_estep_reg, everything in registers (described at the kernel).
+// Above it, k_estep_fused:
 // One workgroup = 8 wavefronts, persistent over its share of the samples, "rounds" of TPR = 8 / QS
 // tiles of 64 samples:
 //   phase A (lane = sample, parameters as SGPR operands exactly like k_logpdf): a tile's K components
@@ -30,6 +32,45 @@
 namespace {
 
 constexpr int FW = PMC_F_WAVES;          // wavefronts per workgroup
+
+// exp(x) for x <= 0: the device library's algorithm and constants (k = rint(x log2 e), r = x - k ln 2 in two
+// pieces, degree-11 polynomial, ldexp) without its overflow branch, and with the underflow branch replaced by
+// a clamp of the argument -- the same bits as exp() for every x <= 0 (ldexp rounds the subnormal results,
+// -1075 and below give 0); 18 instead of 24 vector instructions.  NaN arguments give 0, not NaN: callers
+// poison the sample weight instead (below).
+struct ExpConst {
+    double log2e, nln2hi, nln2lo, c[9];
+    __device__ __forceinline__ ExpConst()
+    {
+        log2e = __longlong_as_double(0x3ff71547652b82feLL);
+        nln2hi = __longlong_as_double(0xbfe62e42fefa39efLL);
+        nln2lo = __longlong_as_double(0xbc7abc9e3b39803fLL);
+        c[0] = __longlong_as_double(0x3e5ade156a5dcb37LL);
+        c[1] = __longlong_as_double(0x3e928af3fca7ab0cLL);
+        c[2] = __longlong_as_double(0x3ec71dee623fde64LL);
+        c[3] = __longlong_as_double(0x3efa01997c89e6b0LL);
+        c[4] = __longlong_as_double(0x3f2a01a014761f6eLL);
+        c[5] = __longlong_as_double(0x3f56c16c1852b7b0LL);
+        c[6] = __longlong_as_double(0x3f81111111122322LL);
+        c[7] = __longlong_as_double(0x3fa55555555502a1LL);
+        c[8] = __longlong_as_double(0x3fc5555555555511LL);
+    }
+};
+__device__ __forceinline__ double exp_le0(double x, const ExpConst &E)
+{
+    const double xc = max_f64(x, -1075.0);
+    const double k = rint(xc * E.log2e);
+    double r = fma(k, E.nln2hi, xc);
+    r = fma(k, E.nln2lo, r);
+    double p = fma(E.c[0], r, E.c[1]);
+#pragma unroll
+    for (int i = 2; i < 9; ++i) p = fma(r, p, E.c[i]);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)k);
+}
+
 
 template <int D> struct FusedGeom {
     static constexpr int G = (D + 3) / 4;                         // coordinate groups of 4
@@ -64,15 +105,10 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
     constexpr int G = GEO::G, PIT = GEO::PIT, NBLK = GEO::NBLK, T = pmc_tri(D);
     constexpr bool AUG = GEO::AUG;
     constexpr int STRIDE = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
-    // D <= PMC_F_PERLANE_MAX: the statistics phase keeps lane = sample and accumulates the 1 + D + T moments
-    // of its components per lane with plain multiply-adds (D = 2: 10 vector instructions per tile and
-    // component against 8 + 4 MFMA = 24 slots' worth; measured 0.459 -> 0.430 ms per 4e6 samples x 32
-    // components).  From D = 3 on the NCH (1 + D + T) accumulators cost more occupancy than they save (0.49 -> 0.53)
-    constexpr bool PL = D <= PMC_F_PERLANE_MAX;
     extern __shared__ double lds[];
     const int K = a.K;
     const int QS = a.qs, TPR = FW / QS;                            // wavefronts per tile, tiles per round
-    double *xi = lds;                                              // [TPR][64][PIT] sample rows  (PL: [TPR][PIT][64])
+    double *xi = lds;                                              // [TPR][64][PIT] sample rows
     double *ub = xi + TPR * 64 * PIT;                              // [TPR][K][64]     a_nk, then u_nk, tile-major
     double *zero = ub + (size_t)TPR * K * 64;                      // [64]             u of a component slot beyond K
     double *red = zero + 64;                                       // [3][FW][64]      soft-max exchange
@@ -105,13 +141,6 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) acc2[j][b] = 0.0;
     }
-    double pacc[PL ? NCH : 1][PL ? PS : 1];                        // per-lane moments: sum u | sum u d | sum u d d^T
-    if constexpr (PL) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-#pragma unroll
-            for (int p = 0; p < PS; ++p) pacc[j][p] = 0.0;
-    }
     if (threadIdx.x < 64) zero[threadIdx.x] = 0.0;                 // (the first barrier of a round orders it)
     double sc_a = 0.0;                                             // VB: E[log q(Z)] part; PMC: sum w log q
 
@@ -130,14 +159,9 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
             double xv[D];
             load_row<D, PADDED>(a.x, n, a.N, a.dreal, xv);
             if (q == 0) {                                          // wave-uniform
-                if constexpr (PL) {
+                double *row = xi + (size_t)(ta * 64 + lane) * PIT;
 #pragma unroll
-                    for (int j = 0; j < D; ++j) xi[(size_t)(ta * PIT + j) * 64 + lane] = xv[j];
-                } else {
-                    double *row = xi + (size_t)(ta * 64 + lane) * PIT;
-#pragma unroll
-                    for (int j = 0; j < 4 * G; ++j) row[j] = j < D ? xv[j] : ((AUG && j == D) ? 1.0 : 0.0);
-                }
+                for (int j = 0; j < 4 * G; ++j) row[j] = j < D ? xv[j] : ((AUG && j == D) ? 1.0 : 0.0);
             }
             cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
 #pragma unroll PMC_F_UNROLL_A
@@ -213,31 +237,7 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
         __syncthreads();
 
         // ------------------------------------------------------------------ phase B
-        if constexpr (PL) {
-            for (int t = ts0; t < TPR; t += TS) {
-                double xr[D];
-#pragma unroll
-                for (int i = 0; i < D; ++i) xr[i] = xi[(size_t)(t * PIT + i) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    const int c = cb + CW * j;
-                    cdouble *pk = (cdouble *)a.pack + (size_t)(c < K ? c : 0) * STRIDE;
-                    const double u = c < K ? ub[((size_t)t * K + c) * 64 + lane] : 0.0;      // wave-uniform select
-                    double d[D];
-#pragma unroll
-                    for (int i = 0; i < D; ++i) d[i] = xr[i] - pk[i];
-                    pacc[j][0] += u;
-                    int p = 1 + D;
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-                        const double ud = u * d[i];
-                        pacc[j][1 + i] += ud;
-#pragma unroll
-                        for (int jj = 0; jj <= i; ++jj, ++p) pacc[j][p] = fma(ud, d[jj], pacc[j][p]);
-                    }
-                }
-            }
-        } else {
+        {
             for (int t = ts0; t < TPR; t += TS) {
                 const double *xt = xi + (size_t)(t * 64 + srow) * PIT + ci;
                 const double *utile = ub + srow;
@@ -284,19 +284,7 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
 
     // ---------------------------------------------------------------------- results
     const long long chunk = (long long)blockIdx.x * TS + ts0;
-    if constexpr (PL) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c = cb + CW * j;
-            if (c >= K) continue;
-            double *out = a.partials + ((size_t)chunk * K + c) * PS;
-#pragma unroll
-            for (int p = 0; p < PS; ++p) {
-                const double v = wave_sum(pacc[j][p]);
-                if (lane == 0) out[p] = v;
-            }
-        }
-    } else {
+    {
         // accumulator lane layouts: acc2 -- lane 16 i + 4 blk + j; acc0 / acc1 -- per (sample, ci)
     #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -352,6 +340,233 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// D <= PMC_F_REG_MAX_DIM: the whole E-step of a (tile, component group) in REGISTERS.
+//
+// A wavefront keeps lane = sample throughout, owns KQ <= pmc_freg_kqmax(D) components of its tile and
+// carries the 1 + D + D(D+1)/2 moments of each of them per lane over all its rounds: a_nk, e_nk and u_nk
+// never leave the vector registers, nothing is parked in LDS and the statistics need no second data layout.
+// LDS only carries the soft-max exchange between the QS wavefronts that share a tile (row maximum, then the
+// sum -- two barriers per round, none if K <= KQ).  The 64 per-lane moments are summed once, at the end.
+// Per (sample, component) at D = 2: 13 + 20 + 5 + 10 vector instructions against 77 of the LDS form above
+// (profiles/r02_fused_small_d.txt).
+// ---------------------------------------------------------------------------------------------
+
+#if PMC_D <= PMC_F_REG_MAX_DIM
+
+__host__ __device__ constexpr int freg_min_waves(int D, int KQ)
+{
+#ifdef PMC_F_REG_MIN_WAVES
+    return PMC_F_REG_MIN_WAVES;
+#else
+    return (pmc_stats_stride_c(D) * KQ <= 24) ? 4 : 2;      // accumulators: 2 registers each
+#endif
+}
+
+template <int D, bool PADDED, int KIND, int KQ, bool FULL>
+__global__ __launch_bounds__(FW * 64, freg_min_waves(D, KQ)) void k_estep_reg(const PmcArgsF a)
+{
+    constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
+    __shared__ double red[3][FW][64];
+    const int K = a.K;
+    const int QS = a.qs, TPR = FW / QS;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ta = w / QS, q = w % QS;
+    const int k0 = q * KQ;
+    const int nk = FULL ? KQ : ((K - k0 < KQ) ? K - k0 : KQ);      // >= 1 (geometry: (QS - 1) KQ < K)
+    // parameters of component slot j; slots beyond nk repeat the last component: harmless for the row
+    // maximum, skipped (wave-uniform branches) everywhere else
+    int slot[KQ];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) slot[j] = ((FULL || j < nk) ? k0 + j : k0 + nk - 1) * STRIDE;
+
+    const ExpConst EC;
+    double acc[KQ][PS];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j)
+#pragma unroll
+        for (int p = 0; p < PS; ++p) acc[j][p] = 0.0;
+    double sc_a = 0.0;
+
+    const long long nrounds = (a.ntiles + TPR - 1) / TPR;
+    const long long r0 = (long long)blockIdx.x * a.rounds_per_wg;
+    long long r1 = r0 + a.rounds_per_wg;
+    if (r1 > nrounds) r1 = nrounds;
+    // the next round's sample row and weight are loaded a round ahead
+    double xn[D], swn;
+    auto fetch = [&](long long round) {
+        const long long n = (round * TPR + ta) * 64 + lane;
+        load_row<D, PADDED>(a.x, n, a.N, a.dreal, xn);
+        swn = n < a.N ? (a.sample_w != nullptr ? a.sample_w[n] : 1.0) : 0.0;
+    };
+    fetch(r0);
+    for (long long round = r0; round < r1; ++round) {
+        double xv[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) xv[i] = xn[i];
+        double swv = swn;
+        if (round + 1 < r1) fetch(round + 1);
+        // the parameters are re-read through the scalar cache every round: kept live over the loop, KQ x 10
+        // doubles do not fit the scalar registers and come back as v_readlane spills (16 extra vector
+        // instructions per pair at KQ = 8)
+        cdouble *pb = (cdouble *)a.pack;
+        asm volatile("" : "+s"(pb));
+        cdouble *pks[KQ];
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) pks[j] = pb + slot[j];
+        {   // a NaN or infinite coordinate makes every a_nk NaN in the reference; exp_le0 would turn that into
+            // zeros, so the sample's weight carries the NaN instead (0 * finite = 0 otherwise)
+            double t = xv[0];
+#pragma unroll
+            for (int i = 1; i < D; ++i) t += xv[i];
+            swv = fma(0.0, t, swv);
+        }
+        // ---- pass 1: a_nk and the row maximum                       (variational.pyx:675-727, pmc.pyx:24-34)
+        double av[KQ];
+        double M = a.max_init_zero ? 0.0 : -DBL_MAX;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const double maha = mahalanobis<D>(xv, pks[j]);
+            double expo;
+            av[j] = component_value<D, KIND>(maha, pks[j] + D + T, expo);
+            M = max_f64(av[j], M);                                  // NaN never wins, as with the reference's >
+        }
+        if (QS > 1) {
+            red[0][w][lane] = M;
+            __syncthreads();
+            M = a.max_init_zero ? 0.0 : -DBL_MAX;
+            for (int qq = 0; qq < QS; ++qq) M = max_f64(red[0][ta * QS + qq][lane], M);
+        }
+        // ---- pass 2: one exp per pair, the row sum                   (variational.pyx:741-743, _regularize.pyx:79)
+        double s = 0.0, tb = 0.0;
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            if (FULL || j < nk) {
+                const double lr = av[j] - M;
+                const double e = exp_le0(lr, EC);
+                if constexpr (KIND == PMC_KIND_VB) {
+                    s += e;
+                    tb = fma(e, max_f64(lr, -1075.0), tb);             // sum_k e_k (a_k - M), for E[log q(Z)]; e = 0 there
+                } else {
+                    s += pks[j][D + T + 4] * e;
+                }
+                av[j] = e;
+            }
+        }
+        if (QS > 1) {
+            red[1][w][lane] = s;
+            if constexpr (KIND == PMC_KIND_VB) red[2][w][lane] = tb;
+            __syncthreads();
+            s = 0.0;
+            tb = 0.0;
+            for (int qq = 0; qq < QS; ++qq) {
+                s += red[1][ta * QS + qq][lane];
+                if constexpr (KIND == PMC_KIND_VB) tb += red[2][ta * QS + qq][lane];
+            }
+        }
+        // the per-sample part of the scalar sum (a log) takes turns among the tile's wavefronts: they meet at the
+        // next barrier anyway, and the one that always did it was always the last to arrive
+        const int logq = (int)(round & (QS - 1));
+        // ---- pass 3: u_nk and its moments                            (variational.pyx:748-755, :855-932; pmc.pyx:36-43, :188-222)
+        double f0, f1 = 0.0;
+        if constexpr (KIND == PMC_KIND_VB) {
+            f0 = 1. / s;
+            if (q == logq) sc_a += swv * fma(tb, f0, log(f0));       // variational.pyx:1003-1013
+        } else {
+            const double lse = log(s) + M;                           // _regularize.pyx:81
+            f0 = exp(M);
+            f1 = exp(lse) + TINY;                                    // pmc.pyx:41
+            if (q == logq) sc_a += swv * lse;                        // pmc.pyx:388-391
+        }
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            if (FULL || j < nk) {
+                double u;
+                if constexpr (KIND == PMC_KIND_VB) {
+                    u = swv * zero_to_tiny(av[j] * f0);
+                } else {
+                    // exp(log q_k) = e exp(M) first: it underflows where the reference's does (pmc.pyx:39)
+                    double rho = (av[j] * f0) * pks[j][D + T + 4];
+                    rho /= f1;
+                    u = swv * rho;
+                }
+                double d[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) d[i] = xv[i] - pks[j][i];
+                acc[j][0] += u;
+                int p = 1 + D;
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const double ud = u * d[i];
+                    acc[j][1 + i] += ud;
+#pragma unroll
+                    for (int jj = 0; jj <= i; ++jj, ++p) acc[j][p] = fma(ud, d[jj], acc[j][p]);
+                }
+            }
+        }
+    }
+
+    // ---- results: one partial vector per (workgroup, tile slot), layout of k_stats' partials
+    const long long chunk = (long long)blockIdx.x * TPR + ta;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        if (FULL || j < nk) {
+            double *out = a.partials + ((size_t)chunk * K + k0 + j) * PS;
+#pragma unroll
+            for (int p = 0; p < PS; ++p) {
+                const double v = wave_sum(acc[j][p]);
+                if (lane == 0) out[p] = v;
+            }
+        }
+    }
+    __shared__ double sred[FW];
+    const double v = wave_sum(sc_a);
+    if (lane == 0) sred[w] = v;
+    __syncthreads();
+    if (threadIdx.x < PMC_NSCALARS) {
+        double tot = 0.0;
+        const int slot = (KIND == PMC_KIND_VB) ? 0 : 3;
+        if ((int)threadIdx.x == slot) {
+#pragma unroll
+            for (int i = 0; i < FW; ++i) tot += sred[i];
+        }
+        a.spartials[(size_t)blockIdx.x * PMC_NSCALARS + threadIdx.x] = tot;
+    }
+}
+
+template <int KIND, int KQ> hipError_t launch_reg_kq(const PmcArgsF &a, unsigned grid, hipStream_t st)
+{
+    if constexpr (KQ <= pmc_freg_kqmax(D_)) {
+        if (a.K == a.qs * KQ)
+            hipLaunchKernelGGL((k_estep_reg<D_, P_, KIND, KQ, true>), dim3(grid), dim3(FW * 64), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_estep_reg<D_, P_, KIND, KQ, false>), dim3(grid), dim3(FW * 64), 0, st, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int KIND> hipError_t launch_reg_k(const PmcArgsF &a, unsigned grid, hipStream_t st)
+{
+    switch (a.kq) {
+    case 1: return launch_reg_kq<KIND, 1>(a, grid, st);
+    case 2: return launch_reg_kq<KIND, 2>(a, grid, st);
+    case 3: return launch_reg_kq<KIND, 3>(a, grid, st);
+    case 4: return launch_reg_kq<KIND, 4>(a, grid, st);
+    case 5: return launch_reg_kq<KIND, 5>(a, grid, st);
+    case 6: return launch_reg_kq<KIND, 6>(a, grid, st);
+    case 7: return launch_reg_kq<KIND, 7>(a, grid, st);
+    case 8: return launch_reg_kq<KIND, 8>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+#endif   // PMC_D <= PMC_F_REG_MAX_DIM
+
+#if PMC_D > PMC_F_REG_MAX_DIM
+
 template <int KIND, int NCH> hipError_t launch_fused_kq(const PmcArgsF &a, unsigned grid, hipStream_t st)
 {
     const size_t lds = sizeof(double) * fused_lds_doubles(D_, a.qs, a.K);
@@ -378,16 +593,29 @@ template <int KIND> hipError_t launch_fused_k(int nch, const PmcArgsF &a, unsign
     }
 }
 
+#endif   // PMC_D > PMC_F_REG_MAX_DIM
+
 }  // namespace
 
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_fused_d, PMC_D, PMC_PADDED)(int kind, int nch, const PmcArgsF &a,
                                                                             unsigned grid, hipStream_t st)
 {
+#if PMC_D <= PMC_F_REG_MAX_DIM
+    (void)nch;
+    if (!a.reg) return hipErrorInvalidValue;               // the dispatcher's geometry and this unit disagree
+    switch (kind) {
+    case PMC_KIND_GAUSS: return launch_reg_k<PMC_KIND_GAUSS>(a, grid, st);
+    case PMC_KIND_VB: return launch_reg_k<PMC_KIND_VB>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+#else
+    if (a.reg) return hipErrorInvalidValue;
     switch (kind) {
     case PMC_KIND_GAUSS: return launch_fused_k<PMC_KIND_GAUSS>(nch, a, grid, st);
     case PMC_KIND_VB: return launch_fused_k<PMC_KIND_VB>(nch, a, grid, st);
     default: return hipErrorInvalidValue;
     }
+#endif
 }
 
 extern "C" int PMC_UNIT_NAME_X(pmc_fused_lds_bytes_d, PMC_D, PMC_PADDED)(int qs, int K)

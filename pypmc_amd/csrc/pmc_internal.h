@@ -11,14 +11,26 @@ constexpr int PMC_A_WAVES = 4;     // wavefronts (tiles) per workgroup in the pe
 // responsibility phase (so K <= PMC_F_WAVES / 2 * PMC_F_KQMAX = 32), largest compiled dimension
 #define PMC_F_WAVES 8
 #define PMC_F_KQMAX 8
-#ifndef PMC_F_PERLANE_MAX
-#define PMC_F_PERLANE_MAX 2
-#endif
 #ifndef PMC_F_UNROLL_A
 #define PMC_F_UNROLL_A 2
 #endif
 #define PMC_FUSED_MAX_DIM 7
 #define PMC_FUSED_MAX_K 32
+// ... and its register-resident form for D <= PMC_F_REG_MAX_DIM (k_estep_reg): pmc_freg_kqmax(D) components per
+// wavefront -- their per-lane moments, 1 + D + D(D+1)/2 each, are what the registers have to hold -- so
+// K <= PMC_F_WAVES * pmc_freg_kqmax(D).  Measured per 4e6 samples (ms; LDS form | 4 | 8 components per wavefront):
+//   D = 1:  K = 32  0.356 | 0.346 | 0.288        D = 2:  K = 8  0.129 | 0.130 | 0.143,  K = 16  - | 0.221 | 0.225,
+//   K = 32  0.428 | 0.406 | 0.403;     D = 3: the LDS form with its matrix-pipe statistics wins (K = 32: 0.493 | 0.517).
+#ifndef PMC_F_REG_MAX_DIM
+#define PMC_F_REG_MAX_DIM 2
+#endif
+__host__ __device__ constexpr int pmc_freg_kqmax(int D)
+{
+    return D > PMC_F_REG_MAX_DIM ? 0 : (D == 1 ? 8 : 4);
+}
+// Below this many components the one-kernel form loses to the two kernels from D = 5 on (K = 8, 4e6 samples:
+// D = 5  0.277 against 0.258 ms, D = 7  0.308 against 0.285; D = 3  0.156 against 0.209 the other way round)
+#define PMC_FUSED_MIN_K_FROM_D5 9
 
 // Mahalanobis engines of the per-sample kernels (pmc_persample.hip) by compiled dimension, and with
 // them the layout of the triangular factor in the parameter pack (pmc_pack_components):
@@ -113,6 +125,7 @@ struct PmcArgsF {
     double *spartials;    // gridDim.x * PMC_NSCALARS
     long long ntiles;
     int rounds_per_wg;
+    int reg;              // 1: register-resident form (k_estep_reg): qs wavefronts x kq components per tile
 };
 
 // propose kernel

@@ -258,7 +258,8 @@ def test_fused_estep_vs_oracle(be, orc, D, K, N, weighted):
     from pypmc_amd.backend import ComponentSet
     from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
     from pypmc_amd._lib import PMC_KIND_VB, PMC_KIND_GAUSS
-    fusable = int(be.lib.pmc_padded_dim(D) <= 7)          # beyond, pmc_estep is the two kernels (still tested here)
+    dp = be.lib.pmc_padded_dim(D)
+    fusable = int(dp <= 7 and not (dp >= 5 and K < 9))    # otherwise pmc_estep is the two kernels (still tested here)
     assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_VB, 0) == fusable
     assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 1) == fusable
     assert be.lib.pmc_estep_is_fused(K, D, 1, 1) == 0 and be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 2) == 0
@@ -305,6 +306,39 @@ def test_fused_estep_vs_oracle(be, orc, D, K, N, weighted):
     np.testing.assert_allclose(M1, np.einsum('n,nk,nki->ki', swv, rho, d), rtol=1e-9, atol=1e-10)
     M2ref = np.einsum('n,nk,nki,nkj->kij', swv, rho, d, d)
     np.testing.assert_allclose(M2, M2ref, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(M2ref).max()))
+
+
+@pytest.mark.parametrize("D,K", [(1, 3), (2, 5), (2, 32), (3, 4), (5, 9), (7, 32), (8, 5)])
+def test_estep_nan_sample_poisons_the_statistics(be, orc, D, K):
+    """A sample with a NaN coordinate makes every a_nk of its row NaN in the reference (variational.pyx:675-755,
+    pmc.pyx:23-43) and with it every sum it enters.  The register form of the one-kernel path uses an exp
+    without NaN handling and carries the NaN in the sample's weight instead: same outcome, on every path.
+    (Infinite coordinates are not pinned: the reference's full quadratic form turns them into NaN, the
+    triangular form here into maha = inf, i.e. rho = 0 for the PMC update.)"""
+    from pypmc_amd.backend import ComponentSet
+    mu, cov, w = mk(K, D, 40 + D)
+    x, _ = draw(mu, cov, w, 300, 3)
+    nu = D + 3. + np.arange(K)
+    W = np.linalg.inv(cov) / nu[:, None, None]
+    W = 0.5 * (W + W.transpose(0, 2, 1))
+    cs = ComponentSet(2, mu, W, c0=np.full(K, D / 2.), c1=nu, c2=np.log(w), c3=np.linalg.slogdet(W)[1])
+    gs = gauss_set(mu, cov, w)[0]
+    clean_vb = be.tohost(be.estep(x, cs, 0)["stats"]).copy()
+    assert np.isfinite(clean_vb).all()
+    ref = orc.vb_estep(x, None, mu, W, np.full(K, 2.), nu, np.log(w), np.linalg.slogdet(W)[1] + D * np.log(2. * np.pi))
+    assert np.isfinite(ref["N_comp"]).all()
+    for bad in (np.nan,):
+        xb = x.copy()
+        xb[137, D - 1] = bad
+        refb = orc.vb_estep(xb, None, mu, W, np.full(K, 2.), nu, np.log(w), np.linalg.slogdet(W)[1] + D * np.log(2. * np.pi))
+        assert np.isnan(refb["N_comp"]).all(), "the reference loops give NaN here"
+        for comps, mode in ((cs, 0), (gs, 1)):
+            one = be.tohost(be.estep(xb, comps, mode)["stats"])
+            two = be.tohost(be.estep(xb, comps, mode, want_r=True)["stats"])
+            k0 = 8                                                  # [scalars | K x (sum u, sum u d, sum u d d^T) | ...]
+            ps = 1 + D + D * (D + 1) // 2
+            for got, path in ((one, "pmc_estep"), (two, "two kernels")):
+                assert np.isnan(got[k0:k0 + K * ps:ps]).all(), (path, mode, bad)
 
 
 @pytest.mark.parametrize("tag", ["d2k3", "d5k4"])
