@@ -131,9 +131,13 @@ template <int N> __device__ __forceinline__ void fmac_bcast(double &acc, double 
 // (scripts/microbench/fp64_oprates.hip).  A NaN operand loses, as it does against the reference's ">".
 __device__ __forceinline__ double max_f64(double a, double b)
 {
+#ifdef PMC_LIBM_LSE            // A/B switch (scripts/tune_unit.sh): the compiler's and the library's forms
+    return a > b ? a : b;
+#else
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 
 // r == 0 ? tiny : r for r >= +0 (variational.pyx:751-753) on the integer pipe: tiny = 0x0010000000000000 has a
@@ -141,9 +145,13 @@ __device__ __forceinline__ double max_f64(double a, double b)
 // for the fp64 compare and its two selects.
 __device__ __forceinline__ double zero_to_tiny(double r)
 {
+#ifdef PMC_LIBM_LSE
+    return r == 0.0 ? TINY : r;
+#else
     const unsigned lo = (unsigned)__double2loint(r), hi = (unsigned)__double2hiint(r);
     const unsigned h2 = ((lo | hi) == 0u) ? 0x00100000u : hi;
     return __hiloint2double((int)h2, (int)lo);
+#endif
 }
 
 // a_nk from maha_nk, in the reference's operation order (see enum pmc_kind).
@@ -166,17 +174,78 @@ __device__ __forceinline__ double component_value(double maha, cdouble *c, doubl
     }
 }
 
-// One step of the streaming log-sum-exp  log sum_k w_k exp(a_k) = m + log s  with
-// m = running max, s = sum_k w_k exp(a_k - m)   (one exp per step).
-// (Measured and dropped, round 2: an own exp for non-positive arguments -- degree-13 Taylor polynomial
-// with its constants as SGPR operands, 23 instead of the library's 32 vector instructions, within 1 ulp --
-// was 4-7 % SLOWER in k_logpdf at D = 2 ... 8 and neutral in the fused E-step kernel.)
-__device__ __forceinline__ void lse_step(double a, double w, double &m, double &s)
+// exp(x) for x <= 0: the device library's algorithm and constants (k = rint(x log2 e), r = x - k ln 2 in two
+// pieces, degree-11 polynomial, ldexp) without its overflow branch, and with the underflow branch replaced by
+// a clamp of the argument -- the same bits as exp() for every x <= 0 (ldexp rounds the subnormal results,
+// -1075 and below give 0); 18 instead of 24 vector instructions.  NaN arguments give 0, not NaN: callers
+// poison the sample weight instead (below).
+struct ExpConst {
+    double log2e, nln2hi, nln2lo, c[9];
+    __device__ __forceinline__ ExpConst()
+    {
+        log2e = __longlong_as_double(0x3ff71547652b82feLL);
+        nln2hi = __longlong_as_double(0xbfe62e42fefa39efLL);
+        nln2lo = __longlong_as_double(0xbc7abc9e3b39803fLL);
+        c[0] = __longlong_as_double(0x3e5ade156a5dcb37LL);
+        c[1] = __longlong_as_double(0x3e928af3fca7ab0cLL);
+        c[2] = __longlong_as_double(0x3ec71dee623fde64LL);
+        c[3] = __longlong_as_double(0x3efa01997c89e6b0LL);
+        c[4] = __longlong_as_double(0x3f2a01a014761f6eLL);
+        c[5] = __longlong_as_double(0x3f56c16c1852b7b0LL);
+        c[6] = __longlong_as_double(0x3f81111111122322LL);
+        c[7] = __longlong_as_double(0x3fa55555555502a1LL);
+        c[8] = __longlong_as_double(0x3fc5555555555511LL);
+    }
+};
+// (exp_clamped: the argument is already max_f64(x, -1075.0) -- callers that need the clamped value themselves)
+__device__ __forceinline__ double exp_clamped(double xc, const ExpConst &E)
 {
+#ifdef PMC_LIBM_LSE
+    return exp(xc);
+#endif
+    const double k = rint(xc * E.log2e);
+    double r = fma(k, E.nln2hi, xc);
+    r = fma(k, E.nln2lo, r);
+    double p = fma(E.c[0], r, E.c[1]);
+#pragma unroll
+    for (int i = 2; i < 9; ++i) p = fma(r, p, E.c[i]);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)k);
+}
+__device__ __forceinline__ double exp_le0(double x, const ExpConst &E) { return exp_clamped(max_f64(x, -1075.0), E); }
+
+
+// mask ? x1 : x0 for an all-ones / all-zeros mask, on the integer pipe (v_bfi_b32 per word: 0.5 issue slots each;
+// the fp64 compare-and-select the compiler emits for "c ? x1 : x0" costs 6.8, scripts/microbench/fp64_oprates.hip)
+__device__ __forceinline__ double bit_select(unsigned mask, double x1, double x0)
+{
+    const unsigned lo = ((unsigned)__double2loint(x1) & mask) | ((unsigned)__double2loint(x0) & ~mask);
+    const unsigned hi = ((unsigned)__double2hiint(x1) & mask) | ((unsigned)__double2hiint(x0) & ~mask);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// One step of the streaming log-sum-exp  log sum_k w_k exp(a_k) = m + log s  with
+// m = running max, s = sum_k w_k exp(a_k - m)   (one exp per step):
+//     a <= m:  s += w exp(a - m)             a > m:  s = s exp(m - a) + w,  m = a.
+// Both are  s = A e + B  with e = exp(-|a - m|): the sign word of a - m picks (A, B) = (w, s) or (s, w) on the
+// integer pipe (a - m = +0 or a positive value with a zero high word count as "a > m": e = 1, both forms agree).
+// A NaN a_k adds nothing here (exp_le0); k_logpdf adds the row's poison (0 or NaN) to the result instead.
+__device__ __forceinline__ void lse_step(double a, double w, double &m, double &s, const ExpConst &E)
+{
+#ifdef PMC_LIBM_LSE
     const double e = exp(-fabs(a - m));
     const bool gt = a > m;
     s = gt ? fma(s, e, w) : fma(w, e, s);
     m = gt ? a : m;
+#else
+    const double d = a - m;
+    const double e = exp_le0(-fabs(d), E);
+    const unsigned below = (unsigned)(__double2hiint(d) >> 31);       // all ones: a < m
+    s = fma(bit_select(below, w, s), e, bit_select(below, s, w));
+    m = max_f64(a, m);
+#endif
 }
 
 __device__ __forceinline__ double wave_sum(double v)

@@ -33,45 +33,6 @@ namespace {
 
 constexpr int FW = PMC_F_WAVES;          // wavefronts per workgroup
 
-// exp(x) for x <= 0: the device library's algorithm and constants (k = rint(x log2 e), r = x - k ln 2 in two
-// pieces, degree-11 polynomial, ldexp) without its overflow branch, and with the underflow branch replaced by
-// a clamp of the argument -- the same bits as exp() for every x <= 0 (ldexp rounds the subnormal results,
-// -1075 and below give 0); 18 instead of 24 vector instructions.  NaN arguments give 0, not NaN: callers
-// poison the sample weight instead (below).
-struct ExpConst {
-    double log2e, nln2hi, nln2lo, c[9];
-    __device__ __forceinline__ ExpConst()
-    {
-        log2e = __longlong_as_double(0x3ff71547652b82feLL);
-        nln2hi = __longlong_as_double(0xbfe62e42fefa39efLL);
-        nln2lo = __longlong_as_double(0xbc7abc9e3b39803fLL);
-        c[0] = __longlong_as_double(0x3e5ade156a5dcb37LL);
-        c[1] = __longlong_as_double(0x3e928af3fca7ab0cLL);
-        c[2] = __longlong_as_double(0x3ec71dee623fde64LL);
-        c[3] = __longlong_as_double(0x3efa01997c89e6b0LL);
-        c[4] = __longlong_as_double(0x3f2a01a014761f6eLL);
-        c[5] = __longlong_as_double(0x3f56c16c1852b7b0LL);
-        c[6] = __longlong_as_double(0x3f81111111122322LL);
-        c[7] = __longlong_as_double(0x3fa55555555502a1LL);
-        c[8] = __longlong_as_double(0x3fc5555555555511LL);
-    }
-};
-__device__ __forceinline__ double exp_le0(double x, const ExpConst &E)
-{
-    const double xc = max_f64(x, -1075.0);
-    const double k = rint(xc * E.log2e);
-    double r = fma(k, E.nln2hi, xc);
-    r = fma(k, E.nln2lo, r);
-    double p = fma(E.c[0], r, E.c[1]);
-#pragma unroll
-    for (int i = 2; i < 9; ++i) p = fma(r, p, E.c[i]);
-    p = fma(r, p, 0.5);
-    p = fma(r, p, 1.0);
-    p = fma(r, p, 1.0);
-    return ldexp(p, (int)k);
-}
-
-
 template <int D> struct FusedGeom {
     static constexpr int G = (D + 3) / 4;                         // coordinate groups of 4
     static constexpr bool AUG = (D % 4) != 0;                     // room for the constant 1 in the last group

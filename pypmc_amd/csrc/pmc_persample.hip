@@ -369,6 +369,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 
     // the mixture itself (kind KIND), then -- pmc_importance_weights only -- the TARGET mixture of the
     // importance weights (kind KIND2), evaluated on the same registers: the samples are read once
+    const ExpConst EC;
+    double poison = 0.0;                                 // NaN if the row has a NaN / infinite coordinate (lse_step)
     auto mixture = [&](auto kind, const double *gpack, const int K, const bool first) -> double {
         constexpr int KD = decltype(kind)::value;
         double m = (first && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
@@ -382,9 +384,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
                 const long long col = ((cint64 *)pk)[D + T + 5];
                 if (valid) a.individual[n * a.ld + col] = v;
             }
-            lse_step(v, pk[D + T + 4], m, s);
+            lse_step(v, pk[D + T + 4], m, s, EC);
+            poison = fma(0.0, v, poison);
         }
-        return log(s) + m;                               // _regularize.pyx:81
+        return (log(s) + m) + poison;                    // _regularize.pyx:81
     };
     const double lse = mixture(ic<KIND>{}, a.pack, a.K, true);
     double lse_target = 0.0;
@@ -485,6 +488,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
         // term, the product chain that undoes them in the normalisation pass).
         const bool literal = a.log_rho != nullptr;       // wave-uniform: the N x K matrix log_rho is wanted
         double M = a.max_init_zero ? 0.0 : -DBL_MAX;
+        // exp_le0 below turns a NaN a_nk into e = 0.  The VB normalisation makes that NaN again (0 / 0); the PMC
+        // kinds would get rho = 0 where the reference has NaN, so there the sample's weight carries it
+        double poison = 0.0;
+        const ExpConst EC;
         cdouble *pk = (cdouble *)a.pack;
         engine.begin(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);
         for (int k = 0; k < K; ++k, pk += STRIDE) {
@@ -498,12 +505,13 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     if (valid) a.exponent[n * a.ld + col] = expo;
                 }
             }
-            M = fmax(v, M);                               // (a NaN value leaves M alone, like `if v > M`)
+            M = max_f64(v, M);                            // (a NaN value leaves M alone, like `if v > M`)
+            if constexpr (KIND != PMC_KIND_VB) poison = fma(0.0, v, poison);
             if (k < klds) pl[k * 64] = v;                 // wave-uniform branch
             else ut[(size_t)k * 64] = v;
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
-        const double swv = valid ? sw : 0.0;             // (one select per sample instead of one per pair)
+        const double swv = valid ? sw + poison : 0.0;    // (one select per sample instead of one per pair)
         auto parked_global = [&](int k) { return ut[(size_t)k * 64]; };
         auto parked_lds = [&](int k) { return pl[k * 64]; };
 
@@ -512,8 +520,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
         // parked last are re-read first, while they are still in L2.
         double s = 0.0, tb = 0.0;
         auto expstep = [&](int k, double v) {
-            const double lr = v - M;                      // variational.pyx:741
-            const double e = exp(lr);                     // :742 / _regularize.pyx:79
+            const double lr = max_f64(v - M, -1075.0);    // variational.pyx:741 (below the clamp e = 0 either way)
+            const double e = exp_clamped(lr, EC);         // :742 / _regularize.pyx:79
             if constexpr (KIND == PMC_KIND_VB) {
                 tb = fma(e, lr, tb);                      // sum_k e_k (a_k - M): the dominant component adds exactly 0
                 s += e;
@@ -551,8 +559,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 }
             } else {
                 auto step = [&](int k, double e) {
-                    double r = e * norm_inv;
-                    if (r == 0.0) r = TINY;
+                    const double r = zero_to_tiny(e * norm_inv);
                     ut[(size_t)k * 64] = swv * r;
                     if (a.r != nullptr) {
                         const long long col = ((cint64 *)((cdouble *)a.pack + (size_t)k * STRIDE))[D + T + 5];
