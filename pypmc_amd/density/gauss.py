@@ -1,10 +1,17 @@
 """Gaussian density with its log-pdf on the GPU (reference: pypmc/density/gauss.pyx)."""
+import itertools
+
 import numpy as np
 
 from .base import ProbabilityDensity
 from ..tools._linalg import chol_inv_det
 from ..backend import ComponentSet, get_backend
 from .._lib import PMC_KIND_GAUSS, check_dim
+
+
+# every parameter state of a component gets a process-unique stamp (set by update / _assign, shared by copies,
+# which hold the same parameters): density.mixture.component_set keys its cache of uploaded parameter packs on it
+_STAMPS = itertools.count(1)
 
 
 def _as_matrix(sigma):
@@ -41,6 +48,7 @@ class Gauss(ProbabilityDensity):
         self.cholesky_sigma, self.inv_sigma, self.log_det_sigma = cholesky_sigma, inv_sigma, log_det_sigma
         # gauss.pyx:56
         self.log_normalization = -0.5 * self.dim * np.log(2 * np.pi) - 0.5 * self.log_det_sigma
+        self._stamp = next(_STAMPS)
 
     def __deepcopy__(self, memo):
         """Components are value objects made of a few arrays and scalars; copying them attribute by attribute
@@ -56,6 +64,7 @@ class Gauss(ProbabilityDensity):
         self.mu, self.sigma, self.dim = mu, sigma, len(mu)
         self.cholesky_sigma, self.inv_sigma, self.log_det_sigma = cholesky_sigma, inv_sigma, log_det_sigma
         self.log_normalization = -0.5 * self.dim * np.log(2 * np.pi) - 0.5 * self.log_det_sigma
+        self._stamp = next(_STAMPS)
 
     # -- kernel description ------------------------------------------------------------------
     kind = PMC_KIND_GAUSS

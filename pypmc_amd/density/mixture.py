@@ -2,6 +2,8 @@
 (reference: pypmc/density/mixture.pyx)."""
 from copy import deepcopy
 
+from collections import OrderedDict
+
 import numpy as np
 
 from .base import ProbabilityDensity
@@ -10,9 +12,19 @@ from .student_t import StudentT
 from ..backend import ComponentSet, get_backend
 
 
+_SETS = OrderedDict()        # the last few ComponentSets built, with the parameter pack the backend uploaded for them
+_SETS_MAX = 8
+
+
 def component_set(components, weights, columns=None, ld=None):
     """ComponentSet of homogeneous Gauss / StudentT ``components`` (None if they are of another
-    or of mixed type).  ``columns`` selects a subset, ``ld`` is the total component count."""
+    or of mixed type).  ``columns`` selects a subset, ``ld`` is the total component count.
+
+    Evaluating the same mixture again -- every ``ImportanceSampler.run`` between two proposal updates, every
+    ``multi_evaluate`` of a target mixture -- finds its set here and with it the pack already on the device
+    (K Cholesky factors of the precision matrices and an upload otherwise: 0.6 ms at K = 128, D = 40).  The key
+    is the components' parameter stamps (``update`` renews them), the means and the weights themselves: both
+    are plain arrays the reference lets callers change in place."""
     comps = list(components)
     if not comps:
         return None
@@ -21,13 +33,22 @@ def component_set(components, weights, columns=None, ld=None):
         return None
     idx = list(range(len(comps))) if columns is None else list(columns)
     sel = [comps[k] for k in idx]
+    mu = np.array([c.mu for c in sel], dtype=np.float64).reshape(len(sel), -1)
+    wts = np.asarray(weights, dtype=np.float64)[idx]
+    total = len(comps) if ld is None else ld
+    key = (first, tuple(c._stamp for c in sel), mu.tobytes(), wts.tobytes(), tuple(idx), total)
+    hit = _SETS.get(key)
+    if hit is not None:
+        _SETS.move_to_end(key)
+        return hit
     consts = np.array([c._kernel_constants() for c in sel], dtype=np.float64).reshape(len(sel), 4)
-    return ComponentSet(first.kind,
-                        np.array([c.mu for c in sel], dtype=np.float64).reshape(len(sel), -1),
-                        np.array([c.inv_sigma for c in sel], dtype=np.float64),
-                        consts[:, 0], consts[:, 1], consts[:, 2], consts[:, 3],
-                        weight=np.asarray(weights, dtype=np.float64)[idx], column=idx,
-                        ld=len(comps) if ld is None else ld)
+    cs = ComponentSet(first.kind, mu, np.array([c.inv_sigma for c in sel], dtype=np.float64),
+                      consts[:, 0], consts[:, 1], consts[:, 2], consts[:, 3],
+                      weight=wts, column=idx, ld=total)
+    _SETS[key] = cs
+    if len(_SETS) > _SETS_MAX:
+        _SETS.popitem(last=False)
+    return cs
 
 
 class MixtureDensity(ProbabilityDensity):

@@ -2,7 +2,7 @@
 import numpy as np
 from scipy.special import gammaln
 
-from .gauss import Gauss
+from .gauss import Gauss, _STAMPS
 from .._lib import PMC_KIND_STUDENT_T
 
 
@@ -27,6 +27,7 @@ class StudentT(Gauss):
             - 0.5 * self.dim * np.log(self.dof * np.pi) - 0.5 * self.log_det_sigma
         self._eval_prefactor = -.5 * (self.dof + self.dim)      # student_t.pyx:116
         self._inv_dof = 1. / self.dof                           # :117
+        self._stamp = next(_STAMPS)                             # (dof is part of the parameter state)
 
     def _assign(self, mu, sigma, cholesky_sigma, inv_sigma, log_det_sigma, dof):
         Gauss._assign(self, mu, sigma, cholesky_sigma, inv_sigma, log_det_sigma)
@@ -35,6 +36,7 @@ class StudentT(Gauss):
             - 0.5 * self.dim * np.log(self.dof * np.pi) - 0.5 * self.log_det_sigma
         self._eval_prefactor = -.5 * (self.dof + self.dim)
         self._inv_dof = 1. / self.dof
+        self._stamp = next(_STAMPS)
 
     def _kernel_constants(self):
         return self.log_normalization, self._eval_prefactor, self._inv_dof, self.dof

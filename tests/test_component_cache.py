@@ -1,0 +1,63 @@
+"""density.mixture.component_set keeps the last few ComponentSets (and with them the parameter pack the backend
+uploaded): the key must follow every way the reference lets a caller change a mixture."""
+import copy
+
+import numpy as np
+
+from pypmc_amd.density.mixture import component_set, create_gaussian_mixture, create_t_mixture
+
+
+def _mix(K=4, D=3, seed=0, t=False):
+    rs = np.random.RandomState(seed)
+    mu = rs.normal(size=(K, D))
+    cov = np.array([np.eye(D) * (1. + k) for k in range(K)])
+    return create_t_mixture(mu, cov, np.full(K, 5.), None) if t else create_gaussian_mixture(mu, cov)
+
+
+def test_same_parameters_same_set():
+    m = _mix()
+    a = component_set(m.components, m.weights)
+    assert component_set(m.components, m.weights) is a
+    assert component_set(copy.deepcopy(m).components, m.weights) is a          # a copy holds the same parameters
+    assert component_set(m.components, m.weights, [1, 2], 4) is not a          # a subset is another set
+    assert component_set(m.components, m.weights, [1, 2], 4) is component_set(m.components, m.weights, [1, 2], 4)
+
+
+def test_every_change_makes_a_new_set():
+    m = _mix()
+    a = component_set(m.components, m.weights)
+    m.components[2].update(m.components[2].mu, 2. * m.components[2].sigma)
+    b = component_set(m.components, m.weights)
+    assert b is not a and np.array_equal(b.precision[2], m.components[2].inv_sigma)
+    m.components[1].mu[0] += 1.                                               # in place, as the reference allows
+    c = component_set(m.components, m.weights)
+    assert c is not b and c.mu[1, 0] == m.components[1].mu[0]
+    m.weights[0] = 0.
+    m.normalize()
+    d = component_set(m.components, m.weights)
+    assert d is not c and d.weight[0] == 0.
+    removed = m.prune()
+    assert len(removed) == 1
+    e = component_set(m.components, m.weights)
+    assert e is not d and e.K == 3
+
+
+def test_student_t_dof_is_part_of_the_state():
+    m = _mix(t=True)
+    a = component_set(m.components, m.weights)
+    c = m.components[0]
+    c.update(c.mu, c.sigma, 7.)
+    b = component_set(m.components, m.weights)
+    assert b is not a and b.c3[0] == 7.
+
+
+def test_batched_update_renews_the_stamps():
+    from pypmc_amd.tools._linalg import chol_inv_det_batch
+    m = _mix()
+    a = component_set(m.components, m.weights)
+    sig = np.array([c.sigma * 3. for c in m.components])
+    chol, inv, logdet = chol_inv_det_batch(sig)
+    for k, c in enumerate(m.components):
+        c._assign(c.mu.copy(), sig[k], chol[k], inv[k], float(logdet[k]))
+    b = component_set(m.components, m.weights)
+    assert b is not a and np.allclose(b.precision, inv)
