@@ -217,13 +217,20 @@ __device__ __forceinline__ double exp_clamped(double xc, const ExpConst &E)
 __device__ __forceinline__ double exp_le0(double x, const ExpConst &E) { return exp_clamped(max_f64(x, -1075.0), E); }
 
 
-// mask ? x1 : x0 for an all-ones / all-zeros mask, on the integer pipe (v_bfi_b32 per word: 0.5 issue slots each;
-// the fp64 compare-and-select the compiler emits for "c ? x1 : x0" costs 6.8, scripts/microbench/fp64_oprates.hip)
-__device__ __forceinline__ double bit_select(unsigned mask, double x1, double x0)
+// v_bfi_b32: (mask & a) | (~mask & b).  Inline asm because the compiler turns the C expression back into the
+// compare + v_cndmask form it was written to avoid (one compare feeding four selects: ~7 issue slots against 2,
+// scripts/microbench/fp64_oprates.hip).  One operand may be a uniform (scalar register) value.
+__device__ __forceinline__ unsigned bfi_vs(unsigned mask, unsigned a_uniform, unsigned b)
 {
-    const unsigned lo = ((unsigned)__double2loint(x1) & mask) | ((unsigned)__double2loint(x0) & ~mask);
-    const unsigned hi = ((unsigned)__double2hiint(x1) & mask) | ((unsigned)__double2hiint(x0) & ~mask);
-    return __hiloint2double((int)hi, (int)lo);
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "s"(a_uniform), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned bfi_sv(unsigned mask, unsigned a, unsigned b_uniform)
+{
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "s"(b_uniform));
+    return r;
 }
 
 // One step of the streaming log-sum-exp  log sum_k w_k exp(a_k) = m + log s  with
@@ -231,7 +238,8 @@ __device__ __forceinline__ double bit_select(unsigned mask, double x1, double x0
 //     a <= m:  s += w exp(a - m)             a > m:  s = s exp(m - a) + w,  m = a.
 // Both are  s = A e + B  with e = exp(-|a - m|): the sign word of a - m picks (A, B) = (w, s) or (s, w) on the
 // integer pipe (a - m = +0 or a positive value with a zero high word count as "a > m": e = 1, both forms agree).
-// A NaN a_k adds nothing here (exp_le0); k_logpdf adds the row's poison (0 or NaN) to the result instead.
+// ``w`` is the component's weight, uniform over the wavefront.  A NaN a_k adds nothing here (the clamp turns
+// exp's argument into -1075); k_logpdf adds the row's poison (0 or NaN) to the result instead.
 __device__ __forceinline__ void lse_step(double a, double w, double &m, double &s, const ExpConst &E)
 {
 #ifdef PMC_LIBM_LSE
@@ -241,9 +249,15 @@ __device__ __forceinline__ void lse_step(double a, double w, double &m, double &
     m = gt ? a : m;
 #else
     const double d = a - m;
-    const double e = exp_le0(-fabs(d), E);
-    const unsigned below = (unsigned)(__double2hiint(d) >> 31);       // all ones: a < m
-    s = fma(bit_select(below, w, s), e, bit_select(below, s, w));
+    double arg;                                                      // max(-|d|, -1075): source modifiers are free
+    asm("v_max_f64 %0, -|%1|, %2" : "=v"(arg) : "v"(d), "v"(-1075.0));
+    const double e = exp_clamped(arg, E);
+    const unsigned below = (unsigned)(__double2hiint(d) >> 31);      // all ones: a < m
+    const unsigned wlo = (unsigned)__double2loint(w), whi = (unsigned)__double2hiint(w);
+    const unsigned slo = (unsigned)__double2loint(s), shi = (unsigned)__double2hiint(s);
+    const double A = __hiloint2double((int)bfi_vs(below, whi, shi), (int)bfi_vs(below, wlo, slo));   // below ? w : s
+    const double B = __hiloint2double((int)bfi_sv(below, shi, whi), (int)bfi_sv(below, slo, wlo));   // below ? s : w
+    s = fma(A, e, B);
     m = max_f64(a, m);
 #endif
 }
