@@ -48,6 +48,24 @@ class ComponentSet(object):
         assert self.ld > int(self.column.max())
 
 
+class LogpdfTiles(object):
+    """Component log-densities a_nk a weighting pass kept on the device (library tile-major layout), together
+    with what they belong to: the sample count and the ComponentSet -- i.e. the parameter state -- they were
+    evaluated with.  ``gaussian_pmc(..., component_logpdf=tiles)`` uses them only for that very mixture."""
+
+    def __init__(self, data, N, comps):
+        self.data, self.N, self.K, self.comps = data, int(N), int(comps.K), comps
+
+    def matches(self, comps_full):
+        """True if ``comps_full`` (complete mixture) has the parameters these values were computed with
+        (the weights do not enter a_nk)."""
+        c = self.comps
+        return comps_full is c or (comps_full.kind == c.kind and comps_full.K == c.K and
+                                   np.array_equal(comps_full.mu, c.mu) and
+                                   np.array_equal(comps_full.precision, c.precision) and
+                                   np.array_equal(comps_full.c0, c.c0))
+
+
 def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -186,7 +204,7 @@ class HipBackend(object):
     # ------------------------------------------------------------------ operations
     def logpdf(self, x, comps, want_out=True, individual=None, want_individual=False,
                max_init_zero=False, log_target=None, sample_w=None, want_scalars=False, pack=None,
-               out=None):
+               out=None, keep=False):
         """pmc_mixture_logpdf.  ``x`` N x D device tensor.  Returns dict(out, individual, weights,
         scalars) of device tensors (None where not requested).  ``out``: optional contiguous
         N-vector on the device to receive log q (e.g. a row of combine_weights' q matrix)."""
@@ -207,15 +225,23 @@ class HipBackend(object):
         sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
         scalars = self.zeros(NSCALARS) if want_scalars else None
         ws = self._workspace(N, comps.K, D) if want_scalars else None
+        tiles = self._new_tiles(N, comps) if keep else None
         _lib.check(self._timed(
-            "pmc_mixture_logpdf[K=%d]" % comps.K, self.lib.pmc_mixture_logpdf,
+            "pmc_mixture_logpdf[K=%d]" % comps.K, self.lib.pmc_mixture_logpdf_keep,
             self._p(x), N, D, self._p(pack), comps.K, comps.kind, int(bool(max_init_zero)),
             self._p(out), self._p(individual), comps.ld, self._p(lt), self._p(weights), self._p(sw),
-            self._p(scalars), self._p(ws), self._stream()), "pmc_mixture_logpdf")
-        return dict(out=out, individual=individual, weights=weights, scalars=scalars)
+            self._p(scalars), self._p(ws), self._p(tiles.data) if keep else None, self._stream()), "pmc_mixture_logpdf")
+        return dict(out=out, individual=individual, weights=weights, scalars=scalars, tiles=tiles)
+
+    def _new_tiles(self, N, comps):
+        """Buffer for the component log-densities a kept weighting pass leaves behind (see LogpdfTiles)."""
+        assert comps.ld == comps.K and bool((comps.column == np.arange(comps.K)).all()), \
+            "component log-densities are kept for complete mixtures only"
+        n = int(self.lib.pmc_logpdf_tiles_size(N, comps.K))
+        return LogpdfTiles(self.empty(max(n, 1)), N, comps)
 
     def importance_weights(self, x, comps, target, sample_w=None, want_out=False, want_log_target=False,
-                           pack=None, target_pack=None):
+                           pack=None, target_pack=None, keep=False):
         """pmc_importance_weights: w = exp(log P - log q) for a mixture target P (``target``) and proposal
         q (``comps``) in one pass over ``x``.  Returns dict(weights, scalars, out, log_target)."""
         x = self.asdevice(x)
@@ -229,12 +255,13 @@ class HipBackend(object):
         sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
         scalars = self.zeros(NSCALARS)
         ws = self._workspace(N, max(comps.K, target.K), D)
+        tiles = self._new_tiles(N, comps) if keep else None
         _lib.check(self._timed(
-            "pmc_importance_weights[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights,
+            "pmc_importance_weights[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights_keep,
             self._p(x), N, D, self._p(pack), comps.K, comps.kind, self._p(target_pack), target.K, target.kind,
             self._p(out), self._p(lt), self._p(weights), self._p(sw), self._p(scalars), self._p(ws),
-            self._stream()), "pmc_importance_weights")
-        return dict(weights=weights, scalars=scalars, out=out, log_target=lt)
+            self._p(tiles.data) if keep else None, self._stream()), "pmc_importance_weights")
+        return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=tiles)
 
     def weight_sums(self, w):
         """(sum w, sum w log w [zeros masked], sum w^2) as a device tensor of NSCALARS doubles."""
@@ -348,6 +375,28 @@ class HipBackend(object):
             self._p(x), N, D, self._p(pack), K, self._p(u), self._p(flat[NSCALARS:]), self._p(ws),
             self._stream()), "pmc_sufficient_stats")
         return dict(stats=flat, r=r, log_rho=log_rho, exponent=expo)
+
+    def estep_from_tiles(self, x, comps, tiles, max_init_zero=False, sample_w=None, out=None):
+        """pmc_estep_from_tiles: the Rao-Blackwellised Gaussian PMC E-step of the samples ``tiles`` were made on,
+        rho from the kept component log-densities instead of new Mahalanobis forms.  ``comps`` may be a subset
+        of the mixture behind ``tiles`` (its columns name the positions).  Same return value as ``estep``."""
+        x = self.asdevice(x)
+        N, D = x.shape
+        assert comps.kind == PMC_KIND_GAUSS and D == comps.D
+        assert tiles.N == N and comps.ld == tiles.K, "kept log-densities belong to another sample set / mixture"
+        K = comps.K
+        pack = self.pack(comps)
+        sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
+        ps = int(self.lib.pmc_stats_stride(D))
+        nflat = NSCALARS + K * ps + 2 * K
+        flat = out if out is not None else self.zeros(nflat)
+        assert flat.numel() == nflat
+        _lib.check(self._timed(
+            "pmc_estep_from_tiles", self.lib.pmc_estep_from_tiles,
+            self._p(x), N, D, self._p(pack), K, int(bool(max_init_zero)), self._p(sw), self._p(tiles.data), tiles.K,
+            self._p(self._tilebuf("u", N, K)), self._p(flat[NSCALARS:]), self._p(flat),
+            self._p(self._workspace(N, K, D)), self._stream()), "pmc_estep_from_tiles")
+        return dict(stats=flat, r=None, log_rho=None, exponent=None)
 
     def weighted_moments(self, x, w):
         """sum w | sum w (x - x_0) | sum w (x - x_0)(x - x_0)^T of weighted samples through the

@@ -71,6 +71,8 @@ def build(jobs=None, force=False, verbose=False):
     headers.append(os.path.join(CSRC, "pmc_device.h"))
     asrc = os.path.join(CSRC, "pmc_api.hip")
     work = [(os.path.join(OBJ, "pmc_api.o"), asrc, [], [asrc] + headers, force)]
+    tsrc = os.path.join(CSRC, "pmc_tiles.hip")        # one unit for all dimensions (PMC_D is not used by it)
+    work.append((os.path.join(OBJ, "pmc_tiles.o"), tsrc, ["-DPMC_D=1"], [tsrc] + headers, force))
     for d, padded in dim_list():
         for p in ((0, 1) if padded else (0,)):
             for unit in ("persample", "stats", "propose", "fused"):

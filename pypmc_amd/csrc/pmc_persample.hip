@@ -384,6 +384,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
                 const long long col = ((cint64 *)pk)[D + T + 5];
                 if (valid) a.individual[n * a.ld + col] = v;
             }
+            if (first && a.atile != nullptr)             // wave-uniform: keep a_nk for the PMC update of these samples
+                a.atile[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = v;
             lse_step(v, pk[D + T + 4], m, s, EC);
             poison = fma(0.0, v, poison);
         }

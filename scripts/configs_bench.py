@@ -134,6 +134,21 @@ def main():
     t = timed(iteration, 3)
     out["cfg5_pmc_loop_D40_K128_N1.25e7_per_iteration"] = dict(iteration_s=t, samples_per_s=N / t, **info)
 
+    # the same loop with the update reusing the component log-densities the weighting pass kept
+    def iteration_reuse():
+        t0 = time.perf_counter()
+        run = sampler.run_device(N, trace_sort=True, keep_component_logpdf=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"], mincount=0, rb=True,
+                     copy=False, component_logpdf=run["component_logpdf"])
+        torch.cuda.synchronize()
+        info["propose_weight_s"], info["update_s"] = t1 - t0, time.perf_counter() - t1
+        info["perplexity"] = perp_from_sums(run["weight_sums"][0], run["weight_sums"][1], N)
+    t = timed(iteration_reuse, 3)
+    out["cfg5_pmc_loop_D40_K128_N1.25e7_per_iteration_reusing_component_logpdf"] = \
+        dict(iteration_s=t, samples_per_s=N / t, **info)
+
     text = json.dumps(out, indent=1)
     print(text)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

@@ -225,7 +225,7 @@ def test_cfg5_full_loop_1p25e7_per_gpu(be, orc):
     for it in range(2):
         old = sampler.proposal
         old_set = component_set(old.components, old.weights)
-        run = sampler.run_device(N, trace_sort=True)
+        run = sampler.run_device(N, trace_sort=True, keep_component_logpdf=it == 1)
         x, wts, origin = run["samples"], run["weights"], run["origin"]
         assert tuple(x.shape) == (N, D) and tuple(wts.shape) == (N,) and tuple(origin.shape) == (N,)
         # counts / origins: exactly the host generator's multinomial draw, ordered by component
@@ -251,7 +251,19 @@ def test_cfg5_full_loop_1p25e7_per_gpu(be, orc):
                          None, None, list(range(K)))
         assert rel(r, ref) < 1e-10
         old_mu = np.array([c.mu for c in old.components])
-        pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=False)
+        if it == 1:
+            # second iteration: the update reuses the component log-densities the weighting pass kept (12.8 GB
+            # here) -- and gives, bit for bit, what the update that evaluates the proposal again gives
+            twice = pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=True)
+            pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=False,
+                                             component_logpdf=run["component_logpdf"])
+            np.testing.assert_array_equal(sampler.proposal.weights, twice.weights)
+            for a_, b_ in zip(sampler.proposal.components, twice.components):
+                np.testing.assert_array_equal(a_.mu, b_.mu)
+                np.testing.assert_array_equal(a_.sigma, b_.sigma)
+            del twice
+        else:
+            pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=False)
         new = sampler.proposal
         assert new.normalized() and (new.weights > 0).all() and len(new) == K
         for c in new.components:
