@@ -94,6 +94,17 @@ int main(int argc, char **argv)
     // one call (at D = 4 one fused kernel: pmc_estep_is_fused() says d_u could be NULL)
     PMC_OK_(pmc_estep(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, PMC_RESP_PMC_RB, 0, d_w, nullptr, d_u, nullptr, nullptr,
                       d_stats + 8, d_stats, d_ws, stream));
+    // the same iteration evaluating the proposal ONCE: the weighting pass keeps the component log-densities, the
+    // update forms rho from them (no Mahalanobis forms) -- N_k must come out the same to rounding (at D = 4 the
+    // call above is the one-kernel E-step, whose sums are ordered differently; from D = 8 on: bit for bit)
+    double *d_tiles, *d_w2, *d_stats2, *d_scalars2;
+    HIP_OK(hipMalloc(&d_tiles, sizeof(double) * pmc_logpdf_tiles_size(N, K)));
+    HIP_OK(hipMalloc(&d_w2, sizeof(double) * N));
+    HIP_OK(hipMalloc(&d_stats2, sizeof(double) * nstats));
+    HIP_OK(hipMalloc(&d_scalars2, sizeof(double) * 8));
+    PMC_OK_(pmc_importance_weights_keep(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, d_tpack, K, PMC_KIND_GAUSS, nullptr,
+                                        nullptr, d_w2, nullptr, d_scalars2, d_ws, d_tiles, stream));
+    PMC_OK_(pmc_estep_from_tiles(d_x, N, D, d_pack, K, 0, d_w2, d_tiles, K, d_u, d_stats2 + 8, d_stats2, d_ws, stream));
     HIP_OK(hipStreamSynchronize(stream));
     pmc_timing timings[8];
     int ntimings = 0;
@@ -111,6 +122,14 @@ int main(int argc, char **argv)
     std::printf("sums %.17g %.17g %.17g\n", scalars[0], scalars[1], scalars[2]);
     for (int k = 0; k < K; ++k) std::printf("N_k %d %.17g\n", k, stats[8 + k * pmc_stats_stride(D)]);
     std::printf("fused %d\n", pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, PMC_RESP_PMC_RB));
+    std::vector<double> stats2(nstats);
+    HIP_OK(hipMemcpy(stats2.data(), d_stats2, sizeof(double) * nstats, hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (int64_t i = 8; i < 8 + K * pmc_stats_stride(D); ++i) {
+        const double scale = std::fabs(stats[i]) > 1e-300 ? std::fabs(stats[i]) : 1.0;
+        worst = std::fmax(worst, std::fabs(stats2[i] - stats[i]) / scale);
+    }
+    std::printf("from_tiles worst relative difference %.3g\n", worst);
     for (int i = 0; i < ntimings && i < 8; ++i)
         std::printf("timing %s: %d launches, %.4f ms, %.3g flop, %.3g bytes\n", timings[i].name, timings[i].calls,
                     timings[i].ms, timings[i].flops, timings[i].bytes);

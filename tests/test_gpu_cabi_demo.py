@@ -45,5 +45,8 @@ def test_cabi_demo_matches_oracle(tmp_path):
     # the E-step went through the fused kernel, and the library's own timing reported it
     assert "fused 1" in res
     timing = [line for line in res if line.startswith("timing ")]
-    assert any(line.startswith("timing k_logpdf: 1 launches") for line in timing)
+    assert any(line.startswith("timing k_logpdf: 2 launches") for line in timing)       # plain + keeping
     assert any(line.startswith("timing k_estep_fused: 1 launches") for line in timing)
+    # the evaluate-once iteration (pmc_importance_weights_keep + pmc_estep_from_tiles) gave the same statistics
+    worst = float([line for line in res if line.startswith("from_tiles")][0].split()[-1])
+    assert worst < 1e-11
