@@ -159,7 +159,8 @@ template <int D, int KIND>
 __device__ __forceinline__ double component_value(double maha, cdouble *c, double &expo)
 {
     if constexpr (KIND == PMC_KIND_GAUSS) {
-        return c[0] - 0.5 * maha;                       // gauss.pyx:151
+        return fma(-0.5, maha, c[0]);                   // gauss.pyx:151  c0 - 0.5 maha: the halving is exact, so
+                                                        // one fused instruction rounds exactly as the two do
     } else if constexpr (KIND == PMC_KIND_STUDENT_T) {
         double t = maha;                                  // student_t.pyx:159-164
         t *= c[2];
@@ -170,7 +171,7 @@ __device__ __forceinline__ double component_value(double maha, cdouble *c, doubl
         return t;
     } else {
         expo = c[0] + c[1] * maha;                        // variational.pyx:798
-        return c[2] + 0.5 * (c[3] - expo);                // variational.pyx:691
+        return fma(0.5, c[3] - expo, c[2]);               // variational.pyx:691  (exact halving: same bits, one instruction)
     }
 }
 
