@@ -94,17 +94,18 @@ int main(int argc, char **argv)
     // one call (at D = 4 one fused kernel: pmc_estep_is_fused() says d_u could be NULL)
     PMC_OK_(pmc_estep(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, PMC_RESP_PMC_RB, 0, d_w, nullptr, d_u, nullptr, nullptr,
                       d_stats + 8, d_stats, d_ws, stream));
-    // the same iteration evaluating the proposal ONCE: the weighting pass keeps the component log-densities, the
+    // the same iteration evaluating the proposal ONCE: the weighting pass keeps the Mahalanobis forms, the
     // update forms rho from them (no Mahalanobis forms) -- N_k must come out the same to rounding (at D = 4 the
     // call above is the one-kernel E-step, whose sums are ordered differently; from D = 8 on: bit for bit)
     double *d_tiles, *d_w2, *d_stats2, *d_scalars2;
-    HIP_OK(hipMalloc(&d_tiles, sizeof(double) * pmc_logpdf_tiles_size(N, K)));
+    HIP_OK(hipMalloc(&d_tiles, sizeof(double) * pmc_maha_tiles_size(N, K)));
     HIP_OK(hipMalloc(&d_w2, sizeof(double) * N));
     HIP_OK(hipMalloc(&d_stats2, sizeof(double) * nstats));
     HIP_OK(hipMalloc(&d_scalars2, sizeof(double) * 8));
     PMC_OK_(pmc_importance_weights_keep(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, d_tpack, K, PMC_KIND_GAUSS, nullptr,
                                         nullptr, d_w2, nullptr, d_scalars2, d_ws, d_tiles, stream));
-    PMC_OK_(pmc_estep_from_tiles(d_x, N, D, d_pack, K, 0, d_w2, d_tiles, K, d_u, d_stats2 + 8, d_stats2, d_ws, stream));
+    PMC_OK_(pmc_estep_from_tiles(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, 0, d_w2, d_tiles, K, d_u, nullptr, d_stats2 + 8,
+                                 d_stats2, d_ws, stream));
     HIP_OK(hipStreamSynchronize(stream));
     pmc_timing timings[8];
     int ntimings = 0;

@@ -268,29 +268,32 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
  * The reference evaluates the proposal's component densities on the same samples twice per PMC iteration:
  * for the importance weights (pypmc/sampler/importance_sampling.py:197-215 through
  * pypmc/density/mixture.pyx:112-156) and again inside the update (pypmc/mix_adapt/pmc.pyx:23-43,
- * calculate_rho_rb).  The *_keep variants of the two weighting calls are the calls above with one more
- * output: d_logpdf_tiles (pmc_logpdf_tiles_size(N, K) doubles, or NULL) receives the component log-densities
- * a_nk of the FIRST mixture (the proposal) in the library's tile-major layout, column = position in d_pack.
+ * calculate_rho_rb; student_t_pmc also needs the Mahalanobis forms themselves, pmc.pyx:602-610).
+ * The *_keep variants of the two weighting calls are the calls above with one more output: d_maha_tiles
+ * (pmc_maha_tiles_size(N, K) doubles, or NULL) receives the Mahalanobis forms maha_nk of the FIRST mixture
+ * (the proposal) in the library's tile-major layout, column = position in d_pack.
  *
- * pmc_estep_from_tiles is then the Rao-Blackwellised Gaussian PMC E-step (pmc_estep with kind GAUSS, mode
- * PMC_RB) of the SAME samples in the SAME order, with rho formed from the kept values instead of new
- * Mahalanobis forms: d_pack describes the components to update (any subset of the proposal's, its `column`
- * entries naming their positions in the kept tiles, K_tiles = the proposal's component count) and must hold
- * the parameters the tiles were made with.  Results equal pmc_estep's bit for bit.  d_u (K*ceil(N/64)*64
- * doubles) is required; d_stats, d_scalars, d_workspace as for pmc_estep.
+ * pmc_estep_from_tiles is then the Rao-Blackwellised PMC E-step (pmc_estep with kind GAUSS or STUDENT_T, mode
+ * PMC_RB) of the SAME samples in the SAME order, with a_nk, rho [gamma and the dof sums] formed from the kept
+ * values instead of new quadratic forms: d_pack describes the components to update (any subset of the
+ * proposal's, its `column` entries naming their positions in the kept tiles, K_tiles = the proposal's
+ * component count) and must hold the parameters the tiles were made with.  Results equal pmc_estep's
+ * two-kernel path bit for bit.  d_u (K*ceil(N/64)*64 doubles) is required, d_vsums (2 K) for Student-t;
+ * d_stats, d_scalars, d_workspace as for pmc_estep.
  */
-int64_t pmc_logpdf_tiles_size(int64_t N, int K);
+int64_t pmc_maha_tiles_size(int64_t N, int K);
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                             int max_init_zero, double *d_out, double *d_individual, int64_t ld,
                             const double *d_log_target, double *d_weights, const double *d_sample_w,
-                            double *d_scalars, void *d_workspace, double *d_logpdf_tiles, void *stream);
+                            double *d_scalars, void *d_workspace, double *d_maha_tiles, void *stream);
 int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                                 const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                 double *d_log_target_out, double *d_weights, const double *d_sample_w,
-                                double *d_scalars, void *d_workspace, double *d_logpdf_tiles, void *stream);
-int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pack, int K, int max_init_zero,
-                         const double *d_sample_w, const double *d_logpdf_tiles, int K_tiles, double *d_u,
-                         double *d_stats, double *d_scalars, void *d_workspace, void *stream);
+                                double *d_scalars, void *d_workspace, double *d_maha_tiles, void *stream);
+int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                         int max_init_zero, const double *d_sample_w, const double *d_maha_tiles, int K_tiles,
+                         double *d_u, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
+                         void *stream);
 
 /* ---- kernel timing ----------------------------------------------------------------------------- */
 /*

@@ -68,12 +68,13 @@ SIGNATURES = {
     "pmc_get_timings": (_int, [_vp, _int, C.POINTER(C.c_int)]),
     "pmc_estep_is_fused": (_int, [_int, _int, _int, _int]),
     "pmc_estep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "pmc_logpdf_tiles_size": (_i64, [_i64, _int]),
+    "pmc_maha_tiles_size": (_i64, [_i64, _int]),
     "pmc_mixture_logpdf_keep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp]),
     "pmc_importance_weights_keep": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp]),
-    "pmc_estep_from_tiles": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_estep_from_tiles": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
+                                    _vp]),
 }
 
 

@@ -48,22 +48,20 @@ class ComponentSet(object):
         assert self.ld > int(self.column.max())
 
 
-class LogpdfTiles(object):
-    """Component log-densities a_nk a weighting pass kept on the device (library tile-major layout), together
-    with what they belong to: the sample count and the ComponentSet -- i.e. the parameter state -- they were
-    evaluated with.  ``gaussian_pmc(..., component_logpdf=tiles)`` uses them only for that very mixture."""
+class MahaTiles(object):
+    """Mahalanobis forms maha_nk a weighting pass kept on the device (library tile-major layout), together with
+    what they belong to: the sample count and the ComponentSet -- i.e. the parameter state -- they were evaluated
+    with.  ``gaussian_pmc / student_t_pmc(..., mahalanobis=tiles)`` use them only for that very mixture."""
 
     def __init__(self, data, N, comps):
         self.data, self.N, self.K, self.comps = data, int(N), int(comps.K), comps
 
     def matches(self, comps_full):
-        """True if ``comps_full`` (complete mixture) has the parameters these values were computed with
-        (the weights do not enter a_nk)."""
+        """True if ``comps_full`` (complete mixture) has the means and precisions these values were computed
+        with (the weights and the normalisations do not enter maha_nk)."""
         c = self.comps
-        return comps_full is c or (comps_full.kind == c.kind and comps_full.K == c.K and
-                                   np.array_equal(comps_full.mu, c.mu) and
-                                   np.array_equal(comps_full.precision, c.precision) and
-                                   np.array_equal(comps_full.c0, c.c0))
+        return comps_full is c or (comps_full.K == c.K and np.array_equal(comps_full.mu, c.mu) and
+                                   np.array_equal(comps_full.precision, c.precision))
 
 
 def _dptr(a):
@@ -234,11 +232,11 @@ class HipBackend(object):
         return dict(out=out, individual=individual, weights=weights, scalars=scalars, tiles=tiles)
 
     def _new_tiles(self, N, comps):
-        """Buffer for the component log-densities a kept weighting pass leaves behind (see LogpdfTiles)."""
+        """Buffer for the Mahalanobis forms a kept weighting pass leaves behind (see MahaTiles)."""
         assert comps.ld == comps.K and bool((comps.column == np.arange(comps.K)).all()), \
-            "component log-densities are kept for complete mixtures only"
-        n = int(self.lib.pmc_logpdf_tiles_size(N, comps.K))
-        return LogpdfTiles(self.empty(max(n, 1)), N, comps)
+            "Mahalanobis forms are kept for complete mixtures only"
+        n = int(self.lib.pmc_maha_tiles_size(N, comps.K))
+        return MahaTiles(self.empty(max(n, 1)), N, comps)
 
     def importance_weights(self, x, comps, target, sample_w=None, want_out=False, want_log_target=False,
                            pack=None, target_pack=None, keep=False):
@@ -377,13 +375,14 @@ class HipBackend(object):
         return dict(stats=flat, r=r, log_rho=log_rho, exponent=expo)
 
     def estep_from_tiles(self, x, comps, tiles, max_init_zero=False, sample_w=None, out=None):
-        """pmc_estep_from_tiles: the Rao-Blackwellised Gaussian PMC E-step of the samples ``tiles`` were made on,
-        rho from the kept component log-densities instead of new Mahalanobis forms.  ``comps`` may be a subset
-        of the mixture behind ``tiles`` (its columns name the positions).  Same return value as ``estep``."""
+        """pmc_estep_from_tiles: the Rao-Blackwellised PMC E-step (Gauss or Student-t) of the samples ``tiles``
+        were made on, a_nk / rho / gamma from the kept Mahalanobis forms instead of new quadratic forms.
+        ``comps`` may be a subset of the mixture behind ``tiles`` (its columns name the positions).  Same
+        return value as ``estep``."""
         x = self.asdevice(x)
         N, D = x.shape
-        assert comps.kind == PMC_KIND_GAUSS and D == comps.D
-        assert tiles.N == N and comps.ld == tiles.K, "kept log-densities belong to another sample set / mixture"
+        assert comps.kind in (PMC_KIND_GAUSS, PMC_KIND_STUDENT_T) and D == comps.D
+        assert tiles.N == N and comps.ld == tiles.K, "kept Mahalanobis forms belong to another sample set / mixture"
         K = comps.K
         pack = self.pack(comps)
         sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
@@ -391,11 +390,13 @@ class HipBackend(object):
         nflat = NSCALARS + K * ps + 2 * K
         flat = out if out is not None else self.zeros(nflat)
         assert flat.numel() == nflat
+        vsums = flat[NSCALARS + K * ps:] if comps.kind == PMC_KIND_STUDENT_T else None
         _lib.check(self._timed(
             "pmc_estep_from_tiles", self.lib.pmc_estep_from_tiles,
-            self._p(x), N, D, self._p(pack), K, int(bool(max_init_zero)), self._p(sw), self._p(tiles.data), tiles.K,
-            self._p(self._tilebuf("u", N, K)), self._p(flat[NSCALARS:]), self._p(flat),
-            self._p(self._workspace(N, K, D)), self._stream()), "pmc_estep_from_tiles")
+            self._p(x), N, D, self._p(pack), K, comps.kind, int(bool(max_init_zero)), self._p(sw),
+            self._p(tiles.data), tiles.K, self._p(self._tilebuf("u", N, K)), self._p(vsums),
+            self._p(flat[NSCALARS:]), self._p(flat), self._p(self._workspace(N, K, D)), self._stream()),
+            "pmc_estep_from_tiles")
         return dict(stats=flat, r=None, log_rho=None, exponent=None)
 
     def weighted_moments(self, x, w):

@@ -23,7 +23,7 @@
     extern "C" hipError_t pmc_launch_propose_d##d##_p##p(const PmcArgsP &, unsigned, hipStream_t);         \
     extern "C" hipError_t pmc_launch_fused_d##d##_p##p(int, int, const PmcArgsF &, unsigned, hipStream_t); \
     extern "C" int pmc_fused_lds_bytes_d##d##_p##p(int, int);
-extern "C" hipError_t pmc_launch_resp_tiles(const PmcArgsT &, unsigned, hipStream_t);
+extern "C" hipError_t pmc_launch_resp_tiles(int, const PmcArgsT &, unsigned, hipStream_t);
 #define PMC_DECL_X(d) PMC_DECL_UNIT(d, 0)
 #define PMC_DECL_XP(d) PMC_DECL_UNIT(d, 0) PMC_DECL_UNIT(d, 1)
 PMC_DIM_LIST(PMC_DECL_X, PMC_DECL_XP)
@@ -588,7 +588,7 @@ static int finish_scalars(const double *partials, long long nblocks, double *d_s
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                             int max_init_zero, double *d_out, double *d_individual, int64_t ld,
                             const double *d_log_target, double *d_weights, const double *d_sample_w,
-                            double *d_scalars, void *d_workspace, double *d_logpdf_tiles, void *stream)
+                            double *d_scalars, void *d_workspace, double *d_maha_tiles, void *stream)
 {
     if (N < 0 || K < 1 || !d_pack) return fail(PMC_EINVAL, "pmc_mixture_logpdf: bad N/K/pack");
     if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T)
@@ -606,10 +606,10 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         std::memset(&a, 0, sizeof(a));
         a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
         a.ld = ld; a.out = d_out; a.individual = d_individual; a.log_target = d_log_target;
-        a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_logpdf_tiles;
+        a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_maha_tiles;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K, D),
-                8.0 * N * (D + 1 + (d_individual ? K : 0) + (d_logpdf_tiles ? K : 0)));
+                8.0 * N * (D + 1 + (d_individual ? K : 0) + (d_maha_tiles ? K : 0)));
         hipError_t e = ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
@@ -629,7 +629,7 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
 int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                                 const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                 double *d_log_target_out, double *d_weights, const double *d_sample_w,
-                                double *d_scalars, void *d_workspace, double *d_logpdf_tiles, void *stream)
+                                double *d_scalars, void *d_workspace, double *d_maha_tiles, void *stream)
 {
     if (N < 0 || K < 1 || K_target < 1 || !d_pack || !d_target_pack)
         return fail(PMC_EINVAL, "pmc_importance_weights: bad N/K/pack");
@@ -647,9 +647,9 @@ int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const doubl
         std::memset(&a, 0, sizeof(a));
         a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.ld = K;
         a.pack2 = d_target_pack; a.K2 = K_target; a.log_target_out = d_log_target_out;
-        a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_logpdf_tiles;
+        a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_maha_tiles;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
-        Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D), 8.0 * N * (D + 1 + (d_logpdf_tiles ? K : 0)));
+        Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D), 8.0 * N * (D + 1 + (d_maha_tiles ? K : 0)));
         hipError_t e = ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
@@ -666,7 +666,7 @@ int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_
                                        d_log_target_out, d_weights, d_sample_w, d_scalars, d_workspace, nullptr, stream);
 }
 
-int64_t pmc_logpdf_tiles_size(int64_t N, int K)
+int64_t pmc_maha_tiles_size(int64_t N, int K)
 {
     if (N < 0 || K < 1) return 0;
     return (int64_t)ceil_div(N, PMC_TILE) * K * PMC_TILE;
@@ -933,31 +933,44 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     return finish_scalars(a.spartials, g.grid, d_scalars, st);
 }
 
-int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pack, int K, int max_init_zero,
-                         const double *d_sample_w, const double *d_logpdf_tiles, int K_tiles, double *d_u,
-                         double *d_stats, double *d_scalars, void *d_workspace, void *stream)
+int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                         int max_init_zero, const double *d_sample_w, const double *d_maha_tiles, int K_tiles,
+                         double *d_u, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
+                         void *stream)
 {
     if (N < 0 || K < 1 || K_tiles < 1 || !d_pack || !d_stats || !d_scalars || !d_workspace)
         return fail(PMC_EINVAL, "pmc_estep_from_tiles: bad N/K/pack/stats/scalars/workspace");
+    if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T)
+        return fail(PMC_EINVAL, "pmc_estep_from_tiles: kind must be GAUSS or STUDENT_T (got %d)", kind);
+    if (kind == PMC_KIND_STUDENT_T && !d_vsums) return fail(PMC_EINVAL, "pmc_estep_from_tiles: Student-t needs d_vsums");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
         hipError_t e0 = hipMemsetAsync(d_stats, 0, sizeof(double) * (size_t)K * pmc_stats_stride_c(D), st);
+        if (e0 == hipSuccess && d_vsums) e0 = hipMemsetAsync(d_vsums, 0, sizeof(double) * 2 * (size_t)K, st);
         if (e0 != hipSuccess) return hipfail(e0, "hipMemsetAsync");
         return finish_scalars((const double *)d_workspace, 0, d_scalars, st);
     }
-    if (!d_x || !d_logpdf_tiles || !d_u) return fail(PMC_EINVAL, "pmc_estep_from_tiles: d_x / d_logpdf_tiles / d_u is NULL");
-    const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    if (!d_x || !d_maha_tiles || !d_u) return fail(PMC_EINVAL, "pmc_estep_from_tiles: d_x / d_maha_tiles / d_u is NULL");
+    const long long ntiles = ceil_div(N, PMC_TILE), nblocks = ceil_div(ntiles, PMC_A_WAVES);
+    double *vpartials = (double *)((char *)d_workspace + scalar_partials_bytes(N));
     PmcArgsT a;
     std::memset(&a, 0, sizeof(a));
-    a.atile = d_logpdf_tiles; a.N = N; a.ld = K_tiles; a.pack = d_pack; a.K = K;
-    a.stride = pmc_pack_stride_c(ks->dim); a.woff = ks->dim + pmc_tri(ks->dim) + 4;
-    a.max_init_zero = max_init_zero; a.sample_w = d_sample_w; a.u = d_u; a.partials = (double *)d_workspace;
+    a.mtile = d_maha_tiles; a.N = N; a.ld = K_tiles; a.dreal = D; a.pack = d_pack; a.K = K;
+    a.stride = pmc_pack_stride_c(ks->dim); a.coff = ks->dim + pmc_tri(ks->dim);
+    a.max_init_zero = max_init_zero; a.sample_w = d_sample_w; a.u = d_u;
+    a.vpartials = kind == PMC_KIND_STUDENT_T ? vpartials : nullptr; a.partials = (double *)d_workspace;
     {
-        Timed t(T_RESP, st, 40.0 * (double)N * K, 8.0 * N * 3 * K);
-        hipError_t e = pmc_launch_resp_tiles(a, (unsigned)nblocks, st);
+        Timed t(T_RESP, st, 50.0 * (double)N * K, 8.0 * N * 4 * K);
+        hipError_t e = pmc_launch_resp_tiles(kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_resp_tiles launch");
+    }
+    if (kind == PMC_KIND_STUDENT_T) {
+        hipLaunchKernelGGL(k_finish_vsums, dim3((unsigned)(2 * K)), dim3(256), 0, st, (const double *)vpartials,
+                           ntiles, K, d_vsums);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hipfail(e, "k_finish_vsums launch");
     }
     int rc = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
     if (rc != PMC_OK) return rc;

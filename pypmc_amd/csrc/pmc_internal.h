@@ -87,7 +87,7 @@ struct PmcArgsA {
     double *weights;
     const double *sample_w;
     const long long *latent;
-    double *atile;        // k_logpdf: tile-major a_nk of the FIRST mixture, kept for pmc_estep_from_tiles (or NULL)
+    double *atile;        // k_logpdf: tile-major maha_nk of the FIRST mixture, kept for pmc_estep_from_tiles (or NULL)
     double *u;            // tile-major responsibilities (output)
     double *scratch;      // tile-major scratch (Student-t: maha between the two passes)
     double *vpartials;    // Student-t: ntiles * K * 2 per-wavefront sums of v1, v2
@@ -95,18 +95,20 @@ struct PmcArgsA {
     double *partials;     // gridDim.x * PMC_NSCALARS
 };
 
-// responsibilities from kept component log-densities (pmc_tiles.hip, one unit for all dimensions)
+// responsibilities from kept Mahalanobis forms (pmc_tiles.hip, one unit for all dimensions)
 struct PmcArgsT {
-    const double *atile;  // ntiles x ld x 64: a_nk as k_logpdf kept them, column = position in ITS pack
+    const double *mtile;  // ntiles x ld x 64: maha_nk as k_logpdf kept them, column = position in ITS pack
     long long N;
     int ld;               // components of the mixture the tiles were made with
-    const double *pack;   // this call's components: weight and column are read at woff / woff + 1
+    int dreal;            // sample dimension (Student-t: gamma = (nu + D) / (nu + maha))
+    const double *pack;   // this call's components
     int K;
     int stride;           // doubles per component in the pack
-    int woff;             // offset of the weight in a component's block (the column follows it)
+    int coff;             // offset of c0..c3 | weight | column in a component's block
     int max_init_zero;
     const double *sample_w;
     double *u;            // ntiles x K x 64, tile-major (output)
+    double *vpartials;    // Student-t: ntiles x K x 2 per-wavefront sums (or NULL)
     double *partials;     // gridDim.x * PMC_NSCALARS (or NULL)
 };
 

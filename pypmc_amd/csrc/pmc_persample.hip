@@ -371,6 +371,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
     // importance weights (kind KIND2), evaluated on the same registers: the samples are read once
     const ExpConst EC;
     double poison = 0.0;                                 // NaN if the row has a NaN / infinite coordinate (lse_step)
+    const bool keep_tile = a.atile != nullptr && ((n >> 6) << 6) < a.N;     // (the buffer ends with the last live tile)
     auto mixture = [&](auto kind, const double *gpack, const int K, const bool first) -> double {
         constexpr int KD = decltype(kind)::value;
         double m = (first && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
@@ -384,8 +385,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
                 const long long col = ((cint64 *)pk)[D + T + 5];
                 if (valid) a.individual[n * a.ld + col] = v;
             }
-            if (first && a.atile != nullptr)             // wave-uniform: keep a_nk for the PMC update of these samples
-                a.atile[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = v;
+            if (first && keep_tile)                      // wave-uniform: keep maha_nk for the PMC update of these samples
+                a.atile[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = maha;
             lse_step(v, pk[D + T + 4], m, s, EC);
             poison = fma(0.0, v, poison);
         }

@@ -1,20 +1,23 @@
-// pmc_tiles.hip -- Rao-Blackwellised PMC responsibilities from KEPT component log-densities.
+// pmc_tiles.hip -- Rao-Blackwellised PMC responsibilities from KEPT Mahalanobis forms.
 //
 // A PMC iteration evaluates the proposal's component densities twice on the same samples: once for the
 // importance weights (importance_sampling.py:197-215 through mixture.pyx:112-156) and once more inside the
-// update (pmc.pyx:23-43 calculate_rho_rb evaluates every component again).  k_logpdf can keep its a_nk
-// tile-major (PmcArgsA::atile); this kernel then forms rho without touching x or the Mahalanobis forms:
-// 8 K bytes per sample read twice and written once instead of K (D^2 + 4 D + 40) flops -- at D = 40, K = 128
-// that is 6 ms instead of 55 per 1.25e7 samples.
+// update (pmc.pyx:23-43 calculate_rho_rb evaluates every component again; student_t_pmc additionally needs
+// the Mahalanobis form itself, pmc.pyx:602-610).  k_logpdf can keep maha_nk tile-major (PmcArgsA::atile);
+// this kernel then forms a_nk, rho [and gamma, the dof sums] without touching x or the quadratic forms:
+// 8 K bytes per sample read three times and written once instead of K (D^2 + 4 D + 40) flops -- at D = 40,
+// K = 128 that is ~10 ms instead of 55 per 1.25e7 samples.
 //
-// Same arithmetic, in the same order, as k_resp's PMC branch (pmc_persample.hip): row maximum, e = exp(a - M)
-// and s = sum w e over the components in DESCENDING order, rho = (e exp(M)) w / (exp(log s + M) + tiny) -- the
-// two paths agree bit for bit (tests/test_gpu_kernels.py::test_estep_from_kept_logpdf).
+// Same arithmetic, in the same order, as k_resp's PMC branch (pmc_persample.hip): a_nk = component_value(maha),
+// row maximum, e = exp(a - M) and s = sum w e over the components in DESCENDING order,
+// rho = (e exp(M)) w / (exp(log s + M) + tiny) -- the two paths agree bit for bit
+// (tests/test_gpu_kernels.py::test_estep_from_kept_logpdf).
 // One unit for all sample dimensions (compiled with -DPMC_D=1, which it does not use).
 #include "pmc_device.h"
 
 namespace {
 
+template <int KIND>
 __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT a)
 {
     const int lane = threadIdx.x & 63;
@@ -24,14 +27,19 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT 
     const int K = a.K;
     double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (tile * 64 < a.N) {                                           // wave-uniform
-        const double *at = a.atile + (size_t)tile * a.ld * 64 + lane;
+        const double *mt = a.mtile + (size_t)tile * a.ld * 64 + lane;
         double *ut = a.u + (size_t)tile * K * 64 + lane;
-        cdouble *pk = (cdouble *)a.pack + a.woff;
+        double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)tile * K * 2 : nullptr;
+        cdouble *pk = (cdouble *)a.pack + a.coff;                    // c0 c1 c2 c3 | weight | column of component 0
+        auto value = [&](int k) {
+            cdouble *c = pk + (size_t)k * a.stride;
+            double expo;
+            return component_value<1, KIND>(mt[(size_t)((cint64 *)c)[5] * 64], c, expo);
+        };
         const ExpConst EC;
         double M = a.max_init_zero ? 0.0 : -DBL_MAX, poison = 0.0;
         for (int k = 0; k < K; ++k) {
-            const long long col = ((cint64 *)(pk + (size_t)k * a.stride))[1];
-            const double v = at[(size_t)col * 64];
+            const double v = value(k);
             M = max_f64(v, M);
             poison = fma(0.0, v, poison);
         }
@@ -39,20 +47,33 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT 
         const double swv = valid ? sw + poison : 0.0;
         double s = 0.0;
         for (int k = K - 1; k >= 0; --k) {
-            cdouble *c = pk + (size_t)k * a.stride;
-            const double v = at[(size_t)((cint64 *)c)[1] * 64];
-            const double lr = max_f64(v - M, -1075.0);
+            const double lr = max_f64(value(k) - M, -1075.0);
             const double e = exp_clamped(lr, EC);
-            s += c[0] * e;                                           // _regularize.pyx:79
+            s += pk[(size_t)k * a.stride + 4] * e;                   // _regularize.pyx:79
             ut[(size_t)k * 64] = e;
         }
         const double lse = log(s) + M;                               // _regularize.pyx:81
         const double denom = exp(lse) + TINY;                        // pmc.pyx:41
         const double em = exp(M);
         for (int k = K - 1; k >= 0; --k) {
-            double rho = (ut[(size_t)k * 64] * em) * pk[(size_t)k * a.stride];
+            cdouble *c = pk + (size_t)k * a.stride;
+            double rho = (ut[(size_t)k * 64] * em) * c[4];
             rho /= denom;
-            ut[(size_t)k * 64] = swv * rho;
+            const double wr = swv * rho;
+            if constexpr (KIND == PMC_KIND_STUDENT_T) {
+                const double maha = mt[(size_t)((cint64 *)c)[5] * 64];
+                const double nu = c[3];
+                const double gamma = (nu + (double)a.dreal) / (nu + maha);   // pmc.pyx:610
+                ut[(size_t)k * 64] = wr * gamma;
+                const double s1 = wave_sum(wr);                              // pmc.pyx:612 / :669, as in k_resp
+                const double s2 = wave_sum(wr * log(.5 * (maha + nu)));
+                if (lane == 0) {
+                    vp[2 * k] = s1;
+                    vp[2 * k + 1] = s2;
+                }
+            } else {
+                ut[(size_t)k * 64] = wr;
+            }
         }
         sc[3] = swv * lse;                                           // pmc.pyx:388-391
     }
@@ -61,8 +82,13 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT 
 
 }  // namespace
 
-extern "C" hipError_t pmc_launch_resp_tiles(const PmcArgsT &a, unsigned grid, hipStream_t st)
+extern "C" hipError_t pmc_launch_resp_tiles(int kind, const PmcArgsT &a, unsigned grid, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_resp_tiles, dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    if (kind == PMC_KIND_GAUSS)
+        hipLaunchKernelGGL(k_resp_tiles<PMC_KIND_GAUSS>, dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    else if (kind == PMC_KIND_STUDENT_T)
+        hipLaunchKernelGGL(k_resp_tiles<PMC_KIND_STUDENT_T>, dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@ from scipy.optimize import brentq
 from scipy.special import digamma
 
 from .. import parallel
-from .._lib import PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT, PMC_KIND_GAUSS
+from .._lib import PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT
 from ..backend import get_backend
 from ..density.gauss import Gauss
 from ..density.student_t import StudentT
@@ -28,7 +28,7 @@ from ..tools._linalg import single_threaded_blas, chol_inv_det_batch
 logger = logging.getLogger(__name__)
 
 
-def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, component_logpdf=None):
+def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis=None):
     """Argument checks, live-component bookkeeping and the device pass
     (reference: pmc.pyx:53-118).  Returns density, live_components (after ``mincount`` pruning),
     the indices the statistics were computed for, the host statistics, the weight normalisation
@@ -81,12 +81,12 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
             raise TypeError('``density`` must have only Gauss or only StudentT components')
         mode = PMC_RESP_PMC_RB if rb else PMC_RESP_PMC_LATENT
         # dead components' all-zero columns take part in the row maximum (pmc.pyx:24-34)
-        if component_logpdf is not None and rb and cs.kind == PMC_KIND_GAUSS:
-            # the weighting pass kept log q_k(x_n) of these very samples: rho without a second evaluation
+        if mahalanobis is not None and rb:
+            # the weighting pass kept maha_nk of these very samples: rho without a second evaluation
             full = component_set(density.components, density.weights)
-            if component_logpdf.N != N_local or not component_logpdf.matches(full):
-                raise ValueError('``component_logpdf`` was not computed with this density on these samples')
-            res = be.estep_from_tiles(samples, cs, component_logpdf, max_init_zero=len(live_components) < K,
+            if mahalanobis.N != N_local or not mahalanobis.matches(full):
+                raise ValueError('``mahalanobis`` was not computed with this density on these samples')
+            res = be.estep_from_tiles(samples, cs, mahalanobis, max_init_zero=len(live_components) < K,
                                       sample_w=weights)
         else:
             res = be.estep(samples, cs, mode, max_init_zero=len(live_components) < K,
@@ -197,18 +197,18 @@ def _apply_updates(density, live_components, new_params, need_renormalize):
 
 
 def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=0, copy=True,
-                 backend=None, component_logpdf=None):
+                 backend=None, mahalanobis=None):
     """Adapt a Gaussian mixture ``density`` to the (weighted) ``samples`` it proposed
     (reference: pmc.pyx:120-246, same signature and semantics).
 
-    ``component_logpdf`` (extension): what ``ImportanceSampler.run_device(..., keep_component_logpdf=True)``
-    returned for these samples -- the Rao-Blackwellised update then reuses the component log-densities of the
-    weighting pass instead of evaluating the proposal a second time, as the reference does (pmc.pyx:23-43)."""
+    ``mahalanobis`` (extension): what ``ImportanceSampler.run_device(..., keep_mahalanobis=True)`` returned for
+    these samples -- the Rao-Blackwellised update then reuses the Mahalanobis forms of the weighting pass
+    instead of evaluating the proposal a second time, as the reference does (pmc.pyx:23-43)."""
     assert samples is not None
     if isinstance(samples, np.ndarray):          # device-resident tensors pass through untouched
         samples = np.ascontiguousarray(samples, dtype=np.float64)
     density, live, stat_comps, stats, norm, renorm = \
-        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, component_logpdf)
+        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis)
     _, S0, M1, M2, _, _ = stats
     if stat_comps:
         shift = np.array([density.components[k].mu for k in stat_comps])
@@ -228,15 +228,15 @@ def _dof_condition(const):
 
 
 def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solver_steps=100,
-                  mindof=1e-5, maxdof=1e3, mincount=0, copy=True, backend=None):
+                  mindof=1e-5, maxdof=1e3, mincount=0, copy=True, backend=None, mahalanobis=None):
     """Adapt a Student-t mixture ``density`` (means, covariances and -- unless
     ``dof_solver_steps`` is 0 -- degrees of freedom) to the (weighted) ``samples`` it proposed
-    (reference: pmc.pyx:499-739, same signature and semantics)."""
+    (reference: pmc.pyx:499-739, same signature and semantics; ``mahalanobis``: see ``gaussian_pmc``)."""
     assert samples is not None
     if isinstance(samples, np.ndarray):
         samples = np.ascontiguousarray(samples, dtype=np.float64)
     density, live, stat_comps, stats, norm, renorm = \
-        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend)
+        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis)
     _, S0g, M1, M2, V1, V2 = stats        # S0g = sum w rho gamma, V1 = sum w rho
     D = density.dim
     new = {}

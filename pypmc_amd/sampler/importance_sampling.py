@@ -112,16 +112,16 @@ class ImportanceSampler(object):
         this_samples = self._get_samples(N, trace_sort=False)
         self._calculate_weights(this_samples, N)
 
-    def run_device(self, N, trace_sort=False, target_density=None, store=False, keep_component_logpdf=False):
+    def run_device(self, N, trace_sort=False, target_density=None, store=False, keep_mahalanobis=False):
         """Extension for device-resident loops (BASELINE config 5): propose N samples ON THE GPU,
         weight them there and return ``dict(samples, weights, origin, weight_sums)`` of device
         tensors.  With a mixture target (``target_density``, default: the object whose ``evaluate``
         was given as ``target``) nothing N-sized crosses PCIe; any other target is called on a host
         copy of the samples and only its N log-values are uploaded.  ``store=True`` (needs
         ``device=True`` at construction) generates into / records in the DeviceHistory objects.
-        ``keep_component_logpdf=True`` additionally returns ``component_logpdf``: the proposal's component
-        log-densities on these samples, kept on the device for ``gaussian_pmc(..., component_logpdf=...)``
-        (8 K bytes per sample)."""
+        ``keep_mahalanobis=True`` additionally returns ``mahalanobis``: the Mahalanobis forms of the samples
+        under the proposal's components, kept on the device for ``gaussian_pmc / student_t_pmc(...,
+        mahalanobis=...)`` (8 K bytes per sample)."""
         from ..density.mixture import MixtureDensity, component_set
         be = get_backend(self._backend)
         if store and not self.device:
@@ -138,12 +138,12 @@ class ImportanceSampler(object):
             # mixture target: log P, log q, the weights and the perplexity sums in one pass over x
             res = be.importance_weights(x, prop_set, component_set(tgt.components, tgt.weights),
                                         want_log_target=store and self.target_values is not None,
-                                        keep=keep_component_logpdf)
+                                        keep=keep_mahalanobis)
             log_target = res["log_target"]
         else:
             log_target = be.asdevice(self._target_values(be.tohost(x), N))
             res = be.logpdf(x, prop_set, want_out=False, log_target=log_target, want_scalars=True,
-                            keep=keep_component_logpdf)
+                            keep=keep_mahalanobis)
         sc = be.tohost(res["scalars"])
         if sc[4] > 0:
             raise OverflowError('math range error')
@@ -153,7 +153,7 @@ class ImportanceSampler(object):
             if self.target_values is not None:
                 self.target_values.append(N)[:, 0] = log_target
         return dict(samples=x, weights=res["weights"], origin=origin, weight_sums=self.last_weight_sums,
-                    component_logpdf=res.get("tiles"))
+                    mahalanobis=res.get("tiles"))
 
     def _get_samples(self, N, trace_sort):
         this_run = self.samples.append(N)

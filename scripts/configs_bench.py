@@ -137,16 +137,16 @@ def main():
     # the same loop with the update reusing the component log-densities the weighting pass kept
     def iteration_reuse():
         t0 = time.perf_counter()
-        run = sampler.run_device(N, trace_sort=True, keep_component_logpdf=True)
+        run = sampler.run_device(N, trace_sort=True, keep_mahalanobis=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"], mincount=0, rb=True,
-                     copy=False, component_logpdf=run["component_logpdf"])
+                     copy=False, mahalanobis=run["mahalanobis"])
         torch.cuda.synchronize()
         info["propose_weight_s"], info["update_s"] = t1 - t0, time.perf_counter() - t1
         info["perplexity"] = perp_from_sums(run["weight_sums"][0], run["weight_sums"][1], N)
     t = timed(iteration_reuse, 3)
-    out["cfg5_pmc_loop_D40_K128_N1.25e7_per_iteration_reusing_component_logpdf"] = \
+    out["cfg5_pmc_loop_D40_K128_N1.25e7_per_iteration_reusing_mahalanobis"] = \
         dict(iteration_s=t, samples_per_s=N / t, **info)
 
     text = json.dumps(out, indent=1)

@@ -225,7 +225,7 @@ def test_cfg5_full_loop_1p25e7_per_gpu(be, orc):
     for it in range(2):
         old = sampler.proposal
         old_set = component_set(old.components, old.weights)
-        run = sampler.run_device(N, trace_sort=True, keep_component_logpdf=it == 1)
+        run = sampler.run_device(N, trace_sort=True, keep_mahalanobis=it == 1)
         x, wts, origin = run["samples"], run["weights"], run["origin"]
         assert tuple(x.shape) == (N, D) and tuple(wts.shape) == (N,) and tuple(origin.shape) == (N,)
         # counts / origins: exactly the host generator's multinomial draw, ordered by component
@@ -256,7 +256,7 @@ def test_cfg5_full_loop_1p25e7_per_gpu(be, orc):
             # here) -- and gives, bit for bit, what the update that evaluates the proposal again gives
             twice = pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=True)
             pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=False,
-                                             component_logpdf=run["component_logpdf"])
+                                             mahalanobis=run["mahalanobis"])
             np.testing.assert_array_equal(sampler.proposal.weights, twice.weights)
             for a_, b_ in zip(sampler.proposal.components, twice.components):
                 np.testing.assert_array_equal(a_.mu, b_.mu)

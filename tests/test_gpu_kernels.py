@@ -344,43 +344,57 @@ def test_estep_nan_sample_poisons_the_statistics(be, orc, D, K):
 @pytest.mark.parametrize("D,K,N", [(2, 3, 1000), (5, 9, 257), (8, 17, 4097), (20, 32, 3000), (32, 5, 640), (40, 40, 1500),
                                    (13, 7, 1), (3, 33, 65)])
 def test_estep_from_kept_logpdf(be, orc, D, K, N):
-    """pmc_mixture_logpdf_keep / pmc_importance_weights_keep leave the proposal's a_nk on the device;
-    pmc_estep_from_tiles turns them into the Rao-Blackwellised PMC statistics -- bit for bit what the two
-    kernels compute from the samples (same arithmetic in the same order), for the whole mixture and for a
-    live subset with dead components in the row maximum; the weighting pass itself is unchanged."""
+    """pmc_mixture_logpdf_keep / pmc_importance_weights_keep leave the proposal's Mahalanobis forms on the
+    device; pmc_estep_from_tiles turns them into the Rao-Blackwellised PMC statistics -- bit for bit what the
+    two kernels compute from the samples (same arithmetic in the same order), Gauss and Student-t (gamma and
+    the dof sums included), for the whole mixture and for a live subset with dead components in the row
+    maximum; the weighting pass itself is unchanged."""
     mu, cov, w = mk(K, D, 500 + D + K)
     x, _ = draw(mu, cov, w, N, 23)
     rs = np.random.RandomState(N)
     sw = rs.uniform(0.5, 1.5, N)
-    full = gauss_set(mu, cov, w)[0]
     tmu, tcov, tw = mk(2, D, 77)
     target = gauss_set(tmu, tcov, tw)[0]
-    plain = be.importance_weights(x, full, target, want_out=True)
-    kept = be.importance_weights(x, full, target, want_out=True, keep=True)
-    for key in ("weights", "out", "scalars"):
-        np.testing.assert_array_equal(be.tohost(kept[key]), be.tohost(plain[key]))
-    tiles = kept["tiles"]
-    assert tiles.N == N and tiles.K == K and tiles.matches(full)
-    # the kept values ARE the component log-densities (oracle: 1e-10; the public matrix of the same kernel: exact)
-    ind = be.tohost(be.logpdf(x, full, want_out=False, want_individual=True)["individual"])
-    t = be.tohost(tiles.data).reshape(-1, K, 64)
-    got = np.concatenate([t[i].T for i in range(t.shape[0])])[:N]
-    np.testing.assert_array_equal(got, ind)
-    also = be.logpdf(x, full, want_out=True, keep=True)["tiles"]
-    np.testing.assert_array_equal(be.tohost(also.data)[:tiles.data.numel()], be.tohost(tiles.data))
-    two = be.tohost(be.estep(x, full, 1, sample_w=sw, want_r=True)["stats"])
-    pre = be.tohost(be.estep_from_tiles(x, full, tiles, sample_w=sw)["stats"])
-    np.testing.assert_array_equal(pre, two)
-    if K > 2:                                    # a live subset: dead components' zeros take part in the maximum
-        live = [k for k in range(K) if k % 3 != 1]
-        wl = w.copy()
-        wl[[k for k in range(K) if k % 3 == 1]] = 0.
-        sub = gauss_set(mu[live], cov[live], wl[live], columns=live, ld=K)[0]
-        two = be.tohost(be.estep(x, sub, 1, max_init_zero=True, sample_w=sw, want_r=True)["stats"])
-        pre = be.tohost(be.estep_from_tiles(x, sub, tiles, max_init_zero=True, sample_w=sw)["stats"])
+    dof = 3. + np.arange(K) % 5
+    for family in ("gauss", "student"):
+        def make(m, c, ww, **kw):
+            if family == "gauss":
+                return gauss_set(m, c, ww, **kw)[0]
+            from pypmc_amd.backend import ComponentSet
+            base = student_set(m, c, ww, kw.pop("dof"))[0]
+            return ComponentSet(1, base.mu, base.precision, base.c0, base.c1, base.c2, base.c3, weight=ww,
+                                column=kw.get("columns"), ld=kw.get("ld"))
+        full = make(mu, cov, w) if family == "gauss" else make(mu, cov, w, dof=dof)
+        plain = be.importance_weights(x, full, target, want_out=True)
+        kept = be.importance_weights(x, full, target, want_out=True, keep=True)
+        for key in ("weights", "out", "scalars"):
+            np.testing.assert_array_equal(be.tohost(kept[key]), be.tohost(plain[key]))
+        tiles = kept["tiles"]
+        assert tiles.N == N and tiles.K == K and tiles.matches(full)
+        # the kept values are the Mahalanobis forms: -2 (log q_k - log_norm_k) for the Gaussian family
+        t = be.tohost(tiles.data).reshape(-1, K, 64)
+        maha = np.concatenate([t[i].T for i in range(t.shape[0])])[:N]
+        d = x[:, None, :] - mu[None]
+        ref = np.einsum('nki,kij,nkj->nk', d, full.precision, d)
+        np.testing.assert_allclose(maha, ref, rtol=1e-10, atol=1e-12)
+        also = be.logpdf(x, full, want_out=True, keep=True)["tiles"]
+        np.testing.assert_array_equal(be.tohost(also.data)[:tiles.data.numel()], be.tohost(tiles.data))
+        two = be.tohost(be.estep(x, full, 1, sample_w=sw, want_r=True)["stats"])
+        pre = be.tohost(be.estep_from_tiles(x, full, tiles, sample_w=sw)["stats"])
         np.testing.assert_array_equal(pre, two)
-    other = gauss_set(mu + 1e-3, cov, w)[0]
-    assert not tiles.matches(other)
+        if family == "student":
+            assert np.all(pre[-2 * K:] != 0.)                       # the dof sums are there
+        if K > 2:                                    # a live subset: dead components' zeros take part in the maximum
+            live = [k for k in range(K) if k % 3 != 1]
+            wl = w.copy()
+            wl[[k for k in range(K) if k % 3 == 1]] = 0.
+            sub = make(mu[live], cov[live], wl[live], columns=live, ld=K) if family == "gauss" else \
+                make(mu[live], cov[live], wl[live], columns=live, ld=K, dof=dof[live])
+            two = be.tohost(be.estep(x, sub, 1, max_init_zero=True, sample_w=sw, want_r=True)["stats"])
+            pre = be.tohost(be.estep_from_tiles(x, sub, tiles, max_init_zero=True, sample_w=sw)["stats"])
+            np.testing.assert_array_equal(pre, two)
+        other = make(mu + 1e-3, cov, w) if family == "gauss" else make(mu + 1e-3, cov, w, dof=dof)
+        assert not tiles.matches(other)
 
 
 @pytest.mark.parametrize("tag", ["d2k3", "d5k4"])
