@@ -742,9 +742,12 @@ def test_kernel_timings_through_the_abi(be):
 
 
 @pytest.mark.parametrize("D,K,N", [(2, 300, 500), (3, 1000, 130), (5, 33, 1000), (8, 129, 300), (20, 200, 257),
-                                   (40, 130, 100), (64, 70, 65), (1, 500, 64)])
+                                   (40, 130, 100), (64, 70, 65), (1, 500, 64), (1, 33, 300), (1, 50, 1000), (1, 64, 129),
+                                   (1, 65, 200), (2, 33, 200)])
 def test_many_components(be, orc, D, K, N):
-    """K far beyond the component counts the kernels are tuned for (and beyond the fused path's 32)"""
+    """K far beyond the component counts the kernels are tuned for (and beyond the one-kernel E-step's 32;
+    at D = 1 its register form takes up to 64 components, 8 per wavefront)"""
+    assert be.lib.pmc_estep_is_fused(K, D, 0, 1) == int(D == 1 and K <= 64)
     from pypmc_amd.mix_adapt._stats import split_stats
     mu, cov, w = mk(K, D, 1200 + D)
     x, _ = draw(mu, cov, w, N, 21)
