@@ -102,6 +102,11 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True):
                 note("vb x_mean", float(np.max(np.abs(xm[live] - ref["x_mean_comp"][live]))), 1e-9, ctx)
                 note("vb S", float(np.max(np.abs(S[live] - ref["S"][live]))), 1e-8, ctx)
             note("vb elq", abs(sc[0] - ref["expectation_log_q_Z"]) / (abs(ref["expectation_log_q_Z"]) + 1e-6), 1e-9, ctx)
+            # the same E-step through pmc_estep (small D: ONE kernel, register or LDS form) against the two kernels
+            one = be.tohost(be.estep(x, vcs, 0, sample_w=sw)["stats"])
+            two = be.tohost(out["stats"])
+            note("vb one-kernel stats", float(np.max(np.abs(one - two) / (np.abs(two) + 1e-9 * np.abs(two).max() + 1e-300))),
+                 1e-9, ctx)
             # PMC Rao-Blackwell responsibilities + statistics
             iwts = rs.uniform(0.1, 2.0, N)
             out = be.estep(x, cs, 1, sample_w=iwts, want_r=True)
@@ -116,6 +121,15 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True):
             d = x[:, None, :] - mu[None, :, :]
             M2ref = np.einsum('n,nk,nki,nkj->kij', iwts, rho, d, d)
             note("pmc M2", float(np.max(np.abs(M2 - M2ref) / (np.abs(M2ref) + 1e-6 * np.abs(M2ref).max()))), 1e-8, ctx)
+            one = be.tohost(be.estep(x, cs, 1, sample_w=iwts)["stats"])
+            two = be.tohost(out["stats"])
+            note("pmc one-kernel stats", float(np.max(np.abs(one - two) / (np.abs(two) + 1e-9 * np.abs(two).max() + 1e-300))),
+                 1e-9, ctx)
+            # the evaluate-once iteration: Mahalanobis forms kept by the weighting pass -> the same statistics, bitwise
+            kept = be.importance_weights(x, cs, ComponentSet(0, tmu, tinv, c0=tln, weight=tw), keep=True)
+            assert np.array_equal(be.tohost(kept["weights"]), be.tohost(iw["weights"])), ("kept weights", ctx)
+            pre = be.tohost(be.estep_from_tiles(x, cs, kept["tiles"], sample_w=iwts)["stats"])
+            assert np.array_equal(pre, two), ("estep_from_tiles differs from the two kernels", ctx)
         if verbose:
             print("round %d ok" % rnd, flush=True)
     return worst
