@@ -252,10 +252,11 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  * sufficient statistics of the samples, d_stats as pmc_sufficient_stats and d_scalars / d_vsums as
  * pmc_responsibilities produce them -- without the public N x K matrices.
  *
- * For small sample dimensions (pmc_estep_is_fused() != 0: compiled dimension <= 7, K <= 32, VB or
- * Gaussian Rao-Blackwell PMC) ONE kernel does both and the N x K responsibilities never leave the
- * compute units: d_u and d_scratch may then be NULL.  Otherwise the call is pmc_responsibilities
- * followed by pmc_sufficient_stats through d_u (and d_scratch / d_vsums for Student-t).
+ * For small sample dimensions (pmc_estep_is_fused() != 0: compiled dimension <= 7 and K <= 32 -- K <= 64 at
+ * D = 1, K >= 9 from D = 5 on, where the two kernels are faster below -- VB or Gaussian Rao-Blackwell PMC)
+ * ONE kernel does both and the N x K responsibilities never leave the compute units: d_u and d_scratch may
+ * then be NULL.  Ask pmc_estep_is_fused(), do not re-derive the rule.  Otherwise the call is
+ * pmc_responsibilities followed by pmc_sufficient_stats through d_u (and d_scratch / d_vsums for Student-t).
  */
 int pmc_estep_is_fused(int K, int D, int kind, int mode);
 int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, int mode,
