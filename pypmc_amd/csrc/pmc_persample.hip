@@ -595,7 +595,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     // per-wavefront sums of sample_w*rho and sample_w*rho*log(.5(maha+nu)), the
                     // N-sized parts of pmc.pyx:612 (alpha) and :669 (dof condition)
                     const double s1 = wave_sum(wr);
-                    const double s2 = wave_sum(wr * log(.5 * (maha + nu)));
+                    const double s2 = wave_sum(wr * log_pos(.5 * (maha + nu)));
                     if (lane == 0) {
                         vp[2 * k] = s1;
                         vp[2 * k + 1] = s2;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT 
                 const double gamma = (nu + (double)a.dreal) / (nu + maha);   // pmc.pyx:610
                 ut[(size_t)k * 64] = wr * gamma;
                 const double s1 = wave_sum(wr);                              // pmc.pyx:612 / :669, as in k_resp
-                const double s2 = wave_sum(wr * log(.5 * (maha + nu)));
+                const double s2 = wave_sum(wr * log_pos(.5 * (maha + nu)));
                 if (lane == 0) {
                     vp[2 * k] = s1;
                     vp[2 * k + 1] = s2;
