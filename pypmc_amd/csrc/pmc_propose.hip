@@ -58,9 +58,17 @@ __device__ __forceinline__ void normal_pair(const Philox &g, unsigned long long 
     g(n, draw, r);
     double u1, u2;
     uniforms(r, u1, u2);
+#ifdef PMC_PROPOSE_LIBM
     const double rad = sqrt(-2.0 * log(u1));
     double s, c;
     sincos(6.283185307179586476925286766559 * u2, &s, &c);
+#else
+    // u1 is a positive normal number (>= 2^-53): the lean log; the angle 2 pi u2 as a multiple of pi needs no
+    // range reduction against pi at all
+    const double rad = sqrt(-2.0 * log_pos(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+#endif
     z0 = rad * c;
     z1 = rad * s;
 }
