@@ -9,7 +9,8 @@
 //     x_n = mu_k + L_k z sqrt(nu_k / c),  c ~ chi^2(nu_k)  (Student-t)
 // Random numbers: Philox4x32-10, counter = (sample index, draw index), key = seed -- stateless, so
 // the stream of a sample does not depend on the launch geometry or on how samples are sharded over
-// GPUs (every rank passes its global sample offset).  Normals by Box-Muller from 53-bit uniforms;
+// GPUs (every rank passes its global sample offset).  Normals by Box-Muller from 53-bit uniforms (lean log,
+// sincospi: the angle is a multiple of pi by construction);
 // chi-square(nu) = 2 Gamma(nu/2) by Marsaglia-Tsang rejection.  Sample values are statistically
 // (not bitwise) equivalent to numpy's MT19937 stream, as SURVEY section 7 ("RNG parity") states.
 #include "pmc_device.h"
@@ -106,21 +107,73 @@ __device__ __forceinline__ double chi_square(const Philox &g, unsigned long long
     return 2.0 * result * boost;
 }
 
-template <int D, bool PADDED>
-__global__ __launch_bounds__(256) void k_propose(const PmcArgsP a)
+constexpr int PCH = 16;          // coordinates staged per pass
+constexpr int PPITCH = PCH + 1;  // row pitch of the staging buffer in doubles (odd: conflict-free column writes)
+
+// x_i = mu_i + scale * sum_{j <= i} L_ij z_j, coordinates in passes of PCH through the wavefront's LDS stage so
+// that they leave in 128-byte row segments (4 rows per store instruction) instead of 64 scattered 8-byte
+// stores per coordinate.  The factor is read through pointer type P: the scalar cache when the whole wavefront
+// draws from one component (samples arrive ordered by component, so all but K - 1 wavefronts do: the
+// coefficient becomes an SGPR operand of the multiply-add instead of a 64-lane vector load of one address),
+// ordinary loads otherwise.
+template <int D, bool PADDED, class P>
+__device__ __forceinline__ void affine_out(P L, P mu, int dreal, const double (&z)[D], double scale, double *st,
+                                           int lane, double *__restrict__ out, int rows)
 {
+#pragma unroll
+    for (int c0 = 0; c0 < D; c0 += PCH) {
+        if (PADDED && c0 >= dreal) break;
+#pragma unroll
+        for (int i = c0; i < c0 + PCH && i < D; ++i) {
+            double acc = 0.0;
+            if (!PADDED || i < dreal) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) acc = fma(L[i * dreal + j], z[j], acc);
+                acc = mu[i] + acc * scale;
+            }
+            st[lane * PPITCH + (i - c0)] = acc;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wavefront's LDS writes have landed
+        const int ncol = (dreal - c0 < PCH) ? dreal - c0 : PCH;  // columns of this pass
+        if (ncol == PCH) {
+            // lane = (row within a group of 4, column): 16 store instructions of 4 x 128 contiguous bytes
+#pragma unroll
+            for (int r0 = 0; r0 < 64; r0 += 4) {
+                const int r = r0 + (lane >> 4), c = lane & 15;
+                if (r < rows) out[(long long)r * dreal + c0 + c] = st[r * PPITCH + c];
+            }
+        } else {
+            for (int e = lane; e < rows * ncol; e += 64) {
+                const int r = e / ncol, c = e - r * ncol;
+                out[(long long)r * dreal + c0 + c] = st[r * PPITCH + c];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // the reads are done before the next pass overwrites
+    }
+}
+
+// (two wavefronts per SIMD: the unrolled Box-Muller pairs take every register they are given -- 316 at D = 40
+//  without a bound, one wavefront per SIMD; bounded to 256: 5.3 -> 4.2 ms per 1.25e7 samples; to 128 it spills: 6.2)
+template <int D, bool PADDED>
+__global__ __launch_bounds__(256, 2) void k_propose(const PmcArgsP a)
+{
+    __shared__ double stage[4][64 * PPITCH];
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (n >= a.N) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n0 = n - lane;                               // first sample of this wavefront
+    if (n0 >= a.N) return;                                       // wave-uniform
+    const bool valid = n < a.N;
     const int dreal = PADDED ? a.dreal : D;
     // component of sample n: offsets[k] <= n < offsets[k+1]  (binary search, K+1 entries)
+    const long long nn = valid ? n : a.N - 1;
     int lo = 0, hi = a.K;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (a.offsets[mid] <= n) lo = mid; else hi = mid;
+        if (a.offsets[mid] <= nn) lo = mid; else hi = mid;
     }
     const int k = lo;
     const Philox g = {(unsigned)a.seed, (unsigned)(a.seed >> 32)};
-    const unsigned long long gn = (unsigned long long)(a.first_sample + n);   // global sample index
+    const unsigned long long gn = (unsigned long long)(a.first_sample + nn);  // global sample index
 
     double z[D];
 #pragma unroll
@@ -135,18 +188,17 @@ __global__ __launch_bounds__(256) void k_propose(const PmcArgsP a)
         const double nu = a.dof[k];
         scale = sqrt(nu / chi_square(g, gn, 0x10000u, nu));      // student_t.pyx:55
     }
-    const double *__restrict__ L = a.chol + (size_t)k * dreal * dreal;   // lower triangular, row-major
-    const double *__restrict__ mu = a.mu + (size_t)k * dreal;
-    double *__restrict__ out = a.x + n * (long long)dreal;
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        if (PADDED && i >= dreal) break;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j <= i; ++j) acc = fma(L[i * dreal + j], z[j], acc);
-        out[i] = mu[i] + acc * scale;
+    const int rows = (int)((a.N - n0 < 64) ? a.N - n0 : 64);     // samples of this wavefront
+    double *__restrict__ out = a.x + n0 * (long long)dreal;
+    const int kfirst = __builtin_amdgcn_readfirstlane(k);
+    if (__all(k == kfirst)) {                                    // wave-uniform branch
+        affine_out<D, PADDED>((cdouble *)(a.chol + (size_t)kfirst * dreal * dreal),
+                              (cdouble *)(a.mu + (size_t)kfirst * dreal), dreal, z, scale, stage[wave], lane, out, rows);
+    } else {
+        affine_out<D, PADDED>(a.chol + (size_t)k * dreal * dreal, a.mu + (size_t)k * dreal, dreal, z, scale,
+                              stage[wave], lane, out, rows);
     }
-    if (a.origin != nullptr) a.origin[n] = k;
+    if (a.origin != nullptr && valid) a.origin[n] = k;
 }
 
 }  // namespace
