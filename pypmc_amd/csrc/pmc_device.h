@@ -191,6 +191,14 @@ __device__ __forceinline__ double log_pos(double t)
 #endif
 }
 
+// log of a per-sample quantity (a row sum, a normalisation): the lean form when every lane of the wavefront holds a
+// positive normal number -- the rule; the library's otherwise (a row sum that underflowed to 0 must give -inf).
+__device__ __forceinline__ double log_any(double t)
+{
+    if (__all(t >= 2.2250738585072014e-308 && t <= DBL_MAX)) return log_pos(t);      // (a NaN fails the test)
+    return log(t);
+}
+
 // a_nk from maha_nk, in the reference's operation order (see enum pmc_kind).
 template <int D, int KIND>
 __device__ __forceinline__ double component_value(double maha, cdouble *c, double &expo)

@@ -181,9 +181,9 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
                 ut[(size_t)k * 64] = swv * r;
             }
             // sum_k r_k (a_k - M + log norm_inv) with sum_k r_k = 1   (variational.pyx:1003-1013)
-            if (q == 0) sc_a += swv * fma(tb, norm_inv, log(norm_inv));
+            if (q == 0) sc_a += swv * fma(tb, norm_inv, log_any(norm_inv));
         } else {
-            const double lse = log(s) + M;                         // _regularize.pyx:81
+            const double lse = log_any(s) + M;                     // _regularize.pyx:81
             const double denom = exp(lse) + TINY;                  // pmc.pyx:41
             const double em = exp(M);
             cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(FW * 64, freg_min_waves(D, KQ)) void k_estep_reg(co
         double f0, f1 = 0.0;
         if constexpr (KIND == PMC_KIND_VB) {
             f0 = 1. / s;
-            if (q == logq) sc_a += swv * fma(tb, f0, log(f0));       // variational.pyx:1003-1013
+            if (q == logq) sc_a += swv * fma(tb, f0, log_any(f0));   // variational.pyx:1003-1013
         } else {
-            const double lse = log(s) + M;                           // _regularize.pyx:81
+            const double lse = log_any(s) + M;                       // _regularize.pyx:81
             f0 = exp(M);
             f1 = exp(lse) + TINY;                                    // pmc.pyx:41
             if (q == logq) sc_a += swv * lse;                        // pmc.pyx:388-391

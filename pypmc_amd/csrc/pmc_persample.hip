@@ -390,7 +390,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
             lse_step(v, pk[D + T + 4], m, s, EC);
             poison = fma(0.0, v, poison);
         }
-        return (log(s) + m) + poison;                    // _regularize.pyx:81
+        return (log_any(s) + m) + poison;                    // _regularize.pyx:81
     };
     const double lse = mixture(ic<KIND>{}, a.pack, a.K, true);
     double lse_target = 0.0;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
         if constexpr (KIND == PMC_KIND_VB) {
             // variational.pyx:748-755: r = exp(log_rho - max) / norm, zeros -> tiny, log_rho += log(1/norm)
             const double norm_inv = 1. / s;
-            const double log_norm_inv = log(norm_inv);
+            const double log_norm_inv = log_any(norm_inv);
             double elq;
             if (literal) {
                 elq = 0.0;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             // pmc.pyx:36-41: rho = exp(log q_k) * w_k / (exp(log_denominator) + tiny)
             // product form: exp(log q_k) = e_k exp(M), formed BEFORE anything else touches it, so where the
             // reference's exp(log q_k) underflows (log q_k < -708: denormal, then zero) this product does too.
-            const double lse = log(s) + M;                // _regularize.pyx:81
+            const double lse = log_any(s) + M;            // _regularize.pyx:81
             const double denom = exp(lse) + TINY;
             const double em = exp(M);
             const long long lat = (a.mode == PMC_RESP_PMC_LATENT && valid) ? a.latent[n] : -1;

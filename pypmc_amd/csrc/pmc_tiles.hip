@@ -52,7 +52,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT 
             s += pk[(size_t)k * a.stride + 4] * e;                   // _regularize.pyx:79
             ut[(size_t)k * 64] = e;
         }
-        const double lse = log(s) + M;                               // _regularize.pyx:81
+        const double lse = log_any(s) + M;                           // _regularize.pyx:81
         const double denom = exp(lse) + TINY;                        // pmc.pyx:41
         const double em = exp(M);
         for (int k = K - 1; k >= 0; --k) {
