@@ -185,12 +185,11 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
         } else {
             const double lse = log_any(s) + M;                     // _regularize.pyx:81
             const double denom = exp(lse) + TINY;                  // pmc.pyx:41
-            const double em = exp(M);
+            const double em = exp(M), inv_denom = 1. / denom;
             cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
             for (int k = k0; k < k1; ++k, pk += STRIDE) {
                 // exp(log q_k) = e exp(M) first: it underflows where the reference's does (pmc.pyx:39)
-                double rho = (ut[(size_t)k * 64] * em) * pk[D + T + 4];
-                rho /= denom;
+                const double rho = ((ut[(size_t)k * 64] * em) * pk[D + T + 4]) * inv_denom;
                 ut[(size_t)k * 64] = swv * rho;
             }
             if (q == 0) sc_a += swv * lse;                         // pmc.pyx:388-391
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(FW * 64, freg_min_waves(D, KQ)) void k_estep_reg(co
         } else {
             const double lse = log_any(s) + M;                       // _regularize.pyx:81
             f0 = exp(M);
-            f1 = exp(lse) + TINY;                                    // pmc.pyx:41
+            f1 = 1. / (exp(lse) + TINY);                             // pmc.pyx:41 (one division per sample)
             if (q == logq) sc_a += swv * lse;                        // pmc.pyx:388-391
         }
 #pragma unroll
@@ -448,9 +447,7 @@ __global__ __launch_bounds__(FW * 64, freg_min_waves(D, KQ)) void k_estep_reg(co
                     u = swv * zero_to_tiny(av[j] * f0);
                 } else {
                     // exp(log q_k) = e exp(M) first: it underflows where the reference's does (pmc.pyx:39)
-                    double rho = (av[j] * f0) * pks[j][D + T + 4];
-                    rho /= f1;
-                    u = swv * rho;
+                    u = swv * (((av[j] * f0) * pks[j][D + T + 4]) * f1);
                 }
                 double d[D];
 #pragma unroll

@@ -10,7 +10,7 @@
 //
 // Same arithmetic, in the same order, as k_resp's PMC branch (pmc_persample.hip): a_nk = component_value(maha),
 // row maximum, e = exp(a - M) and s = sum w e over the components in DESCENDING order,
-// rho = (e exp(M)) w / (exp(log s + M) + tiny) -- the two paths agree bit for bit
+// rho = (e exp(M)) w * (1 / (exp(log s + M) + tiny)) -- the two paths agree bit for bit
 // (tests/test_gpu_kernels.py::test_estep_from_kept_logpdf).
 // One unit for all sample dimensions (compiled with -DPMC_D=1, which it does not use).
 #include "pmc_device.h"
@@ -54,11 +54,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT 
         }
         const double lse = log_any(s) + M;                           // _regularize.pyx:81
         const double denom = exp(lse) + TINY;                        // pmc.pyx:41
-        const double em = exp(M);
+        const double em = exp(M), inv_denom = 1. / denom;
         for (int k = K - 1; k >= 0; --k) {
             cdouble *c = pk + (size_t)k * a.stride;
-            double rho = (ut[(size_t)k * 64] * em) * c[4];
-            rho /= denom;
+            const double rho = ((ut[(size_t)k * 64] * em) * c[4]) * inv_denom;
             const double wr = swv * rho;
             if constexpr (KIND == PMC_KIND_STUDENT_T) {
                 const double maha = mt[(size_t)((cint64 *)c)[5] * 64];
