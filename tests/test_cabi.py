@@ -74,6 +74,26 @@ def test_host_side_entry_points():
     assert "component 1" in _lib.last_error()
 
 
+def test_evaluate_once_entry_points_check_their_arguments():
+    """pmc_maha_tiles_size and the argument checks of pmc_estep_from_tiles (they return before any launch)."""
+    from pypmc_amd import _lib
+    lib = _lib.load()
+    assert lib.pmc_maha_tiles_size(1, 3) == 3 * 64 and lib.pmc_maha_tiles_size(65, 2) == 2 * 2 * 64
+    assert lib.pmc_maha_tiles_size(0, 5) == 0 and lib.pmc_maha_tiles_size(-1, 5) == 0 and lib.pmc_maha_tiles_size(10, 0) == 0
+    buf = np.zeros(64)
+    p = buf.ctypes.data_as(C.c_void_p)          # never dereferenced: every call below fails its checks first
+    args = lambda **kw: [kw.get("x", p), kw.get("N", 10), kw.get("D", 2), kw.get("pack", p), kw.get("K", 2),
+                         kw.get("kind", 0), 0, None, kw.get("tiles", p), kw.get("K_tiles", 2), kw.get("u", p),
+                         kw.get("vsums", None), kw.get("stats", p), kw.get("scalars", p), kw.get("ws", p), None]
+    for bad, needle in ((dict(K=0), "bad N/K"), (dict(K_tiles=0), "bad N/K"), (dict(pack=None), "bad N/K"),
+                        (dict(stats=None), "bad N/K"), (dict(ws=None), "bad N/K"), (dict(N=-1), "bad N/K"),
+                        (dict(kind=2), "kind must be GAUSS or STUDENT_T"), (dict(kind=1), "Student-t needs d_vsums"),
+                        (dict(D=65), "not supported"), (dict(x=None), "is NULL"), (dict(tiles=None), "is NULL"),
+                        (dict(u=None), "is NULL")):
+        assert lib.pmc_estep_from_tiles(*args(**bad)) == -1, bad
+        assert needle in _lib.last_error(), (bad, _lib.last_error())
+
+
 def test_no_silent_cpu_fallback():
     import torch
     if torch.cuda.is_available():

@@ -597,6 +597,18 @@ def test_importance_weights_errors(be):
     assert rc == 0
 
 
+def test_evaluate_once_with_no_samples(be):
+    """N = 0 through the keeping weighting pass and pmc_estep_from_tiles: zero statistics, zero sums, no launch."""
+    mu, cov, w = mk(3, 4, 5)
+    g = gauss_set(mu, cov, w)[0]
+    t = student_set(mu, cov, w, np.full(3, 4.))[0]
+    for cs in (g, t):
+        kept = be.importance_weights(np.zeros((0, 4)), cs, g, keep=True)
+        assert kept["tiles"].N == 0 and not be.tohost(kept["scalars"]).any()
+        out = be.tohost(be.estep_from_tiles(np.zeros((0, 4)), cs, kept["tiles"])["stats"])
+        assert out.shape[0] == be.stats_len(3, 4) and not out.any()
+
+
 def test_rho_where_the_reference_underflows(be, orc):
     """pmc.pyx:36-41 computes rho = exp(log q_k) w_k / (exp(lse) + tiny): for samples so far out that
     log q_k < -708 the numerator is denormal or zero although the ratio is representable.  The
