@@ -221,10 +221,10 @@ __device__ __forceinline__ double component_value(double maha, cdouble *c, doubl
 }
 
 // exp(x) for x <= 0: the device library's algorithm and constants (k = rint(x log2 e), r = x - k ln 2 in two
-// pieces, degree-11 polynomial, ldexp) without its overflow branch, and with the underflow branch replaced by
-// a clamp of the argument -- the same bits as exp() for every x <= 0 (ldexp rounds the subnormal results,
-// -1075 and below give 0); 18 instead of 24 vector instructions.  NaN arguments give 0, not NaN: callers
-// poison the sample weight instead (below).
+// pieces, degree-11 polynomial, ldexp) without its overflow branch, with the underflow branch replaced by a
+// clamp of the argument (ldexp rounds the subnormal results, -1075 and below give 0) and the rounding done
+// with a shifter constant -- within an ulp of exp(); 16 instead of 24 vector instructions.  NaN arguments give
+// 0, not NaN: callers poison the sample weight instead (below).
 struct ExpConst {
     double log2e, nln2hi, nln2lo, c[9];
     __device__ __forceinline__ ExpConst()
@@ -249,7 +249,13 @@ __device__ __forceinline__ double exp_clamped(double xc, const ExpConst &E)
 #ifdef PMC_LIBM_LSE
     return exp(xc);
 #endif
-    const double k = rint(xc * E.log2e);
+    // k = rint(xc log2 e) by the shifter constant 1.5 * 2^52: one fused multiply-add leaves the rounded value in the
+    // low mantissa bits -- as an integer in the low word (|k| < 2^31) and, after subtracting the shifter again, as
+    // a double.  (2 instructions instead of multiply, v_rndne, v_cvt_i32; a product within half an ulp of a tie
+    // may round to the other neighbour than the library's two-step rounding: r then ends up 1e-16 outside
+    // [-ln2/2, ln2/2], which the polynomial does not notice.)
+    const double shifted = fma(xc, E.log2e, 6755399441055744.0);
+    const double k = shifted - 6755399441055744.0;
     double r = fma(k, E.nln2hi, xc);
     r = fma(k, E.nln2lo, r);
     double p = fma(E.c[0], r, E.c[1]);
@@ -258,31 +264,25 @@ __device__ __forceinline__ double exp_clamped(double xc, const ExpConst &E)
     p = fma(r, p, 0.5);
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
-    return ldexp(p, (int)k);
+    return ldexp(p, __double2loint(shifted));
 }
 __device__ __forceinline__ double exp_le0(double x, const ExpConst &E) { return exp_clamped(max_f64(x, -1075.0), E); }
 
 
 // v_bfi_b32: (mask & a) | (~mask & b).  Inline asm because the compiler turns the C expression back into the
 // compare + v_cndmask form it was written to avoid (one compare feeding four selects: ~7 issue slots against 2,
-// scripts/microbench/fp64_oprates.hip).  One operand may be a uniform (scalar register) value.
-__device__ __forceinline__ unsigned bfi_vs(unsigned mask, unsigned a_uniform, unsigned b)
+// scripts/microbench/fp64_oprates.hip).
+__device__ __forceinline__ unsigned bfi_vv(unsigned mask, unsigned a, unsigned b)
 {
     unsigned r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "s"(a_uniform), "v"(b));
-    return r;
-}
-__device__ __forceinline__ unsigned bfi_sv(unsigned mask, unsigned a, unsigned b_uniform)
-{
-    unsigned r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "s"(b_uniform));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
     return r;
 }
 
 // One step of the streaming log-sum-exp  log sum_k w_k exp(a_k) = m + log s  with
 // m = running max, s = sum_k w_k exp(a_k - m)   (one exp per step):
 //     a <= m:  s += w exp(a - m)             a > m:  s = s exp(m - a) + w,  m = a.
-// Both are  s = A e + B  with e = exp(-|a - m|): the sign word of a - m picks (A, B) = (w, s) or (s, w) on the
+// Both are formed with e = exp(-|a - m|) and the sign word of a - m picks one on the
 // integer pipe (a - m = +0 or a positive value with a zero high word count as "a > m": e = 1, both forms agree).
 // ``w`` is the component's weight, uniform over the wavefront.  A NaN a_k adds nothing here (the clamp turns
 // exp's argument into -1075); k_logpdf adds the row's poison (0 or NaN) to the result instead.
@@ -299,11 +299,11 @@ __device__ __forceinline__ void lse_step(double a, double w, double &m, double &
     asm("v_max_f64 %0, -|%1|, %2" : "=v"(arg) : "v"(d), "v"(-1075.0));
     const double e = exp_clamped(arg, E);
     const unsigned below = (unsigned)(__double2hiint(d) >> 31);      // all ones: a < m
-    const unsigned wlo = (unsigned)__double2loint(w), whi = (unsigned)__double2hiint(w);
-    const unsigned slo = (unsigned)__double2loint(s), shi = (unsigned)__double2hiint(s);
-    const double A = __hiloint2double((int)bfi_vs(below, whi, shi), (int)bfi_vs(below, wlo, slo));   // below ? w : s
-    const double B = __hiloint2double((int)bfi_sv(below, shi, whi), (int)bfi_sv(below, slo, wlo));   // below ? s : w
-    s = fma(A, e, B);
+    // both updates, then the sign word of a - m picks one: two multiply-adds and two v_bfi (selecting the operands
+    // first would be four v_bfi and one multiply-add)
+    const double up = fma(s, e, w), stay = fma(w, e, s);
+    s = __hiloint2double((int)bfi_vv(below, (unsigned)__double2hiint(stay), (unsigned)__double2hiint(up)),
+                         (int)bfi_vv(below, (unsigned)__double2loint(stay), (unsigned)__double2loint(up)));
     m = max_f64(a, m);
 #endif
 }
