@@ -47,6 +47,9 @@ __device__ __forceinline__ void component_sync()
 #ifndef PMC_RESIDENT_MAX_DIM_RESP
 #define PMC_RESIDENT_MAX_DIM_RESP 8
 #endif
+#ifndef PMC_RESP_SYNC_FROM
+#define PMC_RESP_SYNC_FROM 20
+#endif
 
 extern __shared__ double dyn_lds[];   // [MFMA engine: 2 parameter buffers] [k_resp: parked values]
 
@@ -76,19 +79,29 @@ template <int D, bool PADDED, int ENGINE> struct MahaEngine {
 #endif
     // (the responsibility kernel, whose wavefronts also park their values, keeps both from D = 10 on:
     //  D = 12 0.85 -> 1.18 ms without)
-    bool resident;
+    bool resident, sync;
     static __device__ __forceinline__ bool fits(int K, int maxdim = PMC_RESIDENT_MAX_DIM)
     {
         return D <= maxdim && K * pmc_pack_stride_c(D) * 8 <= PMC_RESIDENT_BYTES;
     }
+    // The per-component barrier pays from D = 20 on in the responsibility kernel (whose wavefronts also park their
+    // values and drift apart less): ms per 4e6 samples x 32 components with / without it: D = 12 0.768 / 0.729,
+    // D = 16 1.085 / 1.042, D = 20 1.303 / 1.381, D = 24 1.73 / 1.99, D = 30 2.72 / 3.27; the log-pdf kernel keeps it
+    // from D = 16 on (D = 16 neutral, D = 20 1.32 / 1.41, D = 30 2.75 / 2.99).
+    static_assert(PMC_RESIDENT_MAX_DIM != PMC_RESIDENT_MAX_DIM_RESP, "the two kernels are told apart by this bound");
+    static __device__ __forceinline__ bool syncs(int maxdim)
+    {
+        return maxdim == PMC_RESIDENT_MAX_DIM || D >= PMC_RESP_SYNC_FROM;
+    }
     __device__ __forceinline__ void begin(const double *, int K, int maxdim = PMC_RESIDENT_MAX_DIM)
     {
         resident = fits(K, maxdim);
+        sync = syncs(maxdim);
     }
     __device__ __forceinline__ double eval(cdouble *pk, int)
     {
         if (!resident) {                                  // workgroup-uniform
-            component_sync();
+            if (sync) component_sync();
             touch_component<D>(pk);
         }
         return mahalanobis<D>(xv, pk);
@@ -96,7 +109,7 @@ template <int D, bool PADDED, int ENGINE> struct MahaEngine {
     // a wavefront without samples keeps the workgroup's barrier count
     __device__ static __forceinline__ void idle(const double *, int K, int maxdim = PMC_RESIDENT_MAX_DIM)
     {
-        if (fits(K, maxdim)) return;
+        if (fits(K, maxdim) || !syncs(maxdim)) return;
         for (int k = 0; k < K; ++k) component_sync();
     }
 };
