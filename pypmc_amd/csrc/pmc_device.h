@@ -79,7 +79,18 @@ template <int LINES, int FIRST> __device__ __forceinline__ void touch16(cdouble 
 template <int D> __device__ __forceinline__ void touch_component(cdouble *pk)
 {
     constexpr int LINES = pmc_pack_stride_c(D) * 8 / 64;
+#ifdef PMC_TOUCH_BLOCKS
     static_for<0, (LINES + 15) / 16>([&](auto B) { touch16<LINES, decltype(B)::value * 16>(pk); });
+#else
+    // exactly LINES loads and ONE wait (the assembler repeats the line; blocks of 16 with a wait each cost a
+    // scalar round trip per block -- two at D = 16 / 20, four at D = 30 -- and up to 12 redundant loads)
+    int dummy;
+    asm volatile(".set pmc_touch_i, 0\n .rept %2\n s_load_dword %0, %1, pmc_touch_i*64\n .set pmc_touch_i, pmc_touch_i+1\n .endr\n"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(dummy)
+                 : "s"(pk), "n"(LINES)
+                 : "memory");
+#endif
 }
 
 // Workgroup barrier behind LDS-DMA (global_load_lds): every wavefront first waits for ITS OWN pieces to have
