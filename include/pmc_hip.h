@@ -82,9 +82,16 @@ int pmc_device_count(void);
 int pmc_device_arch(int device, char *buf, size_t buflen);
 
 /* ---- dimensions ---------------------------------------------------------------------------- */
-/* largest supported sample dimension */
+/* largest supported sample dimension (1024).  Up to pmc_max_compiled_dim() (64) the kernels are compiled per
+   dimension, fully unrolled, with a sample's coordinates in registers; beyond it the run-time-dimension unit
+   takes over (the reference's loops take any length, pypmc/tools/_linalg.pyx:32-37): the Mahalanobis forms and
+   the second moments as 16 x 16 x 4 fp64 MFMA tiles, everything else the same kernels.  That unit keeps one
+   scratch of its own: pmc_mixture_logpdf / pmc_importance_weights allocate the N x K forms stream-ordered
+   (hipMallocAsync / hipFreeAsync on the caller's stream) unless the caller keeps them (d_maha_tiles). */
 int pmc_max_dim(void);
-/* compiled kernel dimension used for D (>= D), or PMC_EINVAL if D is unsupported */
+int pmc_max_compiled_dim(void);
+/* compiled kernel dimension used for D (>= D; D itself beyond pmc_max_compiled_dim()), or PMC_EINVAL if D is
+   unsupported */
 int pmc_padded_dim(int D);
 /* doubles per component in a pack for sample dimension D */
 int64_t pmc_pack_stride(int D);

@@ -15,14 +15,15 @@ PMC_KIND_GAUSS, PMC_KIND_STUDENT_T, PMC_KIND_VB = 0, 1, 2
 PMC_RESP_VB, PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT = 0, 1, 2
 PMC_OK, PMC_EINVAL, PMC_ENOTPOSDEF, PMC_EHIP, PMC_ENODEVICE = 0, -1, -2, -3, -4
 NSCALARS = 8
-MAX_DIM = 64      # largest sample dimension the kernels are compiled for (== pmc_max_dim(), tested)
+MAX_DIM = 1024    # largest sample dimension (== pmc_max_dim(), tested): per-dimension kernels up to 64, the
+                  # run-time-dimension unit (csrc/pmc_big.hip) beyond
 
 
 def check_dim(dim):
-    """Sample dimensions beyond the compiled kernels are refused where a density is built, not at
-    its first evaluation (the reference's loops take any length, pypmc/tools/_linalg.pyx:32-37)."""
+    """Sample dimensions beyond the kernels' limit are refused where a density is built, not at its
+    first evaluation (the reference's loops take any length, pypmc/tools/_linalg.pyx:32-37)."""
     if dim > MAX_DIM:
-        raise ValueError("pypmc_amd's gfx950 kernels are compiled for sample dimensions up to %d "
+        raise ValueError("pypmc_amd's gfx950 kernels take sample dimensions up to %d "
                          "(got %d); there is no CPU fallback" % (MAX_DIM, dim))
 
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     "pmc_device_count": (_int, []),
     "pmc_device_arch": (_int, [_int, C.c_char_p, C.c_size_t]),
     "pmc_max_dim": (_int, []),
+    "pmc_max_compiled_dim": (_int, []),
     "pmc_padded_dim": (_int, [_int]),
     "pmc_pack_stride": (_i64, [_int]),
     "pmc_tile": (_int, []),

@@ -73,6 +73,11 @@ def build(jobs=None, force=False, verbose=False):
     work = [(os.path.join(OBJ, "pmc_api.o"), asrc, [], [asrc] + headers, force)]
     tsrc = os.path.join(CSRC, "pmc_tiles.hip")        # one unit for all dimensions (PMC_D is not used by it)
     work.append((os.path.join(OBJ, "pmc_tiles.o"), tsrc, ["-DPMC_D=1"], [tsrc] + headers, force))
+    # the run-time-dimension unit (sample dimensions beyond the compiled ones): its own kernels plus the per-sample
+    # and propose units compiled for "dimension 0"
+    for unit, src in (("big", "pmc_big.hip"), ("persample_d0_p0", "pmc_persample.hip"), ("propose_d0_p0", "pmc_propose.hip")):
+        src = os.path.join(CSRC, src)
+        work.append((os.path.join(OBJ, "pmc_%s.o" % unit), src, ["-DPMC_D=0", "-DPMC_PADDED=0"], [src] + headers, force))
     for d, padded in dim_list():
         for p in ((0, 1) if padded else (0,)):
             for unit in ("persample", "stats", "propose", "fused"):

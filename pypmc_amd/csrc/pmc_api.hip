@@ -24,6 +24,13 @@
     extern "C" hipError_t pmc_launch_fused_d##d##_p##p(int, int, const PmcArgsF &, unsigned, hipStream_t); \
     extern "C" int pmc_fused_lds_bytes_d##d##_p##p(int, int);
 extern "C" hipError_t pmc_launch_resp_tiles(int, const PmcArgsT &, unsigned, hipStream_t);
+// the run-time-dimension unit (pmc_big.hip, pmc_persample.hip / pmc_propose.hip compiled with PMC_D = 0)
+extern "C" hipError_t pmc_launch_logpdf_d0_p0(int, int, const PmcArgsA &, unsigned, hipStream_t);
+extern "C" hipError_t pmc_launch_resp_d0_p0(int, const PmcArgsA &, unsigned, hipStream_t);
+extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &, hipStream_t);
+extern "C" hipError_t pmc_launch_big_stats(const PmcArgsB &, unsigned, hipStream_t);
+extern "C" void pmc_big_stats_config(int, int *, int *);
+extern "C" hipError_t pmc_launch_propose_big(const PmcArgsP &, unsigned, hipStream_t);
 #define PMC_DECL_X(d) PMC_DECL_UNIT(d, 0)
 #define PMC_DECL_XP(d) PMC_DECL_UNIT(d, 0) PMC_DECL_UNIT(d, 1)
 PMC_DIM_LIST(PMC_DECL_X, PMC_DECL_XP)
@@ -119,8 +126,33 @@ double flops_pairs(double N, int K, int D) { return N * K * ((double)D * D + 4.0
 double flops_stats(double N, int K, int D) { return N * K * (1.0 + 2.0 * D + (double)D * (D + 1)); }
 
 // kernel set (and with it the compiled dimension) for a sample dimension D
+// kernel sets of the run-time-dimension unit, one per dimension asked for (they differ in `dim` and the
+// statistics geometry only); entries are never removed, so the pointers handed out stay valid
+const PmcKernelSet *big_kernels_for(int D)
+{
+    static std::mutex m;
+    static std::vector<PmcKernelSet *> sets;
+    std::lock_guard<std::mutex> lock(m);
+    for (const PmcKernelSet *ks : sets)
+        if (ks->dim == D) return ks;
+    PmcKernelSet *ks = new PmcKernelSet();
+    ks->dim = D;
+    ks->padded = 2;
+    pmc_big_stats_config(D, &ks->stats_nsub, &ks->stats_waves);
+    ks->logpdf = &pmc_launch_logpdf_d0_p0;
+    ks->resp = &pmc_launch_resp_d0_p0;
+    ks->stats = &pmc_launch_big_stats;
+    ks->config = nullptr;
+    ks->propose = &pmc_launch_propose_big;
+    ks->fused = nullptr;
+    ks->fused_lds_bytes = nullptr;
+    sets.push_back(ks);
+    return ks;
+}
+
 const PmcKernelSet *kernels_for(int D)
 {
+    if (D > PMC_MAX_DIM) return D <= PMC_BIG_MAX_DIM ? big_kernels_for(D) : nullptr;
     for (int i = 0; i < g_ndims; ++i) {
         PmcKernelSet *ks = nullptr;
         if (g_dims[i].dim == D) ks = &g_dims[i].exact;
@@ -394,6 +426,26 @@ FusedGeom fused_geom(long long N, int K, int dim)
     return g;
 }
 
+// Run-time-dimension unit: maha_nk of `pack` for all samples into `mtile` (tile-major, pmc_maha_tiles_size doubles)
+hipError_t big_maha(const double *d_x, long long N, int D, const double *d_pack, int K, double *mtile, hipStream_t st)
+{
+    PmcArgsM m;
+    std::memset(&m, 0, sizeof(m));
+    m.x = d_x; m.N = N; m.D = D; m.pack = d_pack; m.K = K; m.stride = pmc_pack_stride_c(D); m.mtile = mtile;
+    const int D4 = (D + 3) & ~3;
+    m.subtiles_per_wg = D4 * 512 <= 65536 ? 4 : (D4 * 256 <= 65536 ? 2 : 1);
+    return pmc_launch_big_maha(m, st);
+}
+// stream-ordered scratch of the library's own (the Mahalanobis forms of the run-time-dimension unit when the caller
+// does not keep them): allocated and freed on the caller's stream
+struct StreamScratch {
+    void *p = nullptr;
+    hipStream_t st;
+    explicit StreamScratch(hipStream_t s) : st(s) {}
+    hipError_t get(size_t bytes) { return hipMallocAsync(&p, bytes, st); }
+    ~StreamScratch() { if (p) (void)hipFreeAsync(p, st); }
+};
+
 size_t scalar_partials_bytes(long long N)
 {
     const long long blocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
@@ -428,13 +480,14 @@ int pmc_device_arch(int device, char *buf, size_t buflen)
     return PMC_OK;
 }
 
-int pmc_max_dim(void) { return PMC_MAX_DIM; }
+int pmc_max_dim(void) { return PMC_BIG_MAX_DIM; }
+int pmc_max_compiled_dim(void) { return PMC_MAX_DIM; }
 
 int pmc_padded_dim(int D)
 {
     if (D < 1) return fail(PMC_EINVAL, "dimension must be >= 1 (got %d)", D);
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     return ks->dim;
 }
 
@@ -463,7 +516,7 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
 {
     if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     const StatsGeom g = stats_geom(N > 0 ? N : 1, K, ks);
     const size_t stats = (size_t)g.nchunks * K * pmc_stats_stride_c(ks->dim) * sizeof(double);
     const size_t scal = scalar_partials_bytes(N) +
@@ -484,7 +537,7 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
 {
     if (K < 1 || !mu || !prec || !pack) return fail(PMC_EINVAL, "pmc_pack_components: bad argument");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     const int Dp = ks->dim, Tp = pmc_tri(Dp), stride = pmc_pack_stride_c(Dp);
     std::vector<double> R((size_t)D * D);
     for (int k = 0; k < K; ++k) {
@@ -594,7 +647,7 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
     if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T)
         return fail(PMC_EINVAL, "pmc_mixture_logpdf: kind must be GAUSS or STUDENT_T (got %d)", kind);
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     if (d_individual && ld < K) return fail(PMC_EINVAL, "pmc_mixture_logpdf: ld (%lld) < K (%d)", (long long)ld, K);
     if (d_log_target && !d_weights) return fail(PMC_EINVAL, "pmc_mixture_logpdf: d_log_target needs d_weights");
     if (d_scalars && !d_workspace) return fail(PMC_EINVAL, "pmc_mixture_logpdf: d_scalars needs d_workspace");
@@ -610,6 +663,18 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K, D),
                 8.0 * N * (D + 1 + (d_individual ? K : 0) + (d_maha_tiles ? K : 0)));
+        StreamScratch scratch(st);
+        if (ks->padded == 2) {
+            double *mt = d_maha_tiles;
+            if (!mt) {
+                hipError_t em = scratch.get(sizeof(double) * (size_t)pmc_maha_tiles_size(N, K));
+                if (em != hipSuccess) return hipfail(em, "hipMallocAsync (Mahalanobis forms)");
+                mt = (double *)scratch.p;
+            }
+            hipError_t em = big_maha(d_x, N, D, d_pack, K, mt, st);
+            if (em != hipSuccess) return hipfail(em, "k_big_maha launch");
+            a.mtile = mt;
+        }
         hipError_t e = ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
@@ -639,7 +704,7 @@ int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const doubl
     if (N > 0 && (!d_x || !d_weights)) return fail(PMC_EINVAL, "pmc_importance_weights: d_x / d_weights is NULL");
     if (d_scalars && !d_workspace) return fail(PMC_EINVAL, "pmc_importance_weights: d_scalars needs d_workspace");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     hipStream_t st = (hipStream_t)stream;
     const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
     if (nblocks > 0) {
@@ -650,6 +715,19 @@ int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const doubl
         a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_maha_tiles;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D), 8.0 * N * (D + 1 + (d_maha_tiles ? K : 0)));
+        StreamScratch scratch(st);
+        if (ks->padded == 2) {
+            const size_t n1 = (size_t)pmc_maha_tiles_size(N, K), n2 = (size_t)pmc_maha_tiles_size(N, K_target);
+            hipError_t em = scratch.get(sizeof(double) * ((d_maha_tiles ? 0 : n1) + n2));
+            if (em != hipSuccess) return hipfail(em, "hipMallocAsync (Mahalanobis forms)");
+            double *mt2 = (double *)scratch.p;
+            double *mt = d_maha_tiles ? d_maha_tiles : mt2 + n2;
+            em = big_maha(d_x, N, D, d_pack, K, mt, st);
+            if (em == hipSuccess) em = big_maha(d_x, N, D, d_target_pack, K_target, mt2, st);
+            if (em != hipSuccess) return hipfail(em, "k_big_maha launch");
+            a.mtile = mt;
+            a.mtile2 = mt2;
+        }
         hipError_t e = ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
@@ -694,7 +772,7 @@ int pmc_propose(const double *d_mu, const double *d_chol, const double *d_dof, c
     if (N < 0 || K < 1 || !d_mu || !d_chol || !d_offsets || (N > 0 && !d_x))
         return fail(PMC_EINVAL, "pmc_propose: bad argument");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     if (N == 0) return PMC_OK;
     PmcArgsP a;
     std::memset(&a, 0, sizeof(a));
@@ -741,7 +819,7 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
 {
     if (N < 0 || K < 1 || !d_pack || !d_u) return fail(PMC_EINVAL, "pmc_responsibilities: bad N/K/pack/u");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     if (mode == PMC_RESP_VB) {
         if (kind != PMC_KIND_VB) return fail(PMC_EINVAL, "pmc_responsibilities: mode VB needs kind VB");
     } else if (mode == PMC_RESP_PMC_RB || mode == PMC_RESP_PMC_LATENT) {
@@ -772,6 +850,13 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
         a.r = d_r; a.log_rho = d_log_rho; a.exponent = d_exponent;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         Timed t(T_RESP, st, flops_pairs((double)N, K, D), 8.0 * N * (D + K));
+        if (ks->padded == 2) {
+            // the Mahalanobis forms go into the responsibility buffer itself: pass 1 of k_resp reads a pair's
+            // form and parks its value in the same place
+            hipError_t em = big_maha(d_x, N, D, d_pack, K, d_u, st);
+            if (em != hipSuccess) return hipfail(em, "k_big_maha launch");
+            a.mtile = d_u;
+        }
         hipError_t e = ks->resp(kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_resp launch");
     }
@@ -793,7 +878,7 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
     if (N > 0 && !d_x) return fail(PMC_EINVAL, "pmc_sufficient_stats: d_x is NULL");
     if (((uintptr_t)d_x & 7u) != 0) return fail(PMC_EINVAL, "pmc_sufficient_stats: d_x must be 8-byte aligned");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     hipStream_t st = (hipStream_t)stream;
     const int PS = pmc_stats_stride_c(D);
     if (N == 0) {
@@ -893,7 +978,7 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     if (N < 0 || K < 1 || !d_pack || !d_stats || !d_scalars || !d_workspace)
         return fail(PMC_EINVAL, "pmc_estep: bad N/K/pack/stats/scalars/workspace");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     if (N == 0) {                                          // no samples: zero statistics, zero sums
         hipStream_t st0 = (hipStream_t)stream;
         hipError_t e0 = hipMemsetAsync(d_stats, 0, sizeof(double) * (size_t)K * pmc_stats_stride_c(D), st0);
@@ -944,7 +1029,7 @@ int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pa
         return fail(PMC_EINVAL, "pmc_estep_from_tiles: kind must be GAUSS or STUDENT_T (got %d)", kind);
     if (kind == PMC_KIND_STUDENT_T && !d_vsums) return fail(PMC_EINVAL, "pmc_estep_from_tiles: Student-t needs d_vsums");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_MAX_DIM);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
         hipError_t e0 = hipMemsetAsync(d_stats, 0, sizeof(double) * (size_t)K * pmc_stats_stride_c(D), st);

@@ -47,11 +47,18 @@ __host__ __device__ constexpr int pmc_freg_kqmax(int D)
 #ifndef PMC_MFMA_FROM
 #define PMC_MFMA_FROM 32
 #endif
-enum { PMC_ENG_SGPR = 0, PMC_ENG_DPP = 1, PMC_ENG_MFMA = 2 };
+//   TILES compiled "dimension" 0 = any sample dimension at run time (the unit behind D > PMC_MAX_DIM): the
+//         Mahalanobis forms come from a kernel of their own (k_big_maha, pmc_big.hip: 16 x 16 x 4 fp64 MFMA over
+//         row-major R) as tile-major maha_nk, and the per-sample kernels only read them
+enum { PMC_ENG_SGPR = 0, PMC_ENG_DPP = 1, PMC_ENG_MFMA = 2, PMC_ENG_TILES = 3 };
 __host__ __device__ constexpr int pmc_engine(int D)
 {
-    return (D >= PMC_MFMA_FROM && D % 4 == 0) ? PMC_ENG_MFMA : (D >= PMC_DPP_FROM ? PMC_ENG_DPP : PMC_ENG_SGPR);
+    return D == 0 ? PMC_ENG_TILES
+                  : ((D >= PMC_MFMA_FROM && D % 4 == 0) ? PMC_ENG_MFMA : (D >= PMC_DPP_FROM ? PMC_ENG_DPP : PMC_ENG_SGPR));
 }
+// largest sample dimension of the run-time-dimension unit (its kernels stage 16 samples x D doubles per wavefront
+// in LDS: 128 KB at D = 1024)
+#define PMC_BIG_MAX_DIM 1024
 
 // Components k_resp parks in LDS: 19 x 512 B per wavefront is what 16 wavefronts per CU (4 per SIMD, the
 // register-limited occupancy) leave room for in 160 KB (19: 3.35-3.38 ms, 16: 3.40-3.44 ms at N = 1e7, K = 32,
@@ -88,6 +95,8 @@ struct PmcArgsA {
     const double *sample_w;
     const long long *latent;
     double *atile;        // k_logpdf: tile-major maha_nk of the FIRST mixture, kept for pmc_estep_from_tiles (or NULL)
+    const double *mtile;  // run-time-dimension unit: tile-major maha_nk of `pack` (k_big_maha made them), else NULL
+    const double *mtile2; //   ... and of `pack2`
     double *u;            // tile-major responsibilities (output)
     double *scratch;      // tile-major scratch (Student-t: maha between the two passes)
     double *vpartials;    // Student-t: ntiles * K * 2 per-wavefront sums of v1, v2
@@ -146,6 +155,18 @@ struct PmcArgsF {
     int reg;              // 1: register-resident form (k_estep_reg): qs wavefronts x kq components per tile
 };
 
+// run-time-dimension unit (pmc_big.hip): Mahalanobis forms of N samples x K components, tile-major
+struct PmcArgsM {
+    const double *x;
+    long long N;
+    int D;                // sample dimension = dimension the pack was made for
+    const double *pack;
+    int K;
+    int stride;           // doubles per component in the pack
+    double *mtile;        // ntiles x K x 64 (output)
+    int subtiles_per_wg;  // 16-sample sub-tiles (= wavefronts) per workgroup: 4, 2 or 1 -- what the LDS holds
+};
+
 // propose kernel
 struct PmcArgsP {
     const double *mu;             // K x dreal
@@ -160,8 +181,8 @@ struct PmcArgsP {
 };
 
 struct PmcKernelSet {
-    int dim;              // compiled dimension
-    int padded;           // 1: accepts dreal <= dim
+    int dim;              // compiled dimension (run-time-dimension unit: the dimension itself)
+    int padded;           // 1: accepts dreal <= dim;  2: the run-time-dimension unit (D > PMC_MAX_DIM)
     int stats_nsub;       // row subsets per component in the statistics kernel
     int stats_waves;      // wavefronts per workgroup in the statistics kernel
     hipError_t (*logpdf)(int kind, int kind2, const PmcArgsA &, unsigned grid, hipStream_t);

@@ -364,6 +364,41 @@ template <int D, bool PADDED> struct MahaEngine<D, PADDED, PMC_ENG_MFMA> {
     }
 };
 
+// Compiled "dimension" 0: the sample dimension is a run-time value (D > PMC_MAX_DIM).  k_big_maha (pmc_big.hip)
+// has already written maha_nk tile-major -- into the kept-tiles buffer, the responsibility buffer itself or a
+// scratch -- and the per-sample kernels below run unchanged on top of it: eval() is one coalesced load.
+template <bool PADDED> struct MahaEngine<0, PADDED, PMC_ENG_TILES> {
+    static constexpr int LDS_DOUBLES = 0;
+    const double *m1, *m2, *pack1, *cur;
+    size_t tile;
+    int lane;
+    __device__ __forceinline__ void load(const PmcArgsA &a, long long tile_, int lane_)
+    {
+        tile = (size_t)(tile_ * 64 < a.N ? tile_ : 0);     // a wavefront beyond the samples reads tile 0 (discarded)
+        lane = lane_;
+        m1 = a.mtile;
+        m2 = a.mtile2;
+        pack1 = a.pack;
+    }
+    __device__ __forceinline__ void begin(const double *pack, int K, int = 0)
+    {
+        cur = (pack == pack1 ? m1 : m2) + tile * K * 64 + lane;
+    }
+    __device__ __forceinline__ double eval(cdouble *, int k) { return cur[(size_t)k * 64]; }
+    __device__ static __forceinline__ void idle(const double *, int, int = 0) {}
+};
+
+// D, D(D+1)/2 and the pack's component stride: compile-time constants of a compiled dimension, run-time values of
+// unit 0
+template <int D> struct Dims {
+    static constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D), DT = D + pmc_tri(D);
+    __device__ __forceinline__ explicit Dims(int) {}
+};
+template <> struct Dims<0> {
+    int T, STRIDE, DT;
+    __device__ __forceinline__ explicit Dims(int d) : T(pmc_tri(d)), STRIDE(pmc_pack_stride_c(d)), DT(d + pmc_tri(d)) {}
+};
+
 template <int D> __host__ __device__ constexpr int pmc_use_mfma() { return pmc_engine(D); }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,7 +408,7 @@ template <int D> __host__ __device__ constexpr int pmc_use_mfma() { return pmc_e
 template <int D, bool PADDED, int KIND, int KIND2>
 __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(const PmcArgsA a)
 {
-    constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
+    const Dims<D> dm(a.dreal);
     const long long n = ((long long)blockIdx.x * PMC_A_WAVES * 64) + threadIdx.x;
     const bool valid = n < a.N;
 
@@ -390,17 +425,17 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         double m = (first && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
         cdouble *pk = (cdouble *)gpack;
         engine.begin(gpack, K);                          // (the global pointer: vector loads of the DPP engine)
-        for (int k = 0; k < K; ++k, pk += STRIDE) {
+        for (int k = 0; k < K; ++k, pk += dm.STRIDE) {
             const double maha = engine.eval(pk, k);
             double expo;
-            const double v = component_value<D, KD>(maha, pk + D + T, expo);
+            const double v = component_value<D, KD>(maha, pk + dm.DT, expo);
             if (first && a.individual != nullptr) {
-                const long long col = ((cint64 *)pk)[D + T + 5];
+                const long long col = ((cint64 *)pk)[dm.DT + 5];
                 if (valid) a.individual[n * a.ld + col] = v;
             }
             if (first && keep_tile)                      // wave-uniform: keep maha_nk for the PMC update of these samples
                 a.atile[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = maha;
-            lse_step(v, pk[D + T + 4], m, s, EC);
+            lse_step(v, pk[dm.DT + 4], m, s, EC);
             poison = fma(0.0, v, poison);
         }
         return (log_any(s) + m) + poison;                    // _regularize.pyx:81
@@ -474,7 +509,7 @@ __device__ __forceinline__ void descend(int khi, int klo, Load load, Step step)
 template <int D, bool PADDED, int KIND>
 __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_resp(const PmcArgsA a)
 {
-    constexpr int T = pmc_tri(D), STRIDE = pmc_pack_stride_c(D);
+    const Dims<D> dm(a.dreal);
     const int lane = threadIdx.x & 63;
     const long long tile = (long long)blockIdx.x * PMC_A_WAVES +
                            __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -510,14 +545,14 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
         const ExpConst EC;
         cdouble *pk = (cdouble *)a.pack;
         engine.begin(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);
-        for (int k = 0; k < K; ++k, pk += STRIDE) {
+        for (int k = 0; k < K; ++k, pk += dm.STRIDE) {
             const double maha = engine.eval(pk, k);
             double expo = 0.0;
-            const double v = component_value<D, KIND>(maha, pk + D + T, expo);
+            const double v = component_value<D, KIND>(maha, pk + dm.DT, expo);
             if constexpr (KIND == PMC_KIND_STUDENT_T) mt[(size_t)k * 64] = maha;
             if constexpr (KIND == PMC_KIND_VB) {
                 if (a.exponent != nullptr) {
-                    const long long col = ((cint64 *)pk)[D + T + 5];
+                    const long long col = ((cint64 *)pk)[dm.DT + 5];
                     if (valid) a.exponent[n * a.ld + col] = expo;
                 }
             }
@@ -542,7 +577,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 tb = fma(e, lr, tb);                      // sum_k e_k (a_k - M): the dominant component adds exactly 0
                 s += e;
             } else {
-                s += ((cdouble *)a.pack + (size_t)k * STRIDE)[D + T + 4] * e;
+                s += ((cdouble *)a.pack + (size_t)k * dm.STRIDE)[dm.DT + 4] * e;
             }
             if (!literal) {                               // wave-uniform
                 if (k < klds) pl[k * 64] = e;
@@ -560,8 +595,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             double elq;
             if (literal) {
                 elq = 0.0;
-                pk = (cdouble *)a.pack + (size_t)(K - 1) * STRIDE;
-                for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
+                pk = (cdouble *)a.pack + (size_t)(K - 1) * dm.STRIDE;
+                for (int k = K - 1; k >= 0; --k, pk -= dm.STRIDE) {
                     double lr = (k < klds ? pl[k * 64] : ut[(size_t)k * 64]) - M;
                     double r = exp(lr);
                     r *= norm_inv;
@@ -569,7 +604,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     lr += log_norm_inv;
                     elq += r * lr;                        // variational.pyx:1003-1013
                     ut[(size_t)k * 64] = swv * r;
-                    const long long col = ((cint64 *)pk)[D + T + 5];
+                    const long long col = ((cint64 *)pk)[dm.DT + 5];
                     if (valid && a.r != nullptr) a.r[n * a.ld + col] = r;
                     if (valid) a.log_rho[n * a.ld + col] = lr;
                 }
@@ -578,7 +613,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     const double r = zero_to_tiny(e * norm_inv);
                     ut[(size_t)k * 64] = swv * r;
                     if (a.r != nullptr) {
-                        const long long col = ((cint64 *)((cdouble *)a.pack + (size_t)k * STRIDE))[D + T + 5];
+                        const long long col = ((cint64 *)((cdouble *)a.pack + (size_t)k * dm.STRIDE))[dm.DT + 5];
                         if (valid) a.r[n * a.ld + col] = r;
                     }
                 };
@@ -618,10 +653,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 }
             };
             if (a.mode == PMC_RESP_PMC_LATENT || literal) {
-                pk = (cdouble *)a.pack + (size_t)(K - 1) * STRIDE;
-                for (int k = K - 1; k >= 0; --k, pk -= STRIDE) {
-                    cdouble *c = pk + D + T;
-                    const long long col = ((cint64 *)pk)[D + T + 5];
+                pk = (cdouble *)a.pack + (size_t)(K - 1) * dm.STRIDE;
+                for (int k = K - 1; k >= 0; --k, pk -= dm.STRIDE) {
+                    cdouble *c = pk + dm.DT;
+                    const long long col = ((cint64 *)pk)[dm.DT + 5];
                     double rho;
                     if (a.mode == PMC_RESP_PMC_LATENT) {
                         rho = (lat == col) ? 1. : 0.;         // pmc.pyx:49-50
@@ -635,9 +670,9 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 // one division per sample, a multiplication per pair (a fp64 division is ~14 instructions)
                 const double inv_denom = 1. / denom;
                 auto step = [&](int k, double e) {
-                    cdouble *pkk = (cdouble *)a.pack + (size_t)k * STRIDE;
-                    const double rho = ((e * em) * pkk[D + T + 4]) * inv_denom;
-                    emit(k, rho, pkk + D + T, ((cint64 *)pkk)[D + T + 5]);
+                    cdouble *pkk = (cdouble *)a.pack + (size_t)k * dm.STRIDE;
+                    const double rho = ((e * em) * pkk[dm.DT + 4]) * inv_denom;
+                    emit(k, rho, pkk + dm.DT, ((cint64 *)pkk)[dm.DT + 5]);
                 };
                 descend(K, klds, parked_global, step);
                 descend(klds, 0, parked_lds, step);

@@ -107,6 +107,7 @@ __device__ __forceinline__ double chi_square(const Philox &g, unsigned long long
     return 2.0 * result * boost;
 }
 
+#if PMC_D > 0
 constexpr int PCH = 16;          // coordinates staged per pass
 constexpr int PPITCH = PCH + 1;  // row pitch of the staging buffer in doubles (odd: conflict-free column writes)
 
@@ -201,11 +202,99 @@ __global__ __launch_bounds__(256, 2) void k_propose(const PmcArgsP a)
     if (a.origin != nullptr && valid) a.origin[n] = k;
 }
 
+#else   // PMC_D == 0: the run-time-dimension unit (D > PMC_MAX_DIM)
+
+// x = mu_k + scale L_k z without D registers per lane: the lane's normals are written into its own row of the output
+// first and transformed IN PLACE, 16 coordinates at a time from the last block to the first -- block I needs
+// z_j for j < 16 (I + 1) only, all still intact, and its result overwrites z of block I.  16 accumulators and 16
+// staged z per lane; L through pointer type P (the scalar cache when the wavefront draws from one component).
+template <class P>
+__device__ __forceinline__ void affine_in_place(P L, P mu, int D, double scale, double *row)
+{
+    const int G = (D + 15) >> 4;
+    for (int I = G - 1; I >= 0; --I) {
+        double acc[16];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) acc[ii] = 0.0;
+        for (int J = 0; J <= I; ++J) {
+            double z[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) z[jj] = (16 * J + jj < D) ? row[16 * J + jj] : 0.0;
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) {
+                const int i = 16 * I + ii;
+                const int ic_ = i < D ? i : D - 1;                  // rows beyond D: computed on row D - 1, discarded
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = 16 * J + jj;
+                    const int jc = j < D ? j : D - 1;               // columns beyond D: z = 0
+                    // the strict upper triangle is never read (mixture.pyx only multiplies by the lower factor)
+                    if (J < I || jj <= ii) acc[ii] = fma(L[(long long)ic_ * D + jc], (J < I || jj <= ii) ? z[jj] : 0.0, acc[ii]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            const int i = 16 * I + ii;
+            if (i < D) row[i] = mu[i] + acc[ii] * scale;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_propose_big(const PmcArgsP a)
+{
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long n0 = n - lane;
+    if (n0 >= a.N) return;                                       // wave-uniform
+    const bool valid = n < a.N;
+    const int D = a.dreal;
+    const long long nn = valid ? n : a.N - 1;
+    int lo = 0, hi = a.K;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.offsets[mid] <= nn) lo = mid; else hi = mid;
+    }
+    const int k = lo;
+    const Philox g = {(unsigned)a.seed, (unsigned)(a.seed >> 32)};
+    const unsigned long long gn = (unsigned long long)(a.first_sample + nn);
+    double scale = 1.0;
+    if (a.dof != nullptr) {
+        const double nu = a.dof[k];
+        scale = sqrt(nu / chi_square(g, gn, 0x10000u, nu));      // student_t.pyx:55
+    }
+    const int kfirst = __builtin_amdgcn_readfirstlane(k);
+    const bool uniform = __all(k == kfirst);
+    if (valid) {
+        double *row = a.x + n * (long long)D;
+        for (int j = 0; j < D; j += 2) {
+            double z0, z1;
+            normal_pair(g, gn, (unsigned)(j >> 1), z0, z1);
+            row[j] = z0;
+            if (j + 1 < D) row[j + 1] = z1;
+        }
+        if (uniform)
+            affine_in_place((cdouble *)(a.chol + (size_t)kfirst * D * D), (cdouble *)(a.mu + (size_t)kfirst * D), D, scale, row);
+        else
+            affine_in_place(a.chol + (size_t)k * D * D, a.mu + (size_t)k * D, D, scale, row);
+        if (a.origin != nullptr) a.origin[n] = k;
+    }
+}
+#endif
+
 }  // namespace
 
+#if PMC_D > 0
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_propose_d, PMC_D, PMC_PADDED)(const PmcArgsP &a, unsigned grid,
                                                                               hipStream_t st)
 {
     hipLaunchKernelGGL((k_propose<D_, P_>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
+#else
+extern "C" hipError_t pmc_launch_propose_big(const PmcArgsP &a, unsigned grid, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_propose_big, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+#endif

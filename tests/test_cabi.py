@@ -31,9 +31,10 @@ def test_library_exports_every_declared_symbol():
 def test_host_side_entry_points():
     from pypmc_amd import _lib
     lib = _lib.load()
-    assert lib.pmc_max_dim() == 64 and lib.pmc_tile() == 64
+    assert lib.pmc_max_dim() == 1024 and lib.pmc_max_compiled_dim() == 64 and lib.pmc_tile() == 64
     assert lib.pmc_padded_dim(20) == 20 and lib.pmc_padded_dim(9) == 10 and lib.pmc_padded_dim(33) == 40
-    assert lib.pmc_padded_dim(65) < 0 and "not supported" in _lib.last_error()
+    assert lib.pmc_padded_dim(65) == 65 and lib.pmc_padded_dim(1024) == 1024          # the run-time-dimension unit
+    assert lib.pmc_padded_dim(1025) < 0 and "not supported" in _lib.last_error()
     assert lib.pmc_padded_dim(0) < 0
     assert lib.pmc_stats_stride(20) == 1 + 20 + 210
     assert lib.pmc_tile_buffer_len(65, 3) == 2 * 3 * 64
@@ -88,7 +89,7 @@ def test_evaluate_once_entry_points_check_their_arguments():
     for bad, needle in ((dict(K=0), "bad N/K"), (dict(K_tiles=0), "bad N/K"), (dict(pack=None), "bad N/K"),
                         (dict(stats=None), "bad N/K"), (dict(ws=None), "bad N/K"), (dict(N=-1), "bad N/K"),
                         (dict(kind=2), "kind must be GAUSS or STUDENT_T"), (dict(kind=1), "Student-t needs d_vsums"),
-                        (dict(D=65), "not supported"), (dict(x=None), "is NULL"), (dict(tiles=None), "is NULL"),
+                        (dict(D=1025), "not supported"), (dict(x=None), "is NULL"), (dict(tiles=None), "is NULL"),
                         (dict(u=None), "is NULL")):
         assert lib.pmc_estep_from_tiles(*args(**bad)) == -1, bad
         assert needle in _lib.last_error(), (bad, _lib.last_error())
