@@ -432,8 +432,6 @@ hipError_t big_maha(const double *d_x, long long N, int D, const double *d_pack,
     PmcArgsM m;
     std::memset(&m, 0, sizeof(m));
     m.x = d_x; m.N = N; m.D = D; m.pack = d_pack; m.K = K; m.stride = pmc_pack_stride_c(D); m.mtile = mtile;
-    const int D4 = (D + 3) & ~3;
-    m.subtiles_per_wg = D4 * 512 <= 65536 ? 4 : (D4 * 256 <= 65536 ? 2 : 1);
     return pmc_launch_big_maha(m, st);
 }
 // stream-ordered scratch of the library's own (the Mahalanobis forms of the run-time-dimension unit when the caller

@@ -29,58 +29,107 @@ extern __shared__ double big_lds[];
 // ---------------------------------------------------------------------------------------------
 // k_big_maha
 // ---------------------------------------------------------------------------------------------
-// blockDim = 64 * subtiles_per_wg; wavefront w of block b owns the 16-sample sub-tile g = b * spw + w, i.e. the
-// lanes 16 (g mod 4) ... + 15 of tile g / 4.  LDS: per wavefront D4 x 16 doubles (D4 = D rounded up to 4),
-// xs[c * 16 + s] = coordinate c of the sub-tile's sample s (zeros beyond D and beyond N).
+// One workgroup = 4 wavefronts = NT sub-tiles of 16 samples (NT = 4: one 64-sample tile; 2 / 1 where the LDS holds
+// no more).  The samples' coordinates are staged ONCE in LDS, xs[c * P + sample] (P = 16 NT + 1: the staging
+// writes -- a lane per coordinate of one row, coalesced in HBM -- land in distinct banks), and serve all K
+// components.  Per component the 16-row blocks of R are dealt to the wavefronts in pairs (I, G16 - 1 - I) of equal
+// total length, so no two wavefronts load the same rows of R, and every A operand feeds NT instructions (one per
+// sub-tile).  A lane fetches 4 consecutive... no: element (r, kk + 4 q + t), t = 0..3 of its row -- the 16 columns
+// of a step are assigned to the instructions' k slots as {kk + 4 q + t : q}, the same for A and B -- one step
+// ahead of the 4 NT instructions that consume them.  The wavefronts' partial |y|^2 meet in LDS (one barrier per
+// component, buffers alternating), summed in wavefront order: bit-reproducible.
+template <int NT>
 __global__ __launch_bounds__(256) void k_big_maha(const PmcArgsM a)
 {
+    constexpr int NS = 16 * NT, P = NS + 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int D = a.D, D4 = (D + 3) & ~3;
-    const long long g = (long long)blockIdx.x * a.subtiles_per_wg + wave;
-    const long long ntiles = (a.N + 63) >> 6;
-    if (g >= ntiles * 4) return;                          // (no barriers in this kernel)
-    const int s = lane & 15, q = lane >> 4;
-    double *xs = big_lds + (size_t)wave * D4 * 16;
+    const int D = a.D, D16 = (D + 15) & ~15, G16 = D16 >> 4;
+    const int i = lane & 15, q = lane >> 4;
+    double *xs = big_lds;                                  // D16 x P
+    double *red = big_lds + (size_t)D16 * P;               // 2 x 4 x NS
+    const long long g0 = (long long)blockIdx.x * NT;       // first sub-tile
+    const long long n0 = g0 * 16;
 
-    const long long row = g * 16 + s;
-    const double *xr = a.x + (row < a.N ? row : 0) * (long long)D;
-    for (int c0 = 0; c0 < D4; c0 += 4) {
-        const int c = c0 + q;
-        xs[c * 16 + s] = (row < a.N && c < D) ? xr[c] : 0.0;
+    // stage: thread -> (sample row, coordinate), coordinates fastest (coalesced); zeros beyond D and beyond N
+    for (int idx = threadIdx.x; idx < NS * D16; idx += 256) {
+        const int sl = idx / D16, c = idx - sl * D16;
+        const long long row = n0 + sl;
+        xs[c * P + sl] = (row < a.N && c < D) ? a.x[row * D + c] : 0.0;
     }
-    // (a wavefront reads only what it wrote: no barrier, the compiler's lgkmcnt wait orders it)
+    __syncthreads();
 
-    const int G16 = (D + 15) >> 4;
-    double *out = a.mtile + ((size_t)(g >> 2) * a.K) * 64 + (size_t)(g & 3) * 16 + s;
+    const int npair = (G16 + 1) >> 1;
     for (int k = 0; k < a.K; ++k) {
         const double *pk = a.pack + (size_t)k * a.stride;
-        double acc2 = 0.0;
-        for (int I = 0; I < G16; ++I) {
-            const int r = 16 * I + s;                     // this lane's row of R (A operand: i = lane & 15)
-            const bool rv = r < D;
-            const int rr = rv ? r : 0;
-            // element (r, c >= r) of the packed upper triangle sits at rbase[c]
-            const double *rbase = pk + D + (long long)rr * D - (long long)rr * (rr - 1) / 2 - rr;
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-            for (int kk = 16 * I; kk < D4; kk += 4) {
-                const int c = kk + q;                     // A: k = lane >> 4;  B: k = lane >> 4
-                const bool cv = c < D;
-                const double A = (rv && cv && c >= r) ? rbase[c] : 0.0;
-                const double mu = cv ? pk[c] : 0.0;
-                const double B = xs[c * 16 + s] - mu;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, acc, 0, 0, 0);
+        double part[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) part[t] = 0.0;
+        for (int p = wave; p < npair; p += 4) {
+            for (int half = 0; half < 2; ++half) {
+                const int I = half == 0 ? p : G16 - 1 - p;
+                if (half == 1 && I == p) break;            // (odd G16: the middle block is its own partner)
+                const int r = 16 * I + i;                  // this lane's row of R (A operand: i = lane & 15)
+                const bool rv = r < D;
+                const int rr = rv ? r : D - 1;
+                // element (r, c >= r) of the packed upper triangle sits at rbase[c]
+                const double *rbase = pk + D + (long long)rr * D - (long long)rr * (rr - 1) / 2 - rr;
+                d4 acc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+                double An[4], mn[4];
+                auto fetch = [&](int kk) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int c = kk + 4 * q + t;
+                        const int cc = c < rr ? rr : (c < D ? c : D - 1);      // inside the row's storage
+                        const double v = rbase[cc];
+                        An[t] = (rv && c >= r && c < D) ? v : 0.0;
+                        const double m = pk[c < D ? c : D - 1];
+                        mn[t] = c < D ? m : 0.0;
+                    }
+                };
+                fetch(16 * I);
+                for (int kk = 16 * I; kk < D16; kk += 16) {
+                    double A[4], mu[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { A[t] = An[t]; mu[t] = mn[t]; }
+                    if (kk + 16 < D16) fetch(kk + 16);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double *xc = xs + (size_t)(kk + 4 * q + t) * P + i;
+#pragma unroll
+                        for (int sub = 0; sub < NT; ++sub) {
+                            const double B = xc[16 * sub] - mu[t];
+                            acc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[sub], 0, 0, 0);
+                        }
+                    }
+                }
+                // C[i][j]: j = sample, i = row of this block -- all 16 rows of a sample are summed below
+#pragma unroll
+                for (int sub = 0; sub < NT; ++sub) {
+                    part[sub] = fma(acc[sub][0], acc[sub][0], part[sub]);
+                    part[sub] = fma(acc[sub][1], acc[sub][1], part[sub]);
+                    part[sub] = fma(acc[sub][2], acc[sub][2], part[sub]);
+                    part[sub] = fma(acc[sub][3], acc[sub][3], part[sub]);
+                }
             }
-            // C[i][j]: j = sample, i = row of this block -- all 16 rows of a sample are summed below
-            acc2 = fma(acc[0], acc[0], acc2);
-            acc2 = fma(acc[1], acc[1], acc2);
-            acc2 = fma(acc[2], acc[2], acc2);
-            acc2 = fma(acc[3], acc[3], acc2);
         }
-        acc2 += __shfl_xor(acc2, 16, 64);
-        acc2 += __shfl_xor(acc2, 32, 64);
-        if (q == 0) out[(size_t)k * 64] = acc2;
+        double *rk = red + (size_t)(k & 1) * 4 * NS;
+#pragma unroll
+        for (int sub = 0; sub < NT; ++sub) {
+            double v = part[sub];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0) rk[wave * NS + 16 * sub + i] = v;
+        }
+        __syncthreads();
+        if (wave == (k & 3) && lane < NS) {
+            const double tot = ((rk[lane] + rk[NS + lane]) + rk[2 * NS + lane]) + rk[3 * NS + lane];
+            const long long g = g0 + (lane >> 4);
+            if (g * 16 < ((a.N + 63) >> 6) * 64)
+                a.mtile[((size_t)(g >> 2) * a.K + k) * 64 + (size_t)(g & 3) * 16 + (lane & 15)] = tot;
+        }
     }
 }
 
@@ -162,18 +211,28 @@ __global__ __launch_bounds__(256) void k_big_stats(const PmcArgsB b)
 
 }  // namespace
 
+template <int NT> static hipError_t launch_maha(const PmcArgsM &a, hipStream_t st)
+{
+    const int D16 = (a.D + 15) & ~15;
+    const size_t lds = sizeof(double) * ((size_t)D16 * (16 * NT + 1) + 2 * 4 * 16 * NT);
+    if (lds > 65536) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_big_maha<NT>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (once != hipSuccess) return once;
+    }
+    const long long nsub = ((a.N + 63) >> 6) * 4;
+    hipLaunchKernelGGL((k_big_maha<NT>), dim3((unsigned)((nsub + NT - 1) / NT)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// sub-tiles per workgroup: as many as fit the LDS next to the reduction buffers (156 KB)
 extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &a, hipStream_t st)
 {
-    const long long nsub = ((a.N + 63) >> 6) * 4;
-    const int spw = a.subtiles_per_wg;
-    const size_t lds = sizeof(double) * (size_t)spw * ((a.D + 3) & ~3) * 16;
-    if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_big_maha),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k_big_maha, dim3((unsigned)((nsub + spw - 1) / spw)), dim3(64 * spw), lds, st, a);
-    return hipGetLastError();
+    const size_t D16 = (size_t)((a.D + 15) & ~15);
+    auto fits = [&](int nt) { return 8 * (D16 * (16 * nt + 1) + 2 * 4 * 16 * nt) <= 156 * 1024; };
+    if (fits(4)) return launch_maha<4>(a, st);
+    if (fits(2)) return launch_maha<2>(a, st);
+    return launch_maha<1>(a, st);
 }
 
 extern "C" hipError_t pmc_launch_big_stats(const PmcArgsB &b, unsigned grid, hipStream_t st)

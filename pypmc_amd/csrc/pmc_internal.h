@@ -164,7 +164,6 @@ struct PmcArgsM {
     int K;
     int stride;           // doubles per component in the pack
     double *mtile;        // ntiles x K x 64 (output)
-    int subtiles_per_wg;  // 16-sample sub-tiles (= wavefronts) per workgroup: 4, 2 or 1 -- what the LDS holds
 };
 
 // propose kernel

@@ -780,7 +780,58 @@ def case_combine_weights_device_inputs(be):
     assert_rel(hist[:][:, 0], g["combined_linear"], what="linear branch, device inputs")
 
 
-ALL_CASES = [case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
+def case_big_dimension(be):
+    """Sample dimensions beyond the per-dimension kernel units (D > 64: the run-time-dimension unit) through the
+    public front-end, against closed-form numpy; the limit (1024) is checked where a density is built."""
+    from pypmc_amd.density.gauss import Gauss
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    rs = np.random.RandomState(72)
+    D, K, N = 72, 3, 700
+    mu = rs.normal(0, 2, (K, D))
+    A = rs.normal(size=(K, D, D))
+    cov = np.einsum('kij,klj->kil', A, A) / D + 0.5 * np.eye(D)
+    w = np.array([.5, .3, .2])
+    mix = create_gaussian_mixture(mu, cov, w)
+    mix._backend = be
+    for c in mix.components:
+        c._backend = be
+    comp = rs.choice(K, N, p=w)
+    x = mu[comp] + np.einsum('nij,nj->ni', np.linalg.cholesky(cov)[comp], rs.normal(size=(N, D)))
+    d = x[:, None, :] - mu[None]
+    maha = np.einsum('nki,kij,nkj->nk', d, np.linalg.inv(cov), d)
+    logq_k = -0.5 * D * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(cov)[1] - 0.5 * maha
+    mx = logq_k.max(axis=1)
+    logq = mx + np.log((w * np.exp(logq_k - mx[:, None])).sum(axis=1))
+    ind = np.empty((N, K))
+    out = mix.multi_evaluate(x, individual=ind)
+    assert_rel(ind, logq_k, rtol=1e-9, what="component log-densities, D = 72")
+    assert_rel(out, logq, rtol=1e-9, what="mixture log-density, D = 72")
+    assert abs(mix.evaluate(x[3]) - logq[3]) < 1e-9 * abs(logq[3])
+    # Rao-Blackwellised Gaussian PMC update (pmc.pyx:120-246) in closed form
+    iw = rs.uniform(0.2, 2.0, N)
+    rho = w * np.exp(logq_k - logq[:, None])
+    res = gaussian_pmc(x, mix, weights=iw, backend=be)
+    wr = iw[:, None] * rho
+    np.testing.assert_allclose(res.weights, wr.sum(axis=0) / iw.sum(), rtol=1e-9)
+    for k in range(K):
+        m = (wr[:, k, None] * x).sum(axis=0) / wr[:, k].sum()
+        dk = x - m
+        S = np.einsum('n,ni,nj->ij', wr[:, k], dk, dk) / wr[:, k].sum()
+        np.testing.assert_allclose(res.components[k].mu, m, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(res.components[k].sigma, S, rtol=1e-7, atol=1e-9)
+    # VB E-step on the same data: N_comp = sum_n r_nk, rows of r sum to one
+    vb = GaussianInference(x, initial_guess=mix, backend=be)
+    vb.E_step()
+    np.testing.assert_allclose(vb.r.sum(axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(vb.N_comp, vb.r.sum(axis=0), rtol=1e-10)
+    np.testing.assert_allclose(vb.x_mean_comp, (vb.r.T @ x) / vb.N_comp[:, None], rtol=1e-8, atol=1e-10)
+    with pytest.raises(ValueError, match="up to 1024"):
+        Gauss(np.zeros(1025), np.eye(1025), backend=be)
+
+
+ALL_CASES = [case_big_dimension, case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
              case_device_history, case_combine_weights_device_inputs, case_reference_known_answers,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,

@@ -492,7 +492,7 @@ def test_edge_cases(be, orc):
     # unsupported dimension
     from pypmc_amd.backend import HipLibraryError
     with pytest.raises(HipLibraryError):
-        be.logpdf(np.zeros((2, 65)), ComponentSet(0, np.zeros((1, 65)), np.eye(65)[None]))
+        be.logpdf(np.zeros((2, 1025)), ComponentSet(0, np.zeros((1, 1025)), np.eye(1025)[None]))
 
 
 @pytest.mark.parametrize("cond", [1e4, 1e8, 1e10])

@@ -25,13 +25,13 @@ def mk(K, D, seed):
     return mu, cov, w / w.sum()
 
 
-@pytest.mark.parametrize("D,K", [(2, 3), (5, 4), (9, 2), (20, 8), (33, 2), (64, 2)])
+@pytest.mark.parametrize("D,K", [(2, 3), (5, 4), (9, 2), (20, 8), (33, 2), (64, 2), (70, 3), (130, 2)])
 def test_gauss_propose(be, D, K):
     from pypmc_amd.density.mixture import create_gaussian_mixture
     mu, cov, w = mk(K, D, 40 + D)
     mix = create_gaussian_mixture(mu, cov, w)
     mix._backend = be
-    N = 400_000
+    N = 400_000 if D <= 64 else 150_000
     np.random.seed(123)
     x, origin = mix.propose(N, trace=True, shuffle=False, device=True)
     np.random.seed(123)
@@ -59,6 +59,28 @@ def test_gauss_propose(be, D, K):
     xs2 = mix.propose(N, device=True).cpu().numpy()
     assert xs2.shape == (N, D) and not np.array_equal(xs2, x)
     np.testing.assert_allclose(np.sort(xs2[:, 0]), np.sort(x[:, 0]))
+
+
+@pytest.mark.parametrize("D,dof", [(65, None), (100, None), (257, None), (80, 6.0)])
+def test_big_dimension_propose_is_the_affine_map_of_its_normals(be, D, dof):
+    """Run-time-dimension unit (D > 64): the kernel writes a sample's normals into its row and transforms them in
+    place, 16 coordinates at a time.  With L = I, mu = 0 it returns the normals themselves [times the Student-t
+    scale]; the general x must then be mu_k + L_k z to rounding -- also in wavefronts that mix components."""
+    K, N = 4, 3000
+    mu, cov, w = mk(K, D, 300 + D)
+    chol = np.linalg.cholesky(cov)
+    counts = np.array([1000, 37, 0, N - 1037])
+    dofs = None if dof is None else np.full(K, dof)
+    z, o = be.propose(np.zeros((K, D)), np.tile(np.eye(D), (K, 1, 1)), dofs, counts, seed=11)
+    x, o2 = be.propose(mu, chol, dofs, counts, seed=11)
+    z, x, o = z.cpu().numpy(), x.cpu().numpy(), o.cpu().numpy()
+    np.testing.assert_array_equal(o, np.repeat(np.arange(K), counts))
+    np.testing.assert_array_equal(o2.cpu().numpy(), o)
+    ref = mu[o] + np.einsum('nij,nj->ni', chol[o], z)
+    np.testing.assert_allclose(x, ref, rtol=1e-12, atol=1e-12)
+    if dof is None:
+        assert abs(z.mean()) < 5 / np.sqrt(z.size) and abs(z.var() - 1) < 0.01
+        assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.08 and abs(np.corrcoef(z[:, 0], z[:, D - 1])[0, 1]) < 0.08
 
 
 def test_student_t_propose(be):
