@@ -136,75 +136,152 @@ __global__ __launch_bounds__(256) void k_big_maha(const PmcArgsM a)
 // ---------------------------------------------------------------------------------------------
 // k_big_stats
 // ---------------------------------------------------------------------------------------------
-// Block -> (chunk, task group) as in k_stats (all groups of a sample chunk on one XCD); 4 wavefronts = 4
-// consecutive tasks (k, p), p = I (I + 1) / 2 + J the 16 x 16 block (I, J <= I) of the lower triangle.
-// A[i][s] = u_s d_s[16 I + i], B[s][j] = d_s[16 J + j], 4 samples per instruction; diagonal tasks also carry the
-// first moments of their 16 coordinates, task (0, 0) the sum of the weights.
-__global__ __launch_bounds__(256) void k_big_stats(const PmcArgsB b)
+// Block -> (chunk, task group) as in k_stats (all groups of a sample chunk on one XCD).  A workgroup = 8
+// wavefronts = 8 consecutive tasks (k, p); p = BI (BI + 1) / 2 + BJ is a block of 16 BT x 16 BT coordinates
+// (BI, BJ <= BI) of the lower triangle, i.e. BT x BT instruction tiles whose 2 BT operands are read once per 4
+// samples: A[i][s] = u_s d_s[16 I + i], B[s][j] = d_s[16 J + j] (a diagonal block skips its upper tiles; it also
+// carries the first moments of its coordinates, block (0, 0) the sum of the weights).  The samples go through LDS
+// in steps of S rows (row-major, DB doubles each, zeros beyond D and beyond the chunk) that all 8 tasks share; the
+// next step's rows are fetched into registers while the matrix pipe works on the current one.
+// BT = 4 (64 x 64 coordinates, 16 accumulator tiles = 128 VGPRs) from D = 97 on: every staged byte then feeds 4x the
+// arithmetic, and the staging traffic -- K x blocks / 8 passes over the samples -- is what binds (D = 128, K = 32:
+// 40 passes with BT = 2, 12 with BT = 4); below, BT = 2 wastes fewer tiles on padding.
+#ifndef PMC_BIG_STATS_WAVES
+#define PMC_BIG_STATS_WAVES 2
+#endif
+template <int BT>
+__global__ __launch_bounds__(512, PMC_BIG_STATS_WAVES) void k_big_stats(const PmcArgsB b, const int S)
 {
+    constexpr int BC = 16 * BT;                           // coordinates per block
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int D = b.dreal;
-    const int G16 = (D + 15) >> 4, npairs = G16 * (G16 + 1) / 2;
+    const int D = b.dreal, DB = (D + BC - 1) / BC * BC;
+    const int GB = DB / BC, nb = GB * (GB + 1) / 2;
     const int bid = blockIdx.x;
     const int qd = bid >> 3;
     const int chunk = (bid & 7) + 8 * (qd / b.ngroups);
     const int group = qd % b.ngroups;
-    const long long task = (long long)group * 4 + wave;
-    const int k = (int)(task / npairs), p = (int)(task % npairs);
-    if (k >= b.K) return;
-    int I = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
-    while (I * (I + 1) / 2 > p) --I;
-    while ((I + 1) * (I + 2) / 2 <= p) ++I;
-    const int J = p - I * (I + 1) / 2;
-    const bool diag = I == J;
+    const long long task = (long long)group * 8 + wave;
+    const int k = (int)(task / nb), p = (int)(task % nb);
+    const bool active = k < b.K;                          // wave-uniform (an idle wavefront still stages and syncs)
+    int BI = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while (BI * (BI + 1) / 2 > p) --BI;
+    while ((BI + 1) * (BI + 2) / 2 <= p) ++BI;
+    const int BJ = p - BI * (BI + 1) / 2;
+    const bool diag = BI == BJ;
 
     const long long t0 = (long long)chunk * b.tiles_per_chunk;
     long long t1 = t0 + b.tiles_per_chunk;
     if (t1 > b.ntiles) t1 = b.ntiles;
-    const int stride = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
-    const double *pk = b.pack + (size_t)k * stride;
-    const int i16 = lane & 15, s = lane >> 4;
-    const int ci = 16 * I + i16, cj = 16 * J + i16;
-    const bool civ = ci < D, cjv = cj < D;
-    const double mui = civ ? pk[ci] : 0.0, muj = cjv ? pk[cj] : 0.0;
-    const int cic = civ ? ci : 0, cjc = cjv ? cj : 0;
-
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    double acc1 = 0.0, acc0 = 0.0;
     long long n1 = t1 * 64;
     if (n1 > b.N) n1 = b.N;
-#pragma unroll 4
-    for (long long n0 = t0 * 64; n0 < n1; n0 += 4) {
-        const long long n = n0 + s;
-        const bool nv = n < n1;
-        const long long nn = nv ? n : n0;
-        const double *xr = b.x + nn * D;
-        const double u = nv ? b.u[((size_t)(nn >> 6) * b.K + k) * 64 + (nn & 63)] : 0.0;
-        const double di = (nv && civ) ? xr[cic] - mui : 0.0;
-        const double dj = diag ? di : ((nv && cjv) ? xr[cjc] - muj : 0.0);
-        const double A = u * di;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A, dj, acc, 0, 0, 0);
-        if (diag) {                                       // wave-uniform
-            acc1 += A;
-            acc0 += u;
+    const int stride = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
+    const double *pk = b.pack + (size_t)(active ? k : 0) * stride;
+    const int i16 = lane & 15, s = lane >> 4;
+    double mi[BT], mj[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+        const int ci = BC * BI + 16 * t + i16, cj = BC * BJ + 16 * t + i16;
+        mi[t] = ci < D ? pk[ci] : 0.0;
+        mj[t] = cj < D ? pk[cj] : 0.0;
+    }
+
+    d4 acc[BT][BT];
+    double f[BT], su = 0.0;
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+        f[t] = 0.0;
+#pragma unroll
+        for (int v = 0; v < BT; ++v) acc[t][v] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+    // staging: element e of a thread is idx = threadIdx.x + 512 e of the step's S x DB image; its global value is
+    // fetched into a register one step ahead
+    constexpr int NPRE = BT == 4 ? 8 : 16;                // S * DB <= 512 NPRE elements per step (registers)
+    const int nimg = S * DB;
+    const int step_row = 512 / DB, step_col = 512 % DB;
+    double pre[NPRE];
+    auto gload = [&](long long nstart) {
+        int sl = threadIdx.x / DB, c = threadIdx.x % DB;
+#pragma unroll
+        for (int e = 0; e < NPRE; ++e) {
+            const long long row = nstart + sl;
+            pre[e] = (threadIdx.x + 512 * e < nimg && row < n1 && c < D) ? b.x[row * D + c] : 0.0;
+            sl += step_row;
+            c += step_col;
+            if (c >= DB) { c -= DB; ++sl; }
+        }
+    };
+    const long long nbeg = t0 * 64;
+    if (nbeg < n1) gload(nbeg);
+    for (long long n0 = nbeg; n0 < n1; n0 += S) {
+        // this step's weights: in flight across the two barriers
+        double uu[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long n = n0 + 4 * j + s;
+            uu[j] = (active && 4 * j < S && n < n1) ? b.u[((size_t)(n >> 6) * b.K + k) * 64 + (n & 63)] : 0.0;
+        }
+        __syncthreads();                                  // the previous step's reads are done
+#pragma unroll
+        for (int e = 0; e < NPRE; ++e)
+            if (threadIdx.x + 512 * e < nimg) big_lds[threadIdx.x + 512 * e] = pre[e];
+        __syncthreads();
+        if (n0 + S < n1) gload(n0 + S);
+        if (!active) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (4 * j >= S) break;                        // uniform
+            // (keeps the unrolled sub-steps apart: left alone the scheduler hoists all their LDS reads -- spills)
+            __builtin_amdgcn_sched_barrier(0);
+            const double u = uu[j];
+            const double *xr = big_lds + (size_t)(4 * j + s) * DB + i16;
+            double A[BT], B[BT];
+#pragma unroll
+            for (int t = 0; t < BT; ++t) {
+                const double a = xr[BC * BI + 16 * t] - mi[t];
+                B[t] = diag ? a : xr[BC * BJ + 16 * t] - mj[t];
+                A[t] = u * a;
+            }
+#pragma unroll
+            for (int t = 0; t < BT; ++t)
+#pragma unroll
+                for (int v = 0; v < BT; ++v)
+                    if (v <= t || !diag)                  // wave-uniform: a diagonal block skips its upper tiles
+                        acc[t][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B[v], acc[t][v], 0, 0, 0);
+            if (diag) {
+#pragma unroll
+                for (int t = 0; t < BT; ++t) f[t] += A[t];
+                su += u;
+            }
         }
     }
+    if (!active) return;
 
     double *out = b.partials + ((size_t)chunk * b.K + k) * PS;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int gi = 16 * I + s + 4 * r, gj = 16 * J + i16;     // C: col = lane & 15, row = (lane >> 4) + 4 r
-        if (gi < D && gj <= gi) out[1 + D + (size_t)gi * (gi + 1) / 2 + gj] = acc[r];
-    }
+    for (int t = 0; t < BT; ++t)
+#pragma unroll
+        for (int v = 0; v < BT; ++v) {
+            if (diag && v > t) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                 // C: col = lane & 15, row = (lane >> 4) + 4 r
+                const int gi = BC * BI + 16 * t + s + 4 * r, gj = BC * BJ + 16 * v + i16;
+                if (gi < D && gj <= gi) out[1 + D + (size_t)gi * (gi + 1) / 2 + gj] = acc[t][v][r];
+            }
+        }
     if (diag) {
-        acc1 += __shfl_xor(acc1, 16, 64);
-        acc1 += __shfl_xor(acc1, 32, 64);
-        if (s == 0 && civ) out[1 + ci] = acc1;
-        if (I == 0) {
-            acc0 += __shfl_xor(acc0, 16, 64);
-            acc0 += __shfl_xor(acc0, 32, 64);
-            if (lane == 0) out[0] = acc0;
+#pragma unroll
+        for (int t = 0; t < BT; ++t) {
+            double m = f[t];
+            m += __shfl_xor(m, 16, 64);
+            m += __shfl_xor(m, 32, 64);
+            const int c = BC * BI + 16 * t + i16;
+            if (s == 0 && c < D) out[1 + c] = m;
+        }
+        if (BI == 0) {
+            su += __shfl_xor(su, 16, 64);
+            su += __shfl_xor(su, 32, 64);
+            if (lane == 0) out[0] = su;
         }
     }
 }
@@ -225,7 +302,8 @@ template <int NT> static hipError_t launch_maha(const PmcArgsM &a, hipStream_t s
     return hipGetLastError();
 }
 
-// sub-tiles per workgroup: as many as fit the LDS next to the reduction buffers (156 KB)
+// sub-tiles per workgroup: as many as fit the LDS next to the reduction buffers (156 KB) -- sharing every A operand
+// among 4 sub-tiles beats a second workgroup per CU (D = 256: 26 against 23 TFLOP/s with 2 sub-tiles, 78 KB)
 extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &a, hipStream_t st)
 {
     const size_t D16 = (size_t)((a.D + 15) & ~15);
@@ -235,16 +313,27 @@ extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &a, hipStream_t st)
     return launch_maha<1>(a, st);
 }
 
+// coordinates per block of the statistics kernel: 64 from D = 97 on, 32 below
+static int stats_bt(int D) { return D > 96 ? 4 : 2; }
+
 extern "C" hipError_t pmc_launch_big_stats(const PmcArgsB &b, unsigned grid, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_big_stats, dim3(grid), dim3(256), 0, st, b);
+    // rows per LDS step: what the staging registers hold (512 threads x 16 / 8 doubles), at most 32
+    const int bt = stats_bt(b.dreal), bc = 16 * bt;
+    const int DB = (b.dreal + bc - 1) / bc * bc;
+    const int cap = 512 * (bt == 4 ? 8 : 16) / DB;
+    const int S = cap >= 32 ? 32 : (cap >= 16 ? 16 : (cap >= 8 ? 8 : 4));
+    const size_t lds = sizeof(double) * (size_t)S * DB;
+    if (bt == 4) hipLaunchKernelGGL(k_big_stats<4>, dim3(grid), dim3(512), lds, st, b, S);
+    else hipLaunchKernelGGL(k_big_stats<2>, dim3(grid), dim3(512), lds, st, b, S);
     return hipGetLastError();
 }
 
 // geometry knobs the dispatcher's stats_geom() uses: tasks per component, wavefronts per workgroup
 extern "C" void pmc_big_stats_config(int D, int *nsub, int *waves)
 {
-    const int G16 = (D + 15) >> 4;
-    *nsub = G16 * (G16 + 1) / 2;
-    *waves = 4;
+    const int bc = 16 * stats_bt(D);
+    const int GB = (D + bc - 1) / bc;
+    *nsub = GB * (GB + 1) / 2;
+    *waves = 8;
 }
