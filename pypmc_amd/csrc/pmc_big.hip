@@ -29,7 +29,7 @@ extern __shared__ double big_lds[];
 // ---------------------------------------------------------------------------------------------
 // k_big_maha
 // ---------------------------------------------------------------------------------------------
-// One workgroup = 4 wavefronts = NT sub-tiles of 16 samples (NT = 4: one 64-sample tile; 2 / 1 where the LDS holds
+// One workgroup = NW wavefronts (4; 8 where the LDS admits a single workgroup per CU) = NT sub-tiles of 16 samples (NT = 4: one 64-sample tile; 2 / 1 where the LDS holds
 // no more).  The samples' coordinates are staged ONCE in LDS, xs[c * P + sample] (P = 16 NT + 1: the staging
 // writes -- a lane per coordinate of one row, coalesced in HBM -- land in distinct banks), and serve all K
 // components.  Per component the 16-row blocks of R are dealt to the wavefronts in pairs (I, G16 - 1 - I) of equal
@@ -38,8 +38,8 @@ extern __shared__ double big_lds[];
 // of a step are assigned to the instructions' k slots as {kk + 4 q + t : q}, the same for A and B -- one step
 // ahead of the 4 NT instructions that consume them.  The wavefronts' partial |y|^2 meet in LDS (one barrier per
 // component, buffers alternating), summed in wavefront order: bit-reproducible.
-template <int NT>
-__global__ __launch_bounds__(256) void k_big_maha(const PmcArgsM a)
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_big_maha(const PmcArgsM a)
 {
     constexpr int NS = 16 * NT, P = NS + 1;
     const int lane = threadIdx.x & 63;
@@ -47,12 +47,12 @@ __global__ __launch_bounds__(256) void k_big_maha(const PmcArgsM a)
     const int D = a.D, D16 = (D + 15) & ~15, G16 = D16 >> 4;
     const int i = lane & 15, q = lane >> 4;
     double *xs = big_lds;                                  // D16 x P
-    double *red = big_lds + (size_t)D16 * P;               // 2 x 4 x NS
+    double *red = big_lds + (size_t)D16 * P;               // 2 x NW x NS
     const long long g0 = (long long)blockIdx.x * NT;       // first sub-tile
     const long long n0 = g0 * 16;
 
     // stage: thread -> (sample row, coordinate), coordinates fastest (coalesced); zeros beyond D and beyond N
-    for (int idx = threadIdx.x; idx < NS * D16; idx += 256) {
+    for (int idx = threadIdx.x; idx < NS * D16; idx += 64 * NW) {
         const int sl = idx / D16, c = idx - sl * D16;
         const long long row = n0 + sl;
         xs[c * P + sl] = (row < a.N && c < D) ? a.x[row * D + c] : 0.0;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_big_maha(const PmcArgsM a)
         double part[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) part[t] = 0.0;
-        for (int p = wave; p < npair; p += 4) {
+        for (int p = wave; p < npair; p += NW) {
             for (int half = 0; half < 2; ++half) {
                 const int I = half == 0 ? p : G16 - 1 - p;
                 if (half == 1 && I == p) break;            // (odd G16: the middle block is its own partner)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_big_maha(const PmcArgsM a)
                 }
             }
         }
-        double *rk = red + (size_t)(k & 1) * 4 * NS;
+        double *rk = red + (size_t)(k & 1) * NW * NS;
 #pragma unroll
         for (int sub = 0; sub < NT; ++sub) {
             double v = part[sub];
@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256) void k_big_maha(const PmcArgsM a)
             if (q == 0) rk[wave * NS + 16 * sub + i] = v;
         }
         __syncthreads();
-        if (wave == (k & 3) && lane < NS) {
-            const double tot = ((rk[lane] + rk[NS + lane]) + rk[2 * NS + lane]) + rk[3 * NS + lane];
+        if (wave == k % NW && lane < NS) {
+            double tot = rk[lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) tot += rk[w * NS + lane];
             const long long g = g0 + (lane >> 4);
             if (g * 16 < ((a.N + 63) >> 6) * 64)
                 a.mtile[((size_t)(g >> 2) * a.K + k) * 64 + (size_t)(g & 3) * 16 + (lane & 15)] = tot;
@@ -288,29 +290,32 @@ __global__ __launch_bounds__(512, PMC_BIG_STATS_WAVES) void k_big_stats(const Pm
 
 }  // namespace
 
-template <int NT> static hipError_t launch_maha(const PmcArgsM &a, hipStream_t st)
+template <int NT, int NW> static hipError_t launch_maha(const PmcArgsM &a, hipStream_t st)
 {
     const int D16 = (a.D + 15) & ~15;
-    const size_t lds = sizeof(double) * ((size_t)D16 * (16 * NT + 1) + 2 * 4 * 16 * NT);
+    const size_t lds = sizeof(double) * ((size_t)D16 * (16 * NT + 1) + 2 * NW * 16 * NT);
     if (lds > 65536) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_big_maha<NT>),
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_big_maha<NT, NW>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (once != hipSuccess) return once;
     }
     const long long nsub = ((a.N + 63) >> 6) * 4;
-    hipLaunchKernelGGL((k_big_maha<NT>), dim3((unsigned)((nsub + NT - 1) / NT)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_big_maha<NT, NW>), dim3((unsigned)((nsub + NT - 1) / NT)), dim3(64 * NW), lds, st, a);
     return hipGetLastError();
 }
 
 // sub-tiles per workgroup: as many as fit the LDS next to the reduction buffers (156 KB) -- sharing every A operand
-// among 4 sub-tiles beats a second workgroup per CU (D = 256: 26 against 23 TFLOP/s with 2 sub-tiles, 78 KB)
+// among 4 sub-tiles beats a second workgroup per CU (D = 256: 26 against 23 TFLOP/s with 2 sub-tiles, 78 KB).
+// Where only one workgroup fits a CU (beyond 78 KB) it has 8 wavefronts, two per SIMD, to hide the operand fetches.
 extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &a, hipStream_t st)
 {
     const size_t D16 = (size_t)((a.D + 15) & ~15);
-    auto fits = [&](int nt) { return 8 * (D16 * (16 * nt + 1) + 2 * 4 * 16 * nt) <= 156 * 1024; };
-    if (fits(4)) return launch_maha<4>(a, st);
-    if (fits(2)) return launch_maha<2>(a, st);
-    return launch_maha<1>(a, st);
+    auto bytes = [&](int nt) { return 8 * (D16 * (16 * nt + 1) + 2 * 8 * 16 * nt); };
+    const int nt = bytes(4) <= 156 * 1024 ? 4 : (bytes(2) <= 156 * 1024 ? 2 : 1);
+    const bool wide = bytes(nt) > 78 * 1024;
+    if (nt == 4) return wide ? launch_maha<4, 8>(a, st) : launch_maha<4, 4>(a, st);
+    if (nt == 2) return wide ? launch_maha<2, 8>(a, st) : launch_maha<2, 4>(a, st);
+    return wide ? launch_maha<1, 8>(a, st) : launch_maha<1, 4>(a, st);
 }
 
 // coordinates per block of the statistics kernel: 64 from D = 97 on, 32 below
