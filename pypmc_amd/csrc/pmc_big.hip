@@ -5,16 +5,20 @@
 // it is GEMM-shaped and the rest reuses the per-sample kernels as they are:
 //
 //   k_big_maha   maha_nk = |R_k (x_n - mu_k)|^2 for all pairs, tile-major -- 16 x 16 x 4 fp64 MFMA: the triangular
-//                product Y = R_k D_k for 16 samples per wavefront, R_k's 16-row blocks as the A operand straight
-//                from the row-major packed factor (L2 / L1: every wavefront walks the same component at the same
-//                time), the samples' coordinates as the B operand from a per-wavefront LDS stage that is filled
-//                once and serves all K components;
+//                product Y = R_k D_k, R_k's 16-row blocks as the A operand straight from the row-major packed factor
+//                (dealt to the workgroup's wavefronts, each operand shared by up to 4 sub-tiles of 16 samples), the
+//                samples' coordinates as the B operand from an LDS stage that is filled once per workgroup and
+//                serves all K components;
 //   k_logpdf<0>, k_resp<0>   (pmc_persample.hip, engine TILES) read those forms -- every fused output, kind and
 //                mode of the compiled units, same code;
-//   k_big_stats  sum u | sum u d | sum u d d^T:  one wavefront per (sample chunk, component, 16 x 16 block of the
-//                lower triangle), 4 samples per v_mfma_f64_16x16x4_f64, partials in k_stats' layout for the same
-//                fixed-order finishing kernel.
-//   (k_propose<0>: pmc_propose.hip)
+//   k_big_stats  sum u | sum u d | sum u d d^T:  one wavefront per (sample chunk, component, block of 32 x 32 or
+//                64 x 64 coordinates of the lower triangle), 4 samples per v_mfma_f64_16x16x4_f64, the samples staged
+//                in LDS for the workgroup's 8 tasks; partials in k_stats' layout for the same fixed-order finishing
+//                kernel.
+//   (k_propose_big: pmc_propose.hip)
+//
+// Measured (profiles/r02_big_dims.txt, 1e6 samples x 32 components): D = 128  log-pdf 15 ms = 36 algorithmic
+// TFLOP/s, statistics 18 ms = 29; D = 256  55 ms = 39 and 67 ms = 32 -- against 42-51 for the compiled D = 64 unit.
 //
 // Operand layouts of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md):  A[i][k] lane 16 k + i,  B[k][j] lane
 // 16 k + j,  C[i][j] lane 16 (i mod 4) + j, register i / 4.

@@ -15,4 +15,5 @@ run cfg5_evaluate_once python "$R/examples/pmc_device_loop.py" 12500000 4
 run cfg5_evaluate_twice python "$R/examples/pmc_device_loop.py" 12500000 4 evaluate-twice
 run estep_d2_k32 python "$R/scripts/kbench.py" --N 4000000 --K 32 --D 2 --reps 5
 run estep_d5_k32 python "$R/scripts/kbench.py" --N 4000000 --K 32 --D 5 --reps 5
+run big_d128 python "$R/scripts/kbench.py" --N 1000000 --K 32 --D 128 --reps 5
 ls "$OUT"/*.csv
