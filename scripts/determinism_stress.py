@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 CASES = [(4, 5, 50_000), (4, 3, 50_000), (2, 7, 33_333), (7, 32, 100_001), (5, 9, 1_000_000),
-         (8, 6, 77_777), (12, 16, 100_000), (20, 32, 300_000), (32, 31, 123_457), (40, 128, 200_000)]
+         (8, 6, 77_777), (12, 16, 100_000), (20, 32, 300_000), (32, 31, 123_457), (40, 128, 200_000),
+         (70, 5, 40_000), (130, 3, 20_001)]          # the last two: the run-time-dimension unit
 
 
 def sweep(reps, cases=CASES, verbose=True):
