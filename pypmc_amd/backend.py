@@ -323,9 +323,12 @@ class HipBackend(object):
         return out, flag
 
     def estep(self, x, comps, mode, max_init_zero=False, sample_w=None, latent=None,
-              want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None):
+              want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None, shift=None):
         """Responsibilities (pmc_responsibilities) followed by the sufficient statistics
         (pmc_sufficient_stats) of the same samples.
+
+        ``shift`` (K x D): take the moments about these points instead of the components' means -- the second
+        pass of mix_adapt when a mean turned out far from its component (``_stats.shift_is_far``).
 
         Returns dict(stats = [scalars(NSCALARS) | K*stats_stride | K*2 Student-t sums] one flat
         device tensor (so that a multi-GPU caller all-reduces a single buffer), r, log_rho,
@@ -349,7 +352,12 @@ class HipBackend(object):
         assert flat.numel() == nflat
         vsums = flat[NSCALARS + K * ps:] if student else None
         ws = self._workspace(N, K, D)
-        if r is None and log_rho is None and expo is None:
+        stats_pack = pack
+        if shift is not None:
+            # only the means of a pack matter to the statistics kernel
+            shift = np.ascontiguousarray(shift, dtype=np.float64).reshape(K, D)
+            stats_pack = self.pack(ComponentSet(PMC_KIND_GAUSS, shift, np.broadcast_to(np.eye(D), (K, D, D)).copy()))
+        if r is None and log_rho is None and expo is None and shift is None:
             # the E-step proper: one call; for small D one kernel, the N x K matrix stays on chip
             fused = bool(self.lib.pmc_estep_is_fused(K, D, comps.kind, int(mode)))
             u = None if fused else self._tilebuf("u", N, K)
@@ -370,7 +378,7 @@ class HipBackend(object):
             "pmc_responsibilities")
         _lib.check(self._timed(
             "pmc_sufficient_stats", self.lib.pmc_sufficient_stats,
-            self._p(x), N, D, self._p(pack), K, self._p(u), self._p(flat[NSCALARS:]), self._p(ws),
+            self._p(x), N, D, self._p(stats_pack), K, self._p(u), self._p(flat[NSCALARS:]), self._p(ws),
             self._stream()), "pmc_sufficient_stats")
         return dict(stats=flat, r=r, log_rho=log_rho, exponent=expo)
 

@@ -26,3 +26,22 @@ class ProbabilityDensity(object):
     def propose(self, N=1, rng=np.random.mtrand):
         """N samples from q drawn with ``rng``."""
         raise NotImplementedError()
+
+
+class LocalDensity(object):
+    """A local density q(x | y) (reference: pypmc/density/base.py:68-105): the proposal interface of the
+    Markov-chain sampler, kept because Gauss / StudentT are specified through their local counterparts."""
+    dim = 0
+    symmetric = False
+
+    def __init__(self):
+        raise NotImplementedError('Do not create instances from this class, use derived classes instead.')
+
+    def evaluate(self, x, y):
+        """log q(x | y)."""
+        raise NotImplementedError()
+
+    def propose(self, y, rng=np.random.mtrand):
+        """One sample from q(. | y) drawn with ``rng``."""
+        raise NotImplementedError()
+

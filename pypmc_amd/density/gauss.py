@@ -3,7 +3,7 @@ import itertools
 
 import numpy as np
 
-from .base import ProbabilityDensity
+from .base import ProbabilityDensity, LocalDensity
 from ..tools._linalg import chol_inv_det
 from ..backend import ComponentSet, get_backend
 from .._lib import PMC_KIND_GAUSS, check_dim
@@ -96,7 +96,50 @@ class Gauss(ProbabilityDensity):
     # -- sampling (host; the generator stream is consumed exactly as the reference does) ---------
     def propose(self, N=1, rng=np.random.mtrand):
         """mu + L z with z ~ N(0, 1)^D drawn sample by sample (reference: gauss.pyx:50-52,
-        :159-163); one (N, D) draw consumes the legacy generator stream identically."""
-        z = rng.normal(0, 1, (int(N), self.dim)) if N else np.empty((0, self.dim))
-        z = np.asarray(z, dtype=float).reshape(int(N), self.dim)
+        :159-163).  With numpy's own generators one (N, D) draw consumes the stream identically; any other
+        ``rng`` object is asked for ``rng.normal(0, 1, dim)`` once per sample, exactly as the reference does."""
+        N = int(N)
+        if not N:
+            return np.empty((0, self.dim))
+        if _is_numpy_rng(rng):
+            z = np.asarray(rng.normal(0, 1, (N, self.dim)), dtype=float).reshape(N, self.dim)
+        else:
+            z = np.array([np.asarray(rng.normal(0, 1, self.dim), dtype=float).reshape(self.dim) for _ in range(N)])
         return self.mu + z.dot(self.cholesky_sigma.T)
+
+
+def _is_numpy_rng(rng):
+    return rng is np.random or rng is np.random.mtrand or isinstance(rng, (np.random.RandomState, np.random.Generator))
+
+
+class LocalGauss(LocalDensity):
+    """Local Gaussian N(x | y, sigma) with redefinable covariance (reference: gauss.pyx:12-67).  ``evaluate`` is
+    the zero-mean Gaussian's log-pdf at x - y on the HIP path; ``propose`` consumes ``rng`` as the reference does."""
+    symmetric = True
+
+    def __init__(self, sigma, backend=None):
+        self._backend = backend
+        self.update(sigma)
+
+    def update(self, sigma):
+        """New covariance; a ``LinAlgError`` leaves the object untouched (gauss.pyx:22-48)."""
+        sigma = _as_matrix(sigma)
+        self._set(Gauss(np.zeros(sigma.shape[0]), sigma, backend=self._backend))       # may raise LinAlgError
+
+    def _set(self, centred):
+        self._centred = centred
+        self.sigma, self.dim = centred.sigma, centred.dim
+        self.cholesky_sigma, self.inv_sigma, self.log_det_sigma = centred.cholesky_sigma, centred.inv_sigma, centred.log_det_sigma
+        self._compute_norm()
+
+    def _compute_norm(self):
+        self.log_normalization = self._centred.log_normalization                      # gauss.pyx:54-56
+
+    def _get_gauss_sample(self, rng):
+        return np.dot(self.cholesky_sigma, rng.normal(0, 1, self.dim))                # gauss.pyx:50-52
+
+    def evaluate(self, x, y):
+        return self._centred.evaluate(np.asarray(x, dtype=float) - np.asarray(y, dtype=float))   # gauss.pyx:59-60
+
+    def propose(self, y, rng=np.random.mtrand):
+        return y + self._get_gauss_sample(rng)                                        # gauss.pyx:66-67

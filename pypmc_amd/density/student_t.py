@@ -2,7 +2,7 @@
 import numpy as np
 from scipy.special import gammaln
 
-from .gauss import Gauss, _STAMPS
+from .gauss import Gauss, LocalGauss, _STAMPS, _as_matrix
 from .._lib import PMC_KIND_STUDENT_T
 
 
@@ -49,3 +49,24 @@ class StudentT(Gauss):
             g = self.cholesky_sigma.dot(rng.normal(0, 1, self.dim))
             out[n] = self.mu + g * np.sqrt(self.dof / rng.chisquare(self.dof))
         return out
+
+
+class LocalStudentT(LocalGauss):
+    """Local Student's t density t_nu(x | y, sigma) with redefinable covariance (reference: student_t.pyx:13-55)."""
+
+    def __init__(self, sigma, dof, backend=None):
+        self.symmetric = True
+        dof = float(dof)
+        assert dof > 0., "Degree of freedom (``dof``) must be greater than zero (got %g)." % dof
+        self.dof = dof
+        self._backend = backend
+        self.update(sigma)
+
+    def update(self, sigma):
+        sigma = _as_matrix(sigma)
+        self._set(StudentT(np.zeros(sigma.shape[0]), sigma, self.dof, backend=self._backend))   # may raise LinAlgError
+
+    def propose(self, y, rng=np.random.mtrand):
+        # one normal vector, then one chi-square per sample (student_t.pyx:49-55)
+        return y + self._get_gauss_sample(rng) * np.sqrt(self.dof / rng.chisquare(self.dof))
+

@@ -44,3 +44,23 @@ def centred_moments(S0_mean, M1, M2, shift, S0_cov=None):
     mean = shift + dbar
     cov = (M2 - n_mean[:, None, None] * np.einsum('ki,kj->kij', dbar, dbar)) / n_cov[:, None, None]
     return mean, cov
+
+
+def shift_is_far(S0, M1, M2, limit=100.):
+    """True if some component's weighted mean lies more than sqrt(limit) of its own standard deviations (in some
+    coordinate) away from the shift its one-pass moments were taken about.  cov = M2/S0 - dbar dbar^T then cancels
+    ~limit leading parts: the relative error of the covariance grows to limit * 1e-16, against the 1e-16 of the
+    reference's two passes (mean first, then moments about it: variational.pyx:806-932, pmc.pyx:188-222).  The
+    callers answer with a second pass of the statistics about the mean just found.  Components without weight
+    (or with non-finite sums) do not count."""
+    S0 = np.asarray(S0, dtype=np.float64)
+    ok = np.isfinite(S0) & (S0 > 1e-200)
+    if not ok.any():
+        return False
+    n = S0[ok][:, None]
+    dbar2 = (M1[ok] / n) ** 2
+    raw = np.einsum('kii->ki', M2[ok]) / n                   # E[d_i^2] about the shift
+    var = np.maximum(raw - dbar2, 1e-14 * raw)
+    with np.errstate(invalid='ignore'):
+        return bool(np.any(dbar2 > limit * var))
+

@@ -22,7 +22,7 @@ from ..backend import get_backend
 from ..density.gauss import Gauss
 from ..density.student_t import StudentT
 from ..density.mixture import MixtureDensity, component_set
-from ._stats import split_stats, centred_moments
+from ._stats import split_stats, centred_moments, shift_is_far, regularize
 from ..tools._linalg import single_threaded_blas, chol_inv_det_batch
 
 logger = logging.getLogger(__name__)
@@ -67,6 +67,21 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
 
     be = get_backend(backend)
     D = density.dim
+    tail0 = np.concatenate(([local_norm], count if count is not None else np.zeros(0)))
+
+    def exchange(flat):
+        """ONE exchange: statistics | weight normalisation | latent histogram travel in the same buffer
+        (on the device when the statistics are, so RCCL reduces it in place)"""
+        nstat = int(flat.shape[0])
+        if parallel.world_size() > 1:
+            joined = be.zeros(nstat + len(tail0))
+            joined[:nstat] = flat
+            joined[nstat:] = be.asdevice(tail0)
+            joined = be.tohost(parallel.all_reduce_sum(joined))
+            return joined[:nstat], joined[nstat:]
+        return be.tohost(flat), tail0
+
+    cs = None
     if live_components and not rb and count is not None and int(count.sum()) == N_local \
             and _is_sorted(latent):
         # non-Rao-Blackwell update of samples that arrive ordered by generating component (what
@@ -96,20 +111,21 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
     else:
         flat, nlive = be.zeros(be.stats_len(1, D)), 0
 
-    # ONE exchange: statistics | weight normalisation | latent histogram travel in the same buffer
-    # (on the device when the statistics are, so RCCL reduces it in place)
-    tail = np.concatenate(([local_norm], count if count is not None else np.zeros(0)))
-    nstat = int(flat.shape[0])
-    if parallel.world_size() > 1:
-        joined = be.zeros(nstat + len(tail))
-        joined[:nstat] = flat
-        joined[nstat:] = be.asdevice(tail)
-        joined = be.tohost(parallel.all_reduce_sum(joined))
-        flat, tail = joined[:nstat], joined[nstat:]
-    else:
-        flat = be.tohost(flat)
+    flat, tail = exchange(flat)
     weight_normalization = float(tail[0])
     stats = split_stats(flat, max(nlive, 1), D)
+    shift = np.array([density.components[k].mu for k in stat_components]).reshape(len(stat_components), D)
+    if cs is not None and shift_is_far(stats[1], stats[2], stats[3]):
+        # a weighted mean far from its proposal component (the first iterations of a badly placed proposal): the
+        # one-pass moments about mu_k would cancel; second pass about the mean just found -- the reference's own
+        # order (mean first, then the covariance about it: pmc.pyx:188-222, :612-632).  Decided on the all-reduced
+        # sums, so every rank takes the same branch.
+        S0 = stats[1]
+        shift = np.where((S0 > 1e-200)[:, None], shift + stats[2] / regularize(S0.copy())[:, None], shift)
+        res = be.estep(samples, cs, mode, max_init_zero=len(live_components) < K, sample_w=weights,
+                       latent=None if rb else latent, shift=shift)
+        flat, tail = exchange(res["stats"])
+        stats = split_stats(flat, max(nlive, 1), D)
 
     if count is not None:
         count = tail[1:]
@@ -123,7 +139,7 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
                 need_renormalize = True
                 logger.warning("Component %i died because of too few (%i) samples." % (k, count[k]))
 
-    return density, live_components, stat_components, stats, weight_normalization, need_renormalize
+    return density, live_components, stat_components, stats, weight_normalization, need_renormalize, shift
 
 
 def _is_sorted(a):
@@ -207,11 +223,10 @@ def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=
     assert samples is not None
     if isinstance(samples, np.ndarray):          # device-resident tensors pass through untouched
         samples = np.ascontiguousarray(samples, dtype=np.float64)
-    density, live, stat_comps, stats, norm, renorm = \
+    density, live, stat_comps, stats, norm, renorm, shift = \
         _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis)
     _, S0, M1, M2, _, _ = stats
     if stat_comps:
-        shift = np.array([density.components[k].mu for k in stat_comps])
         mu, cov = centred_moments(S0, M1, M2, shift)             # pmc.pyx:194-204 / :213-222
         alpha = S0 / norm                                         # :191-193
         pos = {k: i for i, k in enumerate(stat_comps)}
@@ -235,13 +250,12 @@ def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solv
     assert samples is not None
     if isinstance(samples, np.ndarray):
         samples = np.ascontiguousarray(samples, dtype=np.float64)
-    density, live, stat_comps, stats, norm, renorm = \
+    density, live, stat_comps, stats, norm, renorm, shift = \
         _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis)
     _, S0g, M1, M2, V1, V2 = stats        # S0g = sum w rho gamma, V1 = sum w rho
     D = density.dim
     new = {}
     if stat_comps:
-        shift = np.array([density.components[k].mu for k in stat_comps])
         old_dof = np.array([density.components[k].dof for k in stat_comps])
         # mean: normalised by sum w rho gamma; covariance: by sum w rho   (pmc.pyx:620-630)
         mu, cov = centred_moments(S0g, M1, M2, shift, S0_cov=V1)

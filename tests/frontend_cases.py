@@ -780,6 +780,50 @@ def case_combine_weights_device_inputs(be):
     assert_rel(hist[:][:, 0], g["combined_linear"], what="linear branch, device inputs")
 
 
+def case_far_start_values(be):
+    """Moments are taken in ONE pass about the component's current mean; when the weighted mean turns out far from
+    it (start values, a badly placed proposal) mix_adapt repeats the statistics about the mean just found
+    (_stats.shift_is_far), so the covariance keeps the accuracy of the reference's two passes
+    (variational.pyx:806-932, pmc.pyx:188-222) instead of cancelling (d/sigma)^2 leading parts."""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    from pypmc_amd.mix_adapt._stats import shift_is_far
+    rs = np.random.RandomState(4)
+    cov = np.array([[[0.01, 0.003], [0.003, 0.0025]], [[0.1, 0.], [0., 0.02]]])
+    mean = np.array([[1., -4.], [-5., 2.]])
+    x = np.vstack([rs.multivariate_normal(mean[k], cov[k], size=n) for k, n in ((0, 300), (1, 900))])
+    lab = np.repeat([0, 1], [300, 900])
+
+    def two_pass(k, w=None):
+        xs = x[lab == k]
+        ws = np.ones(len(xs)) if w is None else w[lab == k]
+        m = (ws[:, None] * xs).sum(axis=0) / ws.sum()
+        d = xs - m
+        return m, np.einsum('n,ni,nj->ij', ws, d, d) / ws.sum()
+
+    # VB: start means 300 standard deviations away from the clusters (variational_test.py:391-406 uses +2 / +10)
+    vb = GaussianInference(x, 2, m=mean + np.array([[30., -30.], [-30., 30.]]), backend=be)
+    for k in range(2):
+        m, S = two_pass(k)
+        np.testing.assert_allclose(vb.N_comp[k], (300, 900)[k], rtol=1e-12)
+        np.testing.assert_allclose(vb.x_mean_comp[k], m, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(vb.S[k], S, rtol=2e-12, atol=1e-16)     # one pass about m_k: 1e-8 at best
+    # PMC: a proposal whose components sit 100 sigma off the samples they are responsible for
+    iw = rs.uniform(0.5, 1.5, len(x))
+    prop = create_gaussian_mixture(mean + np.array([[1., 1.], [-3., 3.]]), 400. * cov, [.5, .5])
+    prop._backend = be
+    res = gaussian_pmc(x, prop, weights=iw, latent=lab, rb=False, backend=be)
+    for k in range(2):
+        m, S = two_pass(k, iw)
+        np.testing.assert_allclose(res.components[k].mu, m, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(res.components[k].sigma, S, rtol=2e-12, atol=1e-16)
+    # the criterion itself: a mean 3 sigma off its shift is not "far", 30 sigma is
+    S0 = np.array([10.])
+    for off, far in ((3., False), (30., True)):
+        assert shift_is_far(S0, np.array([[off * 10., 0.]]), np.array([[[10. * (1. + off * off), 0.], [0., 10.]]])) is far
+
+
 def case_big_dimension(be):
     """Sample dimensions beyond the per-dimension kernel units (D > 64: the run-time-dimension unit) through the
     public front-end, against closed-form numpy; the limit (1024) is checked where a density is built."""
@@ -831,7 +875,7 @@ def case_big_dimension(be):
         Gauss(np.zeros(1025), np.eye(1025), backend=be)
 
 
-ALL_CASES = [case_big_dimension, case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
+ALL_CASES = [case_far_start_values, case_big_dimension, case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
              case_device_history, case_combine_weights_device_inputs, case_reference_known_answers,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,

@@ -103,7 +103,7 @@ class OracleBackend(object):
         return out, np.array([float(np.count_nonzero(~np.isfinite(out)))])
 
     def estep(self, x, comps, mode, max_init_zero=False, sample_w=None, latent=None,
-              want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None):
+              want_r=False, want_log_rho=False, want_exponent=False, pack=None, out=None, shift=None):
         x = self.asdevice(x)
         N, D = x.shape
         K = comps.K
@@ -137,7 +137,7 @@ class OracleBackend(object):
                 vs[:, 0] = u.sum(axis=0)
                 vs[:, 1] = (u * np.log(.5 * (maha + dof[None, :]))).sum(axis=0)
                 u = u * gamma
-        d = x[:, None, :] - comps.mu[None, :, :]
+        d = x[:, None, :] - (comps.mu if shift is None else np.asarray(shift, dtype=float).reshape(K, D))[None, :, :]
         S0 = u.sum(axis=0)
         M1 = np.einsum('nk,nki->ki', u, d)
         M2 = np.einsum('nk,nki,nkj->kij', u, d, d)
