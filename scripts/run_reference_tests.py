@@ -32,7 +32,7 @@ REF = "/root/reference/pypmc"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-MODULES = ["pypmc.tools.linalg_test", "pypmc.tools.regularize_test", "pypmc.tools.convergence_test",
+MODULES = ["pypmc.density.base_test", "pypmc.tools.linalg_test", "pypmc.tools.regularize_test", "pypmc.tools.convergence_test",
            "pypmc.density.gauss_test", "pypmc.density.student_t_test", "pypmc.density.mixture_test",
            "pypmc.sampler.importance_sampling_test", "pypmc.mix_adapt.pmc_test", "pypmc.mix_adapt.variational_test"]
 
