@@ -363,6 +363,22 @@ StatsGeom stats_geom(long long N, int K, const PmcKernelSet *ks)
     if (want > g.ntiles) want = g.ntiles;
     if (want < 1) want = 1;
     g.nchunks = (int)(ceil_div(want, 8) * 8);              // multiple of the XCD count
+    if (ks->padded == 2) {
+        // run-time-dimension unit: ONE 8-wavefront workgroup per CU (its registers) and long-running workgroups, so
+        // the number of workgroups should fill whole rounds of 256: the chunk count (multiple of 8, partials within
+        // 256 MB) with the fewest idle CUs in the last round, the larger one among equals
+        const double per_chunk = 8.0 * K * pmc_stats_stride_c(ks->dim);
+        long long cmax = (long long)(256.0 * 1024 * 1024 / per_chunk) / 8 * 8;
+        if (cmax > 128) cmax = 128;
+        if (cmax > ceil_div(g.ntiles, 8) * 8) cmax = ceil_div(g.ntiles, 8) * 8;
+        if (cmax < 8) cmax = 8;
+        double best = -1.0;
+        for (long long c = 8; c <= cmax; c += 8) {
+            const long long wgs = c * g.ngroups, rounds = ceil_div(wgs, 256);
+            const double eff = (double)wgs / (256.0 * rounds);
+            if (eff >= best - 1e-9) { best = eff > best ? eff : best; g.nchunks = (int)c; }
+        }
+    }
     g.tiles_per_chunk = (int)ceil_div(g.ntiles, g.nchunks);
     if (g.tiles_per_chunk < 1) g.tiles_per_chunk = 1;
     g.grid = (unsigned)((long long)g.nchunks * g.ngroups);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * NW) void k_big_maha(const PmcArgsM a)
 #ifndef PMC_BIG_STATS_WAVES
 #define PMC_BIG_STATS_WAVES 2
 #endif
-template <int BT>
+template <int BT, int NPRE, int NJ>
 __global__ __launch_bounds__(512, PMC_BIG_STATS_WAVES) void k_big_stats(const PmcArgsB b, const int S)
 {
     constexpr int BC = 16 * BT;                           // coordinates per block
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(512, PMC_BIG_STATS_WAVES) void k_big_stats(const Pm
     long long n1 = t1 * 64;
     if (n1 > b.N) n1 = b.N;
     const int stride = pmc_pack_stride_c(D), PS = pmc_stats_stride_c(D);
-    const double *pk = b.pack + (size_t)(active ? k : 0) * stride;
+    const int kc = active ? k : 0;
+    const double *pk = b.pack + (size_t)kc * stride;
     const int i16 = lane & 15, s = lane >> 4;
     double mi[BT], mj[BT];
 #pragma unroll
@@ -202,40 +203,72 @@ __global__ __launch_bounds__(512, PMC_BIG_STATS_WAVES) void k_big_stats(const Pm
     }
     // staging: element e of a thread is idx = threadIdx.x + 512 e of the step's S x DB image; its global value is
     // fetched into a register one step ahead
-    constexpr int NPRE = BT == 4 ? 8 : 16;                // S * DB <= 512 NPRE elements per step (registers)
+    // NPRE staging registers per thread and NJ sub-steps per step: S * DB <= 512 NPRE elements, S <= 4 NJ rows.  The 16
+    // accumulator tiles of BT = 4 are 128 VGPRs, so it stages less per step (4 x 4 up to D = 512, 8 x 2 beyond)
     const int nimg = S * DB;
     const int step_row = 512 / DB, step_col = 512 % DB;
     double pre[NPRE];
-    auto gload = [&](long long nstart) {
+    // (every load below is unconditional, from a clamped address, and the value is selected afterwards: a
+    //  conditional load is a branch, and behind branches the compiler can no longer count the loads in flight --
+    //  it waited for ALL of them, the prefetch included, in front of the first multiply)
+    // Element e of a thread sits at (row soff[e] of the step, column): offset eoff[e] from the step's first sample,
+    // fixed for the whole chunk (-1: not part of the image or a padding column -> 0).  The address arithmetic per
+    // step is one uniform base; rows beyond the chunk's end (its last step only) fall back to the chunk's last row.
+    int eoff[NPRE], esl[NPRE];
+    {
         int sl = threadIdx.x / DB, c = threadIdx.x % DB;
 #pragma unroll
         for (int e = 0; e < NPRE; ++e) {
-            const long long row = nstart + sl;
-            pre[e] = (threadIdx.x + 512 * e < nimg && row < n1 && c < D) ? b.x[row * D + c] : 0.0;
+            const bool in = (int)threadIdx.x + 512 * e < nimg && c < D;
+            eoff[e] = in ? sl * D + c : -1;
+            esl[e] = sl;
             sl += step_row;
             c += step_col;
             if (c >= DB) { c -= DB; ++sl; }
         }
+    }
+    unsigned premask = 0;                                 // bit e: pre[e] is an element of the image (else 0)
+    auto gload = [&](long long nstart) {
+        const double *xb = b.x + nstart * D;              // uniform
+        const long long left = n1 - nstart;               // rows of this step inside the chunk (uniform)
+        premask = 0;
+        if (left >= S) {
+#pragma unroll
+            for (int e = 0; e < NPRE; ++e) {
+                pre[e] = xb[eoff[e] < 0 ? 0 : eoff[e]];
+                premask |= eoff[e] >= 0 ? (1u << e) : 0u;
+            }
+        } else {
+            const double *xl = b.x + (n1 - 1) * D;        // a row that exists
+#pragma unroll
+            for (int e = 0; e < NPRE; ++e) {
+                const bool in = eoff[e] >= 0 && esl[e] < left;
+                pre[e] = in ? xb[eoff[e]] : xl[0];
+                premask |= in ? (1u << e) : 0u;
+            }
+        }
     };
     const long long nbeg = t0 * 64;
-    if (nbeg < n1) gload(nbeg);
+    gload(nbeg);                                          // (addresses are clamped: harmless for an empty chunk)
     for (long long n0 = nbeg; n0 < n1; n0 += S) {
         // this step's weights: in flight across the two barriers
-        double uu[8];
+        const double *ub = b.u + ((size_t)(n0 >> 6) * b.K + kc) * 64;        // uniform
+        double uu[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long n = n0 + 4 * j + s;
-            uu[j] = (active && 4 * j < S && n < n1) ? b.u[((size_t)(n >> 6) * b.K + k) * 64 + (n & 63)] : 0.0;
+        for (int j = 0; j < NJ; ++j) {
+            // (a step lies inside one 64-sample tile, whose K x 64 block of u exists in full: no clamp)
+            const double v = ub[(int)(n0 & 63) + 4 * j + s];
+            uu[j] = (active && 4 * j < S && n0 + 4 * j + s < n1) ? v : 0.0;
         }
         __syncthreads();                                  // the previous step's reads are done
 #pragma unroll
-        for (int e = 0; e < NPRE; ++e)
-            if (threadIdx.x + 512 * e < nimg) big_lds[threadIdx.x + 512 * e] = pre[e];
+        for (int e = 0; e < NPRE; ++e)                    // (the image is 512 NPRE long: every thread writes all its slots)
+            big_lds[threadIdx.x + 512 * e] = ((premask >> e) & 1u) ? pre[e] : 0.0;
         __syncthreads();
-        if (n0 + S < n1) gload(n0 + S);
+        gload(n0 + S);                                    // unconditional: a branch here hides the load count from the compiler
         if (!active) continue;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             if (4 * j >= S) break;                        // uniform
             // (keeps the unrolled sub-steps apart: left alone the scheduler hoists all their LDS reads -- spills)
             __builtin_amdgcn_sched_barrier(0);
@@ -322,19 +355,23 @@ extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &a, hipStream_t st)
     return wide ? launch_maha<1, 8>(a, st) : launch_maha<1, 4>(a, st);
 }
 
-// coordinates per block of the statistics kernel: 64 from D = 97 on, 32 below
+// coordinates per block of the statistics kernel: 64 from D = 97 on, 32 below (fewer tiles wasted on padding)
 static int stats_bt(int D) { return D > 96 ? 4 : 2; }
 
 extern "C" hipError_t pmc_launch_big_stats(const PmcArgsB &b, unsigned grid, hipStream_t st)
 {
-    // rows per LDS step: what the staging registers hold (512 threads x 16 / 8 doubles), at most 32
+    // rows per LDS step: what the staging registers hold (512 threads x NPRE doubles), at most 4 NJ
     const int bt = stats_bt(b.dreal), bc = 16 * bt;
     const int DB = (b.dreal + bc - 1) / bc * bc;
-    const int cap = 512 * (bt == 4 ? 8 : 16) / DB;
-    const int S = cap >= 32 ? 32 : (cap >= 16 ? 16 : (cap >= 8 ? 8 : 4));
-    const size_t lds = sizeof(double) * (size_t)S * DB;
-    if (bt == 4) hipLaunchKernelGGL(k_big_stats<4>, dim3(grid), dim3(512), lds, st, b, S);
-    else hipLaunchKernelGGL(k_big_stats<2>, dim3(grid), dim3(512), lds, st, b, S);
+    const bool wide = bt == 4 && DB > 512;
+    const int npre = bt == 2 ? 16 : (wide ? 8 : 4), smax = bt == 2 ? 32 : (wide ? 8 : 16);
+    const int cap = 512 * npre / DB;
+    const int S = cap >= smax ? smax : (cap >= 16 ? 16 : (cap >= 8 ? 8 : 4));
+    // LDS image: one element per (thread, staging register), S * DB of them used
+    const size_t lds = sizeof(double) * 512 * npre;
+    if (bt == 2) hipLaunchKernelGGL((k_big_stats<2, 16, 8>), dim3(grid), dim3(512), lds, st, b, S);
+    else if (wide) hipLaunchKernelGGL((k_big_stats<4, 8, 2>), dim3(grid), dim3(512), lds, st, b, S);
+    else hipLaunchKernelGGL((k_big_stats<4, 4, 4>), dim3(grid), dim3(512), lds, st, b, S);
     return hipGetLastError();
 }
 
