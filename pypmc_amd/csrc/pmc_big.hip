@@ -36,8 +36,8 @@ extern __shared__ double big_lds[];
 // One workgroup = NW wavefronts (4; 8 where the LDS admits a single workgroup per CU) = NT sub-tiles of 16 samples (NT = 4: one 64-sample tile; 2 / 1 where the LDS holds
 // no more).  The samples' coordinates are staged ONCE in LDS, xs[c * P + sample] (P = 16 NT + 1: the staging
 // writes -- a lane per coordinate of one row, coalesced in HBM -- land in distinct banks), and serve all K
-// components.  Per component the 16-row blocks of R are dealt to the wavefronts in pairs (I, G16 - 1 - I) of equal
-// total length, so no two wavefronts load the same rows of R, and every A operand feeds NT instructions (one per
+// components.  Per component the 16-row blocks of R are dealt to the wavefronts (longest first, to the least loaded),
+// so no two wavefronts load the same rows of R, and every A operand feeds NT instructions (one per
 // sub-tile).  A lane fetches 4 consecutive... no: element (r, kk + 4 q + t), t = 0..3 of its row -- the 16 columns
 // of a step are assigned to the instructions' k slots as {kk + 4 q + t : q}, the same for A and B -- one step
 // ahead of the 4 NT instructions that consume them.  The wavefronts' partial |y|^2 meet in LDS (one barrier per
@@ -63,16 +63,31 @@ __global__ __launch_bounds__(64 * NW) void k_big_maha(const PmcArgsM a)
     }
     __syncthreads();
 
-    const int npair = (G16 + 1) >> 1;
+    // this wavefront's row blocks: block I costs G16 - I steps; longest first, each to the least loaded wavefront
+    // (the same tiny scalar loop in every wavefront; pairs (I, G16 - 1 - I) would leave a wavefront idle for
+    // G16 = 5, 6: D = 65 ... 96)
+    unsigned long long mine = 0;
+    {
+        int load[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) load[w] = 0;
+        for (int I = 0; I < G16; ++I) {
+            int best = 0;
+#pragma unroll
+            for (int w = 1; w < NW; ++w) best = load[w] < load[best] ? w : best;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) load[w] += (w == best) ? G16 - I : 0;
+            if (best == wave) mine |= 1ull << I;
+        }
+    }
     for (int k = 0; k < a.K; ++k) {
         const double *pk = a.pack + (size_t)k * a.stride;
         double part[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) part[t] = 0.0;
-        for (int p = wave; p < npair; p += NW) {
-            for (int half = 0; half < 2; ++half) {
-                const int I = half == 0 ? p : G16 - 1 - p;
-                if (half == 1 && I == p) break;            // (odd G16: the middle block is its own partner)
+        {
+            for (unsigned long long todo = mine; todo != 0; todo &= todo - 1) {
+                const int I = __builtin_ctzll(todo);
                 const int r = 16 * I + i;                  // this lane's row of R (A operand: i = lane & 15)
                 const bool rv = r < D;
                 const int rr = rv ? r : D - 1;
