@@ -18,7 +18,7 @@
 //   (k_propose_big: pmc_propose.hip)
 //
 // Measured (profiles/r02_big_dims.txt, 1e6 samples x 32 components): D = 128  log-pdf 15 ms = 36 algorithmic
-// TFLOP/s, statistics 18 ms = 29; D = 256  55 ms = 39 and 67 ms = 32 -- against 42-51 for the compiled D = 64 unit.
+// TFLOP/s, statistics 12.7 ms = 42; D = 256  55 ms = 39 and 57 ms = 37 -- against 42-50 for the compiled D = 64 unit.
 //
 // Operand layouts of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md):  A[i][k] lane 16 k + i,  B[k][j] lane
 // 16 k + j,  C[i][j] lane 16 (i mod 4) + j, register i / 4.
