@@ -96,24 +96,30 @@ __global__ __launch_bounds__(64 * NW) void k_big_maha(const PmcArgsM a)
                 d4 acc[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+                // Operands of the NEXT step are fetched raw (unconditional loads from addresses clamped into the
+                // row's storage) and turned into A / mu -- zeros below the diagonal and beyond D -- only when their
+                // step comes: a select right behind its load makes the compiler wait for the load there, and a
+                // conditional fetch is a branch behind which it can no longer count the loads in flight.
                 double An[4], mn[4];
                 auto fetch = [&](int kk) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int c = kk + 4 * q + t;
-                        const int cc = c < rr ? rr : (c < D ? c : D - 1);      // inside the row's storage
-                        const double v = rbase[cc];
-                        An[t] = (rv && c >= r && c < D) ? v : 0.0;
-                        const double m = pk[c < D ? c : D - 1];
-                        mn[t] = c < D ? m : 0.0;
+                        An[t] = rbase[c < rr ? rr : (c < D ? c : D - 1)];
+                        mn[t] = pk[c < D ? c : D - 1];
                     }
                 };
                 fetch(16 * I);
                 for (int kk = 16 * I; kk < D16; kk += 16) {
                     double A[4], mu[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { A[t] = An[t]; mu[t] = mn[t]; }
-                    if (kk + 16 < D16) fetch(kk + 16);
+                    for (int t = 0; t < 4; ++t) {
+                        const int c = kk + 4 * q + t;
+                        A[t] = (rv && c >= r && c < D) ? An[t] : 0.0;
+                        mu[t] = c < D ? mn[t] : 0.0;
+                    }
+                    fetch(kk + 16);                        // (beyond the last step: clamped, unused)
+                    __builtin_amdgcn_sched_barrier(0);     // ... and issued HERE, in front of this step's multiplies
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const double *xc = xs + (size_t)(kk + 4 * q + t) * P + i;
