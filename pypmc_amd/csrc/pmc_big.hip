@@ -170,9 +170,9 @@ __global__ __launch_bounds__(64 * NW) void k_big_maha(const PmcArgsM a)
 // carries the first moments of its coordinates, block (0, 0) the sum of the weights).  The samples go through LDS
 // in steps of S rows (row-major, DB doubles each, zeros beyond D and beyond the chunk) that all 8 tasks share; the
 // next step's rows are fetched into registers while the matrix pipe works on the current one.
-// BT = 4 (64 x 64 coordinates, 16 accumulator tiles = 128 VGPRs) from D = 97 on: every staged byte then feeds 4x the
-// arithmetic, and the staging traffic -- K x blocks / 8 passes over the samples -- is what binds (D = 128, K = 32:
-// 40 passes with BT = 2, 12 with BT = 4); below, BT = 2 wastes fewer tiles on padding.
+// BT = 4 (64 x 64 coordinates, 16 accumulator tiles = 128 VGPRs) or 3, whichever pads less (stats_bt below): every
+// staged byte feeds BT^2 / 4 times the arithmetic of 2 x 2 tiles, whose staging traffic -- K x blocks / 8 passes over
+// the samples: 40 at D = 128, K = 32 against 12 -- and short steps made them slower.
 #ifndef PMC_BIG_STATS_WAVES
 #define PMC_BIG_STATS_WAVES 2
 #endif
@@ -376,21 +376,30 @@ extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &a, hipStream_t st)
     return wide ? launch_maha<1, 8>(a, st) : launch_maha<1, 4>(a, st);
 }
 
-// coordinates per block of the statistics kernel: 64 from D = 97 on, 32 below (fewer tiles wasted on padding)
-static int stats_bt(int D) { return D > 96 ? 4 : 2; }
+// instruction tiles per block side of the statistics kernel: 4 (64 coordinates) or 3 (48), whichever pads the
+// lower triangle with fewer tiles -- D = 65 ... 96: 21 tiles with 3 against 36 with 4; D = 97 ... 128: 36 with 4
+// against 45.  (2 -- 32 coordinates -- wastes least of all and is slower: its steps are too short for their
+// barriers and staging, 13.6 against 12.6 ms at D = 72.)
+static int stats_tiles(int D, int bt)
+{
+    const int bc = 16 * bt, gb = (D + bc - 1) / bc;
+    return gb * (bt * (bt + 1) / 2) + gb * (gb - 1) / 2 * bt * bt;
+}
+static int stats_bt(int D) { return stats_tiles(D, 3) < stats_tiles(D, 4) ? 3 : 4; }
 
 extern "C" hipError_t pmc_launch_big_stats(const PmcArgsB &b, unsigned grid, hipStream_t st)
 {
     // rows per LDS step: what the staging registers hold (512 threads x NPRE doubles), at most 4 NJ
     const int bt = stats_bt(b.dreal), bc = 16 * bt;
     const int DB = (b.dreal + bc - 1) / bc * bc;
-    const bool wide = bt == 4 && DB > 512;
-    const int npre = bt == 2 ? 16 : (wide ? 8 : 4), smax = bt == 2 ? 32 : (wide ? 8 : 16);
+    const bool wide = DB > 512;
+    const int npre = wide ? 8 : 4, smax = wide ? 8 : 16;
     const int cap = 512 * npre / DB;
     const int S = cap >= smax ? smax : (cap >= 16 ? 16 : (cap >= 8 ? 8 : 4));
     // LDS image: one element per (thread, staging register), S * DB of them used
     const size_t lds = sizeof(double) * 512 * npre;
-    if (bt == 2) hipLaunchKernelGGL((k_big_stats<2, 16, 8>), dim3(grid), dim3(512), lds, st, b, S);
+    if (bt == 3 && wide) hipLaunchKernelGGL((k_big_stats<3, 8, 2>), dim3(grid), dim3(512), lds, st, b, S);
+    else if (bt == 3) hipLaunchKernelGGL((k_big_stats<3, 4, 4>), dim3(grid), dim3(512), lds, st, b, S);
     else if (wide) hipLaunchKernelGGL((k_big_stats<4, 8, 2>), dim3(grid), dim3(512), lds, st, b, S);
     else hipLaunchKernelGGL((k_big_stats<4, 4, 4>), dim3(grid), dim3(512), lds, st, b, S);
     return hipGetLastError();
