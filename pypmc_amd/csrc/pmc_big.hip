@@ -11,14 +11,14 @@
 //                serves all K components;
 //   k_logpdf<0>, k_resp<0>   (pmc_persample.hip, engine TILES) read those forms -- every fused output, kind and
 //                mode of the compiled units, same code;
-//   k_big_stats  sum u | sum u d | sum u d d^T:  one wavefront per (sample chunk, component, block of 32 x 32 or
+//   k_big_stats  sum u | sum u d | sum u d d^T:  one wavefront per (sample chunk, component, block of 48 x 48 or
 //                64 x 64 coordinates of the lower triangle), 4 samples per v_mfma_f64_16x16x4_f64, the samples staged
 //                in LDS for the workgroup's 8 tasks; partials in k_stats' layout for the same fixed-order finishing
 //                kernel.
 //   (k_propose_big: pmc_propose.hip)
 //
-// Measured (profiles/r02_big_dims.txt, 1e6 samples x 32 components): D = 128  log-pdf 15 ms = 36 algorithmic
-// TFLOP/s, statistics 12.7 ms = 42; D = 256  55 ms = 39 and 57 ms = 37 -- against 42-50 for the compiled D = 64 unit.
+// Measured (profiles/r02_big_dims.txt, 1e6 samples x 32 components): D = 128  log-pdf 13.5 ms = 40 algorithmic
+// TFLOP/s, statistics 12.6 ms = 43; D = 256  46.5 ms = 46 and 56.5 ms = 38 -- against 42-51 for the compiled D = 64 unit.
 //
 // Operand layouts of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md):  A[i][k] lane 16 k + i,  B[k][j] lane
 // 16 k + j,  C[i][j] lane 16 (i mod 4) + j, register i / 4.
