@@ -51,10 +51,12 @@ def shift_is_far(S0, M1, M2, limit=100.):
     coordinate) away from the shift its one-pass moments were taken about.  cov = M2/S0 - dbar dbar^T then cancels
     ~limit leading parts: the relative error of the covariance grows to limit * 1e-16, against the 1e-16 of the
     reference's two passes (mean first, then moments about it: variational.pyx:806-932, pmc.pyx:188-222).  The
-    callers answer with a second pass of the statistics about the mean just found.  Components without weight
-    (or with non-finite sums) do not count."""
+    callers answer with a second pass of the statistics about the mean just found.  Components that hold less than
+    a millionth of the total weight (dying ones, whose few far samples would ask for a second pass in every
+    iteration until they are pruned) or non-finite sums do not count."""
     S0 = np.asarray(S0, dtype=np.float64)
-    ok = np.isfinite(S0) & (S0 > 1e-200)
+    fin = np.isfinite(S0)
+    ok = fin & (S0 > 1e-200) & (S0 > 1e-6 * S0[fin].sum() if fin.any() else False)
     if not ok.any():
         return False
     n = S0[ok][:, None]
