@@ -8,3 +8,5 @@ __version__ = "0.1.0"
 
 from . import backend, parallel          # noqa: F401
 from . import tools, density, sampler, mix_adapt   # noqa: F401
+
+tools.util.log_to_stdout()                 # pypmc/__init__.py:13

@@ -1,4 +1,4 @@
 from ._history import History, DeviceHistory
 from ._linalg import chol_inv_det, bilinear_sym
 from ._regularize import regularize, logsumexp, logsumexp2D
-from . import convergence, indicator
+from . import convergence, indicator, util
