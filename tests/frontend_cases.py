@@ -780,6 +780,59 @@ def case_combine_weights_device_inputs(be):
     assert_rel(hist[:][:, 0], g["combined_linear"], what="linear branch, device inputs")
 
 
+def case_local_densities(be):
+    """LocalGauss / LocalStudentT (gauss.pyx:12-67, student_t.pyx:13-55): known answers of the reference's tests
+    (gauss_test.py:43-55, student_t_test.py:60-79), the LinAlgError contract and the generator call order."""
+    from pypmc_amd.density.gauss import LocalGauss
+    from pypmc_amd.density.student_t import LocalStudentT
+    sigma = np.array([[0.01, 0.003], [0.003, 0.0025]])
+    x, y = np.array([4.3, 1.1]), np.array([4.35, 1.2])
+    g = LocalGauss(sigma, backend=be)
+    assert g.symmetric and g.dim == 2
+    assert abs(g.evaluate(x, y) - 1.30077135) < 1e-8 and abs(g.evaluate(y, x) - 1.30077135) < 1e-8
+    d = x - y
+    ref = -np.log(2 * np.pi) - 0.5 * np.log(np.linalg.det(sigma)) - 0.5 * d.dot(np.linalg.inv(sigma)).dot(d)
+    assert abs(g.evaluate(x, y) - ref) < 1e-12 * abs(ref)
+    for bad in (np.array([[0.0, 0.0], [0.0, 1.0]]), np.array([[0.01, 0.003], [0.001, 0.0025]])):
+        with pytest.raises(np.linalg.LinAlgError):
+            g.update(bad)
+        with pytest.raises(np.linalg.LinAlgError):
+            LocalGauss(bad, backend=be)
+    np.testing.assert_array_equal(g.sigma, sigma)                    # untouched by the failed updates
+    assert abs(g.evaluate(x, y) - ref) < 1e-12 * abs(ref)
+
+    class Rng(object):                                                # records the calls, returns ones
+        def __init__(self):
+            self.calls = []
+
+        def normal(self, a, b, n):
+            self.calls.append(("normal", n))
+            return np.ones(n)
+
+        def chisquare(self, dof):
+            self.calls.append(("chisquare", dof))
+            return dof
+
+    rng = Rng()
+    np.testing.assert_allclose(g.propose(y, rng), y + np.linalg.cholesky(sigma).dot(np.ones(2)))
+    assert rng.calls == [("normal", 2)]
+    t = LocalStudentT(sigma, 5.0, backend=be)
+    from scipy.special import gammaln
+    maha = d.dot(np.linalg.inv(sigma)).dot(d)
+    reft = gammaln(3.5) - gammaln(2.5) - np.log(5. * np.pi) - 0.5 * np.log(np.linalg.det(sigma)) - 3.5 * np.log(1. + maha / 5.)
+    assert abs(t.evaluate(x, y) - reft) < 1e-12 * abs(reft) and abs(t.evaluate(y, x) - reft) < 1e-12 * abs(reft)
+    rng = Rng()
+    np.testing.assert_allclose(t.propose(y, rng), y + np.linalg.cholesky(sigma).dot(np.ones(2)))   # sqrt(5 / 5) = 1
+    assert rng.calls == [("normal", 2), ("chisquare", 5.0)]
+    with pytest.raises(AssertionError, match="must be greater than zero"):
+        LocalStudentT(sigma, -1.0, backend=be)
+    # Gauss.propose asks a foreign generator once per sample for `dim` normals (gauss.pyx:159-163)
+    from pypmc_amd.density.gauss import Gauss
+    rng = Rng()
+    out = Gauss(y, sigma, backend=be).propose(3, rng)
+    assert out.shape == (3, 2) and rng.calls == [("normal", 2)] * 3
+
+
 def case_far_start_values(be):
     """Moments are taken in ONE pass about the component's current mean; when the weighted mean turns out far from
     it (start values, a badly placed proposal) mix_adapt repeats the statistics about the mean just found
@@ -875,7 +928,7 @@ def case_big_dimension(be):
         Gauss(np.zeros(1025), np.eye(1025), backend=be)
 
 
-ALL_CASES = [case_far_start_values, case_big_dimension, case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
+ALL_CASES = [case_local_densities, case_far_start_values, case_big_dimension, case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
              case_device_history, case_combine_weights_device_inputs, case_reference_known_answers,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,
