@@ -27,6 +27,7 @@
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));        // 16 bytes at 8-byte alignment: one dwordx4 load
 
 extern __shared__ double big_lds[];
 
@@ -91,41 +92,74 @@ __global__ __launch_bounds__(64 * NW) void k_big_maha(const PmcArgsM a)
                 const int r = 16 * I + i;                  // this lane's row of R (A operand: i = lane & 15)
                 const bool rv = r < D;
                 const int rr = rv ? r : D - 1;
-                // element (r, c >= r) of the packed upper triangle sits at rbase[c]
-                const double *rbase = pk + D + (long long)rr * D - (long long)rr * (rr - 1) / 2 - rr;
+                // element (r, c >= r) of the packed upper triangle sits at pk[roff + c]: offsets from the component's
+                // (uniform) base, so a load is base + 32-bit lane offset + immediate
+                const unsigned roff = (unsigned)(D + rr * D - rr * (rr - 1) / 2 - rr);
+                const unsigned lane_a = roff + 4u * q, lane_m = 4u * q;
+                const double *xl = xs + (size_t)(4 * q) * P + i;              // + kk * P: this lane's B operands
                 d4 acc[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-                // Operands of the NEXT step are fetched raw (unconditional loads from addresses clamped into the
-                // row's storage) and turned into A / mu -- zeros below the diagonal and beyond D -- only when their
-                // step comes: a select right behind its load makes the compiler wait for the load there, and a
-                // conditional fetch is a branch behind which it can no longer count the loads in flight.
+                // Operands of the NEXT step are fetched raw (unconditional loads) in front of this step's multiplies
+                // and turned into A / mu -- zeros below the diagonal and beyond D -- only when their step comes: a
+                // select right behind its load makes the compiler wait for the load there, and a conditional fetch
+                // is a branch behind which it can no longer count the loads in flight.  Only a block's first step
+                // (the diagonal) and a last step that reaches beyond D need clamped addresses and selects; all steps
+                // in between -- "interior": every column beyond every row of the block and inside D -- are plain
+                // loads at base + kk (the counters had shown 11.5 vector instructions per matrix instruction:
+                // 38 % of the issue slots for address clamps and selects).
                 double An[4], mn[4];
+                auto interior = [&](int kk) { return kk > 16 * I && kk + 16 <= D; };         // uniform
                 auto fetch = [&](int kk) {
+                    if (interior(kk)) {
+                        // a lane's four columns are adjacent: two 16-byte loads instead of four 8-byte ones -- the
+                        // CU's one vector-memory pipeline walks each of the instruction's 16 rows (cache lines)
+                        // once per instruction, and it, not the matrix pipe, was what the kernel waited for
+                        const d2 a0 = *(const d2 *)(pk + lane_a + (unsigned)kk), a1 = *(const d2 *)(pk + lane_a + (unsigned)kk + 2);
+                        const d2 m0 = *(const d2 *)(pk + lane_m + (unsigned)kk), m1 = *(const d2 *)(pk + lane_m + (unsigned)kk + 2);
+                        An[0] = a0[0], An[1] = a0[1], An[2] = a1[0], An[3] = a1[1];
+                        mn[0] = m0[0], mn[1] = m0[1], mn[2] = m1[0], mn[3] = m1[1];
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int c = kk + 4 * q + t;
-                        An[t] = rbase[c < rr ? rr : (c < D ? c : D - 1)];
-                        mn[t] = pk[c < D ? c : D - 1];
+                        for (int t = 0; t < 4; ++t) {
+                            const int c = kk + 4 * q + t;
+                            An[t] = pk[roff + (unsigned)(c < rr ? rr : (c < D ? c : D - 1))];
+                            mn[t] = pk[c < D ? c : D - 1];
+                        }
                     }
                 };
                 fetch(16 * I);
                 for (int kk = 16 * I; kk < D16; kk += 16) {
                     double A[4], mu[4];
+                    if (interior(kk)) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int c = kk + 4 * q + t;
-                        A[t] = (rv && c >= r && c < D) ? An[t] : 0.0;
-                        mu[t] = c < D ? mn[t] : 0.0;
+                        for (int t = 0; t < 4; ++t) {
+                            A[t] = An[t];
+                            mu[t] = mn[t];
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int c = kk + 4 * q + t;
+                            A[t] = (rv && c >= r && c < D) ? An[t] : 0.0;
+                            mu[t] = c < D ? mn[t] : 0.0;
+                        }
                     }
+                    // this step's B operands: all 4 NT LDS reads issued up front (left to itself the compiler reads each
+                    // pair right in front of its two multiplies and waits for it there: an LDS round trip per pair)
+                    const double *xk = xl + (size_t)kk * P;
+                    double Bv[4][NT];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int sub = 0; sub < NT; ++sub) Bv[t][sub] = xk[t * P + 16 * sub];
                     fetch(kk + 16);                        // (beyond the last step: clamped, unused)
                     __builtin_amdgcn_sched_barrier(0);     // ... and issued HERE, in front of this step's multiplies
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const double *xc = xs + (size_t)(kk + 4 * q + t) * P + i;
 #pragma unroll
                         for (int sub = 0; sub < NT; ++sub) {
-                            const double B = xc[16 * sub] - mu[t];
+                            const double B = Bv[t][sub] - mu[t];
                             acc[sub] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[sub], 0, 0, 0);
                         }
                     }
