@@ -17,8 +17,8 @@
 //                kernel.
 //   (k_propose_big: pmc_propose.hip)
 //
-// Measured (profiles/r02_big_dims.txt, 1e6 samples x 32 components): D = 128  log-pdf 13.5 ms = 40 algorithmic
-// TFLOP/s, statistics 12.6 ms = 43; D = 256  46.5 ms = 46 and 56.5 ms = 38 -- against 42-51 for the compiled D = 64 unit.
+// Measured (profiles/r02_big_dims.txt, 1e6 samples x 32 components): D = 128  log-pdf 13.2 ms = 41 algorithmic
+// TFLOP/s, statistics 12.7 ms = 42; D = 256  44.5 ms = 48 and 56.4 ms = 38 -- against 41-51 for the compiled D = 64 unit.
 //
 // Operand layouts of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md):  A[i][k] lane 16 k + i,  B[k][j] lane
 // 16 k + j,  C[i][j] lane 16 (i mod 4) + j, register i / 4.
