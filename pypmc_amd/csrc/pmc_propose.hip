@@ -219,7 +219,11 @@ __device__ __forceinline__ void affine_in_place(P L, P mu, int D, double scale, 
         for (int J = 0; J <= I; ++J) {
             double z[16];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) z[jj] = (16 * J + jj < D) ? row[16 * J + jj] : 0.0;
+            for (int jj = 0; jj < 16; ++jj) {              // (unconditional load, selected afterwards: no branch)
+                const int j = 16 * J + jj;
+                const double v = row[j < D ? j : D - 1];
+                z[jj] = j < D ? v : 0.0;
+            }
 #pragma unroll
             for (int ii = 0; ii < 16; ++ii) {
                 const int i = 16 * I + ii;
