@@ -34,15 +34,15 @@ extern __shared__ double big_lds[];
 // ---------------------------------------------------------------------------------------------
 // k_big_maha
 // ---------------------------------------------------------------------------------------------
-// One workgroup = NW wavefronts (4; 8 where the LDS admits a single workgroup per CU) = NT sub-tiles of 16 samples (NT = 4: one 64-sample tile; 2 / 1 where the LDS holds
-// no more).  The samples' coordinates are staged ONCE in LDS, xs[c * P + sample] (P = 16 NT + 1: the staging
-// writes -- a lane per coordinate of one row, coalesced in HBM -- land in distinct banks), and serve all K
-// components.  Per component the 16-row blocks of R are dealt to the wavefronts (longest first, to the least loaded),
-// so no two wavefronts load the same rows of R, and every A operand feeds NT instructions (one per
-// sub-tile).  A lane fetches 4 consecutive... no: element (r, kk + 4 q + t), t = 0..3 of its row -- the 16 columns
-// of a step are assigned to the instructions' k slots as {kk + 4 q + t : q}, the same for A and B -- one step
-// ahead of the 4 NT instructions that consume them.  The wavefronts' partial |y|^2 meet in LDS (one barrier per
-// component, buffers alternating), summed in wavefront order: bit-reproducible.
+// One workgroup = NW wavefronts (4; 8 where the LDS admits a single workgroup per CU) = NT sub-tiles of 16 samples
+// (NT = 4: one 64-sample tile; 2 / 1 where the LDS holds no more).  The samples' coordinates are staged ONCE in
+// LDS, xs[c * P + sample] (P = 16 NT + 1: the staging writes -- a lane per coordinate of one row, coalesced in HBM
+// -- land in distinct banks), and serve all K components.  Per component the 16-row blocks of R are dealt to the
+// wavefronts (longest first, to the least loaded), so no two wavefronts load the same rows of R, and every A
+// operand feeds NT instructions (one per sub-tile).  A lane fetches the elements (r, kk + 4 q + t), t = 0..3 of its
+// row -- the 16 columns of a step are assigned to the instructions' k slots as {kk + 4 q + t : q}, the same for A
+// and B -- one step ahead of the 4 NT instructions that consume them.  The wavefronts' partial |y|^2 meet in LDS
+// (one barrier per component, buffers alternating), summed in wavefront order: bit-reproducible.
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void k_big_maha(const PmcArgsM a)
 {
