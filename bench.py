@@ -12,8 +12,14 @@ in HBM before the clock starts:
   VB  : responsibilities of the K=32 variational posterior -> N_k, sum r d, sum r d d^T, E[log q(Z)]
         -> RCCL all-reduce of the statistics vector -> copy to the host   (pmc_responsibilities +
         pmc_sufficient_stats + all_reduce)
-Samples are sharded over ranks (weak scaling, N per GPU fixed); the only collective is the
-all-reduce of K x (1 + D + D(D+1)/2) + 8 doubles.  `value` = samples of all ranks / step time.
+Samples are sharded over ranks (weak scaling, N per GPU fixed, by default; `--scaling strong` fixes the total
+at --n and gives every rank its shard); the only collective is the all-reduce of K x (1 + D + D(D+1)/2) + 8
+doubles, timed by its own event pair (`dist.allreduce_ms`).  `value` = samples of all ranks / step time.
+Under `torch.distributed.run` -- with ONE rank too -- the process group exists and the collective is RCCL's;
+a plain `python bench.py` has no group unless `--force-dist` asks for a one-rank group.
+
+At N = 1 the line also carries BASELINE.json's other configurations (`configs`: 2-5, each timed through the
+public front-end with the samples resident on the device, a few repetitions after the headline's timed loop).
 
 The line also carries the roofline of the dominant kernel (HIP events on the launch stream) and
 a CPU baseline: the C oracle (a bit-exact restatement of the reference's Cython loops, the
@@ -145,6 +151,105 @@ def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
     return out
 
 
+def baseline_configs(be, reps=3):
+    """BASELINE.json's configurations 2-5 on this GPU (one GPU's share where a configuration is quoted on 8),
+    through the public front-end with the samples resident on the device: median wall time of ``reps`` calls
+    (device synchronised on both sides), the library's own per-kernel times (pmc_get_timings) of those calls, and
+    the ALGORITHMIC rate (SURVEY 8(d) flops per sample x N / time) against the fp64 peak.
+    Reference loops: student_t.pyx:154-164, variational.pyx:116-127, pmc.pyx:120-246."""
+    import torch
+    from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture, component_set
+    from pypmc_amd.sampler.importance_sampling import ImportanceSampler
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+
+    def timed(fn):
+        fn()                                             # warm-up (packs, scratch buffers)
+        torch.cuda.synchronize()
+        be.kernel_timings()
+        be.kernel_timing(True)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        be.kernel_timing(False)
+        kern = {k_: v["ms"] / reps for k_, v in be.kernel_timings().items()}
+        return float(np.median(ts)), kern
+
+    def entry(workload, N, flops_per_sample, t, kern, **extra):
+        tf = flops_per_sample * N / t * 1e-12
+        e = {"workload": workload, "N": N, "ms": t * 1e3, "samples_per_s": N / t,
+             "flops_per_sample": flops_per_sample, "tflops": tf, "frac": tf / FP64_PEAK_TFLOPS,
+             "kernel_ms_per_call": kern}
+        e.update(extra)
+        return e
+
+    out = {}
+    t_all = time.perf_counter()
+    # -- config 2: MixtureDensity.multi_evaluate, D=20, K=16 Gaussian, N=1e6
+    D2, K2, N2 = 20, 16, 1_000_000
+    mix = create_gaussian_mixture(*mk(K2, D2, 1))
+    np.random.seed(7)
+    x2 = mix.propose(N2, device=True)
+    cs = component_set(mix.components, mix.weights)
+    t, kern = timed(lambda: be.logpdf(x2, cs))
+    out["cfg2"] = entry("MixtureDensity.multi_evaluate D=20 K=16 Gauss", N2, flops_logpdf(K2, D2), t, kern)
+    del x2
+
+    # -- config 3: Student-t (nu=8) proposal D=30, K=32, N=1e7: importance weights + perplexity sums against the
+    #    SURVEY target (K_t=4 Gaussian mixture), one pass for the two families
+    D3, K3, N3 = 30, 32, 10_000_000
+    mu3, cov3, w3 = mk(K3, D3, 2)
+    prop = create_t_mixture(mu3, cov3, np.full(K3, 8.), w3)
+    tgt = create_gaussian_mixture(*mk(4, D3, 11))
+    np.random.seed(8)
+    x3 = prop.propose(N3, device=True)
+    pcs, tcs = component_set(prop.components, prop.weights), component_set(tgt.components, tgt.weights)
+    t, kern = timed(lambda: be.importance_weights(x3, pcs, tcs))
+    f3 = (K3 + 4) * (D3 * D3 + 4 * D3) + K3 * 80 + 4 * 40      # c_tr = 40, +40 for Student-t's log
+    out["cfg3"] = entry("Student-t nu=8 D=30 K=32 proposal vs K_t=4 Gauss target: weights + perplexity sums",
+                        N3, f3, t, kern)
+    del x3
+
+    # -- config 4: GaussianInference.E_step, D=20, K=64: N=1e7 on one GPU and one GPU's share of 8
+    D4, K4 = 20, 64
+    mix4 = create_gaussian_mixture(*mk(K4, D4, 3))
+    f4 = flops_logpdf(K4, D4) + flops_stats(K4, D4)
+    for label, N4 in (("cfg4", 10_000_000), ("cfg4_share_of_8", 1_250_000)):
+        np.random.seed(9)
+        x4 = mix4.propose(N4, device=True)
+        vb = GaussianInference(x4, initial_guess=mix4)
+        t, kern = timed(vb.E_step)
+        out[label] = entry("GaussianInference.E_step D=20 K=64 (host conversion of the K-sized sums included)",
+                           N4, f4, t, kern)
+        del vb, x4
+
+    # -- config 5: one PMC iteration D=40, K=128, 1.25e7 samples (= N=1e8 over 8 GPUs): propose -> weights vs
+    #    K_t=4 target -> Rao-Blackwell update reusing the Mahalanobis forms the weighting pass kept
+    D5, K5, KT5, N5 = 40, 128, 4, 12_500_000
+    rs = np.random.RandomState(5)
+    tmu, tcov, tw = mk(KT5, D5, 11)
+    tmu /= 3.0                                       # target modes one sigma apart: healthy weights
+    target = create_gaussian_mixture(tmu, tcov, tw)
+    which = np.arange(K5) % KT5
+    proposal = create_gaussian_mixture(tmu[which] + rs.normal(0, 0.15, (K5, D5)), 1.5 * tcov[which])
+    np.random.seed(100)
+    sampler = ImportanceSampler(target.evaluate, proposal)
+
+    def iteration():
+        run = sampler.run_device(N5, trace_sort=True, keep_mahalanobis=True)
+        gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"], mincount=0, rb=True,
+                     copy=False, mahalanobis=run["mahalanobis"])
+    t, kern = timed(iteration)
+    f5 = flops_logpdf(K5 + KT5, D5) + flops_stats(K5, D5) + D5 * (D5 + 1)
+    out["cfg5"] = entry("PMC iteration D=40 K=128: propose -> weights (proposal evaluated once) -> "
+                        "Rao-Blackwell update, one GPU's share of N=1e8 over 8", N5, f5, t, kern)
+    out["seconds"] = time.perf_counter() - t_all
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +258,11 @@ def main():
     ap.add_argument("--n", "--samples-per-gpu", dest="n", type=int, default=10_000_000, help="samples per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --n samples per GPU; strong: --n samples in total, sharded over the ranks")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group (RCCL) even for a single plain python process")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configurations 2-5")
     ap.add_argument("--two-streams", action="store_true",
                     help="run the step's two independent halves (IS pass, VB E-step) side by side on two HIP streams: "
                          "about 4 %% more samples/s, but overlapping kernels stretch each other, so the per-kernel "
@@ -165,19 +275,24 @@ def main():
     from pypmc_amd import parallel
     # torchrun: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; nccl (= RCCL), one GPU per rank.
     # PMC_DIST_BACKEND=gloo is the development aid that lets several ranks share one GPU (tests).
-    rank, world, local_rank = parallel.init_from_env()
+    rank, world, local_rank = parallel.init_from_env(force=args.force_dist)
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
 
     from pypmc_amd.backend import HipBackend, ComponentSet
     be = HipBackend(local_rank)
     dev = be.device
-    N = args.n
+    if args.scaling == "strong":
+        lo, hi = parallel.shard_bounds(args.n, rank, world)
+        N, n_total = hi - lo, args.n
+    else:
+        N, n_total = args.n, args.n * world
+    grouped = dist.is_initialized()
 
     mu, cov, w = mk(K, D, 1)
     tmu, tcov, tw = mk(K_T, D, 11)
     inv, ln = gauss_params(mu, cov)
     tinv, tln = gauss_params(tmu, tcov)
-    vbp = vb_params(mu, cov, w, N * world)
+    vbp = vb_params(mu, cov, w, n_total)
     W, beta, nu, ln_pi, ln_lambda = vbp
     proposal = ComponentSet(0, mu, inv, c0=ln, weight=w)
     target = ComponentSet(0, tmu, tinv, c0=tln, weight=tw)
@@ -225,10 +340,14 @@ def main():
             if events:
                 events[1].record()
             e = be.estep(x, posterior, 0, pack=p_vb, out=stats)
-        flat = parallel.all_reduce_sum(e["stats"])
-        host = flat.cpu()
         if events:
             events[2].record()
+        flat = parallel.all_reduce_sum(e["stats"])
+        if events:
+            events[3].record()
+        host = flat.cpu()
+        if events:
+            events[4].record()
         return r, host
 
     def ev():
@@ -236,7 +355,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     be.kernel_timings()                              # clear the library's record
@@ -244,22 +363,29 @@ def main():
     phase = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        evs = (ev(), ev(), ev())
+        evs = tuple(ev() for _ in range(5))
         r, host = step(evs)
         phase.append(evs)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     be.kernel_timing(False)
-    if world > 1:                                    # MAX over ranks, on the device the backend reduces on
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    n_sum = float(N)
+    if grouped:                                      # MAX over ranks, on the device the backend reduces on
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([float(N)], dtype=torch.float64, device=cdev)      # what the ranks really held
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        n_sum = float(t.item())
+    assert n_sum == float(n_total), (n_sum, n_total)
     ms_per_step = elapsed / args.steps * 1e3
 
-    is_ms = float(np.mean([a.elapsed_time(b) for a, b, c in phase]))
-    vb_ms = float(np.mean([b.elapsed_time(c) for a, b, c in phase]))
+    is_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in phase]))
+    vb_ms = float(np.mean([p[1].elapsed_time(p[4]) for p in phase]))
+    allreduce_ms = float(np.mean([p[2].elapsed_time(p[3]) for p in phase]))
     timings = be.kernel_timings()                    # pmc_get_timings: per kernel launches, ms, algorithmic work
     kern = {k_: v["ms"] / v["calls"] for k_, v in timings.items()}
 
@@ -267,7 +393,7 @@ def main():
     sc = r["scalars"].cpu().numpy()
     perp = float(np.exp(-(sc[1] / sc[0] - np.log(sc[0]))) / N)
     n_k_sum = float(host.numpy()[8:8 + K * be.stats_stride(D)].reshape(K, -1)[:, 0].sum())
-    assert abs(n_k_sum / (N * world) - 1) < 1e-9, "sum_k N_k != N"
+    assert abs(n_k_sum / n_total - 1) < 1e-9, "sum_k N_k != N (the all-reduce did not see every rank)"
 
     if rank == 0:
         hot = {k_: v for k_, v in timings.items() if k_ in ("k_logpdf", "k_resp", "k_stats", "k_estep_fused")}
@@ -279,17 +405,23 @@ def main():
         traffic, traffic_src = measured_traffic(dominant, N)
         line = {
             "metric": "IS samples/sec + VB E-step samples/sec at N=1e7, K=32, D=20",
-            "value": N * world / (ms_per_step * 1e-3),
+            "value": n_total / (ms_per_step * 1e-3),
             "unit": "samples/s through one IS weighting pass plus one VB E-step",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "IS weights (K=32 Gauss proposal, K_t=4 Gauss target, perplexity/ESS sums) "
                                    "+ VB E-step (r_nk, N_k, x_k, S_k, E[log q(Z)], all-reduce)",
-                       "N_per_gpu": N, "K": K, "D": D, "K_target": K_T, "parallelism": "samples sharded x%d" % world,
-                       "streams": 2 if args.two_streams else 1},
-            "is_samples_per_s": N * world / (is_ms * 1e-3),
-            "vb_estep_samples_per_s": N * world / (vb_ms * 1e-3),
+                       "N_per_gpu": N, "N_total": n_total, "K": K, "D": D, "K_target": K_T,
+                       "parallelism": "samples sharded x%d" % world, "streams": 2 if args.two_streams else 1},
+            # the collective as this run issued it: torch.distributed's backend name ("nccl" = RCCL), the rank
+            # count the group reports, and the all-reduce of the statistics vector between its own two events
+            "dist": {"backend": dist.get_backend() if grouped else None,
+                     "world_size": dist.get_world_size() if grouped else 1,
+                     "allreduce_ms": allreduce_ms, "allreduce_doubles": int(stats.numel()),
+                     "group": "torch.distributed process group" if grouped else "none (single process, no collective)"},
+            "is_samples_per_s": n_total / (is_ms * 1e-3),
+            "vb_estep_samples_per_s": n_total / (vb_ms * 1e-3),
             # lower bound: the launch evaluates the K=32 proposal AND the K_t=4 target per sample
             "mixture_logpdf_evals_per_s": N / (per_launch["k_logpdf"]["ms"] * 1e-3),
             "kernel_ms": kern,
@@ -325,8 +457,12 @@ def main():
                                     "all_cores": {"value": cb["all"]["value"], "cores": cb["all"]["cores"],
                                                   "sample": "%d samples, %.1f s, OpenMP over samples"
                                                             % (cb["all"]["n"], cb["all"]["seconds"])}}
+        if world == 1 and not args.no_configs:
+            del x, r
+            torch.cuda.empty_cache()
+            line["configs"] = baseline_configs(be)
         print(json.dumps(line))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -112,6 +112,16 @@ int pmc_pack_components(int K, int D, const double *h_mu, const double *h_precis
                         const double *h_c3, const double *h_weight, const int32_t *h_column,
                         double *h_pack);
 
+/*
+ * A pack that carries only means / shifts: what pmc_sufficient_stats reads of its pack (the moments are taken
+ * about d = x - mu_k).  No matrices are built or factorised -- the second pass of an update whose means turned
+ * out far from the shift (pypmc_amd.mix_adapt._stats.shift_is_far; the reference takes its moments about the
+ * mean it has just computed, variational.pyx:806-932, pmc.pyx:188-222) only needs K x D numbers.  The triangular
+ * factor and c0..c3 are zero, weight 1, column k: such a pack must not be handed to the log-pdf / responsibility
+ * kernels.  h_pack receives K*pmc_pack_stride(D) doubles.
+ */
+int pmc_pack_means(int K, int D, const double *h_mu, double *h_pack);
+
 /* ---- workspace ------------------------------------------------------------------------------ */
 /* bytes of device scratch the calls below need for N samples, K components, dimension D */
 int64_t pmc_workspace_bytes(int64_t N, int K, int D);

@@ -177,9 +177,11 @@ class HipBackend(object):
         return buf
 
     def release(self):
-        """Drop cached scratch buffers."""
+        """Drop cached scratch buffers and the parameter packs cached with the front-end's ComponentSets."""
         self._ws = {}
         self._bufs = {}
+        from .density.mixture import clear_component_cache
+        clear_component_cache()
 
     def pack(self, comps):
         """ComponentSet -> device parameter pack (host Cholesky in pmc_pack_components).  A ComponentSet is
@@ -197,6 +199,14 @@ class HipBackend(object):
             comps.K, comps.D, _dptr(comps.mu), _dptr(comps.precision), _dptr(comps.c0),
             _dptr(comps.c1), _dptr(comps.c2), _dptr(comps.c3), _dptr(comps.weight),
             comps.column.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(host)), "pmc_pack_components")
+        return self.torch.from_numpy(host).to(self.device)
+
+    def _means_pack(self, mu, K, D):
+        """pmc_pack_means: a device pack that carries only the K x D shifts of the statistics kernel."""
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(K, D)
+        stride = _lib.check(self.lib.pmc_pack_stride(D), "pmc_pack_stride")
+        host = np.empty(K * stride, dtype=np.float64)
+        _lib.check(self.lib.pmc_pack_means(K, D, _dptr(mu), _dptr(host)), "pmc_pack_means")
         return self.torch.from_numpy(host).to(self.device)
 
     # ------------------------------------------------------------------ operations
@@ -354,9 +364,8 @@ class HipBackend(object):
         ws = self._workspace(N, K, D)
         stats_pack = pack
         if shift is not None:
-            # only the means of a pack matter to the statistics kernel
-            shift = np.ascontiguousarray(shift, dtype=np.float64).reshape(K, D)
-            stats_pack = self.pack(ComponentSet(PMC_KIND_GAUSS, shift, np.broadcast_to(np.eye(D), (K, D, D)).copy()))
+            # only the means of a pack matter to the statistics kernel: no matrices, no factorisations
+            stats_pack = self._means_pack(shift, K, D)
         if r is None and log_rho is None and expo is None and shift is None:
             # the E-step proper: one call; for small D one kernel, the N x K matrix stays on chip
             fused = bool(self.lib.pmc_estep_is_fused(K, D, comps.kind, int(mode)))
@@ -415,8 +424,7 @@ class HipBackend(object):
         N, D = x.shape
         w = self.asdevice(w).reshape(N)
         shift = self.tohost(x[:1]).reshape(1, D) if N else np.zeros((1, D))
-        cs = ComponentSet(PMC_KIND_GAUSS, shift, np.eye(D)[None])
-        pack = self.pack(cs)
+        pack = self._means_pack(shift, 1, D)
         ntile = (N + self.tile - 1) // self.tile
         u = self.zeros(max(ntile, 1) * self.tile)          # tile-major with K = 1: the weight vector
         u[:N] = w

@@ -612,8 +612,28 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
     return PMC_OK;
 }
 
+int pmc_pack_means(int K, int D, const double *mu, double *pack)
+{
+    if (K < 1 || !mu || !pack) return fail(PMC_EINVAL, "pmc_pack_means: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
+    const int Dp = ks->dim, stride = pmc_pack_stride_c(Dp);
+    std::memset(pack, 0, sizeof(double) * (size_t)K * stride);
+    for (int k = 0; k < K; ++k) {
+        double *pk = pack + (size_t)k * stride;
+        for (int j = 0; j < D; ++j) pk[j] = mu[(size_t)k * D + j];
+        double *c = pk + Dp + pmc_tri(Dp);
+        c[4] = 1.0;
+        const long long col = k;
+        std::memcpy(&c[5], &col, sizeof(col));
+    }
+    return PMC_OK;
+}
+
 // scratch of the scalar finishing kernel -- slices + ticket counter, zeroed once (the counter wraps) -- one per
-// (device, stream): launches on one stream are ordered, different streams never share it
+// (device, stream handle): launches on one stream are ordered, different streams never share it.  A handle that
+// stands for several real streams (hipStreamPerThread, the null stream under per-thread default streams) is NOT
+// supported for concurrent calls from several threads: give each thread a stream of its own.
 struct FinScratch {
     int device;
     hipStream_t stream;
@@ -629,12 +649,15 @@ FinScratch *fin_scratch(hipStream_t st)
     std::lock_guard<std::mutex> lock(m);
     for (FinScratch &f : all)
         if (f.device == dev && f.stream == st) return &f;
+    all.reserve(256);                                       // (pointers handed out stay valid)
+    if (all.size() >= 256) return nullptr;                  // before anything is allocated
     void *p = nullptr;
     const size_t bytes = sizeof(double) * FIN_GROUPS * PMC_NSCALARS + 256;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, bytes) != hipSuccess) return nullptr;
-    all.reserve(256);                                       // (pointers handed out stay valid)
-    if (all.size() >= 256) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess) {
+        (void)hipFree(p);
+        return nullptr;
+    }
     all.push_back(FinScratch{dev, st, (double *)p, (unsigned *)((char *)p + sizeof(double) * FIN_GROUPS * PMC_NSCALARS)});
     return &all.back();
 }

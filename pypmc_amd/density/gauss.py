@@ -9,8 +9,10 @@ from ..backend import ComponentSet, get_backend
 from .._lib import PMC_KIND_GAUSS, check_dim
 
 
-# every parameter state of a component gets a process-unique stamp (set by update / _assign, shared by copies,
-# which hold the same parameters): density.mixture.component_set keys its cache of uploaded parameter packs on it
+# every parameter state of a component gets a process-unique stamp (set by update / _assign, shared by in-process
+# copies, which hold the same parameters): density.mixture.component_set keys its cache of uploaded parameter packs
+# on it.  A stamp never leaves its process: pickling drops it and unpickling draws a new one (__getstate__ /
+# __setstate__), so a component that arrives from another process or from disk cannot collide with a local one.
 _STAMPS = itertools.count(1)
 
 
@@ -58,6 +60,15 @@ class Gauss(ProbabilityDensity):
         for key, value in self.__dict__.items():
             new.__dict__[key] = value.copy() if isinstance(value, np.ndarray) else value
         return new
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_stamp', None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._stamp = next(_STAMPS)
 
     def _assign(self, mu, sigma, cholesky_sigma, inv_sigma, log_det_sigma):
         """``update`` with the factorisation already done (mix_adapt's batched K-sized updates)."""

@@ -23,8 +23,12 @@ def component_set(components, weights, columns=None, ld=None):
     Evaluating the same mixture again -- every ``ImportanceSampler.run`` between two proposal updates, every
     ``multi_evaluate`` of a target mixture -- finds its set here and with it the pack already on the device
     (K Cholesky factors of the precision matrices and an upload otherwise: 0.6 ms at K = 128, D = 40).  The key
-    is the components' parameter stamps (``update`` renews them), the means and the weights themselves: both
-    are plain arrays the reference lets callers change in place."""
+    is the components' parameter stamps (``update`` renews them; they are process-local and renewed when a
+    component is unpickled), the means and the weights themselves: both are plain arrays the reference lets
+    callers change in place.  Only complete mixtures are kept: subsets (``components=``, the live components of
+    a PMC update, the single-component sets of the latent-blocks update) come and go with every call and would
+    only push the sets worth keeping out.  ``clear_component_cache()`` (also called by ``HipBackend.release``)
+    drops the sets and with them the device packs."""
     comps = list(components)
     if not comps:
         return None
@@ -36,19 +40,27 @@ def component_set(components, weights, columns=None, ld=None):
     mu = np.array([c.mu for c in sel], dtype=np.float64).reshape(len(sel), -1)
     wts = np.asarray(weights, dtype=np.float64)[idx]
     total = len(comps) if ld is None else ld
-    key = (first, tuple(c._stamp for c in sel), mu.tobytes(), wts.tobytes(), tuple(idx), total)
-    hit = _SETS.get(key)
-    if hit is not None:
-        _SETS.move_to_end(key)
-        return hit
+    cacheable = columns is None and total == len(comps)
+    if cacheable:
+        key = (first, tuple(c._stamp for c in sel), mu.tobytes(), wts.tobytes(), total)
+        hit = _SETS.get(key)
+        if hit is not None:
+            _SETS.move_to_end(key)
+            return hit
     consts = np.array([c._kernel_constants() for c in sel], dtype=np.float64).reshape(len(sel), 4)
     cs = ComponentSet(first.kind, mu, np.array([c.inv_sigma for c in sel], dtype=np.float64),
                       consts[:, 0], consts[:, 1], consts[:, 2], consts[:, 3],
                       weight=wts, column=idx, ld=total)
-    _SETS[key] = cs
-    if len(_SETS) > _SETS_MAX:
-        _SETS.popitem(last=False)
+    if cacheable:
+        _SETS[key] = cs
+        if len(_SETS) > _SETS_MAX:
+            _SETS.popitem(last=False)
     return cs
+
+
+def clear_component_cache():
+    """Forget the cached ComponentSets (and the device parameter packs kept with them)."""
+    _SETS.clear()
 
 
 class MixtureDensity(ProbabilityDensity):

@@ -73,7 +73,7 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
         """ONE exchange: statistics | weight normalisation | latent histogram travel in the same buffer
         (on the device when the statistics are, so RCCL reduces it in place)"""
         nstat = int(flat.shape[0])
-        if parallel.world_size() > 1:
+        if parallel.active():
             joined = be.zeros(nstat + len(tail0))
             joined[:nstat] = flat
             joined[nstat:] = be.asdevice(tail0)
@@ -82,8 +82,13 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
         return be.tohost(flat), tail0
 
     cs = None
-    if live_components and not rb and count is not None and int(count.sum()) == N_local \
-            and _is_sorted(latent):
+    blocks = bool(live_components) and not rb and count is not None and int(count.sum()) == N_local \
+        and _is_sorted(latent)
+    if not rb and parallel.active():
+        # which form a rank would take depends on its own shard (an empty one counts as sorted); the general form
+        # may answer with a second exchange (far shift, below), so the ranks must agree: blocks only if all can
+        blocks = parallel.all_reduce_scalars(0.0 if blocks else 1.0)[0] == 0.0
+    if blocks:
         # non-Rao-Blackwell update of samples that arrive ordered by generating component (what
         # propose(trace=True) / run(trace_sort=True) deliver): component k only sees its own
         # contiguous block of samples, so the cost is N x D^2 instead of N x K x D^2 -- the
@@ -115,16 +120,19 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
     weight_normalization = float(tail[0])
     stats = split_stats(flat, max(nlive, 1), D)
     shift = np.array([density.components[k].mu for k in stat_components]).reshape(len(stat_components), D)
-    if cs is not None and shift_is_far(stats[1], stats[2], stats[3]):
+    if nlive and shift_is_far(stats[1], stats[2], stats[3]):
         # a weighted mean far from its proposal component (the first iterations of a badly placed proposal): the
         # one-pass moments about mu_k would cancel; second pass about the mean just found -- the reference's own
         # order (mean first, then the covariance about it: pmc.pyx:188-222, :612-632).  Decided on the all-reduced
         # sums, so every rank takes the same branch.
         S0 = stats[1]
         shift = np.where((S0 > 1e-200)[:, None], shift + stats[2] / regularize(S0.copy())[:, None], shift)
-        res = be.estep(samples, cs, mode, max_init_zero=len(live_components) < K, sample_w=weights,
-                       latent=None if rb else latent, shift=shift)
-        flat, tail = exchange(res["stats"])
+        if cs is None:
+            again = _latent_blocks_estep(be, samples, weights, latent, density, live_components, count, K, D, shift)
+        else:
+            again = be.estep(samples, cs, mode, max_init_zero=len(live_components) < K, sample_w=weights,
+                             latent=None if rb else latent, shift=shift)["stats"]
+        flat, tail = exchange(again)
         stats = split_stats(flat, max(nlive, 1), D)
 
     if count is not None:
@@ -149,10 +157,11 @@ def _is_sorted(a):
     return bool((a[1:] >= a[:-1]).all())
 
 
-def _latent_blocks_estep(be, samples, weights, latent, density, live_components, count, K, D):
+def _latent_blocks_estep(be, samples, weights, latent, density, live_components, count, K, D, shift=None):
     """Statistics of the latent (one-hot) responsibilities when the samples are ordered by
     component: one single-component pass per live component over its own block.  Returns the same
-    flat layout as ``backend.estep`` for the live components."""
+    flat layout as ``backend.estep`` for the live components.  ``shift`` (live x D): moments about these
+    points instead of the components' means (the second pass of a far shift)."""
     from .._lib import NSCALARS
     x = be.asdevice(samples)
     lat = be.asdevice(latent, getattr(getattr(be, 'torch', None), 'int64', None))
@@ -169,7 +178,7 @@ def _latent_blocks_estep(be, samples, weights, latent, density, live_components,
         if cs is None:
             raise TypeError('``density`` must have only Gauss or only StudentT components')
         one = be.estep(x[a:b], cs, PMC_RESP_PMC_LATENT, sample_w=None if w is None else w[a:b],
-                       latent=lat[a:b])["stats"]
+                       latent=lat[a:b], shift=None if shift is None else shift[i:i + 1])["stats"]
         flat[NSCALARS + i * ps:NSCALARS + (i + 1) * ps] = one[NSCALARS:NSCALARS + ps]
         flat[NSCALARS + nlive * ps + 2 * i:NSCALARS + nlive * ps + 2 * i + 2] = one[NSCALARS + ps:NSCALARS + ps + 2]
     return flat

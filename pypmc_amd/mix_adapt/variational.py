@@ -362,11 +362,11 @@ class GaussianInference(object):
             indices = np.arange(self.K)
         elif initial_guess == 'random':
             indices = np.random.choice(self.N, size=self.K, replace=False)
-            if parallel.world_size() > 1:
+            if parallel.active():
                 indices = np.rint(parallel.broadcast_from_rank0(indices)).astype(np.int64)
         else:
             raise ValueError('Invalid ``initial_guess``: ' + str(initial_guess))
-        if parallel.world_size() == 1:
+        if not parallel.active():
             return host(self.data[:self.K] if initial_guess == 'first' else self.data[indices])
         return parallel.global_rows(indices, self.N_local, lambda loc: host(self.data[loc]), self.dim)
 

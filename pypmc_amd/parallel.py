@@ -34,6 +34,13 @@ def rank():
     return d.get_rank() if d else 0
 
 
+def active():
+    """True when a process group exists -- the sharded code paths (joined exchange buffer, global rows, one
+    collective per update) are taken then, for a group of one rank as well: a single GPU under ``torchrun
+    --nproc-per-node 1`` runs exactly what eight do."""
+    return _dist() is not None
+
+
 def shard_bounds(N, r=None, world=None):
     """[begin, end) of rank ``r``'s contiguous block of N samples (sizes differ by at most 1)."""
     r = rank() if r is None else r
@@ -43,18 +50,38 @@ def shard_bounds(N, r=None, world=None):
     return begin, begin + base + (1 if r < extra else 0)
 
 
-def init_from_env():
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_from_env(force=False):
     """Join the process group ``torchrun`` set up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): one process per
     GPU, backend "nccl" (= RCCL over xGMI).  ``PMC_DIST_BACKEND=gloo`` is the development aid used by the
     tests: several ranks share the GPUs that exist (RCCL refuses two ranks on one device).
-    Returns (rank, world_size, local device index); a no-op (0, 1, current device) without WORLD_SIZE > 1."""
+    Returns (rank, world_size, local device index).
+
+    A launch under ``torchrun`` (RANK and WORLD_SIZE in the environment) always gets its group, a single rank
+    included -- ``torchrun --nproc-per-node 1`` runs the very collectives an 8-GPU run issues, on one GPU.
+    A plain ``python`` process gets none (0, 1, current device) unless ``force`` (or ``PMC_FORCE_DIST=1``) asks
+    for a one-rank group on a free local port."""
     import os
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    force = force or os.environ.get("PMC_FORCE_DIST", "0") not in ("", "0")
+    if world <= 1 and not launched and not force:
         return 0, 1, torch.cuda.current_device() if torch.cuda.is_available() else 0
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not launched:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     backend = os.environ.get("PMC_DIST_BACKEND", "nccl")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend != "nccl":
@@ -75,14 +102,15 @@ def _collective_device(d):
 
 
 def all_reduce_sum(buf):
-    """In-place sum over ranks of a float64 buffer; returns ``buf``.  A no-op for a single process.
+    """In-place sum over ranks of a float64 buffer; returns ``buf``.  A no-op without a process group; a group
+    of ONE rank still runs the collective (that is how the RCCL path is exercised on a one-GPU box).
 
     The buffer is reduced where the process group's backend works -- RCCL ("nccl") on the GPU, gloo
     on the host -- and staged through the other memory when it lives there: a numpy / CPU buffer
     under nccl goes through a device copy, a device tensor under gloo (the CPU test-suite and
     `PMC_DIST_BACKEND=gloo`, several ranks on one GPU) through a host copy."""
     d = _dist()
-    if d is None or d.get_world_size() == 1:
+    if d is None:
         return buf
     import torch
     dev = _collective_device(d)
@@ -107,7 +135,7 @@ def all_reduce_sum(buf):
 def all_reduce_scalars(*values):
     """Sum a few python floats over ranks (setup-time bookkeeping: global N, global sum of weights)."""
     d = _dist()
-    if d is None or d.get_world_size() == 1:
+    if d is None:
         return tuple(float(v) for v in values)
     a = np.array([float(v) for v in values], dtype=np.float64)
     all_reduce_sum(a)
@@ -118,7 +146,7 @@ def shard_offset(n_local):
     """Global index of this rank's first sample when the ranks hold consecutive blocks of
     ``n_local`` rows each (rank order = sample order), and the global row count."""
     d = _dist()
-    if d is None or d.get_world_size() == 1:
+    if d is None:
         return 0, int(n_local)
     sizes = np.zeros(d.get_world_size(), dtype=np.float64)
     sizes[d.get_rank()] = float(n_local)

@@ -75,12 +75,41 @@ REPLICATED = ("vb_m", "vb_W", "vbf_m0", "vbf_m", "vbf_W", "vbr_m0", "pmc_mu", "p
               "pmc_run_mu", "tpmc_mu", "tpmc_sigma", "tpmc_dof")
 
 
-def run(rank, world, port, workdir, backend_kind="oracle"):
+def collectives(be=None):
+    """The plumbing of pypmc_amd.parallel on whatever process group is up: numpy and device buffers through
+    all_reduce_sum, scalars, shard offsets, rows of the global sample array, rank 0's vector."""
+    from pypmc_amd import parallel
+    world, rank = parallel.world_size(), parallel.rank()
+    out = {}
+    a = np.arange(5, dtype=np.float64) + rank
+    out["ar_numpy"] = parallel.all_reduce_sum(a.copy())
+    out["ar_numpy_expected"] = world * np.arange(5, dtype=np.float64) + sum(range(world))
+    if be is not None and be.name == "hip":
+        t = be.asdevice(a.copy())
+        out["ar_device"] = be.tohost(parallel.all_reduce_sum(t))
+    out["scalars"] = np.array(parallel.all_reduce_scalars(1.0, 2.5 * (rank + 1)))
+    out["scalars_expected"] = np.array([float(world), 2.5 * sum(r + 1 for r in range(world))])
+    n_local = 7 + rank
+    off, total = parallel.shard_offset(n_local)
+    out["offset"] = np.array([off, total])
+    out["offset_expected"] = np.array([sum(7 + r for r in range(rank)), sum(7 + r for r in range(world))])
+    rows = np.arange(n_local * 3, dtype=np.float64).reshape(n_local, 3) + 1000 * rank
+    out["rows"] = parallel.global_rows([0, total - 1, 3], n_local, lambda loc: rows[loc], 3)
+    out["bcast"] = parallel.broadcast_from_rank0(np.array([3.0, 4.0]) + rank)
+    return out
+
+
+def run(rank, world, port, workdir, backend_kind="oracle", pg_backend="gloo"):
     import torch.distributed as dist
     if backend_kind == "hip":
         import torch
         torch.cuda.set_device(0)                     # both ranks share the one GPU of the box
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    if pg_backend == "nccl":                         # RCCL: one rank per device (a single rank on a one-GPU box)
+        import torch
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         from pypmc_amd import parallel
         if backend_kind == "hip":
@@ -91,9 +120,11 @@ def run(rank, world, port, workdir, backend_kind="oracle"):
             be = OracleBackend()
         z = dict(np.load(os.path.join(workdir, "inputs.npz")))
         lo, hi = parallel.shard_bounds(len(z["data"]))
-        assert parallel.world_size() == world and parallel.rank() == rank
+        assert parallel.world_size() == world and parallel.rank() == rank and parallel.active()
         out = case(be, z, lo, hi)
         out["backend"] = np.array(be.name)
+        out["pg_backend"] = np.array(dist.get_backend())
+        out.update({"coll_" + k: v for k, v in collectives(be).items()})
         np.savez(os.path.join(workdir, "rank%d.npz" % rank), **out)
     finally:
         dist.destroy_process_group()

@@ -19,8 +19,24 @@ def test_same_parameters_same_set():
     a = component_set(m.components, m.weights)
     assert component_set(m.components, m.weights) is a
     assert component_set(copy.deepcopy(m).components, m.weights) is a          # a copy holds the same parameters
-    assert component_set(m.components, m.weights, [1, 2], 4) is not a          # a subset is another set
-    assert component_set(m.components, m.weights, [1, 2], 4) is component_set(m.components, m.weights, [1, 2], 4)
+    sub = component_set(m.components, m.weights, [1, 2], 4)
+    assert sub is not a and sub.K == 2 and sub.ld == 4                         # a subset is another set ...
+    assert component_set(m.components, m.weights, [1, 2], 4) is not sub        # ... and is not kept
+
+
+def test_a_stamp_never_leaves_its_process():
+    """advice r2: a component unpickled from another process / from disk must not hit a local component's pack"""
+    import pickle
+    from pypmc_amd.density.mixture import clear_component_cache
+    m = _mix()
+    a = component_set(m.components, m.weights)
+    blob = pickle.dumps(m.components)
+    assert b'_stamp' not in blob
+    back = pickle.loads(blob)
+    assert all(x._stamp != y._stamp for x, y in zip(back, m.components))
+    assert component_set(back, m.weights) is not a                              # same values, but a new state
+    clear_component_cache()
+    assert component_set(m.components, m.weights) is not a
 
 
 def test_every_change_makes_a_new_set():

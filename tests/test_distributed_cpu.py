@@ -43,12 +43,34 @@ def check_two_ranks(single, ranks, N, rtol):
         np.testing.assert_array_equal(ranks[0][key], ranks[1][key], err_msg=key)
 
 
-def spawn_two_ranks(z, backend_kind):
+def spawn_ranks(z, backend_kind, world=2, pg_backend="gloo"):
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as tmp:
         np.savez(os.path.join(tmp, "inputs.npz"), **z)
-        mp.spawn(dist_worker.run, args=(2, _free_port(), tmp, backend_kind), nprocs=2, join=True)
-        return [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(2)]
+        mp.spawn(dist_worker.run, args=(world, _free_port(), tmp, backend_kind, pg_backend), nprocs=world, join=True)
+        return [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(world)]
+
+
+def spawn_two_ranks(z, backend_kind):
+    return spawn_ranks(z, backend_kind, 2)
+
+
+def check_collectives(ranks):
+    """pypmc_amd.parallel's plumbing as each rank saw it (dist_worker.collectives)"""
+    for r, got in enumerate(ranks):
+        np.testing.assert_array_equal(got["coll_ar_numpy"], got["coll_ar_numpy_expected"])
+        if "coll_ar_device" in got:
+            np.testing.assert_array_equal(got["coll_ar_device"], got["coll_ar_numpy_expected"])
+        np.testing.assert_array_equal(got["coll_scalars"], got["coll_scalars_expected"])
+        np.testing.assert_array_equal(got["coll_offset"], got["coll_offset_expected"])
+        np.testing.assert_array_equal(got["coll_bcast"], [3.0, 4.0])
+        total = int(got["coll_offset"][1])
+        # rows 0, total-1, 3 of the global array: rank 0 holds 7 rows (values 0..20), the last rank the last row
+        last_rank = len(ranks) - 1
+        n_last = 7 + last_rank
+        expect = np.array([[0., 1., 2.], np.arange((n_last - 1) * 3, n_last * 3) + 1000. * last_rank, [9., 10., 11.]])
+        np.testing.assert_array_equal(got["coll_rows"], expect)
+        assert total == sum(7 + q for q in range(len(ranks)))
 
 
 def test_two_rank_vb_and_pmc_match_single_process():
@@ -56,6 +78,18 @@ def test_two_rank_vb_and_pmc_match_single_process():
     single = dist_worker.case(OracleBackend(), z, 0, len(z["data"]))
     ranks = spawn_two_ranks(z, "oracle")
     check_two_ranks(single, ranks, len(z["data"]), rtol=1e-10)
+    check_collectives(ranks)
+
+
+def test_one_rank_group_takes_the_sharded_paths():
+    """a process group of ONE rank (what `torchrun --nproc-per-node 1` sets up) runs the collectives and the
+    sharded code paths and reproduces the run without a group"""
+    z = dist_worker.make_inputs(seed=3, N=257)
+    single = dist_worker.case(OracleBackend(), z, 0, len(z["data"]))
+    ranks = spawn_ranks(z, "oracle", world=1)
+    check_collectives(ranks)
+    for key, val in single.items():
+        np.testing.assert_allclose(ranks[0][key], val, rtol=1e-12, atol=1e-13, err_msg=key)
 
 
 def test_first_rows_spanning_ranks():

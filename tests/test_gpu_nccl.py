@@ -1,0 +1,66 @@
+"""The RCCL path for real, on the one GPU of the box: a process group of ONE rank with backend "nccl"
+(torch.distributed's name for RCCL on ROCm) runs every collective the sharded front-end issues -- the joined
+statistics / bookkeeping buffer of the PMC updates, the VB E-step's statistics vector, the rows of the global
+sample array, scalars staged from numpy -- through ncclAllReduce on the device, and bench.py under
+``torch.distributed.run --nproc-per-node 1`` reports what the group really was.  An 8-GPU run issues exactly
+these calls with world_size 8 (reference: pypmc/tools/parallel_sampler.py:58-71 gathers with mpi4py instead)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import dist_worker
+from test_distributed_cpu import check_collectives, spawn_ranks, _free_port
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_one_rank_nccl_group_runs_the_sharded_surface():
+    from pypmc_amd.backend import HipBackend
+    z = dist_worker.make_inputs(seed=21, N=4099)
+    single = dist_worker.case(HipBackend(), z, 0, len(z["data"]))           # no process group in this process
+    ranks = spawn_ranks(z, "hip", world=1, pg_backend="nccl")
+    got = ranks[0]
+    assert str(got["backend"]) == "hip" and str(got["pg_backend"]) == "nccl"
+    check_collectives(ranks)
+    for key, val in single.items():
+        # same kernels on the same rows; the reduced buffer is the sum over ONE rank: nothing may move
+        np.testing.assert_allclose(got[key], val, rtol=1e-13, atol=1e-14, err_msg=key)
+    np.testing.assert_array_equal(got["vbf_m0"], single["vbf_m0"])
+    np.testing.assert_array_equal(got["vbr_m0"], single["vbr_m0"])
+
+
+def _bench(launcher, extra, env=None):
+    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                      "--samples-per-gpu", "400000", "--no-cpu-baseline", "--no-configs"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env or dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_under_torchrun_one_rank_is_rccl(scaling):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("PMC_DIST_BACKEND", None)
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    line = _bench(launcher, ["--scaling", scaling], env)
+    assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1
+    assert line["dist"]["allreduce_ms"] > 0.0 and line["dist"]["allreduce_doubles"] > 0
+    assert line["scaling"] == scaling and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["N_total"] == 400000 and line["config"]["N_per_gpu"] == 400000
+
+
+def test_bench_plain_python_has_no_group_unless_forced():
+    line = _bench([sys.executable], [])
+    assert line["dist"]["backend"] is None and line["dist"]["world_size"] == 1
+    line = _bench([sys.executable], ["--force-dist"])
+    assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1 and line["dist"]["allreduce_ms"] > 0.0
