@@ -274,7 +274,18 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  * ONE kernel does both and the N x K responsibilities never leave the compute units: d_u and d_scratch may
  * then be NULL.  Ask pmc_estep_is_fused(), do not re-derive the rule.  Otherwise the call is
  * pmc_responsibilities followed by pmc_sufficient_stats through d_u (and d_scratch / d_vsums for Student-t).
+ *
+ * From 17 components on (compiled dimensions 8 ... 64, N >= 16384) the statistics half first runs in its
+ * component x monomial form: moments about ONE shift c common to all components (the midrange of their means) are a
+ * plain matrix product U^T Z on v_mfma_f64_16x16x4_f64, re-centred to the components' own shifts on the device.  A
+ * component whose weighted mean turns out further than sqrt(limit) of its own standard deviations from c (default
+ * limit 1000: at most ~3 of the 16 digits lost in the re-centring) sends the call back to the per-component-shift
+ * kernel of pmc_sufficient_stats, on the device, without a host round trip.  pmc_configure() moves both knobs:
+ *   "stats_common_shift_min_k"  (default 17; a huge value switches the form off)
+ *   "stats_common_shift_limit"  (default 1000; 0 switches the form off)
+ * pmc_sufficient_stats itself always takes its moments about the pack's own shifts.
  */
+int pmc_configure(const char *key, double value);
 int pmc_estep_is_fused(int K, int D, int kind, int mode);
 int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, int mode,
               int max_init_zero, const double *d_sample_w, const int64_t *d_latent, double *d_u,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pmc_sufficient_stats": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "pmc_timing_enable": (_int, [_int]),
     "pmc_get_timings": (_int, [_vp, _int, C.POINTER(C.c_int)]),
+    "pmc_configure": (_int, [C.c_char_p, C.c_double]),
     "pmc_estep_is_fused": (_int, [_int, _int, _int, _int]),
     "pmc_estep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmc_maha_tiles_size": (_i64, [_i64, _int]),

@@ -121,6 +121,10 @@ class HipBackend(object):
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    def configure(self, key, value):
+        """pmc_configure: library options ("stats_common_shift_min_k", "stats_common_shift_limit")."""
+        _lib.check(self.lib.pmc_configure(key.encode(), float(value)), "pmc_configure")
+
     def kernel_timing(self, on=True):
         """Switch the library's own kernel timing on / off (pmc_timing_enable: HIP events on the launch
         stream around every hot kernel)."""

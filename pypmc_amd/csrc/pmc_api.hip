@@ -22,7 +22,9 @@
     extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);                                        \
     extern "C" hipError_t pmc_launch_propose_d##d##_p##p(const PmcArgsP &, unsigned, hipStream_t);         \
     extern "C" hipError_t pmc_launch_fused_d##d##_p##p(int, int, const PmcArgsF &, unsigned, hipStream_t); \
-    extern "C" int pmc_fused_lds_bytes_d##d##_p##p(int, int);
+    extern "C" int pmc_fused_lds_bytes_d##d##_p##p(int, int);                                          \
+    extern "C" hipError_t pmc_launch_stats_gemm_d##d##_p##p(const PmcArgsG &, unsigned, hipStream_t);   \
+    extern "C" void pmc_stats_gemm_config_d##d##_p##p(int *, int *, int *);
 extern "C" hipError_t pmc_launch_resp_tiles(int, const PmcArgsT &, unsigned, hipStream_t);
 // the run-time-dimension unit (pmc_big.hip, pmc_persample.hip / pmc_propose.hip compiled with PMC_D = 0)
 extern "C" hipError_t pmc_launch_logpdf_d0_p0(int, int, const PmcArgsA &, unsigned, hipStream_t);
@@ -40,7 +42,8 @@ namespace {
 #define PMC_SET(d, p) \
     {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, \
      &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p, \
-     &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p}
+     &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p, &pmc_launch_stats_gemm_d##d##_p##p, \
+     &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0}
 struct DimEntry {
     int dim;
     bool has_padded;
@@ -76,6 +79,7 @@ const char *const g_timing_names[T_COUNT] = {"k_logpdf", "k_resp", "k_stats", "k
                                              "finishing reductions"};
 struct TimingRec {
     int id;
+    int calls;            // 1, or 0 for a bracket that continues the previous launch of the same kernel
     hipEvent_t a, b;
     double flops, bytes;
 };
@@ -102,11 +106,11 @@ struct Timed {
     TimingRec rec;
     hipStream_t st;
     bool on;
-    Timed(int id, hipStream_t st_, double flops, double bytes) : st(st_), on(false)
+    Timed(int id, hipStream_t st_, double flops, double bytes, int calls = 1) : st(st_), on(false)
     {
         std::lock_guard<std::mutex> lock(g_timing_mutex);
         if (!g_timing_on || g_timing_recs.size() >= PMC_TIMING_MAX_RECORDS) return;
-        rec.id = id; rec.flops = flops; rec.bytes = bytes;
+        rec.id = id; rec.calls = calls; rec.flops = flops; rec.bytes = bytes;
         rec.a = timing_event();
         rec.b = timing_event();
         if (!rec.a || !rec.b) return;
@@ -146,6 +150,9 @@ const PmcKernelSet *big_kernels_for(int D)
     ks->propose = &pmc_launch_propose_big;
     ks->fused = nullptr;
     ks->fused_lds_bytes = nullptr;
+    ks->stats_gemm = nullptr;
+    ks->gemm_config = nullptr;
+    ks->gemm_cols = ks->gemm_slices = ks->gemm_msp = 0;
     sets.push_back(ks);
     return ks;
 }
@@ -158,7 +165,10 @@ const PmcKernelSet *kernels_for(int D)
         if (g_dims[i].dim == D) ks = &g_dims[i].exact;
         else if (g_dims[i].dim > D) ks = g_dims[i].has_padded ? &g_dims[i].padded : nullptr;
         else continue;
-        if (ks && ks->stats_nsub == 0) ks->config(&ks->stats_nsub, &ks->stats_waves);   // idempotent
+        if (ks && ks->stats_nsub == 0) {                                                // idempotent
+            ks->gemm_config(&ks->gemm_cols, &ks->gemm_slices, &ks->gemm_msp);
+            ks->config(&ks->stats_nsub, &ks->stats_waves);
+        }
         return ks;
     }
     return nullptr;
@@ -218,8 +228,9 @@ __global__ __launch_bounds__(256) void k_finish_scalars(const double *__restrict
 // element are 64 independent streams instead of one dependent chain.
 __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__ partials,
                                                       int nchunks, int K, int D, int Dc,
-                                                      double *__restrict__ stats)
+                                                      double *__restrict__ stats, const int *__restrict__ ctl)
 {
+    if (ctl && ctl[PMC_CTL_REDO] == 0) return;            // the common-shift form stands
     const int PS = pmc_stats_stride_c(D), PSc = pmc_stats_stride_c(Dc);
     const long long idx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -232,6 +243,133 @@ __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__
     for (int c = lane; c < nchunks; c += 64) v += partials[((size_t)c * K + k) * PSc + pc];
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) stats[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the common-shift (component x monomial) form of the statistics: plan, reduce, re-centre + check
+// ---------------------------------------------------------------------------------------------
+// Library options (pmc_configure): the form is tried for K >= g_gemm_min_k when the compiled dimension has the
+// kernel; a component whose weighted mean lies further than sqrt(limit) of its own standard deviations (in some
+// coordinate) from the common shift sends the call back to the per-component-shift kernel.
+int g_gemm_min_k = 17;
+double g_gemm_limit = 1000.0;
+
+// c = midrange of the component means per coordinate (minimises the largest |mu_k - c|), ctl = {go, redo}.
+// A priori test with the pack's own scale when the caller knows what the pack describes (kind >= 0): with
+// P = R^T R the precision of component k, 1 / P_ii <= Sigma_ii, so (mu_ki - c_i)^2 P_ii [* nu_k for the VB kind,
+// whose W is the precision / nu] > limit_prior says "too far" -- conservatively; a pass is checked again a
+// posteriori on the data by k_gemm_convert.
+__global__ __launch_bounds__(256) void k_stats_plan(const double *__restrict__ pack, int stride, int K, int D, int Dc,
+                                                    int kind, double limit_prior, double *__restrict__ center,
+                                                    int *__restrict__ ctl)
+{
+    __shared__ int far;
+    if (threadIdx.x == 0) far = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < D; j += 256) {
+        double lo = pack[j], hi = pack[j];
+        for (int k = 1; k < K; ++k) {
+            const double m = pack[(size_t)k * stride + j];
+            lo = m < lo ? m : lo;
+            hi = m > hi ? m : hi;
+        }
+        const double c = 0.5 * lo + 0.5 * hi;
+        center[j] = (c == c && fabs(c) <= 1.7976931348623157e308) ? c : 0.0;
+    }
+    __syncthreads();
+    if (kind >= 0 && pmc_engine(Dc) != PMC_ENG_DPP) {
+        // R upper triangular, packed row-major over the compiled dimension: element (l, i >= l) at
+        // Dc + l Dc - l (l - 1) / 2 + (i - l)
+        for (int idx = threadIdx.x; idx < K * D; idx += 256) {
+            const int k = idx / D, i = idx % D;
+            const double *pk = pack + (size_t)k * stride;
+            double pii = 0.0;
+            for (int l = 0; l <= i; ++l) {
+                const double r = pk[Dc + l * Dc - l * (l - 1) / 2 + (i - l)];
+                pii += r * r;
+            }
+            if (kind == PMC_KIND_VB) pii *= pk[Dc + pmc_tri(Dc) + 1];      // c1 = nu_k
+            const double dlt = pk[i] - center[i];
+            if (dlt * dlt * pii > limit_prior) far = 1;                      // (benign race: every writer stores 1)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl[PMC_CTL_GO] = far ? 0 : 1;
+        ctl[PMC_CTL_REDO] = far ? 1 : 0;
+    }
+}
+
+// totals[k][m] = sum over the nce partial vectors, in a fixed order: thread = monomial (coalesced rows of 64),
+// wavefront w of the workgroup takes the partial vectors w, w + 4, ... in ascending order, the four are added in
+// wavefront order.
+__global__ __launch_bounds__(256) void k_gemm_reduce(const double *__restrict__ partials, int nce, int K, int msp,
+                                                     double *__restrict__ totals, const int *__restrict__ ctl)
+{
+    if (ctl[PMC_CTL_GO] == 0) return;
+    __shared__ double red[4][64];
+    const int k = blockIdx.y, m = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    double v = 0.0;
+    if (m < msp)
+        for (int ce = w; ce < nce; ce += 4) v += partials[((size_t)ce * K + k) * msp + m];
+    red[w][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (w == 0 && m < msp) totals[(size_t)k * msp + m] = ((red[0][m & 63] + red[1][m & 63]) + red[2][m & 63]) + red[3][m & 63];
+}
+
+// One workgroup per component: re-centre the moments from the common shift c to the component's own shift mu_k
+// (what pmc_sufficient_stats returns), and test a posteriori whether the common shift was near enough:
+//   dlt = mu_k - c;   S0' = S0;   M1'_i = M1_i - S0 dlt_i;   M2'_ij = M2_ij - M1_i dlt_j - dlt_i M1_j + S0 dlt_i dlt_j
+//   far  <=>  (M1_i / S0)^2 > limit * var_i,  var_i = M2_ii / S0 - (M1_i / S0)^2,  for a component that holds more
+//             than a millionth of the total weight (the rule of mix_adapt._stats.shift_is_far)
+__global__ __launch_bounds__(256) void k_gemm_convert(const double *__restrict__ totals, int K, int D, int msp,
+                                                      const double *__restrict__ pack, int stride,
+                                                      const double *__restrict__ center, double limit,
+                                                      double *__restrict__ stats, int *__restrict__ ctl)
+{
+    if (ctl[PMC_CTL_GO] == 0) return;
+    const int k = blockIdx.x, PS = pmc_stats_stride_c(D);
+    const double *tk = totals + (size_t)k * msp;
+    const double *mu = pack + (size_t)k * stride;
+    double *out = stats + (size_t)k * PS;
+    const double S0 = tk[0];
+    __shared__ double wsum;
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < K; ++q) {
+            const double s = totals[(size_t)q * msp];
+            if (s == s && fabs(s) <= 1.7976931348623157e308) t += s;
+        }
+        wsum = t;
+    }
+    __syncthreads();
+    const bool counts = S0 > 1e-200 && S0 > 1e-6 * wsum;
+    bool far = false;
+    for (int p = threadIdx.x; p < PS; p += 256) {
+        double v;
+        if (p == 0) v = S0;
+        else if (p <= D) {
+            const int i = p - 1;
+            v = tk[p] - S0 * (mu[i] - center[i]);
+        } else {
+            const int t = p - 1 - D;
+            int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+            while ((i + 1) * (i + 2) / 2 <= t) ++i;
+            while (i * (i + 1) / 2 > t) --i;
+            const int j = t - i * (i + 1) / 2;
+            const double di = mu[i] - center[i], dj = mu[j] - center[j];
+            const double m1i = tk[1 + i], m1j = tk[1 + j];
+            v = ((tk[p] - m1i * dj) - di * m1j) + S0 * di * dj;
+            if (i == j && counts) {
+                const double dbar = m1i / S0, raw = tk[p] / S0;
+                double var = raw - dbar * dbar;
+                if (!(var > 1e-14 * raw)) var = 1e-14 * raw;
+                if (dbar * dbar > limit * var) far = true;
+            }
+        }
+        out[p] = v;
+    }
+    if (far) ctl[PMC_CTL_REDO] = 1;                       // (benign race: every writer stores 1)
 }
 
 // N = 1, D = 1: stats[k] = (u_k, u_k d, u_k d^2), d = x - mu_k   (u tile-major: one tile, lane 0)
@@ -385,6 +523,49 @@ StatsGeom stats_geom(long long N, int K, const PmcKernelSet *ks)
     return g;
 }
 
+// geometry of the component x monomial form (k_stats_gemm): workgroup = (chunk, group of 32 components, column
+// super group); one workgroup per CU is resident (LDS), so about one round of 256
+struct GemmGeom {
+    int ngroups, ncs, nchunks, tiles_per_chunk, nce;
+    long long ntiles;
+    unsigned grid;
+};
+bool gemm_available(const PmcKernelSet *ks) { return ks->stats_gemm != nullptr && ks->gemm_cols > 0; }
+GemmGeom gemm_geom(long long N, int K, const PmcKernelSet *ks)
+{
+    GemmGeom g;
+    g.ntiles = ceil_div(N, PMC_TILE);
+    g.ngroups = (int)ceil_div(K, 32);
+    g.ncs = (int)ceil_div(ks->gemm_msp / 16, ks->gemm_cols);
+    const long long nsub = (long long)g.ngroups * g.ncs;
+    long long c = 256 / nsub / 8 * 8;
+    if (c < 8) c = 8;
+    const long long cmax = ceil_div(ceil_div(g.ntiles, 4), 8) * 8;          // at least ~4 tiles per chunk
+    if (c > cmax) c = cmax;
+    g.nchunks = (int)c;
+    g.tiles_per_chunk = (int)ceil_div(g.ntiles, g.nchunks);
+    if (g.tiles_per_chunk < 1) g.tiles_per_chunk = 1;
+    g.nce = g.nchunks * ks->gemm_slices;
+    g.grid = (unsigned)(g.nchunks * nsub);
+    return g;
+}
+// workspace of a statistics call: [region shared by the two forms' partial sums | centre (Dc doubles) | control block]
+size_t stats_region_bytes(long long N, int K, const PmcKernelSet *ks)
+{
+    const StatsGeom g = stats_geom(N > 0 ? N : 1, K, ks);
+    size_t bytes = (size_t)g.nchunks * K * pmc_stats_stride_c(ks->dim) * sizeof(double);
+    if (gemm_available(ks)) {
+        const GemmGeom gg = gemm_geom(N > 0 ? N : 1, K, ks);
+        const size_t gb = ((size_t)gg.nce + 1) * K * ks->gemm_msp * sizeof(double);      // partial vectors + totals
+        if (gb > bytes) bytes = gb;
+    }
+    return (bytes + 255) & ~(size_t)255;
+}
+size_t stats_tail_bytes(const PmcKernelSet *ks)
+{
+    return gemm_available(ks) ? (((size_t)ks->dim * sizeof(double) + 255) & ~(size_t)255) + 256 : 0;
+}
+
 // fused E-step launch geometry (pmc_fused.hip)
 struct FusedGeom {
     int qs, kq, cw, tpr, rounds_per_wg, reg;
@@ -531,8 +712,7 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
-    const StatsGeom g = stats_geom(N > 0 ? N : 1, K, ks);
-    const size_t stats = (size_t)g.nchunks * K * pmc_stats_stride_c(ks->dim) * sizeof(double);
+    const size_t stats = stats_region_bytes(N, K, ks) + stats_tail_bytes(ks);
     const size_t scal = scalar_partials_bytes(N) +
                         (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
     size_t total = stats > scal ? stats : scal;
@@ -907,8 +1087,10 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
     return PMC_OK;
 }
 
-int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
-                         const double *d_u, double *d_stats, void *d_workspace, void *stream)
+// kind: what d_pack describes (pmc_kind) when the caller is an E-step and the fast common-shift form may be tried;
+// -1: the per-component-shift kernel, always (the public pmc_sufficient_stats)
+static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+                                 const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind)
 {
     if (N < 0 || K < 1 || !d_pack || !d_u || !d_stats || !d_workspace)
         return fail(PMC_EINVAL, "pmc_sufficient_stats: bad argument");
@@ -932,24 +1114,86 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
         return PMC_OK;
     }
     const StatsGeom g = stats_geom(N, K, ks);
+    hipError_t e;
+    int *ctl = nullptr;
+    int counted = 1;
+    if (kind >= 0 && gemm_available(ks) && K >= g_gemm_min_k && N >= 16384 && g_gemm_limit > 0.0) {
+        // The common-shift form first (k_stats_gemm, pmc_stats.hip); the per-component-shift kernel below then
+        // returns at once unless the a-posteriori test of k_gemm_convert asks for it.
+        if (((uintptr_t)d_u & 15u) != 0) return fail(PMC_EINVAL, "pmc_estep: d_u must be 16-byte aligned");
+        const GemmGeom gg = gemm_geom(N, K, ks);
+        char *tail = (char *)d_workspace + stats_region_bytes(N, K, ks);
+        double *center = (double *)tail;
+        ctl = (int *)(tail + (((size_t)ks->dim * sizeof(double) + 255) & ~(size_t)255));
+        double *gpart = (double *)d_workspace;
+        double *totals = gpart + (size_t)gg.nce * K * ks->gemm_msp;
+        const int stride = pmc_pack_stride_c(ks->dim);
+        {
+            Timed t(T_STATS, st, flops_stats((double)N, K, D), 8.0 * N * (D + K));
+            hipLaunchKernelGGL(k_stats_plan, dim3(1), dim3(256), 0, st, d_pack, stride, K, D, ks->dim, kind,
+                               10.0 * g_gemm_limit, center, ctl);
+            e = hipGetLastError();
+            if (e != hipSuccess) return hipfail(e, "k_stats_plan launch");
+            PmcArgsG a;
+            std::memset(&a, 0, sizeof(a));
+            a.x = d_x; a.N = N; a.dreal = D; a.center = center; a.K = K; a.u = d_u; a.partials = gpart;
+            a.ntiles = gg.ntiles; a.nchunks = gg.nchunks; a.tiles_per_chunk = gg.tiles_per_chunk;
+            a.ngroups = gg.ngroups; a.ncs = gg.ncs; a.ctl = ctl;
+            e = ks->stats_gemm(a, gg.grid, st);
+            if (e != hipSuccess) return hipfail(e, "k_stats_gemm launch");
+        }
+        {
+            Timed tf(T_FINISH, st, 0.0, 8.0 * gg.nce * K * ks->gemm_msp);
+            hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)ceil_div(ks->gemm_msp, 64), (unsigned)K), dim3(256), 0, st,
+                               (const double *)gpart, gg.nce, K, ks->gemm_msp, totals, (const int *)ctl);
+            e = hipGetLastError();
+            if (e != hipSuccess) return hipfail(e, "k_gemm_reduce launch");
+            hipLaunchKernelGGL(k_gemm_convert, dim3((unsigned)K), dim3(256), 0, st, (const double *)totals, K, D,
+                               ks->gemm_msp, d_pack, stride, (const double *)center, g_gemm_limit, d_stats, ctl);
+            e = hipGetLastError();
+            if (e != hipSuccess) return hipfail(e, "k_gemm_convert launch");
+        }
+        counted = 0;                                       // the launches below continue this call's record
+    }
     PmcArgsB b;
     std::memset(&b, 0, sizeof(b));
     b.x = d_x; b.N = N; b.dreal = D; b.pack = d_pack; b.K = K; b.u = d_u;
     b.partials = (double *)d_workspace; b.ntiles = g.ntiles; b.nchunks = g.nchunks;
-    b.tiles_per_chunk = g.tiles_per_chunk; b.ngroups = g.ngroups;
-    hipError_t e;
+    b.tiles_per_chunk = g.tiles_per_chunk; b.ngroups = g.ngroups; b.ctl = ctl;
     {
-        Timed t(T_STATS, st, flops_stats((double)N, K, D), 8.0 * N * (D + K));
+        Timed t(T_STATS, st, counted ? flops_stats((double)N, K, D) : 0.0, counted ? 8.0 * N * (D + K) : 0.0, counted);
         e = ks->stats(b, g.grid, st);
     }
     if (e != hipSuccess) return hipfail(e, "k_stats launch");
     const long long total = (long long)K * PS;
-    Timed tf(T_FINISH, st, 0.0, 8.0 * g.nchunks * K * pmc_stats_stride_c(ks->dim));
+    Timed tf(T_FINISH, st, 0.0, 8.0 * g.nchunks * K * pmc_stats_stride_c(ks->dim), counted);
     hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
-                       (const double *)d_workspace, g.nchunks, K, D, ks->dim, d_stats);
+                       (const double *)d_workspace, g.nchunks, K, D, ks->dim, d_stats, (const int *)ctl);
     e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
     return PMC_OK;
+}
+
+int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+                         const double *d_u, double *d_stats, void *d_workspace, void *stream)
+{
+    return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, -1);
+}
+
+int pmc_configure(const char *key, double value)
+{
+    if (!key) return fail(PMC_EINVAL, "pmc_configure: NULL key");
+    if (std::strcmp(key, "stats_common_shift_min_k") == 0) {
+        if (!(value >= 1.0 && value <= 1e9)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 1", key);
+        g_gemm_min_k = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "stats_common_shift_limit") == 0) {
+        if (!(value >= 0.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
+        g_gemm_limit = value;
+        return PMC_OK;
+    }
+    return fail(PMC_EINVAL, "pmc_configure: unknown key '%s'", key);
 }
 
 int pmc_timing_enable(int on)
@@ -977,7 +1221,7 @@ int pmc_get_timings(pmc_timing *h_out, int max_entries, int *n_entries)
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
         if (e != hipSuccess) rc = hipfail(e, "pmc_get_timings: event");
         else {
-            acc[r.id].calls += 1;
+            acc[r.id].calls += r.calls;
             acc[r.id].ms += ms;
             acc[r.id].flops += r.flops;
             acc[r.id].bytes += r.bytes;
@@ -1028,7 +1272,7 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
         int rc = pmc_responsibilities(d_x, N, D, d_pack, K, kind, mode, max_init_zero, d_sample_w, d_latent, d_u,
                                       d_scratch, d_vsums, nullptr, nullptr, nullptr, K, d_scalars, d_workspace, stream);
         if (rc != PMC_OK) return rc;
-        return pmc_sufficient_stats(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream);
+        return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind);
     }
     if (!d_x) return fail(PMC_EINVAL, "pmc_estep: d_x is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -1049,7 +1293,7 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     const long long total = (long long)K * pmc_stats_stride_c(D);
     Timed tf(T_FINISH, st, 0.0, 8.0 * g.nchunks * K * PSc);
     hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
-                       (const double *)a.partials, (int)g.nchunks, K, D, ks->dim, d_stats);
+                       (const double *)a.partials, (int)g.nchunks, K, D, ks->dim, d_stats, (const int *)nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
     return finish_scalars(a.spartials, g.grid, d_scalars, st);
@@ -1096,7 +1340,7 @@ int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pa
     }
     int rc = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
     if (rc != PMC_OK) return rc;
-    return pmc_sufficient_stats(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream);
+    return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind);
 }
 
 }  // extern "C"

@@ -134,7 +134,28 @@ struct PmcArgsB {
     int nchunks;          // multiple of 8 (XCD count)
     int tiles_per_chunk;
     int ngroups;
+    const int *ctl;       // NULL, or the control block of a call that tried the common-shift form first: the kernel
+                          // returns at once unless ctl[PMC_CTL_REDO] != 0
 };
+
+// statistics kernel, component x monomial form (k_stats_gemm): moments about ONE common shift `center`
+struct PmcArgsG {
+    const double *x;
+    long long N;
+    int dreal;
+    const double *center; // dreal doubles (device): the common shift c
+    int K;
+    const double *u;      // tile-major ntiles x K x 64
+    double *partials;     // [nchunks * slices][K][msp]: monomials 1 | d | d d^T lower triangle (row-major i, j <= i), d = x - c
+    long long ntiles;
+    int nchunks;          // multiple of 8 (XCD count)
+    int tiles_per_chunk;
+    int ngroups;          // groups of 32 components
+    int ncs;              // column super groups (workgroups that split the monomials)
+    const int *ctl;       // control block (device): ctl[0] = go -- the kernel returns at once if it is 0
+};
+// control block of a statistics call that may use the common-shift form (device memory, in the workspace)
+enum { PMC_CTL_GO = 0, PMC_CTL_REDO = 1, PMC_CTL_INTS = 4 };
 
 // fused E-step kernel
 struct PmcArgsF {
@@ -191,4 +212,8 @@ struct PmcKernelSet {
     hipError_t (*propose)(const PmcArgsP &, unsigned grid, hipStream_t);
     hipError_t (*fused)(int kind, int qs, const PmcArgsF &, unsigned grid, hipStream_t);
     int (*fused_lds_bytes)(int qs, int K);
+    // component x monomial statistics (NULL / cols_per_wg == 0: this dimension has none)
+    hipError_t (*stats_gemm)(const PmcArgsG &, unsigned grid, hipStream_t);
+    void (*gemm_config)(int *cols_per_wg, int *slices, int *msp);
+    int gemm_cols, gemm_slices, gemm_msp;   // monomial tiles (of 16) per workgroup, sample slices, partial row length
 };

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stats(const PmcArgsB b)
     extern __shared__ double xs[];                        // 2 x-buffers of NS*64 rows, then 2 u-buffers
     // XCD-aware block -> (chunk, task group): hardware places block i on XCD i % 8; all task
     // groups of one sample chunk get the same residue so they share that XCD's L2 copy of the tile.
+    if (b.ctl && b.ctl[PMC_CTL_REDO] == 0) return;        // the common-shift form was accurate: nothing to redo
     const int bid = blockIdx.x;
     const int q = bid >> 3;
     const int chunk = (bid & 7) + 8 * (q / b.ngroups);
@@ -369,6 +370,266 @@ __global__ __launch_bounds__(WAVES * 64) void k_stats(const PmcArgsB b)
     });
 }
 
+
+// =============================================================================================
+// Component x monomial form (k_stats_gemm): the statistics as ONE matrix product per sample block
+// =============================================================================================
+// With a shift c common to all components the three sums are U^T Z:  U[n][k] = u_nk,  Z[n] = (1 | d | d_i d_j, j <= i),
+// d = x_n - c  -- the lower triangle of d~ d~^T for the augmented vector d~ = (d, 1), M = (D+1)(D+2)/2 monomials in
+// the order of the statistics vector.  On v_mfma_f64_16x16x4_f64: A = 16 components x 4 samples of u (no product
+// u * d any more), B = 4 samples x 16 monomials, formed with ONE v_mul_f64 per lane from two LDS reads; a B operand
+// feeds both 16-component row blocks of a 32-component group.  Against the per-component-shift kernel above: no
+// per-component x - mu_k, no u * d, no first-moment adds (16 vector operations per 15 MFMAs there), 96-100 % of the
+// matrix slots useful (231 of 240 columns at D = 20, 861 of 864 at D = 40; there 87.5 %), and the instruction is the
+// one that holds the highest clock.  Measured (scripts/microbench/stats_gemm.hip, the prototype):
+// D = 20, K = 32: 57 algorithmic TFLOP/s (0.73 of the fp64 peak) against 45-47; D = 40, K = 128: 67 (0.855) against 51.
+//
+// The price is numerical: moments about c instead of mu_k lose (|mu_k - c| / sigma_k)^2 leading parts when they are
+// re-centred.  The finishing kernels (pmc_api.hip) re-centre on the device, test every component a posteriori
+// (|mean - c|^2 <= limit * variance in every coordinate) and raise ctl[PMC_CTL_REDO] if one fails: the kernel above
+// then runs as before, otherwise it returns at once.
+//
+// Work decomposition.  Workgroup = (sample chunk, group of 32 components, column super group); its wavefronts are
+// CGW column groups x SL sample slices: a wavefront owns C column tiles (16 monomials each) x 2 row blocks = 2 C
+// accumulator tiles (8 registers each) and every SL-th quarter of each sample tile.  LDS holds NS sample tiles, double
+// buffered: rows of x - c (the subtraction happens once, on the way from the registers the rows were prefetched into;
+// the "1" of d~ sits in a spare slot of each row that the staging never touches) and the u values by LDS-DMA in
+// 1-KiB pieces of two components.  A lane (n = lane & 15, g = lane >> 4) works on sample row 8 g + t of a tile in
+// MFMA step t: rows 8 apart are 16 doubles apart modulo the 32-double bank cycle (row pitch = odd number of 16-byte
+// slots), so the two halves of a wavefront read disjoint banks; the 16 lanes of a row read two of its columns each.
+template <int D> struct GemmCfg {
+    // column tiles per wavefront | column groups per workgroup | sample slices | tiles per pipeline step
+    // (2 C accumulator tiles of 8 registers each have to fit next to ~60 operand / address registers: C = 8 at D = 30
+    // and C = 9 at D = 32 / 64 spilled)
+    static constexpr int C = D <= 8 ? 3 : (D <= 10 ? 5 : (D <= 12 ? 3 : (D <= 20 ? 5 : (D <= 24 ? 6 : (D <= 30 ? 4 :
+                             (D <= 32 ? 3 : (D <= 40 ? 7 : (D <= 48 ? 5 : 6))))))));
+    static constexpr int CGW = D <= 10 ? 1 : (D <= 16 ? 2 : (D <= 20 ? 3 : (D <= 24 ? 4 : (D <= 30 ? 8 : (D <= 32 ? 12 : 8)))));
+    static constexpr int SL = D <= 10 ? 8 : (D <= 20 ? 4 : (D <= 24 ? 2 : 1));
+    static constexpr int NS = D <= 32 ? 2 : 1;
+    static constexpr bool ENABLED = D >= 8;
+    static constexpr int W = CGW * SL;
+    static constexpr int NP = (D + 1) / 2;                 // coordinate pairs per sample
+    static constexpr int PITCH = (NP + 1) | 1;             // 16-byte slots per LDS row: odd, one spare for the "1"
+    static constexpr int ROWD = 2 * PITCH;
+    static constexpr int M = (D + 1) * (D + 2) / 2;
+    static constexpr int NT = (M + 15) / 16;
+    static constexpr int MSP = NT * 16;                    // doubles per component in the partial sums
+    static constexpr int NCS = (NT + C * CGW - 1) / (C * CGW);
+    static constexpr int XT = 64 * ROWD;                   // doubles per x tile
+    static constexpr int UPIECE = 130;                     // a 1-KiB DMA piece (2 components x 64 samples) + 16 bytes
+    static constexpr int UT = 16 * UPIECE;                 // doubles per u tile (32 components)
+    static constexpr size_t LDS_BYTES = sizeof(double) * 2 * NS * (XT + UT);
+};
+
+// sample row (within a tile, before the lane's 8 g) of MFMA step j of a slice: compile-time part ...
+template <int SL> __host__ __device__ constexpr int gemm_row_imm(int j) { return SL == 1 ? (j & 7) + 32 * (j >> 3) : j; }
+// ... and the slice's run-time part
+template <int SL> __device__ __forceinline__ int gemm_row_base(int sl)
+{
+    if constexpr (SL == 1) return 0;
+    else if constexpr (SL == 2) return 32 * sl;
+    else if constexpr (SL == 4) return 4 * (sl & 1) + 32 * (sl >> 1);
+    else if constexpr (SL == 8) return 2 * (sl & 3) + 32 * (sl >> 2);
+    else return (sl & 7) + 32 * (sl >> 3);
+}
+
+typedef double gd4 __attribute__((ext_vector_type(4)));
+typedef double gd2 __attribute__((ext_vector_type(2)));
+typedef double gd2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int D, bool PADDED>
+__global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgsG b)
+{
+    using CF = GemmCfg<D>;
+    constexpr int C = CF::C, CGW = CF::CGW, SL = CF::SL, NS = CF::NS, W = CF::W, R = 2;
+    constexpr int NP = CF::NP, ROWD = CF::ROWD, XT = CF::XT, UT = CF::UT, UPIECE = CF::UPIECE;
+    constexpr int BUFX = NS * XT, BUFU = NS * UT;
+    constexpr int JN = 16 / SL, NSTEP = NS * JN;
+    constexpr int PX = NS * 64 * NP, NPX = (PX + W * 64 - 1) / (W * 64);
+    constexpr int PU = NS * 16, NPU = (PU + W - 1) / W;
+    extern __shared__ double xs[];                         // 2 x buffers, then 2 u buffers
+    if (b.ctl[PMC_CTL_GO] == 0) return;                    // the plan kernel found the components too far apart
+    double *us = xs + 2 * BUFX;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave % CGW, sl = wave / CGW;
+    const int n16 = lane & 15, g = lane >> 4;
+    const int dreal = PADDED ? b.dreal : D;
+    const int npr = (dreal + 1) / 2, ONE = 2 * npr;        // column of the "1": first spare slot behind the data
+    const int M = (dreal + 1) * (dreal + 2) / 2;
+    const long long total = b.N * (long long)dreal;
+
+    // block -> (chunk, component group, column super group); all blocks of a chunk on one XCD (one L2 copy of x)
+    const int bid = blockIdx.x, qb = bid >> 3;
+    const int nsub = b.ngroups * b.ncs;
+    const int chunk = (bid & 7) + 8 * (qb / nsub);
+    const int sub = qb % nsub, group = sub / b.ncs, cs = sub % b.ncs;
+    const int kmin = group * 32;
+    const int nrb = (b.K - kmin) > 16 ? 2 : 1;             // row blocks of 16 components that hold any
+    const long long t0 = (long long)chunk * b.tiles_per_chunk;
+    long long t1 = t0 + b.tiles_per_chunk;
+    if (t1 > b.ntiles) t1 = b.ntiles;
+
+    // this lane's two factors of each of the wavefront's column tiles: LDS offsets (doubles) incl. the lane's rows.
+    // Monomial m in the order of the statistics vector: 0 -> 1 * 1, 1 + j -> 1 * d_j, 1 + D + i(i+1)/2 + j -> d_i * d_j.
+    const int rowbase = (8 * g + gemm_row_base<SL>(sl)) * ROWD;
+    int off1[C], off2[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int ct = (cs * CGW + cg) * C + c;
+        const int m = 16 * ct + n16;
+        int i1 = ONE, i2 = ONE;
+        if (m >= 1 && m <= dreal) i2 = m - 1;
+        else if (m > dreal && m < M) {
+            const int t = m - 1 - dreal;
+            int i = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+            while ((i + 1) * (i + 2) / 2 <= t) ++i;
+            while (i * (i + 1) / 2 > t) --i;
+            i1 = i;
+            i2 = t - i * (i + 1) / 2;
+        }
+        off1[c] = rowbase + i1;
+        off2[c] = rowbase + i2;
+    }
+    int uoff[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int cc = 16 * r + n16;
+        uoff[r] = (cc >> 1) * UPIECE + (cc & 1) * 64 + 8 * g + gemm_row_base<SL>(sl);
+    }
+
+    // the "1" of every row, both buffers (never overwritten: the staging writes data slots only)
+    for (int row = tid; row < 2 * NS * 64; row += 64 * W) xs[row * ROWD + ONE] = 1.0;
+
+    // x staging: piece = one coordinate pair of one row, fixed per thread; global -> registers one step ahead,
+    // minus c on the way into LDS
+    int xl[NPX];                                           // LDS offset (doubles), -1: no piece
+    unsigned xg[NPX];                                      // global offset relative to the step's first row
+    double c0[NPX], c1[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int id = tid + i * W * 64;
+        const int n = id / NP, jp = id % NP;
+        const bool ok = id < PX && jp < npr;
+        xl[i] = ok ? n * ROWD + 2 * jp : -1;
+        xg[i] = (unsigned)(n * dreal + 2 * jp);
+        c0[i] = ok ? b.center[2 * jp] : 0.0;
+        c1[i] = (ok && 2 * jp + 1 < dreal) ? b.center[2 * jp + 1] : 0.0;
+    }
+    gd2 xv[NPX];
+    // rows beyond the chunk or the array are clamped into it (their weights are zero); the array's very last
+    // element of an odd-sized array is fetched one element early and picked from the pair's second half
+    auto xload = [&](long long t) {
+        const long long tt = t < t1 ? t : t0;
+        const long long base = tt * 64 * dreal;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            long long o = base + xg[i];
+            if (o > total - 2) o = total - 2;
+            xv[i] = *(const gd2u *)(b.x + o);
+        }
+    };
+    auto xstore = [&](long long t, double *xbuf) {
+        const long long tt = t < t1 ? t : t0;
+        const long long base = tt * 64 * dreal;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            if (xl[i] >= 0) {
+                const bool last = base + xg[i] == total - 1;
+                gd2 v;
+                v[0] = (last ? xv[i][1] : xv[i][0]) - c0[i];
+                v[1] = xv[i][1] - c1[i];
+                *(gd2 *)(xbuf + xl[i]) = v;
+            }
+        }
+    };
+    const long long ulen = b.ntiles * (long long)b.K * 64;
+    auto udma = [&](long long t, double *ubuf) {
+#pragma unroll
+        for (int i = 0; i < NPU; ++i) {
+            const int id = wave + i * W;
+            if (PU % W == 0 || id < PU) {                  // wave-uniform
+                const int q = id / 16, p = id % 16;
+                const long long tile = (t + q < t1) ? t + q : t0;
+                long long o = (tile * b.K + kmin + 2 * p) * 64 + 2 * lane;
+                if (o > ulen - 2) o = ulen - 2;            // components beyond K: any finite values, rows discarded
+                __builtin_amdgcn_global_load_lds((gvoid_t *)(b.u + o), (lvoid_t *)(ubuf + q * UT + p * UPIECE), 16, 0, 0);
+            }
+        }
+    };
+
+    gd4 acc[R][C];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[r][c] = gd4{0.0, 0.0, 0.0, 0.0};
+
+    xload(t0);
+    udma(t0, us);
+    xstore(t0, xs);
+    dma_barrier();
+    int buf = 0;
+    for (long long t = t0; t < t1; t += NS, buf ^= 1) {
+        const double *xb = xs + buf * BUFX;
+        const double *ub = us + buf * BUFU;
+        xload(t + NS);
+        udma(t + NS, us + (buf ^ 1) * BUFU);
+
+        double ac[R], zc[C], an[R], f1n[C], f2n[C];
+        auto fetch = [&](auto IDX, double (&a)[R], double (&f1)[C], double (&f2)[C]) {
+            constexpr int idx = decltype(IDX)::value, q = idx / JN, j = idx % JN;
+            constexpr int XIMM = (q * 64 + gemm_row_imm<SL>(j)) * ROWD, UIMM = q * UT + gemm_row_imm<SL>(j);
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = ub[uoff[r] + UIMM];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                f1[c] = xb[off1[c] + XIMM];
+                f2[c] = xb[off2[c] + XIMM];
+            }
+        };
+        fetch(ic<0>{}, ac, f1n, f2n);
+#pragma unroll
+        for (int c = 0; c < C; ++c) zc[c] = f1n[c] * f2n[c];
+        static_for<0, NSTEP>([&](auto IDX) {
+            constexpr int idx = decltype(IDX)::value, q = idx / JN;
+            // operands of step idx + 1 are read behind the first row block's multiplies of step idx
+            if constexpr (idx + 1 < NSTEP) fetch(ic<idx + 1>{}, an, f1n, f2n);
+            const bool live = t + q < t1;                  // tiles beyond the chunk: no weight
+            const double a0 = live ? ac[0] : 0.0, a1 = live ? ac[1] : 0.0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, zc[c], acc[0][c], 0, 0, 0);
+            if (nrb > 1) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, zc[c], acc[1][c], 0, 0, 0);
+            }
+            if constexpr (idx + 1 < NSTEP) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ac[r] = an[r];
+#pragma unroll
+                for (int c = 0; c < C; ++c) zc[c] = f1n[c] * f2n[c];
+            }
+        });
+        xstore(t + NS, xs + (buf ^ 1) * BUFX);
+        dma_barrier();
+    }
+
+    // accumulator layout of v_mfma_f64_16x16x4_f64: D[row = (lane >> 4) + 4 reg][col = lane & 15]
+    double *out = b.partials + ((size_t)(chunk * SL + sl) * b.K) * CF::MSP;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int ct = (cs * CGW + cg) * C + c;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int k = kmin + 16 * r + g + 4 * reg;
+                if (k < b.K && ct < CF::NT) out[(size_t)k * CF::MSP + 16 * ct + n16] = acc[r][c][reg];
+            }
+        }
+    }
+}
+
 constexpr int NSUB_ = Blocking<D_>::NSUB;
 #ifdef PMC_STATS_WAVES                                     // tuning override (scripts/tune_stats.sh)
 constexpr int SW_ = PMC_STATS_WAVES;
@@ -386,6 +647,32 @@ extern "C" void PMC_UNIT_NAME_X(pmc_stats_config_d, PMC_D, PMC_PADDED)(int *nsub
 {
     *nsub = NSUB_;
     *waves = SW_;
+}
+
+// geometry of the component x monomial form: monomial tiles per workgroup (0: this dimension has no such kernel),
+// sample slices (partial statistics vectors per chunk), doubles per component in a partial vector
+extern "C" void PMC_UNIT_NAME_X(pmc_stats_gemm_config_d, PMC_D, PMC_PADDED)(int *cols_per_wg, int *slices, int *msp)
+{
+    using CF = GemmCfg<D_>;
+    *cols_per_wg = CF::ENABLED ? CF::C * CF::CGW : 0;
+    *slices = CF::SL;
+    *msp = CF::MSP;
+}
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_stats_gemm_d, PMC_D, PMC_PADDED)(const PmcArgsG &b, unsigned grid,
+                                                                                 hipStream_t st)
+{
+    using CF = GemmCfg<D_>;
+    if constexpr (!CF::ENABLED) return hipErrorInvalidValue;
+    else {
+        static_assert(CF::LDS_BYTES <= 160 * 1024, "k_stats_gemm tile buffers exceed the LDS");
+        static_assert(16 % CF::SL == 0 && CF::W <= 16, "k_stats_gemm slicing");
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stats_gemm<D_, P_>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES);
+        if (once != hipSuccess) return once;
+        hipLaunchKernelGGL((k_stats_gemm<D_, P_>), dim3(grid), dim3(64 * CF::W), CF::LDS_BYTES, st, b);
+        return hipGetLastError();
+    }
 }
 
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_stats_d, PMC_D, PMC_PADDED)(const PmcArgsB &b, unsigned grid,

@@ -1,0 +1,160 @@
+"""The component x monomial form of the sufficient statistics (k_stats_gemm: moments about one common shift as a
+matrix product on v_mfma_f64_16x16x4, re-centred on the device) against the per-component-shift kernel it replaces
+in pmc_estep, and against the oracle: same statistics to rounding where the components are near the common shift,
+the old kernel's numbers bit for bit where the a-posteriori test sends the call back to it.
+Reference loops: variational.pyx:699-932, pmc.pyx:188-222."""
+import numpy as np
+import pytest
+from scipy.special import digamma
+
+from test_gpu_kernels import mk, draw, gauss_set, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from pypmc_amd.backend import HipBackend
+    b = HipBackend()
+    yield b
+    b.configure("stats_common_shift_limit", 1000.0)
+    b.configure("stats_common_shift_min_k", 17)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def vb_set(mu, cov, D, K, seed):
+    from pypmc_amd.backend import ComponentSet
+    rs = np.random.RandomState(seed)
+    nu = D + 2. + rs.uniform(0, 5, K)
+    beta = 1. + rs.uniform(0, 5, K)
+    alpha = 1. + rs.uniform(0, 5, K)
+    W = np.linalg.inv(cov) / nu[:, None, None]
+    W = 0.5 * (W + W.transpose(0, 2, 1))
+    m = mu + 0.1 * rs.normal(size=mu.shape)
+    ln_lambda = sum(digamma(0.5 * (nu + 1. - i)) for i in range(1, D + 1)) + D * np.log(2.) + np.linalg.slogdet(W)[1]
+    ln_pi = digamma(alpha) - digamma(alpha.sum())
+    cs = ComponentSet(2, m, W, c0=D / beta, c1=nu, c2=ln_pi, c3=ln_lambda - D * np.log(2. * np.pi))
+    return cs, (m, W, beta, nu, ln_pi, ln_lambda)
+
+
+def both_forms(be, x, cs, mode, **kw):
+    """statistics of pmc_estep with the common-shift form allowed and with it switched off"""
+    be.configure("stats_common_shift_limit", 1000.0)
+    fast = be.tohost(be.estep(x, cs, mode, **kw)["stats"]).copy()
+    be.configure("stats_common_shift_limit", 0.0)
+    try:
+        slow = be.tohost(be.estep(x, cs, mode, **kw)["stats"]).copy()
+    finally:
+        be.configure("stats_common_shift_limit", 1000.0)
+    return fast, slow
+
+
+def scaled_close(fast, slow, K, D, tol):
+    """the sums of each component against the magnitude of that component's sums of the same order"""
+    from pypmc_amd.mix_adapt._stats import split_stats
+    a, b = split_stats(fast, K, D), split_stats(slow, K, D)
+    np.testing.assert_array_equal(a[0], b[0])                           # scalars come from k_resp: untouched
+    assert_rel(a[1], b[1], rtol=1e-12, what="sum u")
+    for k in range(K):
+        s1 = np.abs(b[2][k]).max() + np.sqrt(np.abs(np.diag(b[3][k])).max() * max(b[1][k], 0.0))
+        assert np.abs(a[2][k] - b[2][k]).max() <= tol * max(s1, 1e-300), ("first moments", k)
+        s2 = np.abs(np.diag(b[3][k])).max()
+        assert np.abs(a[3][k] - b[3][k]).max() <= tol * max(s2, 1e-300), ("second moments", k)
+
+
+@pytest.mark.parametrize("D,K,N", [(8, 17, 20001), (9, 20, 16384), (10, 32, 30000), (12, 33, 25000), (16, 40, 20011),
+                                   (18, 32, 33333), (20, 32, 100003), (20, 64, 50000), (20, 100, 17000),
+                                   (24, 17, 20000), (27, 24, 19999), (30, 32, 20000), (32, 48, 18000),
+                                   (40, 128, 20000), (48, 20, 17001), (57, 18, 16500), (64, 33, 16999)])
+def test_common_shift_form_matches_the_per_component_form(be, D, K, N):
+    mu, cov, w = mk(K, D, 700 + D + K)
+    x, _ = draw(mu, cov, w, N, 3)
+    cs, _ = vb_set(mu, cov, D, K, D * K)
+    rs = np.random.RandomState(N)
+    sw = rs.uniform(0.5, 1.5, N)
+    fast, slow = both_forms(be, x, cs, 0, sample_w=sw)
+    assert not np.array_equal(fast, slow), "the common-shift form did not run"
+    scaled_close(fast, slow, K, D, 1e-11)
+    # bit-reproducible
+    be.configure("stats_common_shift_limit", 1000.0)
+    np.testing.assert_array_equal(be.tohost(be.estep(x, cs, 0, sample_w=sw)["stats"]), fast)
+
+
+def test_common_shift_form_vs_oracle(be, orc):
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    D, K, N = 20, 32, 40000
+    mu, cov, w = mk(K, D, 5)
+    x, _ = draw(mu, cov, w, N, 6)
+    cs, (m, W, beta, nu, ln_pi, ln_lambda) = vb_set(mu, cov, D, K, 7)
+    ref = orc.vb_estep(x, None, m, W, beta, nu, ln_pi, ln_lambda)
+    be.configure("stats_common_shift_limit", 1000.0)
+    flat = be.tohost(be.estep(x, cs, 0)["stats"])
+    sc, S0, M1, M2, _, _ = split_stats(flat, K, D)
+    x_mean, S = centred_moments(S0, M1, M2, m)
+    assert_rel(S0, ref["N_comp"], rtol=1e-11, what="N_comp")
+    live = ref["N_comp"] > 1e-6
+    np.testing.assert_allclose(x_mean[live], ref["x_mean_comp"][live], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(S[live], ref["S"][live], rtol=1e-9, atol=1e-11)
+
+
+def test_far_components_fall_back_to_the_per_component_kernel(be):
+    """modes 300 standard deviations apart: the a-priori test (Gaussian kinds) or the a-posteriori test (VB, whose
+    pack holds W = precision / nu) refuses the common shift, and the result is the old kernel's, bit for bit"""
+    D, K, N = 20, 32, 30000
+    mu, cov, w = mk(K, D, 11)
+    mu = mu * 100.0
+    x, _ = draw(mu, cov, w, N, 12)
+    cs, _ = vb_set(mu, cov, D, K, 13)
+    fast, slow = both_forms(be, x, cs, 0)
+    np.testing.assert_array_equal(fast, slow)
+    gs, _, _ = gauss_set(mu, cov, w)
+    fast, slow = both_forms(be, x, gs, 1)
+    np.testing.assert_array_equal(fast, slow)
+
+
+def test_moderately_separated_components_keep_their_digits(be):
+    """components ~25 standard deviations from the common shift: inside the limit, error of the covariances
+    within 1e-10 of the per-component form"""
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    D, K, N = 16, 32, 60000
+    mu, cov, w = mk(K, D, 21)
+    mu = mu * 4.0
+    x, _ = draw(mu, cov, w, N, 22)
+    gs, _, _ = gauss_set(mu, cov, w)
+    fast, slow = both_forms(be, x, gs, 1)
+    a, b = split_stats(fast, K, D), split_stats(slow, K, D)
+    ma, ca = centred_moments(a[1], a[2], a[3], mu)
+    mb, cb = centred_moments(b[1], b[2], b[3], mu)
+    np.testing.assert_allclose(ma, mb, rtol=1e-12, atol=1e-12)
+    scale = np.abs(np.einsum('kii->ki', cb)).max(axis=1)[:, None, None]
+    assert np.abs(ca - cb).max() / scale.max() < 1e-10 and (np.abs(ca - cb) / scale).max() < 1e-10
+
+
+def test_nan_sample_poisons_the_statistics_in_both_forms(be):
+    D, K, N = 20, 32, 20000
+    mu, cov, w = mk(K, D, 31)
+    x, _ = draw(mu, cov, w, N, 32)
+    x[12345, 7] = np.nan
+    cs, _ = vb_set(mu, cov, D, K, 33)
+    fast, slow = both_forms(be, x, cs, 0)
+    from pypmc_amd.mix_adapt._stats import split_stats
+    for flat in (fast, slow):
+        S0 = split_stats(flat, K, D)[1]
+        assert np.isnan(S0).all()
+
+
+def test_k_below_the_threshold_and_small_n_use_the_per_component_kernel(be):
+    D = 20
+    for K, N in ((16, 30000), (32, 5000)):
+        mu, cov, w = mk(K, D, 41)
+        x, _ = draw(mu, cov, w, N, 42)
+        cs, _ = vb_set(mu, cov, D, K, 43)
+        fast, slow = both_forms(be, x, cs, 0)
+        np.testing.assert_array_equal(fast, slow)
+    with pytest.raises(Exception):
+        be.configure("no_such_key", 1.0)
