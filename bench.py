@@ -151,7 +151,7 @@ def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
     return out
 
 
-def baseline_configs(be, reps=3):
+def baseline_configs(be, reps=3, select=None):
     """BASELINE.json's configurations 2-5 on this GPU (one GPU's share where a configuration is quoted on 8),
     through the public front-end with the samples resident on the device: median wall time of ``reps`` calls
     (device synchronised on both sides), the library's own per-kernel times (pmc_get_timings) of those calls, and
@@ -188,36 +188,41 @@ def baseline_configs(be, reps=3):
 
     out = {}
     t_all = time.perf_counter()
-    # -- config 2: MixtureDensity.multi_evaluate, D=20, K=16 Gaussian, N=1e6
-    D2, K2, N2 = 20, 16, 1_000_000
-    mix = create_gaussian_mixture(*mk(K2, D2, 1))
-    np.random.seed(7)
-    x2 = mix.propose(N2, device=True)
-    cs = component_set(mix.components, mix.weights)
-    t, kern = timed(lambda: be.logpdf(x2, cs))
-    out["cfg2"] = entry("MixtureDensity.multi_evaluate D=20 K=16 Gauss", N2, flops_logpdf(K2, D2), t, kern)
-    del x2
+    want = lambda name: select is None or name in select
+    if want("cfg2"):
+        # -- config 2: MixtureDensity.multi_evaluate, D=20, K=16 Gaussian, N=1e6
+        D2, K2, N2 = 20, 16, 1_000_000
+        mix = create_gaussian_mixture(*mk(K2, D2, 1))
+        np.random.seed(7)
+        x2 = mix.propose(N2, device=True)
+        cs = component_set(mix.components, mix.weights)
+        t, kern = timed(lambda: be.logpdf(x2, cs))
+        out["cfg2"] = entry("MixtureDensity.multi_evaluate D=20 K=16 Gauss", N2, flops_logpdf(K2, D2), t, kern)
+        del x2
 
-    # -- config 3: Student-t (nu=8) proposal D=30, K=32, N=1e7: importance weights + perplexity sums against the
-    #    SURVEY target (K_t=4 Gaussian mixture), one pass for the two families
-    D3, K3, N3 = 30, 32, 10_000_000
-    mu3, cov3, w3 = mk(K3, D3, 2)
-    prop = create_t_mixture(mu3, cov3, np.full(K3, 8.), w3)
-    tgt = create_gaussian_mixture(*mk(4, D3, 11))
-    np.random.seed(8)
-    x3 = prop.propose(N3, device=True)
-    pcs, tcs = component_set(prop.components, prop.weights), component_set(tgt.components, tgt.weights)
-    t, kern = timed(lambda: be.importance_weights(x3, pcs, tcs))
-    f3 = (K3 + 4) * (D3 * D3 + 4 * D3) + K3 * 80 + 4 * 40      # c_tr = 40, +40 for Student-t's log
-    out["cfg3"] = entry("Student-t nu=8 D=30 K=32 proposal vs K_t=4 Gauss target: weights + perplexity sums",
-                        N3, f3, t, kern)
-    del x3
+    if want("cfg3"):
+        # -- config 3: Student-t (nu=8) proposal D=30, K=32, N=1e7: importance weights + perplexity sums against
+        #    the SURVEY target (K_t=4 Gaussian mixture), one pass for the two families
+        D3, K3, N3 = 30, 32, 10_000_000
+        mu3, cov3, w3 = mk(K3, D3, 2)
+        prop = create_t_mixture(mu3, cov3, np.full(K3, 8.), w3)
+        tgt = create_gaussian_mixture(*mk(4, D3, 11))
+        np.random.seed(8)
+        x3 = prop.propose(N3, device=True)
+        pcs, tcs = component_set(prop.components, prop.weights), component_set(tgt.components, tgt.weights)
+        t, kern = timed(lambda: be.importance_weights(x3, pcs, tcs))
+        f3 = (K3 + 4) * (D3 * D3 + 4 * D3) + K3 * 80 + 4 * 40      # c_tr = 40, +40 for Student-t's log
+        out["cfg3"] = entry("Student-t nu=8 D=30 K=32 proposal vs K_t=4 Gauss target: weights + perplexity sums",
+                            N3, f3, t, kern)
+        del x3
 
     # -- config 4: GaussianInference.E_step, D=20, K=64: N=1e7 on one GPU and one GPU's share of 8
     D4, K4 = 20, 64
     mix4 = create_gaussian_mixture(*mk(K4, D4, 3))
     f4 = flops_logpdf(K4, D4) + flops_stats(K4, D4)
     for label, N4 in (("cfg4", 10_000_000), ("cfg4_share_of_8", 1_250_000)):
+        if not want(label):
+            continue
         np.random.seed(9)
         x4 = mix4.propose(N4, device=True)
         vb = GaussianInference(x4, initial_guess=mix4)
@@ -226,6 +231,9 @@ def baseline_configs(be, reps=3):
                            N4, f4, t, kern)
         del vb, x4
 
+    if not want("cfg5"):
+        out["seconds"] = time.perf_counter() - t_all
+        return out
     # -- config 5: one PMC iteration D=40, K=128, 1.25e7 samples (= N=1e8 over 8 GPUs): propose -> weights vs
     #    K_t=4 target -> Rao-Blackwell update reusing the Mahalanobis forms the weighting pass kept
     D5, K5, KT5, N5 = 40, 128, 4, 12_500_000
@@ -263,6 +271,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="create the process group (RCCL) even for a single plain python process")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configurations 2-5")
+    ap.add_argument("--configs-only", default=None, metavar="cfg3,cfg4",
+                    help="profiling aid: run only these configurations (no headline step) and print their block")
     ap.add_argument("--two-streams", action="store_true",
                     help="run the step's two independent halves (IS pass, VB E-step) side by side on two HIP streams: "
                          "about 4 %% more samples/s, but overlapping kernels stretch each other, so the per-kernel "
@@ -281,6 +291,9 @@ def main():
     from pypmc_amd.backend import HipBackend, ComponentSet
     be = HipBackend(local_rank)
     dev = be.device
+    if args.configs_only:
+        print(json.dumps({"configs": baseline_configs(be, select=args.configs_only.split(","))}))
+        return
     if args.scaling == "strong":
         lo, hi = parallel.shard_bounds(args.n, rank, world)
         N, n_total = hi - lo, args.n

@@ -24,7 +24,7 @@
     extern "C" hipError_t pmc_launch_fused_d##d##_p##p(int, int, const PmcArgsF &, unsigned, hipStream_t); \
     extern "C" int pmc_fused_lds_bytes_d##d##_p##p(int, int);                                          \
     extern "C" hipError_t pmc_launch_stats_gemm_d##d##_p##p(const PmcArgsG &, unsigned, hipStream_t);   \
-    extern "C" void pmc_stats_gemm_config_d##d##_p##p(int *, int *, int *);
+    extern "C" void pmc_stats_gemm_config_d##d##_p##p(int *, int *, int *, int *);
 extern "C" hipError_t pmc_launch_resp_tiles(int, const PmcArgsT &, unsigned, hipStream_t);
 // the run-time-dimension unit (pmc_big.hip, pmc_persample.hip / pmc_propose.hip compiled with PMC_D = 0)
 extern "C" hipError_t pmc_launch_logpdf_d0_p0(int, int, const PmcArgsA &, unsigned, hipStream_t);
@@ -43,7 +43,7 @@ namespace {
     {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, \
      &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p, \
      &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p, &pmc_launch_stats_gemm_d##d##_p##p, \
-     &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0}
+     &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0, 0}
 struct DimEntry {
     int dim;
     bool has_padded;
@@ -152,7 +152,7 @@ const PmcKernelSet *big_kernels_for(int D)
     ks->fused_lds_bytes = nullptr;
     ks->stats_gemm = nullptr;
     ks->gemm_config = nullptr;
-    ks->gemm_cols = ks->gemm_slices = ks->gemm_msp = 0;
+    ks->gemm_cols = ks->gemm_slices = ks->gemm_msp = ks->gemm_wgs = 0;
     sets.push_back(ks);
     return ks;
 }
@@ -166,7 +166,7 @@ const PmcKernelSet *kernels_for(int D)
         else if (g_dims[i].dim > D) ks = g_dims[i].has_padded ? &g_dims[i].padded : nullptr;
         else continue;
         if (ks && ks->stats_nsub == 0) {                                                // idempotent
-            ks->gemm_config(&ks->gemm_cols, &ks->gemm_slices, &ks->gemm_msp);
+            ks->gemm_config(&ks->gemm_cols, &ks->gemm_slices, &ks->gemm_msp, &ks->gemm_wgs);
             ks->config(&ks->stats_nsub, &ks->stats_waves);
         }
         return ks;
@@ -253,52 +253,6 @@ __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__
 // coordinate) from the common shift sends the call back to the per-component-shift kernel.
 int g_gemm_min_k = 17;
 double g_gemm_limit = 1000.0;
-
-// c = midrange of the component means per coordinate (minimises the largest |mu_k - c|), ctl = {go, redo}.
-// A priori test with the pack's own scale when the caller knows what the pack describes (kind >= 0): with
-// P = R^T R the precision of component k, 1 / P_ii <= Sigma_ii, so (mu_ki - c_i)^2 P_ii [* nu_k for the VB kind,
-// whose W is the precision / nu] > limit_prior says "too far" -- conservatively; a pass is checked again a
-// posteriori on the data by k_gemm_convert.
-__global__ __launch_bounds__(256) void k_stats_plan(const double *__restrict__ pack, int stride, int K, int D, int Dc,
-                                                    int kind, double limit_prior, double *__restrict__ center,
-                                                    int *__restrict__ ctl)
-{
-    __shared__ int far;
-    if (threadIdx.x == 0) far = 0;
-    __syncthreads();
-    for (int j = threadIdx.x; j < D; j += 256) {
-        double lo = pack[j], hi = pack[j];
-        for (int k = 1; k < K; ++k) {
-            const double m = pack[(size_t)k * stride + j];
-            lo = m < lo ? m : lo;
-            hi = m > hi ? m : hi;
-        }
-        const double c = 0.5 * lo + 0.5 * hi;
-        center[j] = (c == c && fabs(c) <= 1.7976931348623157e308) ? c : 0.0;
-    }
-    __syncthreads();
-    if (kind >= 0 && pmc_engine(Dc) != PMC_ENG_DPP) {
-        // R upper triangular, packed row-major over the compiled dimension: element (l, i >= l) at
-        // Dc + l Dc - l (l - 1) / 2 + (i - l)
-        for (int idx = threadIdx.x; idx < K * D; idx += 256) {
-            const int k = idx / D, i = idx % D;
-            const double *pk = pack + (size_t)k * stride;
-            double pii = 0.0;
-            for (int l = 0; l <= i; ++l) {
-                const double r = pk[Dc + l * Dc - l * (l - 1) / 2 + (i - l)];
-                pii += r * r;
-            }
-            if (kind == PMC_KIND_VB) pii *= pk[Dc + pmc_tri(Dc) + 1];      // c1 = nu_k
-            const double dlt = pk[i] - center[i];
-            if (dlt * dlt * pii > limit_prior) far = 1;                      // (benign race: every writer stores 1)
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        ctl[PMC_CTL_GO] = far ? 0 : 1;
-        ctl[PMC_CTL_REDO] = far ? 1 : 0;
-    }
-}
 
 // totals[k][m] = sum over the nce partial vectors, in a fixed order: thread = monomial (coalesced rows of 64),
 // wavefront w of the workgroup takes the partial vectors w, w + 4, ... in ascending order, the four are added in
@@ -538,7 +492,7 @@ GemmGeom gemm_geom(long long N, int K, const PmcKernelSet *ks)
     g.ngroups = (int)ceil_div(K, 32);
     g.ncs = (int)ceil_div(ks->gemm_msp / 16, ks->gemm_cols);
     const long long nsub = (long long)g.ngroups * g.ncs;
-    long long c = 256 / nsub / 8 * 8;
+    long long c = 256LL * (ks->gemm_wgs > 0 ? ks->gemm_wgs : 1) / nsub / 8 * 8;
     if (c < 8) c = 8;
     const long long cmax = ceil_div(ceil_div(g.ntiles, 4), 8) * 8;          // at least ~4 tiles per chunk
     if (c > cmax) c = cmax;
@@ -1130,13 +1084,10 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
         const int stride = pmc_pack_stride_c(ks->dim);
         {
             Timed t(T_STATS, st, flops_stats((double)N, K, D), 8.0 * N * (D + K));
-            hipLaunchKernelGGL(k_stats_plan, dim3(1), dim3(256), 0, st, d_pack, stride, K, D, ks->dim, kind,
-                               10.0 * g_gemm_limit, center, ctl);
-            e = hipGetLastError();
-            if (e != hipSuccess) return hipfail(e, "k_stats_plan launch");
             PmcArgsG a;
             std::memset(&a, 0, sizeof(a));
-            a.x = d_x; a.N = N; a.dreal = D; a.center = center; a.K = K; a.u = d_u; a.partials = gpart;
+            a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.kind = kind; a.limit_prior = 4.0 * g_gemm_limit;
+            a.center = center; a.K = K; a.u = d_u; a.partials = gpart;
             a.ntiles = gg.ntiles; a.nchunks = gg.nchunks; a.tiles_per_chunk = gg.tiles_per_chunk;
             a.ngroups = gg.ngroups; a.ncs = gg.ncs; a.ctl = ctl;
             e = ks->stats_gemm(a, gg.grid, st);

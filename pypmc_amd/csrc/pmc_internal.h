@@ -143,7 +143,11 @@ struct PmcArgsG {
     const double *x;
     long long N;
     int dreal;
-    const double *center; // dreal doubles (device): the common shift c
+    const double *pack;   // the components: their means give the common shift c (midrange per coordinate), their
+                          // triangular factors the a-priori test (kind >= 0)
+    int kind;             // pmc_kind of `pack`, or -1: no a-priori test
+    double limit_prior;
+    double *center;       // dreal doubles (device, output of workgroup 0): the common shift c
     int K;
     const double *u;      // tile-major ntiles x K x 64
     double *partials;     // [nchunks * slices][K][msp]: monomials 1 | d | d d^T lower triangle (row-major i, j <= i), d = x - c
@@ -152,7 +156,7 @@ struct PmcArgsG {
     int tiles_per_chunk;
     int ngroups;          // groups of 32 components
     int ncs;              // column super groups (workgroups that split the monomials)
-    const int *ctl;       // control block (device): ctl[0] = go -- the kernel returns at once if it is 0
+    int *ctl;             // control block (device, output of workgroup 0): {go, redo}
 };
 // control block of a statistics call that may use the common-shift form (device memory, in the workspace)
 enum { PMC_CTL_GO = 0, PMC_CTL_REDO = 1, PMC_CTL_INTS = 4 };
@@ -214,6 +218,7 @@ struct PmcKernelSet {
     int (*fused_lds_bytes)(int qs, int K);
     // component x monomial statistics (NULL / cols_per_wg == 0: this dimension has none)
     hipError_t (*stats_gemm)(const PmcArgsG &, unsigned grid, hipStream_t);
-    void (*gemm_config)(int *cols_per_wg, int *slices, int *msp);
+    void (*gemm_config)(int *cols_per_wg, int *slices, int *msp, int *wgs_per_cu);
     int gemm_cols, gemm_slices, gemm_msp;   // monomial tiles (of 16) per workgroup, sample slices, partial row length
+    int gemm_wgs;                           // workgroups of it that share a CU
 };

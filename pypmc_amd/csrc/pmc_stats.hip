@@ -401,11 +401,15 @@ template <int D> struct GemmCfg {
     // column tiles per wavefront | column groups per workgroup | sample slices | tiles per pipeline step
     // (2 C accumulator tiles of 8 registers each have to fit next to ~60 operand / address registers: C = 8 at D = 30
     // and C = 9 at D = 32 / 64 spilled)
+#ifdef PMC_GEMM_C                                          // tuning overrides (scripts/tune_unit.sh)
+    static constexpr int C = PMC_GEMM_C, CGW = PMC_GEMM_CGW, SL = PMC_GEMM_SL, NS = PMC_GEMM_NS;
+#else
     static constexpr int C = D <= 8 ? 3 : (D <= 10 ? 5 : (D <= 12 ? 3 : (D <= 20 ? 5 : (D <= 24 ? 6 : (D <= 30 ? 4 :
                              (D <= 32 ? 3 : (D <= 40 ? 7 : (D <= 48 ? 5 : 6))))))));
     static constexpr int CGW = D <= 10 ? 1 : (D <= 16 ? 2 : (D <= 20 ? 3 : (D <= 24 ? 4 : (D <= 30 ? 8 : (D <= 32 ? 12 : 8)))));
     static constexpr int SL = D <= 10 ? 8 : (D <= 20 ? 4 : (D <= 24 ? 2 : 1));
     static constexpr int NS = D <= 32 ? 2 : 1;
+#endif
     static constexpr bool ENABLED = D >= 8;
     static constexpr int W = CGW * SL;
     static constexpr int NP = (D + 1) / 2;                 // coordinate pairs per sample
@@ -418,7 +422,14 @@ template <int D> struct GemmCfg {
     static constexpr int XT = 64 * ROWD;                   // doubles per x tile
     static constexpr int UPIECE = 130;                     // a 1-KiB DMA piece (2 components x 64 samples) + 16 bytes
     static constexpr int UT = 16 * UPIECE;                 // doubles per u tile (32 components)
-    static constexpr size_t LDS_BYTES = sizeof(double) * 2 * NS * (XT + UT);
+    static constexpr size_t LDS_BYTES = sizeof(double) * (2 * NS * (XT + UT) + 64);     // + the common shift
+    // workgroups that share a CU (LDS; their wavefronts' registers fit next to each other up to 3 per SIMD): two
+    // that run out of step hide each other's barriers and pipeline refills
+#ifdef PMC_GEMM_WGS
+    static constexpr int WGS_PER_CU = PMC_GEMM_WGS;
+#else
+    static constexpr int WGS_PER_CU = (LDS_BYTES <= 80 * 1024 && W <= 6) ? 2 : 1;
+#endif
 };
 
 // sample row (within a tile, before the lane's 8 g) of MFMA step j of a slice: compile-time part ...
@@ -433,23 +444,50 @@ template <int SL> __device__ __forceinline__ int gemm_row_base(int sl)
     else return (sl & 7) + 32 * (sl >> 3);
 }
 
+// LDS reads of the inner loop, written out: with an explicit 16-bit offset (the compiler pairs ordinary reads into
+// ds_read2_b64, whose 8-bit offsets need a base register every 2 KB -- dozens, spilled), waited for by lds_wait,
+// which hands the values on so that nothing consumes them earlier.
+template <int IMM> __device__ __forceinline__ void lds_read64(double &v, unsigned addr)
+{
+    static_assert(IMM >= 0 && IMM < 65536 && IMM % 8 == 0, "ds_read_b64 offset");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+}
+template <int N> __device__ __forceinline__ void lds_wait(double (&v)[N])
+{
+    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
+    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    else if constexpr (N == 5)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+    else if constexpr (N == 6)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+    else if constexpr (N == 7)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]));
+    else {
+        static_assert(N == 8, "lds_wait: up to 8 values");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    }
+}
+
 typedef double gd4 __attribute__((ext_vector_type(4)));
 typedef double gd2 __attribute__((ext_vector_type(2)));
 typedef double gd2u __attribute__((ext_vector_type(2), aligned(8)));
 
-template <int D, bool PADDED>
-__global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgsG b)
+// NRB = row blocks of 16 components that hold any (the last group of a K that is not a multiple of 32 may have one)
+template <int D, bool PADDED, int NRB>
+__device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
 {
     using CF = GemmCfg<D>;
-    constexpr int C = CF::C, CGW = CF::CGW, SL = CF::SL, NS = CF::NS, W = CF::W, R = 2;
+    constexpr int C = CF::C, CGW = CF::CGW, SL = CF::SL, NS = CF::NS, W = CF::W, R = NRB;
     constexpr int NP = CF::NP, ROWD = CF::ROWD, XT = CF::XT, UT = CF::UT, UPIECE = CF::UPIECE;
     constexpr int BUFX = NS * XT, BUFU = NS * UT;
     constexpr int JN = 16 / SL, NSTEP = NS * JN;
     constexpr int PX = NS * 64 * NP, NPX = (PX + W * 64 - 1) / (W * 64);
     constexpr int PU = NS * 16, NPU = (PU + W - 1) / W;
-    extern __shared__ double xs[];                         // 2 x buffers, then 2 u buffers
-    if (b.ctl[PMC_CTL_GO] == 0) return;                    // the plan kernel found the components too far apart
-    double *us = xs + 2 * BUFX;
+    double *us = xs + 2 * BUFX;                            // xs: 2 x buffers, then 2 u buffers
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -466,10 +504,67 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
     const int chunk = (bid & 7) + 8 * (qb / nsub);
     const int sub = qb % nsub, group = sub / b.ncs, cs = sub % b.ncs;
     const int kmin = group * 32;
-    const int nrb = (b.K - kmin) > 16 ? 2 : 1;             // row blocks of 16 components that hold any
     const long long t0 = (long long)chunk * b.tiles_per_chunk;
     long long t1 = t0 + b.tiles_per_chunk;
     if (t1 > b.ntiles) t1 = b.ntiles;
+
+    // The plan, made by every workgroup for itself (K x D numbers out of L2; no launch of its own): the common
+    // shift c = midrange of the component means per coordinate (it minimises the largest |mu_k - c|), and the
+    // a-priori test with the pack's own scale when the caller knows what the pack describes (kind >= 0): with
+    // precision = R^T R, 1 / R_ii^2 <= Sigma_ii, so (mu_ki - c_i)^2 R_ii^2 [* nu_k for the VB kind, whose W is the
+    // precision / nu] > limit says "too far apart" -- conservatively; whoever passes is tested again a posteriori,
+    // on the data, by k_gemm_convert.  Workgroup 0 publishes c and the decision for the finishing kernels.
+    double *cen = us + 2 * BUFU;                           // 64 doubles behind the buffers; scratch: the u buffers
+    {
+        constexpr int STRIDE = pmc_pack_stride_c(D);
+        double *lo = us, *hi = us + W * 64;
+        int *farflag = (int *)(us + 2 * W * 64);
+        if (tid == 0) *farflag = 0;
+        const int j = lane < dreal ? lane : 0;
+        double l = b.pack[(size_t)(wave < b.K ? wave : 0) * STRIDE + j], h = l;
+        for (int k = wave + W; k < b.K; k += W) {
+            const double m = b.pack[(size_t)k * STRIDE + j];
+            l = m < l ? m : l;
+            h = m > h ? m : h;
+        }
+        lo[wave * 64 + lane] = l;
+        hi[wave * 64 + lane] = h;
+        __syncthreads();
+        if (tid < 64) {
+            const int wmax = b.K < W ? b.K : W;
+            for (int w = 1; w < wmax; ++w) {
+                l = lo[w * 64 + lane] < l ? lo[w * 64 + lane] : l;
+                h = hi[w * 64 + lane] > h ? hi[w * 64 + lane] : h;
+            }
+            const double c = 0.5 * l + 0.5 * h;
+            cen[lane] = (c == c && fabs(c) <= 1.7976931348623157e308) ? c : 0.0;
+        }
+        __syncthreads();
+        if (b.kind >= 0 && pmc_engine(D) != PMC_ENG_DPP) {
+            // R upper triangular, packed row-major over the compiled dimension: R_ii at D + i D - i (i - 1) / 2
+            bool far = false;
+            for (int idx = tid; idx < b.K * dreal; idx += 64 * W) {
+                const int k = idx / dreal, i = idx - k * dreal;
+                const double *pk = b.pack + (size_t)k * STRIDE;
+                const double rii = pk[D + i * D - i * (i - 1) / 2];
+                double s = rii * rii;
+                if (b.kind == PMC_KIND_VB) s *= pk[D + pmc_tri(D) + 1];          // c1 = nu_k
+                const double dlt = pk[i] - cen[i];
+                far = far || dlt * dlt * s > b.limit_prior;
+            }
+            if (far) *farflag = 1;                         // (benign race: every writer stores 1)
+        }
+        __syncthreads();
+        const int isfar = *farflag;
+        if (blockIdx.x == 0) {
+            if (tid < dreal) b.center[tid] = cen[tid];
+            if (tid == 0) {
+                b.ctl[PMC_CTL_GO] = isfar ? 0 : 1;
+                b.ctl[PMC_CTL_REDO] = isfar ? 1 : 0;
+            }
+        }
+        if (isfar) return;
+    }
 
     // this lane's two factors of each of the wavefront's column tiles: LDS offsets (doubles) incl. the lane's rows.
     // Monomial m in the order of the statistics vector: 0 -> 1 * 1, 1 + j -> 1 * d_j, 1 + D + i(i+1)/2 + j -> d_i * d_j.
@@ -492,31 +587,41 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
         off1[c] = rowbase + i1;
         off2[c] = rowbase + i2;
     }
+    // ... as LDS byte addresses (buffer 0; the buffer and the step go into the reads' immediates)
+    const unsigned xs_addr = (unsigned)(uintptr_t)(lvoid_t *)xs, us_addr = (unsigned)(uintptr_t)(lvoid_t *)us;
+    unsigned a1[C], a2[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        a1[c] = xs_addr + 8u * (unsigned)off1[c];
+        a2[c] = xs_addr + 8u * (unsigned)off2[c];
+    }
     int uoff[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int cc = 16 * r + n16;
-        uoff[r] = (cc >> 1) * UPIECE + (cc & 1) * 64 + 8 * g + gemm_row_base<SL>(sl);
+        // (the four 8-row groups of a 32-row half sit in the order 0, 2, 1, 3 in the LDS image of u -- see udma --
+        // so that the two groups a half-wavefront reads together are 32 banks apart)
+        uoff[r] = (cc >> 1) * UPIECE + (cc & 1) * 64 + 8 * (((g & 1) << 1) | (g >> 1)) + gemm_row_base<SL>(sl);
     }
+    unsigned au[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) au[r] = us_addr + 8u * (unsigned)uoff[r];
 
     // the "1" of every row, both buffers (never overwritten: the staging writes data slots only)
     for (int row = tid; row < 2 * NS * 64; row += 64 * W) xs[row * ROWD + ONE] = 1.0;
 
     // x staging: piece = one coordinate pair of one row, fixed per thread; global -> registers one step ahead,
     // minus c on the way into LDS
-    int xl[NPX];                                           // LDS offset (doubles), -1: no piece
-    unsigned xg[NPX];                                      // global offset relative to the step's first row
-    double c0[NPX], c1[NPX];
-#pragma unroll
-    for (int i = 0; i < NPX; ++i) {
+    // (row and pair of a piece are recomputed where they are needed and c comes from LDS again: the registers are
+    // better spent on accumulators)
+    if (tid == 0 && (dreal & 1)) cen[dreal] = 0.0;         // second half of an odd dimension's last pair
+    __syncthreads();                                       // the plan's scratch is free: the u buffers may be filled
+    auto piece = [&](int i, int &n, int &jp) {
         const int id = tid + i * W * 64;
-        const int n = id / NP, jp = id % NP;
-        const bool ok = id < PX && jp < npr;
-        xl[i] = ok ? n * ROWD + 2 * jp : -1;
-        xg[i] = (unsigned)(n * dreal + 2 * jp);
-        c0[i] = ok ? b.center[2 * jp] : 0.0;
-        c1[i] = (ok && 2 * jp + 1 < dreal) ? b.center[2 * jp + 1] : 0.0;
-    }
+        n = id / NP;
+        jp = id - n * NP;
+        return id < PX && jp < npr;
+    };
     gd2 xv[NPX];
     // rows beyond the chunk or the array are clamped into it (their weights are zero); the array's very last
     // element of an odd-sized array is fetched one element early and picked from the pair's second half
@@ -525,7 +630,9 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
         const long long base = tt * 64 * dreal;
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            long long o = base + xg[i];
+            int n, jp;
+            piece(i, n, jp);
+            long long o = base + (n * dreal + 2 * jp);
             if (o > total - 2) o = total - 2;
             xv[i] = *(const gd2u *)(b.x + o);
         }
@@ -535,12 +642,14 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
         const long long base = tt * 64 * dreal;
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            if (xl[i] >= 0) {
-                const bool last = base + xg[i] == total - 1;
+            int n, jp;
+            if (piece(i, n, jp)) {
+                const bool last = base + (n * dreal + 2 * jp) == total - 1;
+                const gd2 cc = *(const gd2 *)(cen + 2 * jp);
                 gd2 v;
-                v[0] = (last ? xv[i][1] : xv[i][0]) - c0[i];
-                v[1] = xv[i][1] - c1[i];
-                *(gd2 *)(xbuf + xl[i]) = v;
+                v[0] = (last ? xv[i][1] : xv[i][0]) - cc[0];
+                v[1] = xv[i][1] - cc[1];
+                *(gd2 *)(xbuf + n * ROWD + 2 * jp) = v;
             }
         }
     };
@@ -551,8 +660,14 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
             const int id = wave + i * W;
             if (PU % W == 0 || id < PU) {                  // wave-uniform
                 const int q = id / 16, p = id % 16;
-                const long long tile = (t + q < t1) ? t + q : t0;
-                long long o = (tile * b.K + kmin + 2 * p) * 64 + 2 * lane;
+                if (t + q >= t1) {                         // tile beyond the chunk: no weight (wave-uniform, last step only)
+                    *(gd2 *)(ubuf + q * UT + p * UPIECE + 2 * lane) = gd2{0.0, 0.0};
+                    continue;
+                }
+                const long long tile = t + q;
+                // lane -> 16-byte chunk (component 2 p + (lane >> 5), sample pair lane & 31 with bits 2 and 3 swapped)
+                const int pp = lane & 31, sp = (pp & 0x13) | ((pp & 4) << 1) | ((pp & 8) >> 1);
+                long long o = (tile * b.K + kmin + 2 * p) * 64 + (lane >> 5) * 64 + 2 * sp;
                 if (o > ulen - 2) o = ulen - 2;            // components beyond K: any finite values, rows discarded
                 __builtin_amdgcn_global_load_lds((gvoid_t *)(b.u + o), (lvoid_t *)(ubuf + q * UT + p * UPIECE), 16, 0, 0);
             }
@@ -569,47 +684,60 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
     udma(t0, us);
     xstore(t0, xs);
     dma_barrier();
+    // The per-lane address registers are moved from one LDS buffer to the other IN PLACE at the end of a step (as
+    // ordinary pointers into a run-time buffer the compiler kept both sets and spilled accumulators).
     int buf = 0;
+    unsigned dx = 8u * (unsigned)BUFX, du = 8u * (unsigned)BUFU;
     for (long long t = t0; t < t1; t += NS, buf ^= 1) {
-        const double *xb = xs + buf * BUFX;
-        const double *ub = us + buf * BUFU;
         xload(t + NS);
         udma(t + NS, us + (buf ^ 1) * BUFU);
 
         double ac[R], zc[C], an[R], f1n[C], f2n[C];
-        auto fetch = [&](auto IDX, double (&a)[R], double (&f1)[C], double (&f2)[C]) {
+        auto fetch = [&](auto IDX) {
             constexpr int idx = decltype(IDX)::value, q = idx / JN, j = idx % JN;
-            constexpr int XIMM = (q * 64 + gemm_row_imm<SL>(j)) * ROWD, UIMM = q * UT + gemm_row_imm<SL>(j);
-#pragma unroll
-            for (int r = 0; r < R; ++r) a[r] = ub[uoff[r] + UIMM];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                f1[c] = xb[off1[c] + XIMM];
-                f2[c] = xb[off2[c] + XIMM];
-            }
+            constexpr int XIMM = 8 * ((q * 64 + gemm_row_imm<SL>(j)) * ROWD);
+            constexpr int UIMM = 8 * (q * UT + gemm_row_imm<SL>(j));
+            static_for<0, R>([&](auto RR) { lds_read64<UIMM>(an[decltype(RR)::value], au[decltype(RR)::value]); });
+            static_for<0, C>([&](auto CC) {
+                lds_read64<XIMM>(f1n[decltype(CC)::value], a1[decltype(CC)::value]);
+                lds_read64<XIMM>(f2n[decltype(CC)::value], a2[decltype(CC)::value]);
+            });
         };
-        fetch(ic<0>{}, ac, f1n, f2n);
+        auto arrive = [&]() {                              // the operands fetch() asked for: wait, form B
+            lds_wait(an);
+            lds_wait(f1n);
+            lds_wait(f2n);
 #pragma unroll
-        for (int c = 0; c < C; ++c) zc[c] = f1n[c] * f2n[c];
+            for (int r = 0; r < R; ++r) ac[r] = an[r];
+#pragma unroll
+            for (int c = 0; c < C; ++c) zc[c] = f1n[c] * f2n[c];
+        };
+        fetch(ic<0>{});
+        arrive();
         static_for<0, NSTEP>([&](auto IDX) {
-            constexpr int idx = decltype(IDX)::value, q = idx / JN;
-            // operands of step idx + 1 are read behind the first row block's multiplies of step idx
-            if constexpr (idx + 1 < NSTEP) fetch(ic<idx + 1>{}, an, f1n, f2n);
-            const bool live = t + q < t1;                  // tiles beyond the chunk: no weight
-            const double a0 = live ? ac[0] : 0.0, a1 = live ? ac[1] : 0.0;
+            constexpr int idx = decltype(IDX)::value;
+            // operands of step idx + 1 are read in front of the multiplies of step idx
+            if constexpr (idx + 1 < NSTEP) fetch(ic<idx + 1>{});
+            __builtin_amdgcn_sched_barrier(0);             // (... really in front: into registers of their own)
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, zc[c], acc[0][c], 0, 0, 0);
-            if (nrb > 1) {
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, zc[c], acc[1][c], 0, 0, 0);
-            }
-            if constexpr (idx + 1 < NSTEP) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) ac[r] = an[r];
-#pragma unroll
-                for (int c = 0; c < C; ++c) zc[c] = f1n[c] * f2n[c];
-            }
+                for (int c = 0; c < C; ++c) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[r], zc[c], acc[r][c], 0, 0, 0);
+            // (the wait for the next operands stays behind this step's multiplies, and nothing of the step after
+            // next is hoisted into this one)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (idx + 1 < NSTEP) arrive();
+            __builtin_amdgcn_sched_barrier(0);
         });
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            a1[c] += dx;
+            a2[c] += dx;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) au[r] += du;
+        dx = 0u - dx;
+        du = 0u - du;
         xstore(t + NS, xs + (buf ^ 1) * BUFX);
         dma_barrier();
     }
@@ -628,6 +756,16 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
             }
         }
     }
+}
+
+template <int D, bool PADDED>
+__global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgsG b)
+{
+    extern __shared__ double xs[];
+    const int nsub = b.ngroups * b.ncs;
+    const int group = ((blockIdx.x >> 3) % nsub) / b.ncs;
+    if (b.K - group * 32 > 16) stats_gemm_run<D, PADDED, 2>(b, xs);
+    else stats_gemm_run<D, PADDED, 1>(b, xs);
 }
 
 constexpr int NSUB_ = Blocking<D_>::NSUB;
@@ -651,12 +789,14 @@ extern "C" void PMC_UNIT_NAME_X(pmc_stats_config_d, PMC_D, PMC_PADDED)(int *nsub
 
 // geometry of the component x monomial form: monomial tiles per workgroup (0: this dimension has no such kernel),
 // sample slices (partial statistics vectors per chunk), doubles per component in a partial vector
-extern "C" void PMC_UNIT_NAME_X(pmc_stats_gemm_config_d, PMC_D, PMC_PADDED)(int *cols_per_wg, int *slices, int *msp)
+extern "C" void PMC_UNIT_NAME_X(pmc_stats_gemm_config_d, PMC_D, PMC_PADDED)(int *cols_per_wg, int *slices, int *msp,
+                                                                           int *wgs_per_cu)
 {
     using CF = GemmCfg<D_>;
     *cols_per_wg = CF::ENABLED ? CF::C * CF::CGW : 0;
     *slices = CF::SL;
     *msp = CF::MSP;
+    *wgs_per_cu = CF::WGS_PER_CU;
 }
 
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_stats_gemm_d, PMC_D, PMC_PADDED)(const PmcArgsG &b, unsigned grid,

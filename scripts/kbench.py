@@ -84,6 +84,18 @@ def main():
     fl_vb = K * (D * D + 4 * D) + K * (1 + 2 * D + D * (D + 1)) + K * 40
     res["vb_estep"] = dict(ms=t, ms_median=tm, samples_per_s=N / t * 1e3, tflops=N * fl_vb / t * 1e-9,
                            fused=bool(be.lib.pmc_estep_is_fused(K, D, 2, 0)))
+    # the statistics half as pmc_estep runs it (the component x monomial form where it applies): library timing
+    be.kernel_timings()
+    be.kernel_timing(True)
+    for _ in range(args.reps):
+        be.estep(x, vb, 0, pack=vpack, out=out)
+    torch.cuda.synchronize()
+    be.kernel_timing(False)
+    kt = be.kernel_timings()
+    for name in ("k_resp", "k_stats", "k_estep_fused", "finishing reductions"):
+        if name in kt:
+            ms = kt[name]["ms"] / max(kt[name]["calls"], 1)
+            res["estep:" + name] = dict(ms=ms, ms_median=ms, tflops=kt[name]["flops"] / max(kt[name]["calls"], 1) / ms * 1e-9)
     # split: responsibilities alone
     lib = be.lib
     u = be._tilebuf("u", N, K)
