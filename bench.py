@@ -429,7 +429,7 @@ def main():
                        "parallelism": "samples sharded x%d" % world, "streams": 2 if args.two_streams else 1},
             # the collective as this run issued it: torch.distributed's backend name ("nccl" = RCCL), the rank
             # count the group reports, and the all-reduce of the statistics vector between its own two events
-            "dist": {"backend": dist.get_backend() if grouped else None,
+            "dist": {"backend": parallel.collective_name(),
                      "world_size": dist.get_world_size() if grouped else 1,
                      "allreduce_ms": allreduce_ms, "allreduce_doubles": int(stats.numel()),
                      "group": "torch.distributed process group" if grouped else "none (single process, no collective)"},
@@ -476,6 +476,7 @@ def main():
             line["configs"] = baseline_configs(be)
         print(json.dumps(line))
     if grouped:
+        parallel.disable_native_collective()
         dist.destroy_process_group()
 
 

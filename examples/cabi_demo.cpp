@@ -134,5 +134,21 @@ int main(int argc, char **argv)
     for (int i = 0; i < ntimings && i < 8; ++i)
         std::printf("timing %s: %d launches, %.4f ms, %.3g flop, %.3g bytes\n", timings[i].name, timings[i].calls,
                     timings[i].ms, timings[i].flops, timings[i].bytes);
+
+    // the cross-GPU exchange through the library (RCCL opened at run time): a communicator of this ONE rank -- with
+    // more GPUs rank 0 hands `id` to the other processes -- sums the statistics buffer in place on `stream`
+    char id[PMC_COMM_ID_BYTES];
+    pmc_comm *comm = nullptr;
+    PMC_OK_(pmc_comm_unique_id(id));
+    PMC_OK_(pmc_comm_init(0, 1, id, 0, &comm));
+    int rank = -1, world = -1;
+    PMC_OK_(pmc_comm_rank(comm, &rank, &world));
+    PMC_OK_(pmc_comm_allreduce_sum(comm, d_stats, nstats, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(stats2.data(), d_stats, sizeof(double) * nstats, hipMemcpyDeviceToHost));
+    bool same = true;
+    for (int64_t i = 0; i < nstats; ++i) same = same && stats2[i] == stats[i];
+    std::printf("comm rank %d of %d allreduce %s\n", rank, world, same ? "identical" : "DIFFERENT");
+    PMC_OK_(pmc_comm_destroy(comm));
     return 0;
 }

@@ -324,6 +324,30 @@ int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pa
                          double *d_u, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
                          void *stream);
 
+/* ---- the cross-GPU exchange inside the library (optional) ---------------------------------------- */
+/*
+ * One process per GPU, samples sharded by rank; the only exchange of the path is a sum over ranks of the K-sized
+ * statistics buffer of an update ([scalars | stats | vsums | caller's bookkeeping], one contiguous device array).
+ * The reference gathers whole sample histories with mpi4py instead (pypmc/tools/parallel_sampler.py:58-71) and
+ * broadcasts the adapted proposal back (examples/pmc_mpi.py:119-131).
+ *
+ * These entry points run that all-reduce on RCCL (ncclAllReduce, ncclDouble, ncclSum) on the caller's stream,
+ * for callers that have no torch.distributed: librccl is opened at run time on first use (the copy already in the
+ * process if there is one); a process that never calls them does not need it.  Bootstrap as with NCCL itself:
+ * rank 0 calls pmc_comm_unique_id() and hands the PMC_COMM_ID_BYTES bytes to every rank by the caller's own
+ * means (MPI, a file, a socket); every rank then calls pmc_comm_init() -- collectively -- with its rank, the
+ * rank count and the HIP device it drives.  pmc_comm_allreduce_sum() sums d_buf[0..n) over the ranks in place,
+ * stream-ordered, identical result on every rank (so the replicated K-sized host update needs no broadcast).
+ * A communicator of one rank is valid (and is how a one-GPU box exercises the path).
+ */
+#define PMC_COMM_ID_BYTES 128
+typedef struct pmc_comm pmc_comm;
+int pmc_comm_unique_id(void *h_id);
+int pmc_comm_init(int rank, int world, const void *h_id, int device, pmc_comm **out);
+int pmc_comm_rank(const pmc_comm *comm, int *rank, int *world);
+int pmc_comm_allreduce_sum(pmc_comm *comm, double *d_buf, int64_t n, void *stream);
+int pmc_comm_destroy(pmc_comm *comm);
+
 /* ---- kernel timing ----------------------------------------------------------------------------- */
 /*
  * Roofline numbers for callers without a profiler.  While timing is enabled every launch of a hot kernel

@@ -67,6 +67,11 @@ SIGNATURES = {
     "pmc_responsibilities": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pmc_sufficient_stats": (_int, [_vp, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp]),
+    "pmc_comm_unique_id": (_int, [_vp]),
+    "pmc_comm_init": (_int, [_int, _int, _vp, _int, C.POINTER(_vp)]),
+    "pmc_comm_rank": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pmc_comm_allreduce_sum": (_int, [_vp, _vp, _i64, _vp]),
+    "pmc_comm_destroy": (_int, [_vp]),
     "pmc_timing_enable": (_int, [_int]),
     "pmc_get_timings": (_int, [_vp, _int, C.POINTER(C.c_int)]),
     "pmc_configure": (_int, [C.c_char_p, C.c_double]),

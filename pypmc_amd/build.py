@@ -96,7 +96,7 @@ def build(jobs=None, force=False, verbose=False):
     for stale in set(os.path.join(OBJ, f) for f in os.listdir(OBJ) if f.endswith(".o")) - set(objs):
         os.remove(stale)
     if force or not _newer(LIB, objs):
-        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + sorted(objs)
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + sorted(objs) + ["-ldl"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout))

@@ -5,6 +5,8 @@
 #include "pmc_dims.h"
 #include "pmc_internal.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1145,6 +1147,112 @@ int pmc_configure(const char *key, double value)
         return PMC_OK;
     }
     return fail(PMC_EINVAL, "pmc_configure: unknown key '%s'", key);
+}
+
+// ---- RCCL, opened at run time -------------------------------------------------------------------------
+// (the few declarations of rccl.h the library needs; values as in NCCL's public header)
+struct PmcNcclId {                                          // ncclUniqueId (passed by value)
+    char internal[PMC_COMM_ID_BYTES];
+};
+typedef struct pmcNcclComm *pmcNcclComm_t;
+namespace {
+struct RcclApi {
+    int (*GetUniqueId)(void *);
+    int (*CommInitRank)(pmcNcclComm_t *, int, PmcNcclId, int);
+    int (*AllReduce)(const void *, void *, size_t, int, int, pmcNcclComm_t, hipStream_t);
+    int (*CommDestroy)(pmcNcclComm_t);
+    const char *(*GetErrorString)(int);
+    bool ok = false;
+};
+}  // namespace
+struct pmc_comm {
+    pmcNcclComm_t comm;
+    int rank, world, device;
+};
+namespace {
+constexpr int PMC_NCCL_DOUBLE = 8, PMC_NCCL_SUM = 0;       // ncclFloat64, ncclSum
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names)                          // a copy the process already holds (PyTorch-ROCm's)
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *n : names)
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        api.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+        api.CommInitRank = (int (*)(pmcNcclComm_t *, int, PmcNcclId, int))dlsym(h, "ncclCommInitRank");
+        api.AllReduce = (int (*)(const void *, void *, size_t, int, int, pmcNcclComm_t, hipStream_t))dlsym(h, "ncclAllReduce");
+        api.CommDestroy = (int (*)(pmcNcclComm_t))dlsym(h, "ncclCommDestroy");
+        api.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
+    });
+    return api.ok ? &api : nullptr;
+}
+int rcclfail(RcclApi *r, int code, const char *what)
+{
+    return fail(PMC_EHIP, "%s: %s", what, r->GetErrorString ? r->GetErrorString(code) : "RCCL error");
+}
+}  // namespace
+
+int pmc_comm_unique_id(void *h_id)
+{
+    if (!h_id) return fail(PMC_EINVAL, "pmc_comm_unique_id: NULL buffer");
+    RcclApi *r = rccl();
+    if (!r) return fail(PMC_ENODEVICE, "librccl could not be opened (%s)", dlerror() ? dlerror() : "not found");
+    const int rc = r->GetUniqueId(h_id);
+    if (rc != 0) return rcclfail(r, rc, "ncclGetUniqueId");
+    return PMC_OK;
+}
+
+int pmc_comm_init(int rank, int world, const void *h_id, int device, pmc_comm **out)
+{
+    if (!out || !h_id || world < 1 || rank < 0 || rank >= world) return fail(PMC_EINVAL, "pmc_comm_init: bad argument");
+    RcclApi *r = rccl();
+    if (!r) return fail(PMC_ENODEVICE, "librccl could not be opened");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hipfail(e, "hipSetDevice");
+    PmcNcclId id;
+    std::memcpy(id.internal, h_id, PMC_COMM_ID_BYTES);
+    pmcNcclComm_t c = nullptr;
+    const int rc = r->CommInitRank(&c, world, id, rank);
+    if (rc != 0) return rcclfail(r, rc, "ncclCommInitRank");
+    *out = new pmc_comm{c, rank, world, device};
+    return PMC_OK;
+}
+
+int pmc_comm_rank(const pmc_comm *comm, int *rank, int *world)
+{
+    if (!comm) return fail(PMC_EINVAL, "pmc_comm_rank: NULL communicator");
+    if (rank) *rank = comm->rank;
+    if (world) *world = comm->world;
+    return PMC_OK;
+}
+
+int pmc_comm_allreduce_sum(pmc_comm *comm, double *d_buf, int64_t n, void *stream)
+{
+    if (!comm || n < 0 || (n > 0 && !d_buf)) return fail(PMC_EINVAL, "pmc_comm_allreduce_sum: bad argument");
+    if (n == 0) return PMC_OK;
+    RcclApi *r = rccl();
+    if (!r) return fail(PMC_ENODEVICE, "librccl could not be opened");
+    const int rc = r->AllReduce(d_buf, d_buf, (size_t)n, PMC_NCCL_DOUBLE, PMC_NCCL_SUM, comm->comm, (hipStream_t)stream);
+    if (rc != 0) return rcclfail(r, rc, "ncclAllReduce");
+    return PMC_OK;
+}
+
+int pmc_comm_destroy(pmc_comm *comm)
+{
+    if (!comm) return PMC_OK;
+    RcclApi *r = rccl();
+    int rc = 0;
+    if (r && comm->comm) rc = r->CommDestroy(comm->comm);
+    delete comm;
+    if (rc != 0) return rcclfail(r, rc, "ncclCommDestroy");
+    return PMC_OK;
 }
 
 int pmc_timing_enable(int on)

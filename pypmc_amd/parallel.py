@@ -92,7 +92,71 @@ def init_from_env(force=False):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    if os.environ.get("PMC_NATIVE_COLLECTIVE", "0") not in ("", "0"):
+        enable_native_collective(local)
     return dist.get_rank(), dist.get_world_size(), local
+
+
+# ---- the library's own RCCL communicator (include/pmc_hip.h: pmc_comm_*), optional ---------------------------
+_native = None            # (ctypes handle of the pmc_comm, the library) once enable_native_collective() has run
+
+
+def enable_native_collective(device=None):
+    """Run the path's all-reduce through libpmc_hip's own RCCL communicator (``pmc_comm_allreduce_sum``:
+    ncclAllReduce on the caller's stream) instead of ``torch.distributed.all_reduce``.  torch.distributed is then
+    only the bootstrap: rank 0 draws the RCCL unique id, the existing process group carries it to the ranks, every
+    rank joins.  Opt-in (``PMC_NATIVE_COLLECTIVE=1`` makes ``init_from_env`` call this): it is exercised on one
+    rank by the GPU tests; torch.distributed stays the default for multi-GPU runs."""
+    global _native
+    d = _dist()
+    if d is None:
+        raise RuntimeError("enable_native_collective needs an initialised torch.distributed process group")
+    if _native is not None:
+        return
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    ident = (C.c_char * 128)()
+    if d.get_rank() == 0:
+        _lib.check(lib.pmc_comm_unique_id(C.cast(ident, C.c_void_p)), "pmc_comm_unique_id")
+    where = torch.device("cuda", dev) if d.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=where)
+    d.broadcast(t, src=0)
+    ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+    comm = C.c_void_p()
+    _lib.check(lib.pmc_comm_init(d.get_rank(), d.get_world_size(), C.cast(ident, C.c_void_p), dev, C.byref(comm)),
+               "pmc_comm_init")
+    _native = (comm, lib)
+
+
+def disable_native_collective():
+    global _native
+    if _native is not None:
+        comm, lib = _native
+        _native = None
+        lib.pmc_comm_destroy(comm)
+
+
+def collective_name():
+    """what sums the statistics buffer over the ranks: None (no group), 'nccl' / 'gloo' (torch.distributed's
+    backend) or 'rccl:libpmc_hip' (the library's own communicator)"""
+    d = _dist()
+    if d is None:
+        return None
+    return "rccl:libpmc_hip" if _native is not None else d.get_backend()
+
+
+def _native_all_reduce(t):
+    """in-place sum of a float64 CUDA tensor over the ranks through pmc_comm_allreduce_sum, on the current stream"""
+    import ctypes as C
+    import torch
+    from . import _lib
+    comm, lib = _native
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    _lib.check(lib.pmc_comm_allreduce_sum(comm, C.c_void_p(t.data_ptr()), t.numel(), stream), "pmc_comm_allreduce_sum")
 
 
 def _collective_device(d):
@@ -113,6 +177,20 @@ def all_reduce_sum(buf):
     if d is None:
         return buf
     import torch
+    if _native is not None:                             # the library's own communicator: always on the device
+        cuda = torch.device("cuda", torch.cuda.current_device())
+        if isinstance(buf, np.ndarray):
+            t = torch.from_numpy(buf)
+            g = t.to(cuda)
+            _native_all_reduce(g)
+            t.copy_(g)
+        elif buf.is_cuda and buf.is_contiguous():
+            _native_all_reduce(buf)
+        else:
+            g = buf.to(cuda).contiguous()
+            _native_all_reduce(g)
+            buf.copy_(g)
+        return buf
     dev = _collective_device(d)
     if isinstance(buf, np.ndarray):
         t = torch.from_numpy(buf)                       # shares memory with buf

@@ -112,6 +112,8 @@ def run(rank, world, port, workdir, backend_kind="oracle", pg_backend="gloo"):
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         from pypmc_amd import parallel
+        if os.environ.get("PMC_NATIVE_COLLECTIVE", "0") not in ("", "0"):
+            parallel.enable_native_collective(0)
         if backend_kind == "hip":
             from pypmc_amd.backend import HipBackend
             be = HipBackend(0)
@@ -124,7 +126,10 @@ def run(rank, world, port, workdir, backend_kind="oracle", pg_backend="gloo"):
         out = case(be, z, lo, hi)
         out["backend"] = np.array(be.name)
         out["pg_backend"] = np.array(dist.get_backend())
+        out["collective"] = np.array(str(parallel.collective_name()))
         out.update({"coll_" + k: v for k, v in collectives(be).items()})
         np.savez(os.path.join(workdir, "rank%d.npz" % rank), **out)
     finally:
+        from pypmc_amd import parallel as _p
+        _p.disable_native_collective()
         dist.destroy_process_group()

@@ -50,3 +50,5 @@ def test_cabi_demo_matches_oracle(tmp_path):
     # the evaluate-once iteration (pmc_importance_weights_keep + pmc_estep_from_tiles) gave the same statistics
     worst = float([line for line in res if line.startswith("from_tiles")][0].split()[-1])
     assert worst < 1e-11
+    # the library's own RCCL communicator (one rank): the sum over one rank leaves the buffer as it was
+    assert "comm rank 0 of 1 allreduce identical" in res

@@ -35,6 +35,21 @@ def test_one_rank_nccl_group_runs_the_sharded_surface():
     np.testing.assert_array_equal(got["vbr_m0"], single["vbr_m0"])
 
 
+def test_one_rank_through_the_librarys_own_communicator(monkeypatch):
+    """PMC_NATIVE_COLLECTIVE=1: the all-reduce is pmc_comm_allreduce_sum (ncclAllReduce issued by libpmc_hip on the
+    launch stream); torch.distributed only carries the unique id"""
+    from pypmc_amd.backend import HipBackend
+    z = dist_worker.make_inputs(seed=22, N=3001)
+    single = dist_worker.case(HipBackend(), z, 0, len(z["data"]))
+    monkeypatch.setenv("PMC_NATIVE_COLLECTIVE", "1")
+    ranks = spawn_ranks(z, "hip", world=1, pg_backend="nccl")
+    got = ranks[0]
+    assert str(got["collective"]) == "rccl:libpmc_hip"
+    check_collectives(ranks)
+    for key, val in single.items():
+        np.testing.assert_allclose(got[key], val, rtol=1e-13, atol=1e-14, err_msg=key)
+
+
 def _bench(launcher, extra, env=None):
     cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                       "--samples-per-gpu", "400000", "--no-cpu-baseline", "--no-configs"] + extra
@@ -64,3 +79,5 @@ def test_bench_plain_python_has_no_group_unless_forced():
     assert line["dist"]["backend"] is None and line["dist"]["world_size"] == 1
     line = _bench([sys.executable], ["--force-dist"])
     assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1 and line["dist"]["allreduce_ms"] > 0.0
+    line = _bench([sys.executable], ["--force-dist"], dict(os.environ, PMC_NATIVE_COLLECTIVE="1"))
+    assert line["dist"]["backend"] == "rccl:libpmc_hip" and line["dist"]["allreduce_ms"] > 0.0
