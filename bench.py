@@ -103,6 +103,48 @@ def measured_traffic(kernel, N):
     return None, None
 
 
+def live_traffic(kernel, N, timeout=150):
+    """HBM bytes per launch of `kernel`, measured NOW: this script again under rocprofv3 (kernel trace + ONE PMC
+    counter per pass: FETCH_SIZE, then WRITE_SIZE -- separate passes and nothing but the kernel trace beside them,
+    as MI355X_MICROARCH.md prescribes), two steps at the same N.  FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE,
+    KiB -> bytes.  (None, reason) if rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    want = {"k_stats": "k_stats_gemm"}.get(kernel, kernel)      # the statistics kernel pmc_estep runs at K = 32
+    kib = {}
+    work = tempfile.mkdtemp(prefix="pmc_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--n", str(N),
+                   "--no-cpu-baseline", "--no-configs", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if want in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, "no launch of %s in the %s pass" % (want, counter)
+            kib[counter] = sum(per.values()) / len(per)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as exc:
+        return None, "traffic measurement failed: %r" % (exc,)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0, \
+        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one counter per pass) on " \
+        "`bench.py --steps 2 --warmup 1` at the same N; FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KiB -> bytes"
+
+
 def reference_ratio():
     """oracle speed / reference speed on the bench step, timed in the build container where the reference
     runs (scripts/cpu_ratio.py -> profiles/r02_cpu_ratio.json); None if absent"""
@@ -235,7 +277,7 @@ def baseline_configs(be, reps=3, select=None):
         out["seconds"] = time.perf_counter() - t_all
         return out
     # -- config 5: one PMC iteration D=40, K=128, 1.25e7 samples (= N=1e8 over 8 GPUs): propose -> weights vs
-    #    K_t=4 target -> Rao-Blackwell update reusing the Mahalanobis forms the weighting pass kept
+    #    K_t=4 target (the pass leaves u = w rho behind) -> statistics -> K-sized host update
     D5, K5, KT5, N5 = 40, 128, 4, 12_500_000
     rs = np.random.RandomState(5)
     tmu, tcov, tw = mk(KT5, D5, 11)
@@ -247,13 +289,14 @@ def baseline_configs(be, reps=3, select=None):
     sampler = ImportanceSampler(target.evaluate, proposal)
 
     def iteration():
-        run = sampler.run_device(N5, trace_sort=True, keep_mahalanobis=True)
+        run = sampler.run_device(N5, trace_sort=True, prepare_update=True)
         gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"], mincount=0, rb=True,
-                     copy=False, mahalanobis=run["mahalanobis"])
+                     copy=False, mahalanobis=run["mahalanobis"], responsibilities=run["responsibilities"])
     t, kern = timed(iteration)
     f5 = flops_logpdf(K5 + KT5, D5) + flops_stats(K5, D5) + D5 * (D5 + 1)
-    out["cfg5"] = entry("PMC iteration D=40 K=128: propose -> weights (proposal evaluated once) -> "
-                        "Rao-Blackwell update, one GPU's share of N=1e8 over 8", N5, f5, t, kern)
+    out["cfg5"] = entry("PMC iteration D=40 K=128: propose -> weights (proposal evaluated once, responsibilities "
+                        "of the update emitted by the same pass) -> statistics -> host update, one GPU's share of "
+                        "N=1e8 over 8", N5, f5, t, kern)
     out["seconds"] = time.perf_counter() - t_all
     return out
 
@@ -271,6 +314,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="create the process group (RCCL) even for a single plain python process")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configurations 2-5")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure the dominant kernel's HBM traffic (two short rocprofv3 PMC passes of this "
+                         "script); the line then quotes the newest committed summary under profiles/")
     ap.add_argument("--configs-only", default=None, metavar="cfg3,cfg4",
                     help="profiling aid: run only these configurations (no headline step) and print their block")
     ap.add_argument("--two-streams", action="store_true",
@@ -415,7 +461,13 @@ def main():
                       for k_, v in hot.items()}
         dom = per_launch[dominant]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) * 1e-12
-        traffic, traffic_src = measured_traffic(dominant, N)
+        traffic, traffic_src = (None, "switched off") if (args.no_traffic or world > 1) else live_traffic(dominant, N)
+        if traffic is None:
+            why = traffic_src
+            traffic, traffic_src = measured_traffic(dominant, N)
+            if traffic_src:
+                traffic_src = "%s (rocprofv3 PMC passes of an earlier run of this command, scaled to N; not measured " \
+                              "in this run: %s)" % (traffic_src, why)
         line = {
             "metric": "IS samples/sec + VB E-step samples/sec at N=1e7, K=32, D=20",
             "value": n_total / (ms_per_step * 1e-3),
@@ -442,8 +494,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "traffic_source": ("%s (rocprofv3 PMC passes of an earlier run of this command, scaled to N; "
-                                            "not measured in this run)" % traffic_src) if traffic_src else None,
+                         "traffic_source": traffic_src,
                          "timing_source": "pmc_get_timings: HIP events on the launch stream around each kernel, "
                                           "mean over the timed steps",
                          "note": "fp64 kernels (v_fma_f64; k_stats: v_mfma_f64_4x4x4) priced against the fp64 matrix "

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import (HipLibraryError, NotPositiveDefinite, PMC_KIND_GAUSS, PMC_KIND_STUDENT_T,  # noqa: F401
                    NSCALARS)
 
-__all__ = ["ComponentSet", "HipBackend", "get_backend", "set_default_backend", "HipLibraryError",
+__all__ = ["ComponentSet", "Responsibilities", "HipBackend", "get_backend", "set_default_backend", "HipLibraryError",
            "NotPositiveDefinite"]
 
 
@@ -62,6 +62,24 @@ class MahaTiles(object):
         c = self.comps
         return comps_full is c or (comps_full.K == c.K and np.array_equal(comps_full.mu, c.mu) and
                                    np.array_equal(comps_full.precision, c.precision))
+
+
+class Responsibilities(object):
+    """u_nk = w_n rho_nk of a Gaussian proposal on the device (tile-major), left behind by a weighting pass that knew
+    the update follows (``importance_weights(..., emit=True)``), together with what they belong to.
+    ``gaussian_pmc(..., responsibilities=...)`` reduces them to the statistics without any responsibility kernel."""
+
+    def __init__(self, data, N, comps, weights):
+        self.data, self.N, self.K, self.comps, self.weights = data, int(N), int(comps.K), comps, weights
+
+    def matches(self, comps_full, weights):
+        """True for the very mixture (means, precisions, component weights, normalisations) and the very sample
+        weights (the importance weights of that pass) these values were formed with"""
+        c = self.comps
+        same = comps_full is c or (comps_full.K == c.K and comps_full.kind == c.kind and
+                                   np.array_equal(comps_full.mu, c.mu) and np.array_equal(comps_full.precision, c.precision)
+                                   and np.array_equal(comps_full.weight, c.weight) and np.array_equal(comps_full.c0, c.c0))
+        return same and weights is self.weights
 
 
 def _dptr(a):
@@ -253,9 +271,14 @@ class HipBackend(object):
         return MahaTiles(self.empty(max(n, 1)), N, comps)
 
     def importance_weights(self, x, comps, target, sample_w=None, want_out=False, want_log_target=False,
-                           pack=None, target_pack=None, keep=False):
+                           pack=None, target_pack=None, keep=False, emit=False):
         """pmc_importance_weights: w = exp(log P - log q) for a mixture target P (``target``) and proposal
-        q (``comps``) in one pass over ``x``.  Returns dict(weights, scalars, out, log_target)."""
+        q (``comps``) in one pass over ``x``.  Returns dict(weights, scalars, out, log_target[, tiles | responsibilities]).
+        ``emit`` (Gaussian proposal, compiled dimensions, every component alive): the pass also leaves
+        u = w rho for the update (``Responsibilities``; pmc_importance_weights_emit)."""
+        if emit and not keep and sample_w is None and comps.kind == PMC_KIND_GAUSS and comps.D <= 64 \
+                and comps.ld == comps.K and bool((comps.weight != 0).all()):
+            return self._importance_weights_emit(x, comps, target, want_out, want_log_target, pack, target_pack)
         x = self.asdevice(x)
         N, D = x.shape
         assert D == comps.D == target.D, "sample / proposal / target dimensions differ"
@@ -274,6 +297,44 @@ class HipBackend(object):
             self._p(out), self._p(lt), self._p(weights), self._p(sw), self._p(scalars), self._p(ws),
             self._p(tiles.data) if keep else None, self._stream()), "pmc_importance_weights")
         return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=tiles)
+
+    def _importance_weights_emit(self, x, comps, target, want_out, want_log_target, pack, target_pack):
+        x = self.asdevice(x)
+        N, D = x.shape
+        assert D == comps.D == target.D, "sample / proposal / target dimensions differ"
+        pack = self.pack(comps) if pack is None else pack
+        target_pack = self.pack(target) if target_pack is None else target_pack
+        out = self.empty(N) if want_out else None
+        lt = self.empty(N) if want_log_target else None
+        weights = self.empty(N)
+        scalars = self.zeros(NSCALARS)
+        ws = self._workspace(N, max(comps.K, target.K), D)
+        u = self.empty(max(int(self.lib.pmc_tile_buffer_len(N, comps.K)), 1))      # the caller's: outlives this call
+        _lib.check(self._timed(
+            "pmc_importance_weights_emit[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights_emit,
+            self._p(x), N, D, self._p(pack), comps.K, self._p(target_pack), target.K, target.kind,
+            self._p(out), self._p(lt), self._p(weights), self._p(scalars), self._p(ws), self._p(u), self._stream()),
+            "pmc_importance_weights_emit")
+        return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=None,
+                    responsibilities=Responsibilities(u, N, comps, weights))
+
+    def estep_from_u(self, x, comps, resp, out=None):
+        """pmc_estep_from_u: the statistics of responsibilities a weighting pass left behind (``Responsibilities``).
+        Same return value as ``estep``."""
+        x = self.asdevice(x)
+        N, D = x.shape
+        assert resp.N == N and resp.K == comps.K and D == comps.D, "responsibilities belong to another sample set / mixture"
+        K = comps.K
+        ps = int(self.lib.pmc_stats_stride(D))
+        nflat = NSCALARS + K * ps + 2 * K
+        flat = out if out is not None else self.zeros(nflat)
+        assert flat.numel() == nflat
+        flat[:NSCALARS] = 0.
+        _lib.check(self._timed(
+            "pmc_estep_from_u", self.lib.pmc_estep_from_u, self._p(x), N, D, self._p(self.pack(comps)), K, comps.kind,
+            self._p(resp.data), self._p(flat[NSCALARS:]), self._p(self._workspace(N, K, D)), self._stream()),
+            "pmc_estep_from_u")
+        return dict(stats=flat, r=None, log_rho=None, exponent=None)
 
     def weight_sums(self, w):
         """(sum w, sum w log w [zeros masked], sum w^2) as a device tensor of NSCALARS doubles."""

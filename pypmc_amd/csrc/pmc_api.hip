@@ -811,6 +811,9 @@ static int finish_scalars(const double *partials, long long nblocks, double *d_s
     return PMC_OK;
 }
 
+static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+                                 const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind);
+
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                             int max_init_zero, double *d_out, double *d_individual, int64_t ld,
                             const double *d_log_target, double *d_weights, const double *d_sample_w,
@@ -864,10 +867,10 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
                                    d_weights, d_sample_w, d_scalars, d_workspace, nullptr, stream);
 }
 
-int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
-                                const double *d_target_pack, int K_target, int target_kind, double *d_out,
-                                double *d_log_target_out, double *d_weights, const double *d_sample_w,
-                                double *d_scalars, void *d_workspace, double *d_maha_tiles, void *stream)
+static int importance_weights_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                                   const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                                   double *d_log_target_out, double *d_weights, const double *d_sample_w,
+                                   double *d_scalars, void *d_workspace, double *d_maha_tiles, double *d_u, void *stream)
 {
     if (N < 0 || K < 1 || K_target < 1 || !d_pack || !d_target_pack)
         return fail(PMC_EINVAL, "pmc_importance_weights: bad N/K/pack");
@@ -885,9 +888,10 @@ int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const doubl
         std::memset(&a, 0, sizeof(a));
         a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.ld = K;
         a.pack2 = d_target_pack; a.K2 = K_target; a.log_target_out = d_log_target_out;
-        a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_maha_tiles;
+        a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_maha_tiles; a.u = d_u;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
-        Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D), 8.0 * N * (D + 1 + (d_maha_tiles ? K : 0)));
+        Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D),
+                8.0 * N * (D + 1 + (d_maha_tiles ? K : 0) + (d_u ? K : 0)));
         StreamScratch scratch(st);
         if (ks->padded == 2) {
             const size_t n1 = (size_t)pmc_maha_tiles_size(N, K), n2 = (size_t)pmc_maha_tiles_size(N, K_target);
@@ -908,13 +912,44 @@ int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const doubl
     return PMC_OK;
 }
 
+int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                                const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                                double *d_log_target_out, double *d_weights, const double *d_sample_w,
+                                double *d_scalars, void *d_workspace, double *d_maha_tiles, void *stream)
+{
+    return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
+                                   d_log_target_out, d_weights, d_sample_w, d_scalars, d_workspace, d_maha_tiles, nullptr,
+                                   stream);
+}
+
 int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                            const double *d_target_pack, int K_target, int target_kind, double *d_out,
                            double *d_log_target_out, double *d_weights, const double *d_sample_w,
                            double *d_scalars, void *d_workspace, void *stream)
 {
-    return pmc_importance_weights_keep(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
-                                       d_log_target_out, d_weights, d_sample_w, d_scalars, d_workspace, nullptr, stream);
+    return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
+                                   d_log_target_out, d_weights, d_sample_w, d_scalars, d_workspace, nullptr, nullptr, stream);
+}
+
+int pmc_importance_weights_emit(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+                                const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                                double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
+                                double *d_u, void *stream)
+{
+    if (!d_u) return fail(PMC_EINVAL, "pmc_importance_weights_emit: d_u is NULL");
+    if (D > PMC_MAX_DIM)
+        return fail(PMC_EINVAL, "pmc_importance_weights_emit: compiled dimensions only (D <= %d); keep the Mahalanobis "
+                                "forms (pmc_importance_weights_keep) and use pmc_estep_from_tiles", PMC_MAX_DIM);
+    return importance_weights_impl(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, d_target_pack, K_target, target_kind, d_out,
+                                   d_log_target_out, d_weights, nullptr, d_scalars, d_workspace, nullptr, d_u, stream);
+}
+
+int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, const double *d_u,
+                     double *d_stats, void *d_workspace, void *stream)
+{
+    if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T && kind != PMC_KIND_VB)
+        return fail(PMC_EINVAL, "pmc_estep_from_u: unknown kind %d", kind);
+    return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind);
 }
 
 int64_t pmc_maha_tiles_size(int64_t N, int K)

@@ -419,7 +419,11 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
     // importance weights (kind KIND2), evaluated on the same registers: the samples are read once
     const ExpConst EC;
     double poison = 0.0;                                 // NaN if the row has a NaN / infinite coordinate (lse_step)
-    const bool keep_tile = a.atile != nullptr && ((n >> 6) << 6) < a.N;     // (the buffer ends with the last live tile)
+    // kept Mahalanobis forms (pmc_*_keep: a.atile), or -- pmc_importance_weights_emit: a.u -- the place where the
+    // responsibilities of the PMC update will stand: the forms are parked there and replaced below
+    double *const mkeep = a.u != nullptr ? a.u : a.atile;
+    const bool keep_tile = mkeep != nullptr && ((n >> 6) << 6) < a.N;       // (the buffer ends with the last live tile)
+    double m_first = 0.0;                                // row maximum of the FIRST mixture's component values
     auto mixture = [&](auto kind, const double *gpack, const int K, const bool first) -> double {
         constexpr int KD = decltype(kind)::value;
         double m = (first && a.max_init_zero) ? 0.0 : -DBL_MAX, s = 0.0;
@@ -434,10 +438,11 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
                 if (valid) a.individual[n * a.ld + col] = v;
             }
             if (first && keep_tile)                      // wave-uniform: keep maha_nk for the PMC update of these samples
-                a.atile[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = maha;
+                mkeep[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = maha;
             lse_step(v, pk[dm.DT + 4], m, s, EC);
             poison = fma(0.0, v, poison);
         }
+        if (first) m_first = m;
         return (log_any(s) + m) + poison;                    // _regularize.pyx:81
     };
     const double lse = mixture(ic<KIND>{}, a.pack, a.K, true);
@@ -459,6 +464,26 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         sc[4] = (isinf(w) && !isinf(tmp)) ? 1.0 : 0.0;    // math.exp OverflowError
     }
     if (valid) sc[3] = (a.sample_w != nullptr) ? a.sample_w[n] * lse : lse;   // pmc.pyx:388-391
+    if (a.u != nullptr && keep_tile) {
+        // pmc_importance_weights_emit: the Rao-Blackwellised responsibilities of the update that follows, weighted
+        // with the importance weight just formed, u_nk = w_n rho_nk with rho = exp(log q_k) w_k / (exp(lse) + tiny)
+        // (pmc.pyx:23-43) -- the arithmetic of k_resp's PMC branch / k_resp_tiles (exp(a - M) exp(M), so that rho
+        // underflows where the reference's exp(log q_k) does), with the row maximum and the log-sum-exp this pass has
+        // already: every parked form is read ONCE (k_resp_tiles: three times, in a launch of its own).
+        static_assert(KIND == PMC_KIND_GAUSS || KIND == PMC_KIND_STUDENT_T, "emit: density kinds only");
+        const double wn = (a.log_target != nullptr || a.pack2 != nullptr) ? sc[0] : 1.0;
+        const double swv = valid ? wn + poison : 0.0;
+        const double denom = exp(lse) + TINY;                               // pmc.pyx:41
+        const double em = exp(m_first), inv_denom = 1. / denom;
+        double *ut = a.u + (size_t)(n >> 6) * a.K * 64 + (threadIdx.x & 63);
+        cdouble *pk = (cdouble *)a.pack + (size_t)(a.K - 1) * dm.STRIDE + dm.DT;
+        for (int k = a.K - 1; k >= 0; --k, pk -= dm.STRIDE) {               // last written first: still in L2
+            double expo;
+            const double v = component_value<D, KIND>(ut[(size_t)k * 64], pk, expo);
+            const double e = exp_clamped(max_f64(v - m_first, -1075.0), EC);
+            ut[(size_t)k * 64] = swv * (((e * em) * pk[4]) * inv_denom);
+        }
+    }
     if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
 }
 

@@ -28,7 +28,8 @@ from ..tools._linalg import single_threaded_blas, chol_inv_det_batch
 logger = logging.getLogger(__name__)
 
 
-def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis=None):
+def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis=None,
+                        responsibilities=None):
     """Argument checks, live-component bookkeeping and the device pass
     (reference: pmc.pyx:53-118).  Returns density, live_components (after ``mincount`` pruning),
     the indices the statistics were computed for, the host statistics, the weight normalisation
@@ -101,7 +102,13 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
             raise TypeError('``density`` must have only Gauss or only StudentT components')
         mode = PMC_RESP_PMC_RB if rb else PMC_RESP_PMC_LATENT
         # dead components' all-zero columns take part in the row maximum (pmc.pyx:24-34)
-        if mahalanobis is not None and rb:
+        if responsibilities is not None and rb:
+            # the weighting pass left u = w rho of these very samples, weights and parameters: statistics only
+            full = component_set(density.components, density.weights)
+            if len(live_components) < K or responsibilities.N != N_local or not responsibilities.matches(full, weights):
+                raise ValueError('``responsibilities`` were not formed with this density, these samples and weights')
+            res = be.estep_from_u(samples, cs, responsibilities)
+        elif mahalanobis is not None and rb:
             # the weighting pass kept maha_nk of these very samples: rho without a second evaluation
             full = component_set(density.components, density.weights)
             if mahalanobis.N != N_local or not mahalanobis.matches(full):
@@ -222,7 +229,7 @@ def _apply_updates(density, live_components, new_params, need_renormalize):
 
 
 def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=0, copy=True,
-                 backend=None, mahalanobis=None):
+                 backend=None, mahalanobis=None, responsibilities=None):
     """Adapt a Gaussian mixture ``density`` to the (weighted) ``samples`` it proposed
     (reference: pmc.pyx:120-246, same signature and semantics).
 
@@ -233,7 +240,8 @@ def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=
     if isinstance(samples, np.ndarray):          # device-resident tensors pass through untouched
         samples = np.ascontiguousarray(samples, dtype=np.float64)
     density, live, stat_comps, stats, norm, renorm, shift = \
-        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis)
+        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis,
+                            responsibilities)
     _, S0, M1, M2, _, _ = stats
     if stat_comps:
         mu, cov = centred_moments(S0, M1, M2, shift)             # pmc.pyx:194-204 / :213-222

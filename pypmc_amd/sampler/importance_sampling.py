@@ -112,7 +112,8 @@ class ImportanceSampler(object):
         this_samples = self._get_samples(N, trace_sort=False)
         self._calculate_weights(this_samples, N)
 
-    def run_device(self, N, trace_sort=False, target_density=None, store=False, keep_mahalanobis=False):
+    def run_device(self, N, trace_sort=False, target_density=None, store=False, keep_mahalanobis=False,
+                   prepare_update=False):
         """Extension for device-resident loops (BASELINE config 5): propose N samples ON THE GPU,
         weight them there and return ``dict(samples, weights, origin, weight_sums)`` of device
         tensors.  With a mixture target (``target_density``, default: the object whose ``evaluate``
@@ -121,7 +122,12 @@ class ImportanceSampler(object):
         ``device=True`` at construction) generates into / records in the DeviceHistory objects.
         ``keep_mahalanobis=True`` additionally returns ``mahalanobis``: the Mahalanobis forms of the samples
         under the proposal's components, kept on the device for ``gaussian_pmc / student_t_pmc(...,
-        mahalanobis=...)`` (8 K bytes per sample)."""
+        mahalanobis=...)`` (8 K bytes per sample).
+        ``prepare_update=True`` (Gaussian mixture proposal and mixture target): the weighting pass also leaves the
+        Rao-Blackwellised responsibilities of the update that follows, ``responsibilities`` in the result, for
+        ``gaussian_pmc(samples, proposal, weights, ..., responsibilities=...)`` -- no responsibility kernel runs at
+        all; where that form does not apply (Student-t, dead components, D > 64) ``mahalanobis`` is returned
+        instead."""
         from ..density.mixture import MixtureDensity, component_set
         be = get_backend(self._backend)
         if store and not self.device:
@@ -138,7 +144,11 @@ class ImportanceSampler(object):
             # mixture target: log P, log q, the weights and the perplexity sums in one pass over x
             res = be.importance_weights(x, prop_set, component_set(tgt.components, tgt.weights),
                                         want_log_target=store and self.target_values is not None,
-                                        keep=keep_mahalanobis)
+                                        keep=keep_mahalanobis, emit=prepare_update and not keep_mahalanobis)
+            if prepare_update and res.get("responsibilities") is None and res.get("tiles") is None:
+                # the emitting form does not apply here: keep the Mahalanobis forms instead (second pass over them)
+                res = be.importance_weights(x, prop_set, component_set(tgt.components, tgt.weights),
+                                            want_log_target=store and self.target_values is not None, keep=True)
             log_target = res["log_target"]
         else:
             log_target = be.asdevice(self._target_values(be.tohost(x), N))
@@ -153,7 +163,7 @@ class ImportanceSampler(object):
             if self.target_values is not None:
                 self.target_values.append(N)[:, 0] = log_target
         return dict(samples=x, weights=res["weights"], origin=origin, weight_sums=self.last_weight_sums,
-                    mahalanobis=res.get("tiles"))
+                    mahalanobis=res.get("tiles"), responsibilities=res.get("responsibilities"))
 
     def _get_samples(self, N, trace_sort):
         this_run = self.samples.append(N)

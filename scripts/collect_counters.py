@@ -16,7 +16,8 @@ for f in glob.glob(os.path.join(ROOT, "gpurun_out", "sq", "pass*", "**", "*count
     acc = {}
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
-        key = "k_logpdf" if "k_logpdf" in name else "k_resp" if "k_resp" in name else "k_stats" if "k_stats" in name else None
+        key = "k_logpdf" if "k_logpdf" in name else "k_resp" if "k_resp" in name else \
+            "k_stats" if "k_stats_gemm" in name else None      # (plain k_stats<...> returns at once in this run)
         if key is None:
             continue
         d = acc.setdefault((key, row["Counter_Name"]), {})

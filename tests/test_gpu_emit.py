@@ -1,0 +1,114 @@
+"""pmc_importance_weights_emit + pmc_estep_from_u: a weighting pass that knows the Rao-Blackwell update follows
+leaves u_nk = w_n rho_nk (pmc.pyx:23-43, :188) behind and the update is the statistics kernel alone -- against the
+oracle, against the path that keeps the Mahalanobis forms (pmc_estep_from_tiles) and through the front-end."""
+import numpy as np
+import pytest
+
+from test_gpu_kernels import mk, draw, gauss_set, student_set, assert_rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from pypmc_amd.backend import HipBackend
+    return HipBackend()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def untile(be, t, N, K):
+    t = be.tohost(t)[:((N + 63) // 64) * K * 64].reshape(-1, K, 64)
+    return np.concatenate([t[i].T for i in range(t.shape[0])])[:N]
+
+
+@pytest.mark.parametrize("D,K,N", [(1, 2, 70), (2, 3, 1000), (5, 9, 257), (8, 17, 4097), (20, 32, 40000), (23, 5, 129),
+                                   (32, 6, 640), (40, 24, 20000), (64, 3, 200), (9, 33, 20001)])
+def test_emit_matches_oracle_and_the_kept_forms(be, orc, D, K, N):
+    mu, cov, w = mk(K, D, 900 + D + K)
+    x, _ = draw(mu, cov, w, N, 31)
+    tmu, tcov, tw = mk(3, D, 78)
+    tmu = 0.5 * tmu
+    prop, inv, ln = gauss_set(mu, cov, w)
+    target = gauss_set(tmu, tcov, tw)[0]
+    plain = be.importance_weights(x, prop, target, want_out=True)
+    em = be.importance_weights(x, prop, target, want_out=True, emit=True)
+    resp = em["responsibilities"]
+    assert resp is not None and resp.N == N and resp.K == K
+    for key in ("weights", "out", "scalars"):                         # the weighting pass itself is unchanged
+        np.testing.assert_array_equal(be.tohost(em[key]), be.tohost(plain[key]))
+    # u = w rho against the oracle's rho (pmc.pyx:23-43) and the weights just formed
+    wts = be.tohost(em["weights"])
+    rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+    u = untile(be, resp.data, N, K)
+    ref = wts[:, None] * rho
+    normal = ref > 1e-290
+    assert_rel(u[normal], ref[normal], rtol=1e-10, what="u = w rho")
+    assert np.all(u[~normal] <= 1e-280)
+    # the statistics: what the update that keeps the Mahalanobis forms computes, to rounding
+    kept = be.importance_weights(x, prop, target, keep=True)
+    a = be.tohost(be.estep_from_u(x, prop, resp)["stats"])[8:8 + K * (1 + D + D * (D + 1) // 2)]
+    b = be.tohost(be.estep_from_tiles(x, prop, kept["tiles"], sample_w=kept["weights"])["stats"])[8:8 + len(a)]
+    a, b = a.reshape(K, -1), b.reshape(K, -1)
+    scale = np.abs(b).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(a - b) / scale).max() < 1e-11
+    assert resp.matches(prop, em["weights"]) and not resp.matches(prop, kept["weights"])
+    other, _, _ = gauss_set(mu + 1e-3, cov, w)
+    assert not resp.matches(other, em["weights"])
+
+
+def test_emit_falls_back_where_it_does_not_apply(be):
+    D, K, N = 6, 4, 500
+    mu, cov, w = mk(K, D, 5)
+    x, _ = draw(mu, cov, w, N, 6)
+    target = gauss_set(*mk(2, D, 7))[0]
+    st = student_set(mu, cov, w, np.full(K, 5.))[0]
+    assert be.importance_weights(x, st, target, emit=True).get("responsibilities") is None      # Student-t
+    wd = w.copy()
+    wd[1] = 0.
+    dead = gauss_set(mu, cov, wd)[0]
+    assert be.importance_weights(x, dead, target, emit=True).get("responsibilities") is None    # a dead component
+
+
+def test_front_end_iteration_without_a_responsibility_kernel(be):
+    """ImportanceSampler.run_device(prepare_update=True) + gaussian_pmc(responsibilities=...) against the same
+    iteration with the kept Mahalanobis forms"""
+    import pypmc_amd as pypmc
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    D, K, N = 12, 20, 60000
+    tmu, tcov, tw = mk(3, D, 11)
+    target = create_gaussian_mixture(tmu / 3., tcov, tw)
+    rs = np.random.RandomState(5)
+    which = np.arange(K) % 3
+    start = create_gaussian_mixture(tmu[which] / 3. + rs.normal(0, 0.2, (K, D)), 1.5 * tcov[which])
+    results = []
+    for form in ("tiles", "emit"):
+        sampler = pypmc.sampler.importance_sampling.ImportanceSampler(target.evaluate, start,
+                                                                      rng=np.random.RandomState(100))
+        be.kernel_timings()
+        be.kernel_timing(True)
+        run = sampler.run_device(N, trace_sort=True, keep_mahalanobis=form == "tiles", prepare_update=form == "emit")
+        if form == "emit":
+            assert run["responsibilities"] is not None and run["mahalanobis"] is None
+            new = pypmc.mix_adapt.pmc.gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"],
+                                                   responsibilities=run["responsibilities"])
+        else:
+            new = pypmc.mix_adapt.pmc.gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"],
+                                                   mahalanobis=run["mahalanobis"])
+        be.kernel_timing(False)
+        kernels = be.kernel_timings()
+        assert ("k_resp" in kernels) == (form == "tiles")              # no responsibility kernel in the emitting form
+        results.append(new)
+        if form == "emit":
+            with pytest.raises(ValueError):                            # other weights than the pass formed
+                pypmc.mix_adapt.pmc.gaussian_pmc(run["samples"], sampler.proposal, run["weights"].clone(), run["origin"],
+                                                 responsibilities=run["responsibilities"])
+    a, b = results
+    np.testing.assert_allclose(b.weights, a.weights, rtol=1e-11)
+    for ca, cb in zip(a.components, b.components):
+        np.testing.assert_allclose(cb.mu, ca.mu, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(cb.sigma, ca.sigma, rtol=1e-9, atol=1e-12)
