@@ -497,10 +497,11 @@ def main():
                          "traffic_source": traffic_src,
                          "timing_source": "pmc_get_timings: HIP events on the launch stream around each kernel, "
                                           "mean over the timed steps",
-                         "note": "fp64 kernels (v_fma_f64; k_stats: v_mfma_f64_4x4x4) priced against the fp64 matrix "
-                                 "peak, which equals the fp64 vector peak on MI355X; flops = SURVEY 8(d) per-sample "
-                                 "figure x N.  The kernels are power-bound: the chip holds 1.9-2.1 of its 2.4 GHz "
-                                 "under this load (profiles/r02_dpp_engine_ab.txt)",
+                         "note": "fp64 kernels (k_logpdf, k_resp: v_fma_f64 with scalar-cache operands; k_stats = "
+                                 "k_stats_gemm: v_mfma_f64_16x16x4) priced against the fp64 matrix peak, which equals "
+                                 "the fp64 vector peak on MI355X; flops = SURVEY 8(d) per-sample figure x N.  The kernels "
+                                 "are power-bound: the chip holds 1.9-2.1 of its 2.4 GHz under this load "
+                                 "(profiles/r02_dpp_engine_ab.txt, profiles/r03_sq_counters_n1.json)",
                          "algorithmic_bytes": dom["bytes"],
                          "per_kernel_tflops": {k_: v["flops"] / (v["ms"] * 1e-3) * 1e-12 for k_, v in per_launch.items()},
                          "hbm": {"achieved": dom["bytes"] / (dom["ms"] * 1e-3) * 1e-9,
