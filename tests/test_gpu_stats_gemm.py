@@ -158,3 +158,28 @@ def test_k_below_the_threshold_and_small_n_use_the_per_component_kernel(be):
         np.testing.assert_array_equal(fast, slow)
     with pytest.raises(Exception):
         be.configure("no_such_key", 1.0)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_sweep_every_dimension_from_8_to_64(be, seed):
+    """every sample dimension the form exists for -- exact and zero-padded kernel units -- with random K >= 17
+    (complete and ragged last groups of 32), ragged N, VB and Gaussian Rao-Blackwell kinds, weighted or not"""
+    rs = np.random.RandomState(100 + seed)
+    for D in range(8, 65):
+        K = int(rs.choice([17, 31, 32, 33, 48, 49, 64, int(rs.randint(17, 90))]))
+        N = int(rs.randint(16384, 24000))
+        mu, cov, w = mk(K, D, 3000 + 7 * D + seed)
+        x, _ = draw(mu, cov, w, N, 11 + seed)
+        sw = rs.uniform(0.5, 1.5, N) if rs.rand() < 0.5 else None
+        if rs.rand() < 0.5:
+            cs, _ = vb_set(mu, cov, D, K, D + K)
+            mode = 0
+        else:
+            cs = gauss_set(mu, cov, w)[0]
+            mode = 1
+        fast, slow = both_forms(be, x, cs, mode, sample_w=sw)
+        assert not np.array_equal(fast, slow), ("the common-shift form did not run", D, K, N)
+        try:
+            scaled_close(fast, slow, K, D, 1e-11)
+        except AssertionError as exc:
+            raise AssertionError("D=%d K=%d N=%d mode=%d: %s" % (D, K, N, mode, exc))
