@@ -742,8 +742,36 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
         dma_barrier();
     }
 
+    // The SL sample slices of a column group add their accumulators through LDS (the tile buffers are free: the
+    // loop's last barrier is behind every read and every copy), slice by slice in ascending order -- a fixed order,
+    // so the sums stay bit-reproducible -- and slice 0 publishes ONE partial vector per chunk.
+    if constexpr (SL > 1) {
+        static_assert((size_t)CGW * 2 * C * 256 * sizeof(double) <= CF::LDS_BYTES, "slice reduction does not fit the LDS");
+        double *red = xs + (size_t)cg * (R * C * 256) + lane;
+        for (int s = 1; s < SL; ++s) {
+            if (sl == s) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) red[((r * C + c) * 4 + reg) * 64] = acc[r][c][reg];
+            }
+            __syncthreads();
+            if (sl == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) acc[r][c][reg] += red[((r * C + c) * 4 + reg) * 64];
+            }
+            __syncthreads();
+        }
+        if (sl != 0) return;
+    }
     // accumulator layout of v_mfma_f64_16x16x4_f64: D[row = (lane >> 4) + 4 reg][col = lane & 15]
-    double *out = b.partials + ((size_t)(chunk * SL + sl) * b.K) * CF::MSP;
+    double *out = b.partials + ((size_t)chunk * b.K) * CF::MSP;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -794,7 +822,7 @@ extern "C" void PMC_UNIT_NAME_X(pmc_stats_gemm_config_d, PMC_D, PMC_PADDED)(int 
 {
     using CF = GemmCfg<D_>;
     *cols_per_wg = CF::ENABLED ? CF::C * CF::CGW : 0;
-    *slices = CF::SL;
+    *slices = 1;                                           // (the sample slices are summed inside the kernel)
     *msp = CF::MSP;
     *wgs_per_cu = CF::WGS_PER_CU;
 }
