@@ -275,13 +275,18 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  * then be NULL.  Ask pmc_estep_is_fused(), do not re-derive the rule.  Otherwise the call is
  * pmc_responsibilities followed by pmc_sufficient_stats through d_u (and d_scratch / d_vsums for Student-t).
  *
- * From 17 components on (compiled dimensions 8 ... 64, N >= 16384) the statistics half first runs in its
+ * From 21 components on (groups of 32 at least 63 % full; compiled dimensions 8 ... 64; N * ceil(K / 32) >= 524288)
+ * the statistics half first runs in its
  * component x monomial form: moments about ONE shift c common to all components (the midrange of their means) are a
  * plain matrix product U^T Z on v_mfma_f64_16x16x4_f64, re-centred to the components' own shifts on the device.  A
  * component whose weighted mean turns out further than sqrt(limit) of its own standard deviations from c (default
  * limit 1000: at most ~3 of the 16 digits lost in the re-centring) sends the call back to the per-component-shift
  * kernel of pmc_sufficient_stats, on the device, without a host round trip.  pmc_configure() moves both knobs:
  *   "stats_common_shift_min_k"  (default 17; a huge value switches the form off)
+ *   "stats_common_shift_min_fill" (default 0.63: K >= 0.63 * 32 * ceil(K / 32) -- a group of 32 components costs
+ *                                the same however few it holds, so K = 33 ... 40 stays with the per-component kernel)
+ *   "stats_common_shift_min_n"  (default 524288 samples per 32 components: below, the form's three extra launches
+ *                                cost more than it saves; never below 16384 samples)
  *   "stats_common_shift_limit"  (default 1000; 0 switches the form off)
  * pmc_sufficient_stats itself always takes its moments about the pack's own shifts.
  */

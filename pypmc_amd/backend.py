@@ -140,7 +140,8 @@ class HipBackend(object):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def configure(self, key, value):
-        """pmc_configure: library options ("stats_common_shift_min_k", "stats_common_shift_limit")."""
+        """pmc_configure: library options ("stats_common_shift_min_k", "stats_common_shift_min_n",
+        "stats_common_shift_limit")."""
         _lib.check(self.lib.pmc_configure(key.encode(), float(value)), "pmc_configure")
 
     def kernel_timing(self, on=True):

@@ -255,6 +255,14 @@ __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__
 // coordinate) from the common shift sends the call back to the per-component-shift kernel.
 int g_gemm_min_k = 17;
 double g_gemm_limit = 1000.0;
+// ... and from g_gemm_min_n samples per 32 components on: the form costs three launches more (reduce, re-centre, the
+// skipped fallback pair) and its own prologue, ~35 us that pay back at 6.7e-8 ms per sample and 32 components
+// (scripts/gemm_crossover.py, D = 20: N = 262144, K = 32: 0.133 against 0.110 ms; N = 4e6: 1.09 against 1.32)
+long long g_gemm_min_n = 524288;
+// ... and only if the groups of 32 components are filled well enough: a group costs the same whether it holds 1 or 32
+// (one row block is no cheaper than two: the B operands dominate then), so K = 33 ... 40 runs 4-11 % slower than the
+// per-component kernel at D = 20 and K = 41 36 % faster (scripts/gemm_crossover.py ksweep, profiles/r03_gemm_crossover.txt)
+double g_gemm_min_fill = 0.63;
 
 // totals[k][m] = sum over the nce partial vectors, in a fixed order: thread = monomial (coalesced rows of 64),
 // wavefront w of the workgroup takes the partial vectors w, w + 4, ... in ascending order, the four are added in
@@ -1108,7 +1116,8 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
     hipError_t e;
     int *ctl = nullptr;
     int counted = 1;
-    if (kind >= 0 && gemm_available(ks) && K >= g_gemm_min_k && N >= 16384 && g_gemm_limit > 0.0) {
+    if (kind >= 0 && gemm_available(ks) && K >= g_gemm_min_k && g_gemm_limit > 0.0 && N >= 16384 &&
+        (long long)N * ceil_div(K, 32) >= g_gemm_min_n && (double)K >= g_gemm_min_fill * 32.0 * (double)ceil_div(K, 32)) {
         // The common-shift form first (k_stats_gemm, pmc_stats.hip); the per-component-shift kernel below then
         // returns at once unless the a-posteriori test of k_gemm_convert asks for it.
         if (((uintptr_t)d_u & 15u) != 0) return fail(PMC_EINVAL, "pmc_estep: d_u must be 16-byte aligned");
@@ -1174,6 +1183,16 @@ int pmc_configure(const char *key, double value)
     if (std::strcmp(key, "stats_common_shift_min_k") == 0) {
         if (!(value >= 1.0 && value <= 1e9)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 1", key);
         g_gemm_min_k = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "stats_common_shift_min_fill") == 0) {
+        if (!(value >= 0.0 && value <= 1.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [0, 1]", key);
+        g_gemm_min_fill = value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "stats_common_shift_min_n") == 0) {
+        if (!(value >= 0.0 && value <= 9e18)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
+        g_gemm_min_n = (long long)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "stats_common_shift_limit") == 0) {

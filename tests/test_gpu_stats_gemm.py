@@ -16,9 +16,13 @@ pytestmark = pytest.mark.gpu
 def be():
     from pypmc_amd.backend import HipBackend
     b = HipBackend()
+    b.configure("stats_common_shift_min_n", 0)          # the form from 16384 samples on (default: where it pays)
+    b.configure("stats_common_shift_min_fill", 0)       # ... and for any K >= 17 (default: groups of 32 well filled)
     yield b
+    b.configure("stats_common_shift_min_fill", 0.63)
     b.configure("stats_common_shift_limit", 1000.0)
     b.configure("stats_common_shift_min_k", 17)
+    b.configure("stats_common_shift_min_n", 524288)
 
 
 @pytest.fixture(scope="module")
@@ -158,6 +162,20 @@ def test_k_below_the_threshold_and_small_n_use_the_per_component_kernel(be):
         np.testing.assert_array_equal(fast, slow)
     with pytest.raises(Exception):
         be.configure("no_such_key", 1.0)
+    # the default thresholds: 524288 samples per 32 components, groups of 32 at least 63 % full
+    be.configure("stats_common_shift_min_n", 524288)
+    be.configure("stats_common_shift_min_fill", 0.63)
+    try:
+        for K, N, runs in ((32, 300000, False), (64, 300000, True), (32, 600000, True), (20, 600000, False),
+                           (21, 600000, True), (40, 300000, False), (41, 300000, True)):
+            mu, cov, w = mk(K, D, 44)
+            x, _ = draw(mu, cov, w, N, 45)
+            cs, _ = vb_set(mu, cov, D, K, 46)
+            fast, slow = both_forms(be, x, cs, 0)
+            assert np.array_equal(fast, slow) != runs, (K, N)
+    finally:
+        be.configure("stats_common_shift_min_n", 0)
+        be.configure("stats_common_shift_min_fill", 0)
 
 
 @pytest.mark.parametrize("seed", [0, 1])
