@@ -315,9 +315,10 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
  * two-kernel path bit for bit.  d_u (K*ceil(N/64)*64 doubles) is required, d_vsums (2 K) for Student-t;
  * d_stats, d_scalars, d_workspace as for pmc_estep.
  *
- * pmc_importance_weights_emit goes one step further for a Gaussian proposal whose update is known to follow (every
+ * pmc_importance_weights_emit goes one step further for a proposal whose update is known to follow (every
  * component alive, the update's sample weights = these importance weights): the weighting pass itself leaves
- * u_nk = w_n rho_nk (pmc.pyx:23-43, :188) in d_u (pmc_tile_buffer_len(N, K) doubles, the layout
+ * u_nk = w_n rho_nk (pmc.pyx:23-43, :188) [Student-t: w_n rho_nk gamma_nk, pmc.pyx:602-610, and in d_vsums (2 K) the
+ * two sums per component pmc_responsibilities documents] in d_u (pmc_tile_buffer_len(N, K) doubles, the layout
  * pmc_responsibilities writes) -- the forms are parked there during the pass and replaced behind it, each read once,
  * with the row maximum and log-sum-exp the pass has anyway -- and pmc_estep_from_u reduces them to d_stats
  * (pmc_sufficient_stats' layout; the fast common-shift form where it applies, see pmc_estep).  No separate
@@ -325,10 +326,10 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
  * Agrees with pmc_estep_from_tiles to rounding (the log-sum-exp is the streaming one of the weighting pass).
  */
 int64_t pmc_maha_tiles_size(int64_t N, int K);
-int pmc_importance_weights_emit(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+int pmc_importance_weights_emit(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                                 const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                 double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
-                                double *d_u, void *stream);
+                                double *d_u, double *d_vsums, void *stream);
 int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, const double *d_u,
                      double *d_stats, void *d_workspace, void *stream);
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,

@@ -82,7 +82,8 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _vp]),
     "pmc_importance_weights_keep": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp,
                                            _vp, _vp, _vp, _vp]),
-    "pmc_importance_weights_emit": (_int, [_vp, _i64, _int, _vp, _int, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_importance_weights_emit": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _vp]),
     "pmc_estep_from_u": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pmc_estep_from_tiles": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
                                     _vp]),

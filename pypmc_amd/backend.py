@@ -69,8 +69,9 @@ class Responsibilities(object):
     the update follows (``importance_weights(..., emit=True)``), together with what they belong to.
     ``gaussian_pmc(..., responsibilities=...)`` reduces them to the statistics without any responsibility kernel."""
 
-    def __init__(self, data, N, comps, weights):
+    def __init__(self, data, N, comps, weights, vsums=None):
         self.data, self.N, self.K, self.comps, self.weights = data, int(N), int(comps.K), comps, weights
+        self.vsums = vsums            # Student-t: the 2 K sums of the degree-of-freedom condition (device)
 
     def matches(self, comps_full, weights):
         """True for the very mixture (means, precisions, component weights, normalisations) and the very sample
@@ -78,7 +79,8 @@ class Responsibilities(object):
         c = self.comps
         same = comps_full is c or (comps_full.K == c.K and comps_full.kind == c.kind and
                                    np.array_equal(comps_full.mu, c.mu) and np.array_equal(comps_full.precision, c.precision)
-                                   and np.array_equal(comps_full.weight, c.weight) and np.array_equal(comps_full.c0, c.c0))
+                                   and np.array_equal(comps_full.weight, c.weight) and np.array_equal(comps_full.c0, c.c0)
+                                   and np.array_equal(comps_full.c3, c.c3))
         return same and weights is self.weights
 
 
@@ -275,10 +277,10 @@ class HipBackend(object):
                            pack=None, target_pack=None, keep=False, emit=False):
         """pmc_importance_weights: w = exp(log P - log q) for a mixture target P (``target``) and proposal
         q (``comps``) in one pass over ``x``.  Returns dict(weights, scalars, out, log_target[, tiles | responsibilities]).
-        ``emit`` (Gaussian proposal, compiled dimensions, every component alive): the pass also leaves
-        u = w rho for the update (``Responsibilities``; pmc_importance_weights_emit)."""
-        if emit and not keep and sample_w is None and comps.kind == PMC_KIND_GAUSS and comps.D <= 64 \
-                and comps.ld == comps.K and bool((comps.weight != 0).all()):
+        ``emit`` (Gauss / Student-t proposal, compiled dimensions, every component alive): the pass also leaves
+        u = w rho [gamma] for the update (``Responsibilities``; pmc_importance_weights_emit)."""
+        if emit and not keep and sample_w is None and comps.kind in (PMC_KIND_GAUSS, PMC_KIND_STUDENT_T) \
+                and comps.D <= 64 and comps.ld == comps.K and bool((comps.weight != 0).all()):
             return self._importance_weights_emit(x, comps, target, want_out, want_log_target, pack, target_pack)
         x = self.asdevice(x)
         N, D = x.shape
@@ -311,13 +313,14 @@ class HipBackend(object):
         scalars = self.zeros(NSCALARS)
         ws = self._workspace(N, max(comps.K, target.K), D)
         u = self.empty(max(int(self.lib.pmc_tile_buffer_len(N, comps.K)), 1))      # the caller's: outlives this call
+        vsums = self.zeros(2 * comps.K) if comps.kind == PMC_KIND_STUDENT_T else None
         _lib.check(self._timed(
             "pmc_importance_weights_emit[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights_emit,
-            self._p(x), N, D, self._p(pack), comps.K, self._p(target_pack), target.K, target.kind,
-            self._p(out), self._p(lt), self._p(weights), self._p(scalars), self._p(ws), self._p(u), self._stream()),
-            "pmc_importance_weights_emit")
+            self._p(x), N, D, self._p(pack), comps.K, comps.kind, self._p(target_pack), target.K, target.kind,
+            self._p(out), self._p(lt), self._p(weights), self._p(scalars), self._p(ws), self._p(u), self._p(vsums),
+            self._stream()), "pmc_importance_weights_emit")
         return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=None,
-                    responsibilities=Responsibilities(u, N, comps, weights))
+                    responsibilities=Responsibilities(u, N, comps, weights, vsums))
 
     def estep_from_u(self, x, comps, resp, out=None):
         """pmc_estep_from_u: the statistics of responsibilities a weighting pass left behind (``Responsibilities``).
@@ -331,6 +334,8 @@ class HipBackend(object):
         flat = out if out is not None else self.zeros(nflat)
         assert flat.numel() == nflat
         flat[:NSCALARS] = 0.
+        if resp.vsums is not None:
+            flat[NSCALARS + K * ps:] = resp.vsums
         _lib.check(self._timed(
             "pmc_estep_from_u", self.lib.pmc_estep_from_u, self._p(x), N, D, self._p(self.pack(comps)), K, comps.kind,
             self._p(resp.data), self._p(flat[NSCALARS:]), self._p(self._workspace(N, K, D)), self._stream()),

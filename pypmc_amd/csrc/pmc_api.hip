@@ -878,7 +878,8 @@ int pmc_mixture_logpdf(const double *d_x, int64_t N, int D, const double *d_pack
 static int importance_weights_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                                    const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                    double *d_log_target_out, double *d_weights, const double *d_sample_w,
-                                   double *d_scalars, void *d_workspace, double *d_maha_tiles, double *d_u, void *stream)
+                                   double *d_scalars, void *d_workspace, double *d_maha_tiles, double *d_u,
+                                   double *d_vsums, void *stream)
 {
     if (N < 0 || K < 1 || K_target < 1 || !d_pack || !d_target_pack)
         return fail(PMC_EINVAL, "pmc_importance_weights: bad N/K/pack");
@@ -898,6 +899,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         a.pack2 = d_target_pack; a.K2 = K_target; a.log_target_out = d_log_target_out;
         a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_maha_tiles; a.u = d_u;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
+        if (d_u && kind == PMC_KIND_STUDENT_T) a.vpartials = (double *)((char *)d_workspace + scalar_partials_bytes(N));
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D),
                 8.0 * N * (D + 1 + (d_maha_tiles ? K : 0) + (d_u ? K : 0)));
         StreamScratch scratch(st);
@@ -916,6 +918,18 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         hipError_t e = ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
+    if (d_u && kind == PMC_KIND_STUDENT_T) {
+        if (N == 0) {
+            hipError_t e0 = hipMemsetAsync(d_vsums, 0, sizeof(double) * 2 * (size_t)K, st);
+            if (e0 != hipSuccess) return hipfail(e0, "hipMemsetAsync");
+        } else {
+            hipLaunchKernelGGL(k_finish_vsums, dim3((unsigned)(2 * K)), dim3(256), 0, st,
+                               (const double *)((char *)d_workspace + scalar_partials_bytes(N)), ceil_div(N, PMC_TILE), K,
+                               d_vsums);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hipfail(e, "k_finish_vsums launch");
+        }
+    }
     if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
     return PMC_OK;
 }
@@ -927,7 +941,7 @@ int pmc_importance_weights_keep(const double *d_x, int64_t N, int D, const doubl
 {
     return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
                                    d_log_target_out, d_weights, d_sample_w, d_scalars, d_workspace, d_maha_tiles, nullptr,
-                                   stream);
+                                   nullptr, stream);
 }
 
 int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
@@ -936,20 +950,23 @@ int pmc_importance_weights(const double *d_x, int64_t N, int D, const double *d_
                            double *d_scalars, void *d_workspace, void *stream)
 {
     return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
-                                   d_log_target_out, d_weights, d_sample_w, d_scalars, d_workspace, nullptr, nullptr, stream);
+                                   d_log_target_out, d_weights, d_sample_w, d_scalars, d_workspace, nullptr, nullptr, nullptr,
+                                   stream);
 }
 
-int pmc_importance_weights_emit(const double *d_x, int64_t N, int D, const double *d_pack, int K,
+int pmc_importance_weights_emit(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                                 const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                 double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
-                                double *d_u, void *stream)
+                                double *d_u, double *d_vsums, void *stream)
 {
     if (!d_u) return fail(PMC_EINVAL, "pmc_importance_weights_emit: d_u is NULL");
+    if (kind == PMC_KIND_STUDENT_T && (!d_vsums || !d_workspace))
+        return fail(PMC_EINVAL, "pmc_importance_weights_emit: Student-t needs d_vsums and d_workspace");
     if (D > PMC_MAX_DIM)
         return fail(PMC_EINVAL, "pmc_importance_weights_emit: compiled dimensions only (D <= %d); keep the Mahalanobis "
                                 "forms (pmc_importance_weights_keep) and use pmc_estep_from_tiles", PMC_MAX_DIM);
-    return importance_weights_impl(d_x, N, D, d_pack, K, PMC_KIND_GAUSS, d_target_pack, K_target, target_kind, d_out,
-                                   d_log_target_out, d_weights, nullptr, d_scalars, d_workspace, nullptr, d_u, stream);
+    return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
+                                   d_log_target_out, d_weights, nullptr, d_scalars, d_workspace, nullptr, d_u, d_vsums, stream);
 }
 
 int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, const double *d_u,

@@ -477,11 +477,27 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         const double em = exp(m_first), inv_denom = 1. / denom;
         double *ut = a.u + (size_t)(n >> 6) * a.K * 64 + (threadIdx.x & 63);
         cdouble *pk = (cdouble *)a.pack + (size_t)(a.K - 1) * dm.STRIDE + dm.DT;
+        double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)(n >> 6) * a.K * 2 : nullptr;
         for (int k = a.K - 1; k >= 0; --k, pk -= dm.STRIDE) {               // last written first: still in L2
             double expo;
-            const double v = component_value<D, KIND>(ut[(size_t)k * 64], pk, expo);
+            const double maha = ut[(size_t)k * 64];
+            const double v = component_value<D, KIND>(maha, pk, expo);
             const double e = exp_clamped(max_f64(v - m_first, -1075.0), EC);
-            ut[(size_t)k * 64] = swv * (((e * em) * pk[4]) * inv_denom);
+            const double wr = swv * (((e * em) * pk[4]) * inv_denom);
+            if constexpr (KIND == PMC_KIND_STUDENT_T) {
+                // gamma and the two sums of the degree-of-freedom condition, as k_resp / k_resp_tiles form them
+                const double nu = pk[3];
+                const double gamma = (nu + (double)a.dreal) / (nu + maha);          // pmc.pyx:610
+                ut[(size_t)k * 64] = wr * gamma;
+                const double s1 = wave_sum(wr);                                     // pmc.pyx:612 / :669
+                const double s2 = wave_sum(wr * log_pos(.5 * (maha + nu)));
+                if ((threadIdx.x & 63) == 0) {
+                    vp[2 * k] = s1;
+                    vp[2 * k + 1] = s2;
+                }
+            } else {
+                ut[(size_t)k * 64] = wr;
+            }
         }
     }
     if (a.partials != nullptr) block_scalars<5>(sc, a.partials);

@@ -235,7 +235,10 @@ def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=
 
     ``mahalanobis`` (extension): what ``ImportanceSampler.run_device(..., keep_mahalanobis=True)`` returned for
     these samples -- the Rao-Blackwellised update then reuses the Mahalanobis forms of the weighting pass
-    instead of evaluating the proposal a second time, as the reference does (pmc.pyx:23-43)."""
+    instead of evaluating the proposal a second time, as the reference does (pmc.pyx:23-43).
+    ``responsibilities`` (extension): what ``run_device(..., prepare_update=True)`` returned -- u = w rho [gamma] left
+    behind by the weighting pass itself; the update is then the statistics kernel alone.  Both refuse any other
+    density, sample set or weights than the ones they were formed with (``ValueError``)."""
     assert samples is not None
     if isinstance(samples, np.ndarray):          # device-resident tensors pass through untouched
         samples = np.ascontiguousarray(samples, dtype=np.float64)
@@ -260,15 +263,18 @@ def _dof_condition(const):
 
 
 def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solver_steps=100,
-                  mindof=1e-5, maxdof=1e3, mincount=0, copy=True, backend=None, mahalanobis=None):
+                  mindof=1e-5, maxdof=1e3, mincount=0, copy=True, backend=None, mahalanobis=None,
+                  responsibilities=None):
     """Adapt a Student-t mixture ``density`` (means, covariances and -- unless
     ``dof_solver_steps`` is 0 -- degrees of freedom) to the (weighted) ``samples`` it proposed
-    (reference: pmc.pyx:499-739, same signature and semantics; ``mahalanobis``: see ``gaussian_pmc``)."""
+    (reference: pmc.pyx:499-739, same signature and semantics; ``mahalanobis``, ``responsibilities``: see
+    ``gaussian_pmc``)."""
     assert samples is not None
     if isinstance(samples, np.ndarray):
         samples = np.ascontiguousarray(samples, dtype=np.float64)
     density, live, stat_comps, stats, norm, renorm, shift = \
-        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis)
+        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis,
+                            responsibilities)
     _, S0g, M1, M2, V1, V2 = stats        # S0g = sum w rho gamma, V1 = sum w rho
     D = density.dim
     new = {}

@@ -123,11 +123,11 @@ class ImportanceSampler(object):
         ``keep_mahalanobis=True`` additionally returns ``mahalanobis``: the Mahalanobis forms of the samples
         under the proposal's components, kept on the device for ``gaussian_pmc / student_t_pmc(...,
         mahalanobis=...)`` (8 K bytes per sample).
-        ``prepare_update=True`` (Gaussian mixture proposal and mixture target): the weighting pass also leaves the
+        ``prepare_update=True`` (Gauss / Student-t mixture proposal and mixture target): the weighting pass also leaves the
         Rao-Blackwellised responsibilities of the update that follows, ``responsibilities`` in the result, for
         ``gaussian_pmc(samples, proposal, weights, ..., responsibilities=...)`` -- no responsibility kernel runs at
-        all; where that form does not apply (Student-t, dead components, D > 64) ``mahalanobis`` is returned
-        instead."""
+        all (likewise ``student_t_pmc``); where that form does not apply (dead components, D > 64) ``mahalanobis`` is
+        returned instead."""
         from ..density.mixture import MixtureDensity, component_set
         be = get_backend(self._backend)
         if store and not self.device:

@@ -61,13 +61,36 @@ def test_emit_matches_oracle_and_the_kept_forms(be, orc, D, K, N):
     assert not resp.matches(other, em["weights"])
 
 
+@pytest.mark.parametrize("D,K,N", [(2, 3, 1000), (5, 9, 257), (20, 32, 30000), (30, 8, 5000), (40, 24, 20000), (64, 3, 200)])
+def test_emit_student_t(be, orc, D, K, N):
+    """Student-t proposals: u = w rho gamma and the two degree-of-freedom sums, against the kept-forms path"""
+    mu, cov, w = mk(K, D, 950 + D + K)
+    x, _ = draw(mu, cov, w, N, 33)
+    dof = 3. + np.arange(K) % 5
+    prop = student_set(mu, cov, w, dof)[0]
+    target = gauss_set(*mk(3, D, 79))[0]
+    plain = be.importance_weights(x, prop, target, want_out=True)
+    em = be.importance_weights(x, prop, target, want_out=True, emit=True)
+    resp = em["responsibilities"]
+    assert resp is not None and resp.vsums is not None
+    for key in ("weights", "out", "scalars"):
+        np.testing.assert_array_equal(be.tohost(em[key]), be.tohost(plain[key]))
+    kept = be.importance_weights(x, prop, target, keep=True)
+    a = be.tohost(be.estep_from_u(x, prop, resp)["stats"])
+    b = be.tohost(be.estep_from_tiles(x, prop, kept["tiles"], sample_w=kept["weights"])["stats"])
+    ps = 1 + D + D * (D + 1) // 2
+    sa, sb = a[8:8 + K * ps].reshape(K, ps), b[8:8 + K * ps].reshape(K, ps)
+    scale = np.abs(sb).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(sa - sb) / scale).max() < 1e-11
+    np.testing.assert_allclose(a[8 + K * ps:], b[8 + K * ps:], rtol=1e-11, atol=1e-300)     # the dof sums
+    assert np.all(a[8 + K * ps:] != 0.)
+
+
 def test_emit_falls_back_where_it_does_not_apply(be):
     D, K, N = 6, 4, 500
     mu, cov, w = mk(K, D, 5)
     x, _ = draw(mu, cov, w, N, 6)
     target = gauss_set(*mk(2, D, 7))[0]
-    st = student_set(mu, cov, w, np.full(K, 5.))[0]
-    assert be.importance_weights(x, st, target, emit=True).get("responsibilities") is None      # Student-t
     wd = w.copy()
     wd[1] = 0.
     dead = gauss_set(mu, cov, wd)[0]
@@ -112,3 +135,30 @@ def test_front_end_iteration_without_a_responsibility_kernel(be):
     for ca, cb in zip(a.components, b.components):
         np.testing.assert_allclose(cb.mu, ca.mu, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(cb.sigma, ca.sigma, rtol=1e-9, atol=1e-12)
+
+
+def test_front_end_student_t_iteration(be):
+    """student_t_pmc(responsibilities=...) against student_t_pmc(mahalanobis=...): weights, means, covariances and the
+    adapted degrees of freedom"""
+    import pypmc_amd as pypmc
+    from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture
+    D, K, N = 6, 8, 80000
+    tmu, tcov, tw = mk(3, D, 12)
+    target = create_gaussian_mixture(tmu / 3., tcov, tw)
+    rs = np.random.RandomState(6)
+    which = np.arange(K) % 3
+    start = create_t_mixture(tmu[which] / 3. + rs.normal(0, 0.2, (K, D)), 1.5 * tcov[which], np.full(K, 6.))
+    results = []
+    for form in ("tiles", "emit"):
+        sampler = pypmc.sampler.importance_sampling.ImportanceSampler(target.evaluate, start,
+                                                                      rng=np.random.RandomState(101))
+        run = sampler.run_device(N, trace_sort=True, keep_mahalanobis=form == "tiles", prepare_update=form == "emit")
+        kw = dict(responsibilities=run["responsibilities"]) if form == "emit" else dict(mahalanobis=run["mahalanobis"])
+        assert (run["responsibilities"] is not None) == (form == "emit")
+        results.append(pypmc.mix_adapt.pmc.student_t_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"], **kw))
+    a, b = results
+    np.testing.assert_allclose(b.weights, a.weights, rtol=1e-11)
+    for ca, cb in zip(a.components, b.components):
+        np.testing.assert_allclose(cb.mu, ca.mu, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(cb.sigma, ca.sigma, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(cb.dof, ca.dof, rtol=1e-8)
