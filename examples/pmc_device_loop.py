@@ -5,11 +5,11 @@ N-sized array resident on the GPU.  D=40, K=128 Gaussian proposal, K_t=4 Gaussia
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/pmc_device_loop.py ...
 
 Per iteration: counts on the host (rng.multinomial), samples + origins on the device (pmc_propose),
-log P and log q + importance weights + perplexity sums in one pass that also keeps the proposal's Mahalanobis
-forms (pmc_importance_weights_keep), Rao-Blackwell responsibilities from those kept values and the
-sufficient statistics (pmc_estep_from_tiles), one all-reduce when several ranks run, K-sized update on the host.
+log P and log q + importance weights + perplexity sums in one pass that also leaves the Rao-Blackwell
+responsibilities of the update behind (pmc_importance_weights_emit), the sufficient statistics
+(pmc_estep_from_u), one all-reduce when several ranks run, K-sized update on the host.
 With a third argument the update evaluates the components again, as the reference does
-(pmc_responsibilities + pmc_sufficient_stats): same result, 1.4x the time at this shape.
+(pmc_responsibilities + the statistics): same result to rounding, 1.5x the time at this shape.
 """
 import os
 import sys
@@ -57,11 +57,12 @@ sampler = pypmc.sampler.importance_sampling.ImportanceSampler(target.evaluate, p
 for it in range(iters):
     torch.cuda.synchronize()
     t0 = time.time()
-    run = sampler.run_device(N, trace_sort=True, keep_mahalanobis=reuse)
+    run = sampler.run_device(N, trace_sort=True, prepare_update=reuse)
     torch.cuda.synchronize()
     t1 = time.time()
     pypmc.mix_adapt.pmc.gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"],
-                                     mincount=0, rb=True, copy=False, mahalanobis=run["mahalanobis"])
+                                     mincount=0, rb=True, copy=False, mahalanobis=run["mahalanobis"],
+                                     responsibilities=run["responsibilities"])
     torch.cuda.synchronize()
     t2 = time.time()
     S, L, Q = run["weight_sums"]
