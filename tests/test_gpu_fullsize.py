@@ -312,6 +312,41 @@ def test_offsets_beyond_32_bits(be):
     torch.cuda.empty_cache()
 
 
+def test_offsets_beyond_32_bits_common_shift_statistics(be):
+    """the same with K = 32: the statistics run as the component x monomial product (k_stats_gemm) over 2.4e9 sample
+    elements and 3.8e9 responsibilities (31 GB) -- against the per-component-shift kernel on the same u"""
+    import torch
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats
+    D, K, N = 20, 32, 120_000_000
+    rs = np.random.RandomState(1)
+    mu = rs.normal(0, 3, (K, D))
+    inv = np.tile(np.eye(D), (K, 1, 1))
+    ln = np.full(K, -0.5 * D * np.log(2 * np.pi))
+    w = np.full(K, 1. / K)
+    g = torch.Generator(device=be.device).manual_seed(2)
+    x = torch.randn(N, D, dtype=torch.float64, device=be.device, generator=g)
+    comp = torch.randint(0, K, (N,), device=be.device, generator=g)
+    x += torch.tensor(mu, device=be.device)[comp]
+    cs = ComponentSet(0, mu, inv, c0=ln, weight=w)
+    fast = be.estep(x, cs, 1)["stats"].cpu().numpy().copy()
+    be.configure("stats_common_shift_limit", 0.0)
+    try:
+        slow = be.estep(x, cs, 1)["stats"].cpu().numpy().copy()
+    finally:
+        be.configure("stats_common_shift_limit", 1000.0)
+    assert not np.array_equal(fast, slow)
+    a, b = split_stats(fast, K, D), split_stats(slow, K, D)
+    counts = torch.bincount(comp, minlength=K).cpu().numpy()
+    np.testing.assert_allclose(a[1], counts, rtol=1e-4)         # 32 random means: a few pairs are only ~2 sigma apart
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12)
+    for k in range(K):
+        assert np.abs(a[2][k] - b[2][k]).max() <= 1e-10 * (np.abs(b[2][k]).max() + np.sqrt(b[1][k] * np.abs(np.diag(b[3][k])).max()))
+        assert np.abs(a[3][k] - b[3][k]).max() <= 1e-10 * np.abs(np.diag(b[3][k])).max()
+    be.release()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("D,K", [(2, 32), (3, 17), (4, 8), (5, 32), (7, 24), (2, 3)])
 def test_fused_estep_many_rounds(be, D, K):
     """The one-kernel E-step where every workgroup loops over many rounds (LDS buffers reused behind barriers):
