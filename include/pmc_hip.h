@@ -270,7 +270,8 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  * pmc_responsibilities produce them -- without the public N x K matrices.
  *
  * For small sample dimensions (pmc_estep_is_fused() != 0: compiled dimension <= 7 and K <= 32 -- K <= 64 at
- * D = 1, K >= 9 from D = 5 on, where the two kernels are faster below -- VB or Gaussian Rao-Blackwell PMC)
+ * D = 1, K >= 9 from D = 5 on, where the two kernels are faster below -- VB, Gaussian Rao-Blackwell PMC, or
+ * Student-t Rao-Blackwell PMC at D = 3 ... 7)
  * ONE kernel does both and the N x K responsibilities never leave the compute units: d_u and d_scratch may
  * then be NULL.  Ask pmc_estep_is_fused(), do not re-derive the rule.  Otherwise the call is
  * pmc_responsibilities followed by pmc_sufficient_stats through d_u (and d_scratch / d_vsums for Student-t).

@@ -543,7 +543,9 @@ bool fused_eligible(const PmcKernelSet *ks, int K, int kind, int mode)
     if (ks->dim > PMC_FUSED_MAX_DIM || (K > PMC_FUSED_MAX_K && !fused_reg(ks->dim, K))) return false;
     if (ks->dim >= 5 && K < PMC_FUSED_MIN_K_FROM_D5) return false;
     if (mode == PMC_RESP_VB) return kind == PMC_KIND_VB;
-    return mode == PMC_RESP_PMC_RB && kind == PMC_KIND_GAUSS;
+    // (Student-t: the LDS form only, compiled dimensions 3 ... 7)
+    return mode == PMC_RESP_PMC_RB && (kind == PMC_KIND_GAUSS || (kind == PMC_KIND_STUDENT_T && !fused_reg(ks->dim, K) &&
+                                                                  pmc_freg_kqmax(ks->dim) == 0));
 }
 FusedGeom fused_geom(long long N, int K, int dim)
 {
@@ -682,8 +684,8 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     size_t total = stats > scal ? stats : scal;
     if (ks->dim <= PMC_FUSED_MAX_DIM && (K <= PMC_FUSED_MAX_K || fused_reg(ks->dim, K))) {
         const FusedGeom f = fused_geom(N > 0 ? N : 1, K, ks->dim);
-        const size_t fused = ((size_t)f.nchunks * K * pmc_stats_stride_c(ks->dim) + (size_t)f.grid * PMC_NSCALARS) *
-                             sizeof(double);
+        const size_t fused = ((size_t)f.nchunks * K * pmc_stats_stride_c(ks->dim) + (size_t)f.grid * PMC_NSCALARS +
+                              (size_t)f.grid * f.tpr * K * 2) * sizeof(double);        // + Student-t dof sums
         if (fused > total) total = fused;
     }
     return (int64_t)((total + 255) & ~(size_t)255);
@@ -1414,6 +1416,8 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     a.qs = g.qs; a.kq = g.kq; a.cw = g.cw; a.sample_w = d_sample_w; a.ntiles = g.ntiles; a.rounds_per_wg = g.rounds_per_wg; a.reg = g.reg;
     a.partials = (double *)d_workspace;
     a.spartials = a.partials + (size_t)g.nchunks * K * PSc;
+    a.vpartials = a.spartials + (size_t)g.grid * PMC_NSCALARS;
+    if (kind == PMC_KIND_STUDENT_T && !d_vsums) return fail(PMC_EINVAL, "pmc_estep: Student-t needs d_vsums");
     hipError_t e;
     {
         Timed t(T_FUSED, st, flops_pairs((double)N, K, D) + flops_stats((double)N, K, D), 8.0 * N * D);
@@ -1426,6 +1430,12 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
                        (const double *)a.partials, (int)g.nchunks, K, D, ks->dim, d_stats, (const int *)nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
+    if (kind == PMC_KIND_STUDENT_T) {
+        hipLaunchKernelGGL(k_finish_vsums, dim3((unsigned)(2 * K)), dim3(256), 0, st, (const double *)a.vpartials,
+                           (long long)g.grid * g.tpr, K, d_vsums);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hipfail(e, "k_finish_vsums launch");
+    }
     return finish_scalars(a.spartials, g.grid, d_scalars, st);
 }
 

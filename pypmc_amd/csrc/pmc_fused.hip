@@ -104,6 +104,13 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
     }
     if (threadIdx.x < 64) zero[threadIdx.x] = 0.0;                 // (the first barrier of a round orders it)
     double sc_a = 0.0;                                             // VB: E[log q(Z)] part; PMC: sum w log q
+    // Student-t: the two sums of the degree-of-freedom condition (pmc.pyx:612, :659-679) of the wavefront's
+    // phase-A components, lane j keeping those of component k0 + j; log(nu / 2) of that component likewise
+    double vs1 = 0.0, vs2 = 0.0, lognu2 = 0.0;
+    if constexpr (KIND == PMC_KIND_STUDENT_T) {
+        const int kk = k0 + lane < k1 ? k0 + lane : (k1 > k0 ? k1 - 1 : 0);
+        lognu2 = log(.5 * a.pack[(size_t)kk * STRIDE + D + T + 3]);
+    }
 
     const long long nrounds = (a.ntiles + TPR - 1) / TPR;
     const long long r0 = (long long)blockIdx.x * a.rounds_per_wg;
@@ -156,7 +163,8 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
                     ut[(size_t)k * 64] = e;
                 } else {
                     s += pk[D + T + 4] * e;                        // _regularize.pyx:79
-                    ut[(size_t)k * 64] = e;
+                    // (Student-t: a_nk stays parked -- the last pass recovers the Mahalanobis form from it)
+                    if constexpr (KIND != PMC_KIND_STUDENT_T) ut[(size_t)k * 64] = e;
                 }
             }
         }
@@ -189,8 +197,29 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
             cdouble *pk = (cdouble *)a.pack + (size_t)k0 * STRIDE;
             for (int k = k0; k < k1; ++k, pk += STRIDE) {
                 // exp(log q_k) = e exp(M) first: it underflows where the reference's does (pmc.pyx:39)
-                const double rho = ((ut[(size_t)k * 64] * em) * pk[D + T + 4]) * inv_denom;
-                ut[(size_t)k * 64] = swv * rho;
+                if constexpr (KIND == PMC_KIND_STUDENT_T) {
+                    // a = c0 + c1 log(1 + maha / nu) (student_t.pyx:159-164)  =>  L = log(1 + maha / nu) = (a - c0) / c1,
+                    // nu + maha = nu exp(L): gamma = (nu + D) / (nu + maha) (pmc.pyx:610) and
+                    // log((maha + nu) / 2) = log(nu / 2) + L (pmc.pyx:669) without keeping maha next to a.
+                    // L is exact to eps |a| / |c1| in absolute terms, which is its weight in both uses.
+                    const double v = ut[(size_t)k * 64];
+                    const double e = exp(v - M);
+                    const double rho = ((e * em) * pk[D + T + 4]) * inv_denom;
+                    const double wr = swv * rho;
+                    const double nu = pk[D + T + 3];
+                    const double L = (v - pk[D + T]) / pk[D + T + 1];
+                    const double gamma = (nu + (double)D) / (nu * exp(L));
+                    ut[(size_t)k * 64] = wr * gamma;
+                    const double s1 = wave_sum(wr);
+                    const double s2 = wave_sum(wr * (__shfl(lognu2, k - k0, 64) + L));
+                    if (lane == k - k0) {
+                        vs1 += s1;
+                        vs2 += s2;
+                    }
+                } else {
+                    const double rho = ((ut[(size_t)k * 64] * em) * pk[D + T + 4]) * inv_denom;
+                    ut[(size_t)k * 64] = swv * rho;
+                }
             }
             if (q == 0) sc_a += swv * lse;                         // pmc.pyx:388-391
         }
@@ -282,6 +311,14 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
                     }
                 }
             }
+        }
+    }
+    if constexpr (KIND == PMC_KIND_STUDENT_T) {
+        // one entry per (workgroup, tile slot): its QS wavefronts fill their component ranges
+        double *vp = a.vpartials + ((size_t)blockIdx.x * TPR + ta) * K * 2;
+        if (k0 + lane < k1) {
+            vp[2 * (k0 + lane)] = vs1;
+            vp[2 * (k0 + lane) + 1] = vs2;
         }
     }
     // scalars: one value per workgroup
@@ -570,6 +607,7 @@ extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_fused_d, PMC_D, PMC_PADDED)(int
     if (a.reg) return hipErrorInvalidValue;
     switch (kind) {
     case PMC_KIND_GAUSS: return launch_fused_k<PMC_KIND_GAUSS>(nch, a, grid, st);
+    case PMC_KIND_STUDENT_T: return launch_fused_k<PMC_KIND_STUDENT_T>(nch, a, grid, st);
     case PMC_KIND_VB: return launch_fused_k<PMC_KIND_VB>(nch, a, grid, st);
     default: return hipErrorInvalidValue;
     }

@@ -175,6 +175,7 @@ struct PmcArgsF {
     const double *sample_w;
     double *partials;     // gridDim.x * (PMC_F_WAVES / cw) * K * pmc_stats_stride_c(Dcompiled)
     double *spartials;    // gridDim.x * PMC_NSCALARS
+    double *vpartials;    // Student-t: gridDim.x * (PMC_F_WAVES / qs) * K * 2 per-(workgroup, tile slot) sums of v1, v2
     long long ntiles;
     int rounds_per_wg;
     int reg;              // 1: register-resident form (k_estep_reg): qs wavefronts x kq components per tile

@@ -263,7 +263,8 @@ def test_fused_estep_vs_oracle(be, orc, D, K, N, weighted):
     fusable = int(dp <= 7 and not (dp >= 5 and K < 9))    # otherwise pmc_estep is the two kernels (still tested here)
     assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_VB, 0) == fusable
     assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 1) == fusable
-    assert be.lib.pmc_estep_is_fused(K, D, 1, 1) == 0 and be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 2) == 0
+    assert be.lib.pmc_estep_is_fused(K, D, 1, 1) == int(fusable and dp >= 3)       # Student-t: the LDS form only
+    assert be.lib.pmc_estep_is_fused(K, D, PMC_KIND_GAUSS, 2) == 0
     mu, cov, w = mk(K, D, 900 + D + K)
     x, _ = draw(mu, cov, w, N, 19)
     rs = np.random.RandomState(D * K + N)
@@ -307,6 +308,19 @@ def test_fused_estep_vs_oracle(be, orc, D, K, N, weighted):
     np.testing.assert_allclose(M1, np.einsum('n,nk,nki->ki', swv, rho, d), rtol=1e-9, atol=1e-10)
     M2ref = np.einsum('n,nk,nki,nkj->kij', swv, rho, d, d)
     np.testing.assert_allclose(M2, M2ref, rtol=1e-9, atol=1e-10 * max(1.0, np.abs(M2ref).max()))
+    # Student-t PMC (pmc.pyx:602-691): u = w rho gamma and the two sums of the degree-of-freedom condition -- in the
+    # one-kernel form gamma and log((maha + nu) / 2) are recovered from the parked a_nk -- against the two kernels
+    dof = 2.5 + (np.arange(K) % 6) * 1.5
+    ts = student_set(mu, cov, w, dof)[0]
+    fused = be.tohost(be.estep(x, ts, 1, sample_w=sw)["stats"]).copy()
+    two = be.tohost(be.estep(x, ts, 1, sample_w=sw, want_r=True)["stats"])
+    ps = 1 + D + D * (D + 1) // 2
+    a, b = fused[8:8 + K * ps].reshape(K, ps), two[8:8 + K * ps].reshape(K, ps)
+    scale = np.abs(b).max(axis=1, keepdims=True) + 1e-300
+    assert (np.abs(a - b) / scale).max() < 1e-11, "Student-t statistics, one kernel against two"
+    np.testing.assert_allclose(fused[8 + K * ps:], two[8 + K * ps:], rtol=1e-11, atol=1e-300)
+    assert abs(fused[3] - two[3]) <= 1e-12 * abs(two[3])                          # sum w log q
+    np.testing.assert_array_equal(be.tohost(be.estep(x, ts, 1, sample_w=sw)["stats"]), fused)
 
 
 @pytest.mark.parametrize("D,K", [(1, 3), (2, 5), (2, 32), (3, 4), (5, 9), (7, 32), (8, 5)])
