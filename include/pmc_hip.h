@@ -289,6 +289,12 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *   "stats_common_shift_min_n"  (default 524288 samples per 32 components: below, the form's three extra launches
  *                                cost more than it saves; never below 16384 samples)
  *   "stats_common_shift_limit"  (default 1000; 0 switches the form off)
+ *   "estep_grouped_responsibilities" (default 1): with the common-shift statistics the responsibility half can run in
+ *                                groups of 16 components -- every u_nk written once, nothing parked in HBM, no
+ *                                normalisation pass; the per-(sample, group) factors w_n exp(M_g - M) / s are left to the
+ *                                statistics kernel, which multiplies its weight operand with them (VB and Gaussian
+ *                                Rao-Blackwell PMC).  0 never, 1 where it is faster (compiled D <= 16; D = 20, 32, 40
+ *                                from K = 64 on), 2 always.  The workspace holds the factors (8 ceil(K/16) bytes per sample).
  * pmc_sufficient_stats itself always takes its moments about the pack's own shifts.
  */
 int pmc_configure(const char *key, double value);

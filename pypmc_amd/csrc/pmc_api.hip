@@ -20,6 +20,7 @@
 #define PMC_DECL_UNIT(d, p) \
     extern "C" hipError_t pmc_launch_logpdf_d##d##_p##p(int, int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t);   \
+    extern "C" hipError_t pmc_launch_resp_groups_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t);       \
     extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);                                        \
     extern "C" hipError_t pmc_launch_propose_d##d##_p##p(const PmcArgsP &, unsigned, hipStream_t);         \
@@ -42,7 +43,7 @@ PMC_DIM_LIST(PMC_DECL_X, PMC_DECL_XP)
 namespace {
 
 #define PMC_SET(d, p) \
-    {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, \
+    {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, &pmc_launch_resp_groups_d##d##_p##p, \
      &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p, \
      &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p, &pmc_launch_stats_gemm_d##d##_p##p, \
      &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0, 0}
@@ -147,6 +148,7 @@ const PmcKernelSet *big_kernels_for(int D)
     pmc_big_stats_config(D, &ks->stats_nsub, &ks->stats_waves);
     ks->logpdf = &pmc_launch_logpdf_d0_p0;
     ks->resp = &pmc_launch_resp_d0_p0;
+    ks->resp_groups = nullptr;
     ks->stats = &pmc_launch_big_stats;
     ks->config = nullptr;
     ks->propose = &pmc_launch_propose_big;
@@ -263,6 +265,18 @@ long long g_gemm_min_n = 524288;
 // (one row block is no cheaper than two: the B operands dominate then), so K = 33 ... 40 runs 4-11 % slower than the
 // per-component kernel at D = 20 and K = 41 36 % faster (scripts/gemm_crossover.py ksweep, profiles/r03_gemm_crossover.txt)
 double g_gemm_min_fill = 0.63;
+// pmc_estep's responsibilities in groups of 16 with their factors left to k_stats_gemm (k_resp_groups): 0 never,
+// 1 where it pays, 2 wherever the common-shift statistics run.  Where it pays (scripts/resp_groups_ab.py matrix,
+// profiles/r03_resp_groups.txt; responsibilities + statistics, per 2e6 samples): compiled D <= 16 at any K (-2 ... -19 %),
+// D = 20, 32, 40 from K = 64 on (-2 ... -6 %: the parked traffic of k_resp costs clock there); it loses at D = 24, 30, 48,
+// 64 (+2 ... +14 %: 25-40 more registers than k_resp) and is neutral at D = 20, K = 32.
+int g_resp_groups = 1;
+bool resp_groups_pays(int dim, int K)
+{
+    if (g_resp_groups != 1) return g_resp_groups == 2;
+    return dim <= 16 || (K >= 64 && (dim == 20 || dim == 32 || dim == 40));
+}
+
 
 // totals[k][m] = sum over the nce partial vectors, in a fixed order: thread = monomial (coalesced rows of 64),
 // wavefront w of the workgroup takes the partial vectors w, w + 4, ... in ascending order, the four are added in
@@ -334,6 +348,22 @@ __global__ __launch_bounds__(256) void k_gemm_convert(const double *__restrict__
         out[p] = v;
     }
     if (far) ctl[PMC_CTL_REDO] = 1;                       // (benign race: every writer stores 1)
+}
+
+// The common-shift form was refused and u still lacks the factors k_resp_groups left for k_stats_gemm to apply:
+// u_nk *= f_n,group(k), in place, so that the per-component-shift kernel finds what k_resp would have written.
+__global__ __launch_bounds__(256) void k_apply_scale(double *__restrict__ u, const double *__restrict__ gscale,
+                                                     long long ntiles, int K, const int *__restrict__ ctl)
+{
+    if (ctl[PMC_CTL_REDO] == 0) return;                   // (a small grid: the launch is there in every call)
+    const int G = (K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
+    const long long total = ntiles * K * 64;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long tk = idx >> 6;                     // tile * K + k
+        const long long tile = tk / K;
+        const int k = (int)(tk - tile * K);
+        u[idx] *= gscale[(tile * G + k / PMC_RESP_GROUP) * 64 + (idx & 63)];
+    }
 }
 
 // N = 1, D = 1: stats[k] = (u_k, u_k d, u_k d^2), d = x - mu_k   (u tile-major: one tile, lane 0)
@@ -513,7 +543,14 @@ GemmGeom gemm_geom(long long N, int K, const PmcKernelSet *ks)
     g.grid = (unsigned)(g.nchunks * nsub);
     return g;
 }
-// workspace of a statistics call: [region shared by the two forms' partial sums | centre (Dc doubles) | control block]
+// does pmc_estep take the common-shift statistics for this call?  (pmc_configure's knobs)
+bool gemm_selected(const PmcKernelSet *ks, long long N, int K, int kind)
+{
+    return kind >= 0 && gemm_available(ks) && K >= g_gemm_min_k && g_gemm_limit > 0.0 && N >= 16384 &&
+           N * ceil_div(K, 32) >= g_gemm_min_n && (double)K >= g_gemm_min_fill * 32.0 * (double)ceil_div(K, 32);
+}
+// workspace of a statistics call: [region shared by the two forms' partial sums | centre (Dc doubles) | control block |
+// factors of k_resp_groups: ceil(N / 64) x ceil(K / 16) x 64 doubles]
 size_t stats_region_bytes(long long N, int K, const PmcKernelSet *ks)
 {
     const StatsGeom g = stats_geom(N > 0 ? N : 1, K, ks);
@@ -528,6 +565,11 @@ size_t stats_region_bytes(long long N, int K, const PmcKernelSet *ks)
 size_t stats_tail_bytes(const PmcKernelSet *ks)
 {
     return gemm_available(ks) ? (((size_t)ks->dim * sizeof(double) + 255) & ~(size_t)255) + 256 : 0;
+}
+size_t gscale_bytes(long long N, int K, const PmcKernelSet *ks)
+{
+    if (!gemm_available(ks) || !ks->resp_groups) return 0;
+    return (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * (size_t)ceil_div(K, PMC_RESP_GROUP) * 64 * sizeof(double);
 }
 
 // fused E-step launch geometry (pmc_fused.hip)
@@ -678,7 +720,7 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
-    const size_t stats = stats_region_bytes(N, K, ks) + stats_tail_bytes(ks);
+    const size_t stats = stats_region_bytes(N, K, ks) + stats_tail_bytes(ks) + gscale_bytes(N, K, ks);
     const size_t scal = scalar_partials_bytes(N) +
                         (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
     size_t total = stats > scal ? stats : scal;
@@ -822,7 +864,8 @@ static int finish_scalars(const double *partials, long long nblocks, double *d_s
 }
 
 static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K,
-                                 const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind);
+                                 const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind,
+                                 const double *d_gscale = nullptr);
 
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                             int max_init_zero, double *d_out, double *d_individual, int64_t ld,
@@ -1107,8 +1150,10 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
 
 // kind: what d_pack describes (pmc_kind) when the caller is an E-step and the fast common-shift form may be tried;
 // -1: the per-component-shift kernel, always (the public pmc_sufficient_stats)
+// d_gscale: factors k_resp_groups left to be applied to d_u (NULL: d_u is complete); only with the common-shift form
 static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K,
-                                 const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind)
+                                 const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind,
+                                 const double *d_gscale)
 {
     if (N < 0 || K < 1 || !d_pack || !d_u || !d_stats || !d_workspace)
         return fail(PMC_EINVAL, "pmc_sufficient_stats: bad argument");
@@ -1135,8 +1180,8 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
     hipError_t e;
     int *ctl = nullptr;
     int counted = 1;
-    if (kind >= 0 && gemm_available(ks) && K >= g_gemm_min_k && g_gemm_limit > 0.0 && N >= 16384 &&
-        (long long)N * ceil_div(K, 32) >= g_gemm_min_n && (double)K >= g_gemm_min_fill * 32.0 * (double)ceil_div(K, 32)) {
+    if (d_gscale && !gemm_selected(ks, N, K, kind)) return fail(PMC_EINVAL, "statistics: factors without the common-shift form");
+    if (gemm_selected(ks, N, K, kind)) {
         // The common-shift form first (k_stats_gemm, pmc_stats.hip); the per-component-shift kernel below then
         // returns at once unless the a-posteriori test of k_gemm_convert asks for it.
         if (((uintptr_t)d_u & 15u) != 0) return fail(PMC_EINVAL, "pmc_estep: d_u must be 16-byte aligned");
@@ -1152,7 +1197,7 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
             PmcArgsG a;
             std::memset(&a, 0, sizeof(a));
             a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.kind = kind; a.limit_prior = 4.0 * g_gemm_limit;
-            a.center = center; a.K = K; a.u = d_u; a.partials = gpart;
+            a.center = center; a.K = K; a.u = d_u; a.gscale = d_gscale; a.partials = gpart;
             a.ntiles = gg.ntiles; a.nchunks = gg.nchunks; a.tiles_per_chunk = gg.tiles_per_chunk;
             a.ngroups = gg.ngroups; a.ncs = gg.ncs; a.ctl = ctl;
             e = ks->stats_gemm(a, gg.grid, st);
@@ -1168,6 +1213,16 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
                                ks->gemm_msp, d_pack, stride, (const double *)center, g_gemm_limit, d_stats, ctl);
             e = hipGetLastError();
             if (e != hipSuccess) return hipfail(e, "k_gemm_convert launch");
+        }
+        if (d_gscale) {
+            // should the form be refused, the per-component kernel below needs u complete
+            Timed t(T_STATS, st, 0.0, 0.0, 0);
+            const long long total_u = gg.ntiles * (long long)K * 64;
+            const long long blocks = ceil_div(total_u, 256);
+            hipLaunchKernelGGL(k_apply_scale, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (double *)d_u,
+                               d_gscale, gg.ntiles, K, (const int *)ctl);
+            e = hipGetLastError();
+            if (e != hipSuccess) return hipfail(e, "k_apply_scale launch");
         }
         counted = 0;                                       // the launches below continue this call's record
     }
@@ -1202,6 +1257,11 @@ int pmc_configure(const char *key, double value)
     if (std::strcmp(key, "stats_common_shift_min_k") == 0) {
         if (!(value >= 1.0 && value <= 1e9)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 1", key);
         g_gemm_min_k = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "estep_grouped_responsibilities") == 0) {
+        if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(PMC_EINVAL, "pmc_configure: %s is 0, 1 or 2", key);
+        g_resp_groups = (int)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "stats_common_shift_min_fill") == 0) {
@@ -1401,6 +1461,29 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     }
     if (!fused_eligible(ks, K, kind, mode)) {
         if (!d_u) return fail(PMC_EINVAL, "pmc_estep: d_u is required unless pmc_estep_is_fused()");
+        if (ks->resp_groups && gemm_selected(ks, N, K, kind) && resp_groups_pays(ks->dim, K) &&
+            ((kind == PMC_KIND_VB && mode == PMC_RESP_VB) || (kind == PMC_KIND_GAUSS && mode == PMC_RESP_PMC_RB))) {
+            // the statistics will run as the component x monomial product: responsibilities in groups of one row
+            // block, written once, their per-(sample, group) factors left to that kernel (k_resp_groups)
+            if (!d_x) return fail(PMC_EINVAL, "pmc_estep: d_x is NULL");
+            hipStream_t st = (hipStream_t)stream;
+            const long long ntiles = ceil_div(N, PMC_TILE), nblocks = ceil_div(ntiles, PMC_A_WAVES);
+            double *gscale = (double *)((char *)d_workspace + stats_region_bytes(N, K, ks) + stats_tail_bytes(ks));
+            PmcArgsA a;
+            std::memset(&a, 0, sizeof(a));
+            a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero; a.mode = mode;
+            a.ld = K; a.sample_w = d_sample_w; a.u = d_u; a.gscale = gscale; a.klds = PMC_RESP_GROUP;
+            // (the scalar partials share the front of the workspace with the statistics' partial sums: finished first)
+            a.partials = (double *)d_workspace;
+            {
+                Timed t(T_RESP, st, flops_pairs((double)N, K, D), 8.0 * N * (D + K + ceil_div(K, PMC_RESP_GROUP)));
+                hipError_t e = ks->resp_groups(kind, a, (unsigned)nblocks, st);
+                if (e != hipSuccess) return hipfail(e, "k_resp_groups launch");
+            }
+            int rc = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+            if (rc != PMC_OK) return rc;
+            return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind, gscale);
+        }
         int rc = pmc_responsibilities(d_x, N, D, d_pack, K, kind, mode, max_init_zero, d_sample_w, d_latent, d_u,
                                       d_scratch, d_vsums, nullptr, nullptr, nullptr, K, d_scalars, d_workspace, stream);
         if (rc != PMC_OK) return rc;

@@ -102,7 +102,9 @@ struct PmcArgsA {
     double *vpartials;    // Student-t: ntiles * K * 2 per-wavefront sums of v1, v2
     double *r, *log_rho, *exponent;
     double *partials;     // gridDim.x * PMC_NSCALARS
+    double *gscale;       // k_resp_groups: ntiles x ceil(K / 16) x 64 per-(sample, group of 16 components) factors
 };
+constexpr int PMC_RESP_GROUP = 16;   // components per group of k_resp_groups = one row block of k_stats_gemm
 
 // responsibilities from kept Mahalanobis forms (pmc_tiles.hip, one unit for all dimensions)
 struct PmcArgsT {
@@ -150,6 +152,7 @@ struct PmcArgsG {
     double *center;       // dreal doubles (device, output of workgroup 0): the common shift c
     int K;
     const double *u;      // tile-major ntiles x K x 64
+    const double *gscale; // NULL, or per-(sample, 16 components) factors u is still to be multiplied with (k_resp_groups)
     double *partials;     // [nchunks * slices][K][msp]: monomials 1 | d | d d^T lower triangle (row-major i, j <= i), d = x - c
     long long ntiles;
     int nchunks;          // multiple of 8 (XCD count)
@@ -212,6 +215,7 @@ struct PmcKernelSet {
     int stats_waves;      // wavefronts per workgroup in the statistics kernel
     hipError_t (*logpdf)(int kind, int kind2, const PmcArgsA &, unsigned grid, hipStream_t);
     hipError_t (*resp)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
+    hipError_t (*resp_groups)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);   // NULL: none (run-time-dimension unit)
     hipError_t (*stats)(const PmcArgsB &, unsigned grid, hipStream_t);
     void (*config)(int *nsub, int *waves);
     hipError_t (*propose)(const PmcArgsP &, unsigned grid, hipStream_t);

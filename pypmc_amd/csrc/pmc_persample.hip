@@ -724,6 +724,113 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
     if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_resp_groups: the responsibilities of pmc_estep when the statistics follow as k_stats_gemm -- nothing parked in
+// HBM, no normalisation pass.
+//
+// k_resp above needs a sample's row maximum and row sum before it can write a single u_nk, so every a_nk waits in a
+// parking place: LDS for 19 components, the output buffer for the rest -- written, read, written (e), read, written
+// (u): five transfers where one is algorithmic (6.0 against 4.2 GB per 1e7 samples at K = 32, 21 against 6.7 GB at
+// K = 64, where it costs the clock: 1.83 instead of 1.97 GHz).  Here the components go in groups of 16 -- one row block
+// of the statistics kernel's matrix product: a group is parked in LDS (8 KB per wavefront), gets its OWN maximum M_g
+// and sum, and its u'_nk = exp(a_nk - M_g) [times the component weight for the PMC kind] leaves at once, written
+// exactly once.  What is missing in u' is a factor per (sample, group),
+//     VB:   f_ng = w_n exp(M_g - M) / s           PMC:   f_ng = w_n exp(M_g) / (exp(lse) + tiny),
+// with M, s, lse combined across the groups as the streaming log-sum-exp does (one exp per GROUP, not per pair).
+// The factors go into a.gscale (8 ceil(K / 16) bytes per sample) and k_stats_gemm multiplies its weight operand with
+// them (one v_mul_f64 per 16 components x 4 samples).  E[log q(Z)] = sum_k r_k (a_k - M - log s) combines likewise:
+// sum_k e_k (a_k - M) = sum_g c_g (tb_g + (M_g - M) s_g), c_g = exp(M_g - M).
+// zero -> tiny of _update_r (variational.pyx:752) is applied to u' (a pair that underflows against its group's
+// maximum); a pair that only underflows against the row maximum gives 0 where the reference has tiny = 2.2e-308.
+// ---------------------------------------------------------------------------------------------
+template <int D, bool PADDED, int KIND>
+__global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_resp_groups(const PmcArgsA a)
+{
+    static_assert(KIND == PMC_KIND_VB || KIND == PMC_KIND_GAUSS, "k_resp_groups: VB and Gaussian Rao-Blackwell PMC");
+    constexpr int GS = PMC_RESP_GROUP;
+    const Dims<D> dm(a.dreal);
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * PMC_A_WAVES +
+                           __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long n = tile * 64 + lane;
+    const bool valid = n < a.N;
+    const bool tile_live = tile * 64 < a.N;               // wave-uniform
+    const int K = a.K, G = (K + GS - 1) / GS;
+
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    using Engine = MahaEngine<D, PADDED, pmc_use_mfma<D>()>;
+    if (!tile_live) {
+        Engine::idle(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);   // keep the workgroup's barriers / staging
+    } else {
+        Engine engine;
+        engine.load(a, tile, lane);
+        double *ut = a.u + (size_t)tile * K * 64 + lane;
+        double *gs = a.gscale + (size_t)tile * G * 64 + lane;
+        double *pl = dyn_lds + Engine::LDS_DOUBLES + (size_t)(threadIdx.x >> 6) * GS * 64 + lane;
+        const ExpConst EC;
+        double poison = 0.0;                              // NaN if a component value of the row is NaN
+        double Mrun = -DBL_MAX, srun = 0.0, tbrun = 0.0;
+        cdouble *pk = (cdouble *)a.pack;
+        engine.begin(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);
+        for (int g = 0; g < G; ++g) {
+            const int kb = g * GS, kn = (K - kb < GS) ? K - kb : GS;
+            // pass 1 of the group: a_nk -> LDS, the group's maximum
+            double Mg = -DBL_MAX;
+            for (int j = 0; j < kn; ++j, pk += dm.STRIDE) {
+                const double maha = engine.eval(pk, kb + j);
+                double expo = 0.0;
+                const double v = component_value<D, KIND>(maha, pk + dm.DT, expo);
+                Mg = max_f64(v, Mg);
+                poison = fma(0.0, v, poison);
+                pl[j * 64] = v;
+            }
+            // pass 2 of the group: u' = exp(a - M_g) [* w_k], written once
+            double sg = 0.0, tbg = 0.0;
+            auto expstep = [&](int j, double v) {
+                const double lr = max_f64(v - Mg, -1075.0);
+                const double e = exp_clamped(lr, EC);
+                if constexpr (KIND == PMC_KIND_VB) {
+                    tbg = fma(e, lr, tbg);
+                    sg += e;
+                    ut[(size_t)(kb + j) * 64] = zero_to_tiny(e);
+                } else {
+                    const double we = ((cdouble *)a.pack + (size_t)(kb + j) * dm.STRIDE)[dm.DT + 4] * e;
+                    sg += we;
+                    ut[(size_t)(kb + j) * 64] = we;
+                }
+            };
+            descend(kn, 0, [&](int j) { return pl[j * 64]; }, expstep);
+            // the group joins the row's running maximum / sum / bound term; its maximum waits in the factor's place
+            const double Mn = max_f64(Mg, Mrun);
+            const double cr = exp_clamped(max_f64(Mrun - Mn, -1075.0), EC), cg = exp_clamped(max_f64(Mg - Mn, -1075.0), EC);
+            if constexpr (KIND == PMC_KIND_VB)
+                tbrun = cr * fma(max_f64(Mrun - Mn, -1075.0), srun, tbrun) + cg * fma(max_f64(Mg - Mn, -1075.0), sg, tbg);
+            srun = cr * srun + cg * sg;
+            Mrun = Mn;
+            gs[(size_t)g * 64] = Mg;
+        }
+        const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+        const double swv = valid ? sw + poison : 0.0;
+        if constexpr (KIND == PMC_KIND_VB) {
+            // variational.pyx:748-755, :1003-1013
+            const double norm_inv = 1. / srun;
+            sc[0] = swv * fma(tbrun, norm_inv, log_any(norm_inv));
+            const double f = swv * norm_inv;
+            for (int g = 0; g < G; ++g)
+                gs[(size_t)g * 64] = f * exp_clamped(max_f64(gs[(size_t)g * 64] - Mrun, -1075.0), EC);
+        } else {
+            // pmc.pyx:36-41; dead components' zeros take part in the row maximum of the reference (max_init_zero): the
+            // log-sum-exp is the same number whichever maximum it is taken about
+            const double lse = log_any(srun) + Mrun;      // _regularize.pyx:81
+            const double f = swv / (exp(lse) + TINY);
+            for (int g = 0; g < G; ++g) gs[(size_t)g * 64] = f * exp(gs[(size_t)g * 64]);
+            sc[3] = swv * lse;
+        }
+    }
+    if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
+}
+
 template <int KIND, int KIND2> hipError_t launch_logpdf_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
 {
     constexpr size_t lds = sizeof(double) * MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES;
@@ -745,7 +852,34 @@ template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, h
     return hipGetLastError();
 }
 
+template <int KIND> hipError_t launch_resp_groups_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
+                                             (size_t)PMC_A_WAVES * PMC_RESP_GROUP * 64);
+    if constexpr (lds > 65536) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resp_groups<D_, P_, KIND>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (once != hipSuccess) return once;
+    }
+    hipLaunchKernelGGL((k_resp_groups<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_resp_groups_d, PMC_D, PMC_PADDED)(int kind, const PmcArgsA &a,
+                                                                                  unsigned grid, hipStream_t st)
+{
+#if PMC_D == 0
+    return hipErrorNotSupported;
+#else
+    switch (kind) {
+    case PMC_KIND_GAUSS: return launch_resp_groups_k<PMC_KIND_GAUSS>(a, grid, st);
+    case PMC_KIND_VB: return launch_resp_groups_k<PMC_KIND_VB>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+#endif
+}
 
 // kind2: component family of the second (target) mixture of pmc_importance_weights; ignored without one
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_d, PMC_D, PMC_PADDED)(int kind, int kind2, const PmcArgsA &a,

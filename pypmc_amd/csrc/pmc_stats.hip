@@ -421,7 +421,8 @@ template <int D> struct GemmCfg {
     static constexpr int NCS = (NT + C * CGW - 1) / (C * CGW);
     static constexpr int XT = 64 * ROWD;                   // doubles per x tile
     static constexpr int UPIECE = 130;                     // a 1-KiB DMA piece (2 components x 64 samples) + 16 bytes
-    static constexpr int UT = 16 * UPIECE;                 // doubles per u tile (32 components)
+    static constexpr int UT = 17 * UPIECE;                 // doubles per u tile: 32 components + the piece of the factors
+                                                           // k_resp_groups left to be applied (2 row blocks x 64 samples)
     static constexpr size_t LDS_BYTES = sizeof(double) * (2 * NS * (XT + UT) + 64);     // + the common shift
     // workgroups that share a CU (LDS; their wavefronts' registers fit next to each other up to 3 per SIMD): two
     // that run out of step hide each other's barriers and pipeline refills
@@ -477,7 +478,8 @@ typedef double gd2 __attribute__((ext_vector_type(2)));
 typedef double gd2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // NRB = row blocks of 16 components that hold any (the last group of a K that is not a multiple of 32 may have one)
-template <int D, bool PADDED, int NRB>
+// SCALED: u comes from k_resp_groups and is still to be multiplied by a factor per (sample, row block)
+template <int D, bool PADDED, int NRB, bool SCALED>
 __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
 {
     using CF = GemmCfg<D>;
@@ -606,6 +608,9 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
     unsigned au[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) au[r] = us_addr + 8u * (unsigned)uoff[r];
+    // the factor of (row block r, this lane's sample): piece 16 of a tile, natural sample order; the 16 lanes of a
+    // sample read one address
+    const unsigned af = us_addr + 8u * (unsigned)(16 * UPIECE + 8 * g + gemm_row_base<SL>(sl));
 
     // the "1" of every row, both buffers (never overwritten: the staging writes data slots only)
     for (int row = tid; row < 2 * NS * 64; row += 64 * W) xs[row * ROWD + ONE] = 1.0;
@@ -654,7 +659,25 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
         }
     };
     const long long ulen = b.ntiles * (long long)b.K * 64;
+    const int gtot = (b.K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
+    const long long glen = b.ntiles * (long long)gtot * 64;
+    auto fdma = [&](long long t, double *ubuf) {           // the factors of the step's tiles: wavefront q takes tile q
+        if constexpr (SCALED) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                if (wave != q % W) continue;               // wave-uniform
+                if (t + q >= t1) {
+                    *(gd2 *)(ubuf + q * UT + 16 * UPIECE + 2 * lane) = gd2{0.0, 0.0};
+                    continue;
+                }
+                long long o = ((t + q) * gtot + 2 * group) * 64 + 2 * lane;
+                if (o > glen - 2) o = glen - 2;            // a group without a second row block: any finite factor
+                __builtin_amdgcn_global_load_lds((gvoid_t *)(b.gscale + o), (lvoid_t *)(ubuf + q * UT + 16 * UPIECE), 16, 0, 0);
+            }
+        }
+    };
     auto udma = [&](long long t, double *ubuf) {
+        fdma(t, ubuf);
 #pragma unroll
         for (int i = 0; i < NPU; ++i) {
             const int id = wave + i * W;
@@ -688,16 +711,19 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
     // ordinary pointers into a run-time buffer the compiler kept both sets and spilled accumulators).
     int buf = 0;
     unsigned dx = 8u * (unsigned)BUFX, du = 8u * (unsigned)BUFU;
+    unsigned af_cur = af;
     for (long long t = t0; t < t1; t += NS, buf ^= 1) {
         xload(t + NS);
         udma(t + NS, us + (buf ^ 1) * BUFU);
 
-        double ac[R], zc[C], an[R], f1n[C], f2n[C];
+        double ac[R], zc[C], an[R], f1n[C], f2n[C], fn[SCALED ? R : 1];
         auto fetch = [&](auto IDX) {
             constexpr int idx = decltype(IDX)::value, q = idx / JN, j = idx % JN;
             constexpr int XIMM = 8 * ((q * 64 + gemm_row_imm<SL>(j)) * ROWD);
             constexpr int UIMM = 8 * (q * UT + gemm_row_imm<SL>(j));
             static_for<0, R>([&](auto RR) { lds_read64<UIMM>(an[decltype(RR)::value], au[decltype(RR)::value]); });
+            if constexpr (SCALED)
+                static_for<0, R>([&](auto RR) { lds_read64<UIMM + 8 * 64 * decltype(RR)::value>(fn[decltype(RR)::value], af_cur); });
             static_for<0, C>([&](auto CC) {
                 lds_read64<XIMM>(f1n[decltype(CC)::value], a1[decltype(CC)::value]);
                 lds_read64<XIMM>(f2n[decltype(CC)::value], a2[decltype(CC)::value]);
@@ -707,8 +733,9 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
             lds_wait(an);
             lds_wait(f1n);
             lds_wait(f2n);
+            if constexpr (SCALED) lds_wait(fn);
 #pragma unroll
-            for (int r = 0; r < R; ++r) ac[r] = an[r];
+            for (int r = 0; r < R; ++r) ac[r] = SCALED ? an[r] * fn[r] : an[r];
 #pragma unroll
             for (int c = 0; c < C; ++c) zc[c] = f1n[c] * f2n[c];
         };
@@ -736,6 +763,7 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) au[r] += du;
+        af_cur += du;
         dx = 0u - dx;
         du = 0u - du;
         xstore(t + NS, xs + (buf ^ 1) * BUFX);
@@ -792,8 +820,13 @@ __global__ __launch_bounds__(64 * GemmCfg<D>::W) void k_stats_gemm(const PmcArgs
     extern __shared__ double xs[];
     const int nsub = b.ngroups * b.ncs;
     const int group = ((blockIdx.x >> 3) % nsub) / b.ncs;
-    if (b.K - group * 32 > 16) stats_gemm_run<D, PADDED, 2>(b, xs);
-    else stats_gemm_run<D, PADDED, 1>(b, xs);
+    if (b.gscale != nullptr) {
+        if (b.K - group * 32 > 16) stats_gemm_run<D, PADDED, 2, true>(b, xs);
+        else stats_gemm_run<D, PADDED, 1, true>(b, xs);
+    } else {
+        if (b.K - group * 32 > 16) stats_gemm_run<D, PADDED, 2, false>(b, xs);
+        else stats_gemm_run<D, PADDED, 1, false>(b, xs);
+    }
 }
 
 constexpr int NSUB_ = Blocking<D_>::NSUB;

@@ -253,14 +253,17 @@ def test_cfg5_full_loop_1p25e7_per_gpu(be, orc):
         old_mu = np.array([c.mu for c in old.components])
         if it == 1:
             # second iteration: the update reuses the component log-densities the weighting pass kept (12.8 GB
-            # here) -- and gives, bit for bit, what the update that evaluates the proposal again gives
+            # here) -- and gives what the update that evaluates the proposal again gives
             twice = pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=True)
             pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=False,
                                              mahalanobis=run["mahalanobis"])
-            np.testing.assert_array_equal(sampler.proposal.weights, twice.weights)
+            # (to rounding: at this shape the update that evaluates again runs its responsibilities in groups of 16
+            # with the factors applied by the statistics kernel, k_resp_groups -- one rounding more per pair; the
+            # bit-for-bit identity of k_resp and k_resp_tiles is tests/test_gpu_kernels.py::test_estep_from_kept_logpdf)
+            np.testing.assert_allclose(sampler.proposal.weights, twice.weights, rtol=1e-13)
             for a_, b_ in zip(sampler.proposal.components, twice.components):
-                np.testing.assert_array_equal(a_.mu, b_.mu)
-                np.testing.assert_array_equal(a_.sigma, b_.sigma)
+                np.testing.assert_allclose(a_.mu, b_.mu, rtol=1e-12, atol=1e-14)
+                np.testing.assert_allclose(a_.sigma, b_.sigma, rtol=1e-11, atol=1e-14)
             del twice
         else:
             pypmc.mix_adapt.pmc.gaussian_pmc(x, sampler.proposal, wts, origin, mincount=0, rb=True, copy=False)

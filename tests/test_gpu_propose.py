@@ -269,11 +269,13 @@ def test_pmc_update_reuses_the_mahalanobis_forms_of_the_weighting_pass(be, D, K)
     run3 = s3.run_device(20_000, trace_sort=True, keep_mahalanobis=True)
     plain = student_t_pmc(run3["samples"], s3.proposal, run3["weights"], backend=be)
     reuse = student_t_pmc(run3["samples"], s3.proposal, run3["weights"], backend=be, mahalanobis=run3["mahalanobis"])
-    np.testing.assert_array_equal(reuse.weights, plain.weights)
+    # (bitwise from D = 8 on; below, the plain update is the one-kernel Student-t E-step since round 3, which recovers
+    # gamma and the dof sums from the parked a_nk: to rounding)
+    check(reuse.weights, plain.weights)
     for a_, b_ in zip(reuse.components, plain.components):
-        np.testing.assert_array_equal(a_.mu, b_.mu)
-        np.testing.assert_array_equal(a_.sigma, b_.sigma)
-        assert a_.dof == b_.dof
+        check(a_.mu, b_.mu)
+        check(a_.sigma, b_.sigma)
+        assert a_.dof == b_.dof if D >= 8 else abs(a_.dof - b_.dof) <= 1e-8 * b_.dof
 
 
 def test_device_sampler_keeps_its_history_on_the_gpu(be):

@@ -18,7 +18,9 @@ def be():
     b = HipBackend()
     b.configure("stats_common_shift_min_n", 0)          # the form from 16384 samples on (default: where it pays)
     b.configure("stats_common_shift_min_fill", 0)       # ... and for any K >= 17 (default: groups of 32 well filled)
+    b.configure("estep_grouped_responsibilities", 2)    # ... with k_resp_groups in front of it at every dimension
     yield b
+    b.configure("estep_grouped_responsibilities", 1)
     b.configure("stats_common_shift_min_fill", 0.63)
     b.configure("stats_common_shift_limit", 1000.0)
     b.configure("stats_common_shift_min_k", 17)
@@ -62,7 +64,8 @@ def scaled_close(fast, slow, K, D, tol):
     """the sums of each component against the magnitude of that component's sums of the same order"""
     from pypmc_amd.mix_adapt._stats import split_stats
     a, b = split_stats(fast, K, D), split_stats(slow, K, D)
-    np.testing.assert_array_equal(a[0], b[0])                           # scalars come from k_resp: untouched
+    # scalars: E[log q(Z)] / sum w log q from k_resp_groups (combined over groups of 16) against k_resp's two passes
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-10, atol=1e-11)       # (the contract's tolerance on E[log q(Z)])
     assert_rel(a[1], b[1], rtol=1e-12, what="sum u")
     for k in range(K):
         s1 = np.abs(b[2][k]).max() + np.sqrt(np.abs(np.diag(b[3][k])).max() * max(b[1][k], 0.0))
@@ -114,11 +117,50 @@ def test_far_components_fall_back_to_the_per_component_kernel(be):
     mu = mu * 100.0
     x, _ = draw(mu, cov, w, N, 12)
     cs, _ = vb_set(mu, cov, D, K, 13)
-    fast, slow = both_forms(be, x, cs, 0)
-    np.testing.assert_array_equal(fast, slow)
     gs, _, _ = gauss_set(mu, cov, w)
-    fast, slow = both_forms(be, x, gs, 1)
-    np.testing.assert_array_equal(fast, slow)
+    be.configure("estep_grouped_responsibilities", 0)       # k_resp as ever: the fallback is the old path bit for bit
+    try:
+        fast, slow = both_forms(be, x, cs, 0)
+        np.testing.assert_array_equal(fast, slow)
+        fast, slow = both_forms(be, x, gs, 1)
+        np.testing.assert_array_equal(fast, slow)
+    finally:
+        be.configure("estep_grouped_responsibilities", 2)
+    # with the grouped responsibilities the refused form first completes u (u' x factor: one rounding more than
+    # k_resp's e / s) and then runs the same per-component kernel
+    for cset, mode in ((cs, 0), (gs, 1)):
+        fast, slow = both_forms(be, x, cset, mode)
+        scaled_close(fast, slow, K, D, 1e-13)
+
+
+def test_grouped_responsibilities_vs_oracle(be, orc):
+    """k_resp_groups + k_stats_gemm (the pmc_estep of the headline) against the oracle: VB statistics and
+    E[log q(Z)], Gaussian PMC statistics and sum w log q, K = 32 / 40 / 64 incl. a ragged last group of 16"""
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    for D, K, N in ((20, 32, 30000), (12, 56, 20000), (24, 64, 17000)):
+        mu, cov, w = mk(K, D, 60 + K)
+        x, _ = draw(mu, cov, w, N, 61)
+        rs = np.random.RandomState(K)
+        sw = rs.uniform(0.5, 1.5, N)
+        cs, (m, W, beta, nu, ln_pi, ln_lambda) = vb_set(mu, cov, D, K, 62)
+        ref = orc.vb_estep(x, sw, m, W, beta, nu, ln_pi, ln_lambda)
+        flat = be.tohost(be.estep(x, cs, 0, sample_w=sw)["stats"])
+        sc, S0, M1, M2, _, _ = split_stats(flat, K, D)
+        x_mean, S = centred_moments(S0, M1, M2, m)
+        assert_rel(S0, ref["N_comp"], rtol=1e-11, what="N_comp")
+        live = ref["N_comp"] > 1e-6
+        np.testing.assert_allclose(x_mean[live], ref["x_mean_comp"][live], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(S[live], ref["S"][live], rtol=1e-9, atol=1e-11)
+        assert abs(sc[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-11
+        gs, inv, ln = gauss_set(mu, cov, w)
+        rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+        flat = be.tohost(be.estep(x, gs, 1, sample_w=sw)["stats"])
+        sc, S0, M1, M2, _, _ = split_stats(flat, K, D)
+        np.testing.assert_allclose(S0, (sw[:, None] * rho).sum(axis=0), rtol=1e-10, atol=1e-300)
+        d = x[:, None, :] - mu[None]
+        np.testing.assert_allclose(M1, np.einsum('n,nk,nki->ki', sw, rho, d), rtol=1e-9, atol=1e-9)
+        lq = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)[0]
+        assert abs(sc[3] - (sw * lq).sum()) <= 1e-11 * abs((sw * lq).sum())
 
 
 def test_moderately_separated_components_keep_their_digits(be):
