@@ -86,8 +86,9 @@ int pmc_device_arch(int device, char *buf, size_t buflen);
    dimension, fully unrolled, with a sample's coordinates in registers; beyond it the run-time-dimension unit
    takes over (the reference's loops take any length, pypmc/tools/_linalg.pyx:32-37): the Mahalanobis forms and
    the second moments as 16 x 16 x 4 fp64 MFMA tiles, everything else the same kernels.  That unit keeps one
-   scratch of its own: pmc_mixture_logpdf / pmc_importance_weights allocate the N x K forms stream-ordered
-   (hipMallocAsync / hipFreeAsync on the caller's stream) unless the caller keeps them (d_maha_tiles). */
+   scratch of its own: pmc_mixture_logpdf / pmc_importance_weights hold the forms the caller does not keep
+   (d_maha_tiles) in a stream-ordered allocation of at most 256 MiB (hipMallocAsync / hipFreeAsync on the caller's
+   stream) and walk the samples in chunks that fit it (pmc_configure("big_dim_scratch_bytes", ...) moves the bound). */
 int pmc_max_dim(void);
 int pmc_max_compiled_dim(void);
 /* compiled kernel dimension used for D (>= D; D itself beyond pmc_max_compiled_dim()), or PMC_EINVAL if D is

@@ -649,6 +649,55 @@ struct StreamScratch {
     ~StreamScratch() { if (p) (void)hipFreeAsync(p, st); }
 };
 
+// Run-time-dimension unit (D > PMC_MAX_DIM): the per-sample kernel reads the Mahalanobis forms k_big_maha made.  Forms
+// the caller does not keep live in a stream-ordered scratch of BOUNDED size (advice r2: it was 8 N (K + K_target)
+// bytes, 10 GB at N = 1e7, K = 128, outside pmc_workspace_bytes and outside the caller's allocator): the samples go in
+// chunks of a multiple of 256 (one workgroup of the per-sample kernels, so block indices and tile buffers line up),
+// each chunk = k_big_maha [x 2] + k_logpdf<0> on pointers moved to the chunk.
+size_t g_big_scratch_bytes = 256u << 20;                  // pmc_configure("big_dim_scratch_bytes")
+hipError_t big_logpdf(const PmcKernelSet *ks, int kind, int kind2, const PmcArgsA &full, int D, hipStream_t st)
+{
+    const bool keep = full.atile != nullptr;
+    const int K = full.K, K2 = full.pack2 ? full.K2 : 0;
+    const size_t per_sample = sizeof(double) * ((keep ? 0 : K) + K2);
+    long long chunk = full.N;
+    if (per_sample > 0) {
+        chunk = (long long)(g_big_scratch_bytes / per_sample) / 256 * 256;
+        if (chunk < 256) chunk = 256;
+    }
+    StreamScratch scratch(st);
+    if (per_sample > 0) {
+        const long long cn = chunk < full.N ? chunk : full.N;
+        hipError_t em = scratch.get(sizeof(double) * ((keep ? 0 : (size_t)pmc_maha_tiles_size(cn, K)) +
+                                                      (K2 ? (size_t)pmc_maha_tiles_size(cn, K2) : 0)));
+        if (em != hipSuccess) return em;
+    }
+    for (long long n0 = 0; n0 < full.N; n0 += chunk) {
+        const long long n = (full.N - n0 < chunk) ? full.N - n0 : chunk;
+        PmcArgsA a = full;
+        a.x = full.x + n0 * D;
+        a.N = n;
+        if (full.out) a.out = full.out + n0;
+        if (full.log_target_out) a.log_target_out = full.log_target_out + n0;
+        if (full.individual) a.individual = full.individual + n0 * full.ld;
+        if (full.log_target) a.log_target = full.log_target + n0;
+        if (full.weights) a.weights = full.weights + n0;
+        if (full.sample_w) a.sample_w = full.sample_w + n0;
+        if (full.partials) a.partials = full.partials + (n0 / 256) * PMC_NSCALARS;
+        double *mt2 = (double *)scratch.p;
+        double *mt = keep ? full.atile + (n0 / 64) * K * 64 : mt2 + (K2 ? (size_t)pmc_maha_tiles_size(n, K2) : 0);
+        if (keep) a.atile = mt;
+        hipError_t em = big_maha(a.x, n, D, full.pack, K, mt, st);
+        if (em == hipSuccess && K2) em = big_maha(a.x, n, D, full.pack2, K2, mt2, st);
+        if (em != hipSuccess) return em;
+        a.mtile = mt;
+        a.mtile2 = K2 ? mt2 : nullptr;
+        em = ks->logpdf(kind, kind2, a, (unsigned)ceil_div(ceil_div(n, PMC_TILE), PMC_A_WAVES), st);
+        if (em != hipSuccess) return em;
+    }
+    return hipSuccess;
+}
+
 size_t scalar_partials_bytes(long long N)
 {
     const long long blocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
@@ -892,19 +941,7 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K, D),
                 8.0 * N * (D + 1 + (d_individual ? K : 0) + (d_maha_tiles ? K : 0)));
-        StreamScratch scratch(st);
-        if (ks->padded == 2) {
-            double *mt = d_maha_tiles;
-            if (!mt) {
-                hipError_t em = scratch.get(sizeof(double) * (size_t)pmc_maha_tiles_size(N, K));
-                if (em != hipSuccess) return hipfail(em, "hipMallocAsync (Mahalanobis forms)");
-                mt = (double *)scratch.p;
-            }
-            hipError_t em = big_maha(d_x, N, D, d_pack, K, mt, st);
-            if (em != hipSuccess) return hipfail(em, "k_big_maha launch");
-            a.mtile = mt;
-        }
-        hipError_t e = ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
+        hipError_t e = ks->padded == 2 ? big_logpdf(ks, kind, kind, a, D, st) : ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
@@ -947,20 +984,8 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         if (d_u && kind == PMC_KIND_STUDENT_T) a.vpartials = (double *)((char *)d_workspace + scalar_partials_bytes(N));
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D),
                 8.0 * N * (D + 1 + (d_maha_tiles ? K : 0) + (d_u ? K : 0)));
-        StreamScratch scratch(st);
-        if (ks->padded == 2) {
-            const size_t n1 = (size_t)pmc_maha_tiles_size(N, K), n2 = (size_t)pmc_maha_tiles_size(N, K_target);
-            hipError_t em = scratch.get(sizeof(double) * ((d_maha_tiles ? 0 : n1) + n2));
-            if (em != hipSuccess) return hipfail(em, "hipMallocAsync (Mahalanobis forms)");
-            double *mt2 = (double *)scratch.p;
-            double *mt = d_maha_tiles ? d_maha_tiles : mt2 + n2;
-            em = big_maha(d_x, N, D, d_pack, K, mt, st);
-            if (em == hipSuccess) em = big_maha(d_x, N, D, d_target_pack, K_target, mt2, st);
-            if (em != hipSuccess) return hipfail(em, "k_big_maha launch");
-            a.mtile = mt;
-            a.mtile2 = mt2;
-        }
-        hipError_t e = ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
+        hipError_t e = ks->padded == 2 ? big_logpdf(ks, kind, target_kind, a, D, st)
+                                       : ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_u && kind == PMC_KIND_STUDENT_T) {
@@ -1257,6 +1282,11 @@ int pmc_configure(const char *key, double value)
     if (std::strcmp(key, "stats_common_shift_min_k") == 0) {
         if (!(value >= 1.0 && value <= 1e9)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 1", key);
         g_gemm_min_k = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "big_dim_scratch_bytes") == 0) {
+        if (!(value >= 1.0 && value <= 1e15)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 1", key);
+        g_big_scratch_bytes = (size_t)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "estep_grouped_responsibilities") == 0) {

@@ -32,3 +32,33 @@ def test_sweep_big_dimensions(seed):
 def test_very_big_dimension():
     from pypmc_amd.backend import HipBackend
     fuzz_gpu.sweep(seed=3, rounds=1, be=HipBackend(), verbose=False, dims=[520, 1024], kmax=3, nmax=200)
+
+
+def test_big_dimension_scratch_is_bounded_and_chunked():
+    """D > 64: the Mahalanobis forms the caller does not keep live in a scratch of bounded size, the samples go in
+    chunks of a multiple of 256 -- same numbers, bit for bit, as one chunk (advice r2: the scratch was 8 N (K + K_t) bytes)"""
+    import numpy as np
+    from pypmc_amd.backend import HipBackend
+    from test_gpu_kernels import mk, draw, gauss_set
+    be = HipBackend()
+    D, K, N = 72, 5, 5003
+    mu, cov, w = mk(K, D, 4)
+    x, _ = draw(mu, cov, w, N, 5)
+    prop = gauss_set(mu, cov, w)[0]
+    target = gauss_set(*mk(2, D, 6))[0]
+    sw = np.random.RandomState(1).uniform(0.5, 1.5, N)
+
+    def run():
+        a = be.importance_weights(x, prop, target, sample_w=sw, want_out=True, want_log_target=True)
+        b = be.importance_weights(x, prop, target, keep=True)
+        c = be.logpdf(x, prop, want_individual=True, want_scalars=True, log_target=np.zeros(N))
+        return [be.tohost(t).copy() for t in (a["weights"], a["out"], a["log_target"], a["scalars"], b["weights"],
+                                              b["tiles"].data, c["out"], c["individual"], c["scalars"])]
+    whole = run()
+    be.configure("big_dim_scratch_bytes", 64 * 1024)            # 56 bytes per sample -> chunks of 1024 samples
+    try:
+        chunked = run()
+    finally:
+        be.configure("big_dim_scratch_bytes", 256 * 1024 * 1024)
+    for got, ref in zip(chunked, whole):
+        np.testing.assert_array_equal(got, ref)
