@@ -300,6 +300,17 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  */
 int pmc_configure(const char *key, double value);
 int pmc_estep_is_fused(int K, int D, int kind, int mode);
+/*
+ * pmc_estep_about is pmc_estep with the moments taken about other points than the components' own means:
+ * d_shift_pack (NULL = d_pack) is a pack -- e.g. from pmc_pack_means -- whose means are the shifts of d_stats.
+ * GaussianInference takes its moments about the previous iteration's x-bar_k this way: x-bar_k is bit-stable as
+ * soon as the responsibilities are (the reference's two passes have that property, variational.pyx:806-932), and
+ * the far-shift second pass of an update is one call.  Responsibilities, d_scalars and d_vsums do not depend on it.
+ */
+int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, int mode,
+                    int max_init_zero, const double *d_sample_w, const int64_t *d_latent, double *d_u,
+                    double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
+                    const double *d_shift_pack, void *stream);
 int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, int mode,
               int max_init_zero, const double *d_sample_w, const int64_t *d_latent, double *d_u,
               double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,

@@ -77,6 +77,8 @@ SIGNATURES = {
     "pmc_configure": (_int, [C.c_char_p, C.c_double]),
     "pmc_estep_is_fused": (_int, [_int, _int, _int, _int]),
     "pmc_estep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_estep_about": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp]),
     "pmc_maha_tiles_size": (_i64, [_i64, _int]),
     "pmc_mixture_logpdf_keep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp]),

@@ -437,16 +437,18 @@ class HipBackend(object):
         if shift is not None:
             # only the means of a pack matter to the statistics kernel: no matrices, no factorisations
             stats_pack = self._means_pack(shift, K, D)
-        if r is None and log_rho is None and expo is None and shift is None:
-            # the E-step proper: one call; for small D one kernel, the N x K matrix stays on chip
+        if r is None and log_rho is None and expo is None:
+            # the E-step proper: one call (pmc_estep_about: the moments about `shift` when given); for small D one
+            # kernel, the N x K matrix stays on chip
             fused = bool(self.lib.pmc_estep_is_fused(K, D, comps.kind, int(mode)))
             u = None if fused else self._tilebuf("u", N, K)
             scratch = self._tilebuf("scratch", N, K) if student else None
             _lib.check(self._timed(
-                "pmc_estep[fused]" if fused else "pmc_estep", self.lib.pmc_estep,
+                "pmc_estep[fused]" if fused else "pmc_estep", self.lib.pmc_estep_about,
                 self._p(x), N, D, self._p(pack), K, comps.kind, int(mode), int(bool(max_init_zero)),
                 self._p(sw), self._p(lat), self._p(u), self._p(scratch), self._p(vsums),
-                self._p(flat[NSCALARS:]), self._p(flat), self._p(ws), self._stream()), "pmc_estep")
+                self._p(flat[NSCALARS:]), self._p(flat), self._p(ws), self._p(stats_pack if shift is not None else None),
+                self._stream()), "pmc_estep")
             return dict(stats=flat, r=None, log_rho=None, exponent=None)
         u = self._tilebuf("u", N, K)
         scratch = self._tilebuf("scratch", N, K) if student else None

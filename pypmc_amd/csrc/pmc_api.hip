@@ -914,7 +914,7 @@ static int finish_scalars(const double *partials, long long nblocks, double *d_s
 
 static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K,
                                  const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind,
-                                 const double *d_gscale = nullptr);
+                                 const double *d_gscale = nullptr, const double *d_rpack = nullptr);
 
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                             int max_init_zero, double *d_out, double *d_individual, int64_t ld,
@@ -1176,9 +1176,10 @@ int pmc_responsibilities(const double *d_x, int64_t N, int D, const double *d_pa
 // kind: what d_pack describes (pmc_kind) when the caller is an E-step and the fast common-shift form may be tried;
 // -1: the per-component-shift kernel, always (the public pmc_sufficient_stats)
 // d_gscale: factors k_resp_groups left to be applied to d_u (NULL: d_u is complete); only with the common-shift form
+// d_rpack: the pack that holds the triangular factors (for the a-priori test) when d_pack only carries shifts (NULL: d_pack)
 static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K,
                                  const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind,
-                                 const double *d_gscale)
+                                 const double *d_gscale, const double *d_rpack)
 {
     if (N < 0 || K < 1 || !d_pack || !d_u || !d_stats || !d_workspace)
         return fail(PMC_EINVAL, "pmc_sufficient_stats: bad argument");
@@ -1221,7 +1222,8 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
             Timed t(T_STATS, st, flops_stats((double)N, K, D), 8.0 * N * (D + K));
             PmcArgsG a;
             std::memset(&a, 0, sizeof(a));
-            a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.kind = kind; a.limit_prior = 4.0 * g_gemm_limit;
+            a.x = d_x; a.N = N; a.dreal = D; a.pack = d_rpack ? d_rpack : d_pack; a.spack = d_pack; a.kind = kind;
+            a.limit_prior = 4.0 * g_gemm_limit;
             a.center = center; a.K = K; a.u = d_u; a.gscale = d_gscale; a.partials = gpart;
             a.ntiles = gg.ntiles; a.nchunks = gg.nchunks; a.tiles_per_chunk = gg.tiles_per_chunk;
             a.ngroups = gg.ngroups; a.ncs = gg.ncs; a.ctl = ctl;
@@ -1478,6 +1480,16 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
               double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
               void *stream)
 {
+    return pmc_estep_about(d_x, N, D, d_pack, K, kind, mode, max_init_zero, d_sample_w, d_latent, d_u, d_scratch, d_vsums,
+                           d_stats, d_scalars, d_workspace, nullptr, stream);
+}
+
+int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, int mode,
+                    int max_init_zero, const double *d_sample_w, const int64_t *d_latent, double *d_u,
+                    double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
+                    const double *d_shift_pack, void *stream)
+{
+    const double *d_spack = d_shift_pack ? d_shift_pack : d_pack;      // whose means the moments are taken about
     if (N < 0 || K < 1 || !d_pack || !d_stats || !d_scalars || !d_workspace)
         return fail(PMC_EINVAL, "pmc_estep: bad N/K/pack/stats/scalars/workspace");
     const PmcKernelSet *ks = kernels_for(D);
@@ -1512,12 +1524,12 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
             }
             int rc = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
             if (rc != PMC_OK) return rc;
-            return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind, gscale);
+            return sufficient_stats_impl(d_x, N, D, d_spack, K, d_u, d_stats, d_workspace, stream, kind, gscale, d_pack);
         }
         int rc = pmc_responsibilities(d_x, N, D, d_pack, K, kind, mode, max_init_zero, d_sample_w, d_latent, d_u,
                                       d_scratch, d_vsums, nullptr, nullptr, nullptr, K, d_scalars, d_workspace, stream);
         if (rc != PMC_OK) return rc;
-        return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind);
+        return sufficient_stats_impl(d_x, N, D, d_spack, K, d_u, d_stats, d_workspace, stream, kind, nullptr, d_pack);
     }
     if (!d_x) return fail(PMC_EINVAL, "pmc_estep: d_x is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -1527,6 +1539,7 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
     std::memset(&a, 0, sizeof(a));
     a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero;
     a.qs = g.qs; a.kq = g.kq; a.cw = g.cw; a.sample_w = d_sample_w; a.ntiles = g.ntiles; a.rounds_per_wg = g.rounds_per_wg; a.reg = g.reg;
+    a.shift_pack = d_shift_pack;
     a.partials = (double *)d_workspace;
     a.spartials = a.partials + (size_t)g.nchunks * K * PSc;
     a.vpartials = a.spartials + (size_t)g.grid * PMC_NSCALARS;

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(FW * 64, fused_min_waves(D)) void k_estep_fused(con
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = cb + CW * j;
-        const double *pk = a.pack + (size_t)(c < K ? c : 0) * STRIDE;
+        // (the moments are taken about the pack's means unless the caller names other points)
+        const double *pk = (a.shift_pack ? a.shift_pack : a.pack) + (size_t)(c < K ? c : 0) * STRIDE;
         coff[j] = c < K ? c * 64 : TPR * K * 64 - srow;            // beyond K: the zero slot, for every tile
         toff[j] = c < K ? K * 64 : 0;
         acc0[j] = 0.0;
@@ -412,6 +413,12 @@ __global__ __launch_bounds__(FW * 64, freg_min_waves(D, KQ)) void k_estep_reg(co
         cdouble *pks[KQ];
 #pragma unroll
         for (int j = 0; j < KQ; ++j) pks[j] = pb + slot[j];
+        // the points the moments are taken about: the components' means unless the caller names others
+        cdouble *sb = (cdouble *)(a.shift_pack ? a.shift_pack : a.pack);
+        asm volatile("" : "+s"(sb));
+        cdouble *sps[KQ];
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) sps[j] = sb + slot[j];
         {   // a NaN or infinite coordinate makes every a_nk NaN in the reference; exp_le0 would turn that into
             // zeros, so the sample's weight carries the NaN instead (0 * finite = 0 otherwise)
             double t = xv[0];
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(FW * 64, freg_min_waves(D, KQ)) void k_estep_reg(co
                 }
                 double d[D];
 #pragma unroll
-                for (int i = 0; i < D; ++i) d[i] = xv[i] - pks[j][i];
+                for (int i = 0; i < D; ++i) d[i] = xv[i] - sps[j][i];
                 acc[j][0] += u;
                 int p = 1 + D;
 #pragma unroll

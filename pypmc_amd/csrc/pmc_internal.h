@@ -145,8 +145,9 @@ struct PmcArgsG {
     const double *x;
     long long N;
     int dreal;
-    const double *pack;   // the components: their means give the common shift c (midrange per coordinate), their
-                          // triangular factors the a-priori test (kind >= 0)
+    const double *pack;   // the components: their triangular factors serve the a-priori test (kind >= 0)
+    const double *spack;  // the pack whose means are the components' own shifts (= pack unless the caller gave others):
+                          // they give the common shift c (midrange per coordinate) and the re-centring
     int kind;             // pmc_kind of `pack`, or -1: no a-priori test
     double limit_prior;
     double *center;       // dreal doubles (device, output of workgroup 0): the common shift c
@@ -179,6 +180,7 @@ struct PmcArgsF {
     double *partials;     // gridDim.x * (PMC_F_WAVES / cw) * K * pmc_stats_stride_c(Dcompiled)
     double *spartials;    // gridDim.x * PMC_NSCALARS
     double *vpartials;    // Student-t: gridDim.x * (PMC_F_WAVES / qs) * K * 2 per-(workgroup, tile slot) sums of v1, v2
+    const double *shift_pack;   // NULL, or a pack whose means are the points the moments are taken about (else: pack's)
     long long ntiles;
     int rounds_per_wg;
     int reg;              // 1: register-resident form (k_estep_reg): qs wavefronts x kq components per tile

@@ -523,9 +523,9 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
         int *farflag = (int *)(us + 2 * W * 64);
         if (tid == 0) *farflag = 0;
         const int j = lane < dreal ? lane : 0;
-        double l = b.pack[(size_t)(wave < b.K ? wave : 0) * STRIDE + j], h = l;
+        double l = b.spack[(size_t)(wave < b.K ? wave : 0) * STRIDE + j], h = l;
         for (int k = wave + W; k < b.K; k += W) {
-            const double m = b.pack[(size_t)k * STRIDE + j];
+            const double m = b.spack[(size_t)k * STRIDE + j];
             l = m < l ? m : l;
             h = m > h ? m : h;
         }
@@ -551,7 +551,7 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
                 const double rii = pk[D + i * D - i * (i - 1) / 2];
                 double s = rii * rii;
                 if (b.kind == PMC_KIND_VB) s *= pk[D + pmc_tri(D) + 1];          // c1 = nu_k
-                const double dlt = pk[i] - cen[i];
+                const double dlt = b.spack[(size_t)k * STRIDE + i] - cen[i];
                 far = far || dlt * dlt * s > b.limit_prior;
             }
             if (far) *farflag = 1;                         // (benign race: every writer stores 1)

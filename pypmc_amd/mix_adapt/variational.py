@@ -82,23 +82,31 @@ class GaussianInference(object):
                           c2=self.expectation_ln_pi,
                           c3=self.expectation_det_ln_lambda - D * np.log(2. * np.pi))
         be = get_backend(self._backend)
-        res = be.estep(self._data_dev, cs, PMC_RESP_VB, sample_w=self._weights_dev)
+        # The moments are taken about the previous E-step's x_mean_comp once there is one (else about m): x_mean_comp is
+        # then bit-stable as soon as the responsibilities are -- the property of the reference's two passes
+        # (variational.pyx:806-932: mean first, covariance about it) that its test_prune asserts through a bound that
+        # never decreases -- and a mean that wanders off its m_k needs no second pass in the following iterations.
+        prev = getattr(self, '_shift_prev', None)
+        shift = self.m
+        if prev is not None and prev.shape == self.m.shape and np.isfinite(prev).all():
+            shift = prev
+        res = be.estep(self._data_dev, cs, PMC_RESP_VB, sample_w=self._weights_dev, shift=None if shift is self.m else shift)
         flat = be.tohost(parallel.all_reduce_sum(res["stats"]))
         scalars, S0, M1, M2, _, _ = split_stats(flat, self.K, D)
         if not np.isfinite(S0).any():
             raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(S0))
-        shift = self.m
         if shift_is_far(S0, M1, M2):
             # a weighted mean far from its component's m_k (start values, the first iterations): the one-pass
             # moments about m_k would cancel; second pass about the mean just found, as the reference's two passes
             # (variational.pyx:806-932).  The decision is taken on the all-reduced sums: identical on every rank.
-            shift = np.where((S0 > 1e-200)[:, None], self.m + M1 / regularize(S0.copy())[:, None], self.m)
+            shift = np.where((S0 > 1e-200)[:, None], shift + M1 / regularize(S0.copy())[:, None], shift)
             res = be.estep(self._data_dev, cs, PMC_RESP_VB, sample_w=self._weights_dev, shift=shift)
             flat = be.tohost(parallel.all_reduce_sum(res["stats"]))
             scalars, S0, M1, M2, _, _ = split_stats(flat, self.K, D)
         self.N_comp = regularize(S0)
         self.inv_N_comp = 1. / self.N_comp
         self.x_mean_comp, self.S = centred_moments(self.N_comp, M1, M2, shift)
+        self._shift_prev = self.x_mean_comp.copy()
         if not np.isfinite(self.S).any():
             raise np.linalg.LinAlgError('Encountered inf or nan in update of sample covariance\n' + str(self.S))
         self._expectation_log_q_Z = float(scalars[0])
@@ -227,6 +235,8 @@ class GaussianInference(object):
                      'expectation_ln_pi', 'N_comp', 'nu0', 'nu', 'm0', 'm', 'S', 'W0', 'inv_W0', 'W',
                      'log_det_W', 'log_det_W0', 'x_mean_comp'):
             setattr(self, name, np.array(getattr(self, name))[keep])
+        if getattr(self, '_shift_prev', None) is not None:
+            self._shift_prev = self._shift_prev[keep]
         self.E_step()
 
     def run(self, iterations=1000, prune=1., rel_tol=1e-10, abs_tol=1e-5, verbose=False):

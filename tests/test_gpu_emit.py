@@ -162,3 +162,38 @@ def test_front_end_student_t_iteration(be):
         np.testing.assert_allclose(cb.mu, ca.mu, rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(cb.sigma, ca.sigma, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(cb.dof, ca.dof, rtol=1e-8)
+
+
+@pytest.mark.parametrize("D,K,N", [(2, 5, 3000), (5, 12, 5000), (7, 32, 4097), (12, 9, 2000), (20, 32, 30000), (24, 40, 17001)])
+def test_estep_about_other_points(be, orc, D, K, N):
+    """pmc_estep_about: the moments about points of the caller's choice (one-kernel forms, two kernels, common-shift
+    statistics) -- centred results equal to the E-step about the components' own means, and the oracle's"""
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    from test_gpu_stats_gemm import vb_set
+    be.configure("stats_common_shift_min_n", 0)
+    be.configure("stats_common_shift_min_fill", 0)
+    try:
+        mu, cov, w = mk(K, D, 70 + D)
+        x, _ = draw(mu, cov, w, N, 71)
+        cs, (m, W, beta, nu, ln_pi, ln_lambda) = vb_set(mu, cov, D, K, 72)
+        rs = np.random.RandomState(73)
+        shift = m + 0.3 * rs.normal(size=m.shape)
+        ref = orc.vb_estep(x, None, m, W, beta, nu, ln_pi, ln_lambda)
+        own = be.tohost(be.estep(x, cs, 0)["stats"]).copy()
+        other = be.tohost(be.estep(x, cs, 0, shift=shift)["stats"]).copy()
+        np.testing.assert_allclose(other[:8], own[:8], rtol=1e-12, atol=1e-300)          # scalars do not depend on it
+        a, b = split_stats(own, K, D), split_stats(other, K, D)
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-12)
+        xa, Sa = centred_moments(a[1], a[2], a[3], m)
+        xb, Sb = centred_moments(b[1], b[2], b[3], shift)
+        live = ref["N_comp"] > 1e-6
+        np.testing.assert_allclose(xb[live], xa[live], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(Sb[live], Sa[live], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(xb[live], ref["x_mean_comp"][live], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(Sb[live], ref["S"][live], rtol=1e-8, atol=1e-10)
+        # about the mean itself the first moments vanish and the second are the covariance
+        again = split_stats(be.tohost(be.estep(x, cs, 0, shift=xb)["stats"]), K, D)
+        assert np.abs(again[2][live] / again[1][live][:, None]).max() < 1e-10
+    finally:
+        be.configure("stats_common_shift_min_n", 524288)
+        be.configure("stats_common_shift_min_fill", 0.63)
