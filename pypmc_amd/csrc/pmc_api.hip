@@ -274,7 +274,8 @@ int g_resp_groups = 1;
 bool resp_groups_pays(int dim, int K)
 {
     if (g_resp_groups != 1) return g_resp_groups == 2;
-    return dim <= 16 || (K >= 64 && (dim == 20 || dim == 32 || dim == 40));
+    // measured per (D, K) with scripts/resp_groups_ab.py matrix (profiles/r03_resp_groups.txt)
+    return dim <= 16 || dim == 20 || dim == 32 || dim == 40 || (dim == 24 && K >= 128);
 }
 
 
@@ -703,6 +704,14 @@ size_t scalar_partials_bytes(long long N)
     const long long blocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
     return (size_t)(blocks > 0 ? blocks : 1) * PMC_NSCALARS * sizeof(double);
 }
+// k_resp_groups writes its factors while its scalar partials (front of the workspace, growing with N) are still live:
+// the factors start behind whichever is longer, the statistics' regions or those partials
+size_t gscale_offset(long long N, int K, const PmcKernelSet *ks)
+{
+    const size_t a = stats_region_bytes(N, K, ks) + stats_tail_bytes(ks);
+    const size_t b = (scalar_partials_bytes(N > 0 ? N : 1) + 255) & ~(size_t)255;
+    return a > b ? a : b;
+}
 
 }  // namespace
 
@@ -769,7 +778,7 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
-    const size_t stats = stats_region_bytes(N, K, ks) + stats_tail_bytes(ks) + gscale_bytes(N, K, ks);
+    const size_t stats = gscale_offset(N, K, ks) + gscale_bytes(N, K, ks);
     const size_t scal = scalar_partials_bytes(N) +
                         (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
     size_t total = stats > scal ? stats : scal;
@@ -1510,7 +1519,7 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
             if (!d_x) return fail(PMC_EINVAL, "pmc_estep: d_x is NULL");
             hipStream_t st = (hipStream_t)stream;
             const long long ntiles = ceil_div(N, PMC_TILE), nblocks = ceil_div(ntiles, PMC_A_WAVES);
-            double *gscale = (double *)((char *)d_workspace + stats_region_bytes(N, K, ks) + stats_tail_bytes(ks));
+            double *gscale = (double *)((char *)d_workspace + gscale_offset(N, K, ks));
             PmcArgsA a;
             std::memset(&a, 0, sizeof(a));
             a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero; a.mode = mode;

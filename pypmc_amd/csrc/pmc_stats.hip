@@ -631,15 +631,17 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
     // rows beyond the chunk or the array are clamped into it (their weights are zero); the array's very last
     // element of an odd-sized array is fetched one element early and picked from the pair's second half
     auto xload = [&](long long t) {
+        // (uniform 64-bit base + 32-bit lane offset: as 64-bit per-lane addresses these cost register pairs that spilled)
         const long long tt = t < t1 ? t : t0;
-        const long long base = tt * 64 * dreal;
+        const double *__restrict__ xt = b.x + tt * 64 * dreal;                // wave-uniform
+        const long long rem = total - tt * 64 * dreal - 2;                   // last legal pair start relative to xt
+        const int lim = rem > 0x7ffffff0ll ? 0x7ffffff0 : (int)rem;
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
             int n, jp;
             piece(i, n, jp);
-            long long o = base + (n * dreal + 2 * jp);
-            if (o > total - 2) o = total - 2;
-            xv[i] = *(const gd2u *)(b.x + o);
+            const int o = n * dreal + 2 * jp;
+            xv[i] = *(const gd2u *)(xt + (o < lim ? o : lim));
         }
     };
     auto xstore = [&](long long t, double *xbuf) {
@@ -670,12 +672,15 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
                     *(gd2 *)(ubuf + q * UT + 16 * UPIECE + 2 * lane) = gd2{0.0, 0.0};
                     continue;
                 }
-                long long o = ((t + q) * gtot + 2 * group) * 64 + 2 * lane;
-                if (o > glen - 2) o = glen - 2;            // a group without a second row block: any finite factor
-                __builtin_amdgcn_global_load_lds((gvoid_t *)(b.gscale + o), (lvoid_t *)(ubuf + q * UT + 16 * UPIECE), 16, 0, 0);
+                long long o = ((t + q) * gtot + 2 * group) * 64;                     // wave-uniform
+                // the array's very last group has no successor: its second half re-reads the group itself (rows discarded)
+                const int gl = o >= glen - 64 ? (2 * lane) & 63 : 2 * lane;
+                if (o > glen - 64) o = glen - 64;
+                __builtin_amdgcn_global_load_lds((gvoid_t *)(b.gscale + o + gl), (lvoid_t *)(ubuf + q * UT + 16 * UPIECE), 16, 0, 0);
             }
         }
     };
+    const int ulane = (lane >> 5) * 64 + 2 * (((lane & 31) & 0x13) | ((lane & 4) << 1) | ((lane & 8) >> 1));
     auto udma = [&](long long t, double *ubuf) {
         fdma(t, ubuf);
 #pragma unroll
@@ -689,10 +694,12 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
                 }
                 const long long tile = t + q;
                 // lane -> 16-byte chunk (component 2 p + (lane >> 5), sample pair lane & 31 with bits 2 and 3 swapped)
-                const int pp = lane & 31, sp = (pp & 0x13) | ((pp & 4) << 1) | ((pp & 8) >> 1);
-                long long o = (tile * b.K + kmin + 2 * p) * 64 + (lane >> 5) * 64 + 2 * sp;
-                if (o > ulen - 2) o = ulen - 2;            // components beyond K: any finite values, rows discarded
-                __builtin_amdgcn_global_load_lds((gvoid_t *)(b.u + o), (lvoid_t *)(ubuf + q * UT + p * UPIECE), 16, 0, 0);
+                long long o = (tile * b.K + kmin + 2 * p) * 64;                      // wave-uniform
+                // components beyond K read the next tile's (finite values, rows discarded); past the array's very
+                // last component the pair's second half re-reads that component itself
+                const int ul = o >= ulen - 64 ? ulane & 63 : ulane;
+                if (o > ulen - 64) o = ulen - 64;
+                __builtin_amdgcn_global_load_lds((gvoid_t *)(b.u + o + ul), (lvoid_t *)(ubuf + q * UT + p * UPIECE), 16, 0, 0);
             }
         }
     };
