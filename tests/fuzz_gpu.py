@@ -30,23 +30,69 @@ def rel(a, b, floor=1e-300):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
 
 
-def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, nmax=3000):
-    """Returns {quantity: worst relative error}; raises AssertionError naming the failing shape."""
+def stats_err(one, two, K, D, split_stats):
+    """Two forms of the same statistics vector against each other, every block on ITS scale: counts and scalars
+    relative, first moments against sqrt(count * largest second moment), second moments against the component's
+    largest (an off-diagonal entry that nearly cancels carries the rounding of its terms)."""
+    a, b = split_stats(one, K, D), split_stats(two, K, D)
+    tiny = 1e-300
+    e = [np.max(np.abs(a[0] - b[0]) / (np.abs(b[0]) + 1e-9 * np.abs(b[0]).max() + tiny))]
+    cnt = np.abs(b[1]) + 1e-12 * np.abs(b[1]).max() + tiny               # (components nobody belongs to: on the total's scale)
+    e.append(np.max(np.abs(a[1] - b[1]) / cnt))
+    m2 = np.abs(b[3]).reshape(K, -1).max(axis=1)
+    m2 = m2 + 1e-12 * m2.max() + tiny
+    e.append(np.max(np.abs(a[2] - b[2]) / np.sqrt(cnt * m2)[:, None]))
+    e.append(np.max(np.abs(a[3] - b[3]) / m2[:, None, None]))
+    if np.any(b[4]):
+        e.append(np.max(np.abs(a[4] - b[4]) / (np.abs(b[4]) + 1e-12 * np.abs(b[4]).max() + tiny)))
+    return float(max(e))
+
+
+def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, nmax=3000, fast_paths=False):
+    """Returns {quantity: worst relative error}; raises AssertionError naming the failing shape.
+    ``fast_paths``: the large-N forms of pmc_estep -- common-shift statistics (k_stats_gemm), responsibilities in
+    groups (k_resp_groups) -- are switched on at any N / K fill (pmc_configure), and the emitting weighting pass
+    (pmc_importance_weights_emit -> pmc_estep_from_u) is checked against the oracle as well."""
     from oracle import oracle as orc
     from pypmc_amd.backend import HipBackend, ComponentSet
     from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
     be = be or HipBackend()
     rs = np.random.RandomState(seed)
     worst = {}
+    if fast_paths:
+        be.configure("stats_common_shift_min_n", 0)
+        be.configure("stats_common_shift_min_fill", 0)
+        be.configure("stats_common_shift_min_k", 2)
+        be.configure("estep_grouped_responsibilities", 2)
+    try:
+        return _sweep(seed, rounds, be, dims, verbose, kmax, nmax, fast_paths, rs, worst, orc, ComponentSet, split_stats,
+                      centred_moments)
+    finally:
+        if fast_paths:
+            be.configure("stats_common_shift_min_n", 524288)
+            be.configure("stats_common_shift_min_fill", 0.63)
+            be.configure("stats_common_shift_min_k", 17)
+            be.configure("estep_grouped_responsibilities", 1)
+
+
+def _sweep(seed, rounds, be, dims, verbose, kmax, nmax, fast_paths, rs, worst, orc, ComponentSet, split_stats, centred_moments):
 
     def note(name, v, tol, ctx):
         worst[name] = max(worst.get(name, 0.0), v)
         assert v < tol, "%s: %.3g >= %.3g at %s" % (name, v, tol, ctx)
 
+    floor2 = 1e-9
+
+    def two_forms(one, two, K, D):
+        if fast_paths:
+            return stats_err(one, two, K, D, split_stats)
+        return float(np.max(np.abs(one - two) / (np.abs(two) + floor2 * np.abs(two).max() + 1e-300)))
     for rnd in range(rounds):
         for D in dims:
             K = int(rs.randint(1, kmax + 1))
             N = int(rs.choice([1, 2, 63, 64, 65, 127, 129, rs.randint(1, nmax)]))
+            if fast_paths:
+                N = int(rs.choice([16384, 16385, 16447, 20000 + rs.randint(0, 300)]))   # the forms start at 16384 samples
             ctx = dict(D=D, K=K, N=N, seed=seed, round=rnd)
             mu, cov, w = mk(K, D, rs)
             k = rs.choice(K, size=N, p=w)
@@ -105,8 +151,7 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, n
             # the same E-step through pmc_estep (small D: ONE kernel, register or LDS form) against the two kernels
             one = be.tohost(be.estep(x, vcs, 0, sample_w=sw)["stats"])
             two = be.tohost(out["stats"])
-            note("vb one-kernel stats", float(np.max(np.abs(one - two) / (np.abs(two) + 1e-9 * np.abs(two).max() + 1e-300))),
-                 1e-9, ctx)
+            note("vb one-kernel stats", two_forms(one, two, K, D), 1e-9, ctx)
             # PMC Rao-Blackwell responsibilities + statistics
             iwts = rs.uniform(0.1, 2.0, N)
             out = be.estep(x, cs, 1, sample_w=iwts, want_r=True)
@@ -118,19 +163,38 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, n
             note("pmc rho (denormal numerator)", rel(got[~normal], rho[~normal], 1e-200), 5e-2, ctx)
             sc, S0, M1, M2, _, _ = split_stats(be.tohost(out["stats"]), K, D)
             note("pmc alpha", rel(S0, (iwts[:, None] * rho).sum(axis=0), 1e-30), 1e-9, ctx)
-            d = x[:, None, :] - mu[None, :, :]
-            M2ref = np.einsum('n,nk,nki,nkj->kij', iwts, rho, d, d)
+            M2ref = np.empty((K, D, D))
+            for kk in range(K):
+                dk = x - mu[kk]
+                M2ref[kk] = (dk * (iwts * rho[:, kk])[:, None]).T.dot(dk)
             note("pmc M2", float(np.max(np.abs(M2 - M2ref) / (np.abs(M2ref) + 1e-6 * np.abs(M2ref).max() + 1e-300))), 1e-8, ctx)
             # (beyond D ~ 500 every exp(log q_k) underflows in the reference too: rho = 0, M2 = 0)
             one = be.tohost(be.estep(x, cs, 1, sample_w=iwts)["stats"])
             two = be.tohost(out["stats"])
-            note("pmc one-kernel stats", float(np.max(np.abs(one - two) / (np.abs(two) + 1e-9 * np.abs(two).max() + 1e-300))),
-                 1e-9, ctx)
+            note("pmc one-kernel stats", two_forms(one, two, K, D), 1e-9, ctx)
             # the evaluate-once iteration: Mahalanobis forms kept by the weighting pass -> the same statistics, bitwise
             kept = be.importance_weights(x, cs, ComponentSet(0, tmu, tinv, c0=tln, weight=tw), keep=True)
             assert np.array_equal(be.tohost(kept["weights"]), be.tohost(iw["weights"])), ("kept weights", ctx)
             pre = be.tohost(be.estep_from_tiles(x, cs, kept["tiles"], sample_w=iwts)["stats"])
-            assert np.array_equal(pre, two), ("estep_from_tiles differs from the two kernels", ctx)
+            if not fast_paths:
+                assert np.array_equal(pre, two), ("estep_from_tiles differs from the two kernels", ctx)
+            else:                                            # (the statistics may take either form: rounding)
+                note("kept-forms stats", two_forms(pre, two, K, D), 1e-9, ctx)
+            if fast_paths:
+                # the weighting pass that emits u = w rho itself: same weights; statistics of the reference's
+                # importance-weighted Rao-Blackwell update (weights = the pass's own importance weights)
+                tcs = ComponentSet(0, tmu, tinv, c0=tln, weight=tw)
+                em = be.importance_weights(x, cs, tcs, emit=True)
+                resp = em.get("responsibilities")
+                if resp is not None:
+                    from pypmc_amd.backend import NSCALARS as NSC
+                    PS = 1 + D + D * (D + 1) // 2
+                    assert np.array_equal(be.tohost(em["weights"]), be.tohost(iw["weights"])), ("emit weights", ctx)
+                    wts = be.tohost(iw["weights"])
+                    viaw = be.tohost(be.estep(x, cs, 1, sample_w=wts, want_r=True)["stats"])
+                    got = be.tohost(be.estep_from_u(x, cs, resp)["stats"])
+                    got[:NSC] = viaw[:NSC]                 # (the emitting pass leaves its scalars with the weights)
+                    note("emit stats", two_forms(got, viaw, K, D), 1e-9, ctx)
         if verbose:
             print("round %d ok" % rnd, flush=True)
     return worst

@@ -29,6 +29,19 @@ def test_sweep_big_dimensions(seed):
         assert worst[name] < 1e-10, (name, worst[name])
 
 
+# the large-N forms of pmc_estep forced on at 16 384 ... 20 300 samples: exact and padded units from D = 8 (where the
+# common-shift statistics start), K over one, two and three groups of 32 with ragged last groups
+FAST_DIMS = [8, 9, 12, 16, 20, 23, 24, 30, 32, 37, 40, 48, 64]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_sweep_fast_paths(seed):
+    from pypmc_amd.backend import HipBackend
+    worst = fuzz_gpu.sweep(seed=10 + seed, rounds=1, be=HipBackend(), verbose=False, dims=FAST_DIMS, kmax=70, fast_paths=True)
+    for name in ("logpdf", "weights", "vb r", "pmc rho", "vb one-kernel stats", "pmc one-kernel stats"):
+        assert worst[name] < 1e-9, (name, worst[name])
+
+
 def test_very_big_dimension():
     from pypmc_amd.backend import HipBackend
     fuzz_gpu.sweep(seed=3, rounds=1, be=HipBackend(), verbose=False, dims=[520, 1024], kmax=3, nmax=200)
