@@ -56,7 +56,8 @@ def _compile(job):
         return out, 0.0
     import time
     t0 = time.time()
-    cmd = [hipcc()] + HIPCC_FLAGS + defs + ["-c", src, "-o", out]
+    # PMC_EXTRA_FLAGS: development aid (A/B builds of the whole library with extra -D switches; use with --force)
+    cmd = [hipcc()] + HIPCC_FLAGS + os.environ.get("PMC_EXTRA_FLAGS", "").split() + defs + ["-c", src, "-o", out]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stdout))
