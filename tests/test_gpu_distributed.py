@@ -55,7 +55,8 @@ def test_bench_two_ranks_one_gpu():
     assert "cpu_baseline" not in line                  # rank 0 at N=1 only
 
 
-@pytest.mark.parametrize("script,args", [("pmc_device_loop.py", ["100000", "2"]), ("variational.py", ["60000"])])
+@pytest.mark.parametrize("script,args", [("pmc_device_loop.py", ["100000", "2"]), ("variational.py", ["60000"]),
+                                         ("pmc_torchrun.py", ["4000"])])
 def test_examples_under_torchrun(script, args):
     """the multi-rank examples end to end: 4 ranks sharing the one GPU (PMC_DIST_BACKEND=gloo)"""
     env = dict(os.environ, PMC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
@@ -63,4 +64,6 @@ def test_examples_under_torchrun(script, args):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "examples", script)] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert ("iteration 1" in r.stdout) if script.startswith("pmc") else ("converged after" in r.stdout)
+    want = {"pmc_device_loop.py": "iteration 1", "variational.py": "converged after",
+            "pmc_torchrun.py": "10 x 4000 samples on 4 rank(s)"}[script]
+    assert want in r.stdout, r.stdout[-2000:]
