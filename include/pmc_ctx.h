@@ -1,0 +1,143 @@
+/*
+ * pmc_ctx.h -- the handle layer of libpmc_hip.so: HOST pointers in, HOST pointers out.
+ *
+ * include/pmc_hip.h is the kernel-level ABI: device pointers, caller-owned memory, caller's stream, un-normalised
+ * shifted sums.  This header is the layer SURVEY.md section 8(b) lists on top of it -- a context that owns the
+ * device, a stream, the scratch buffers and (optionally) the RCCL communicator; handles for a mixture and for a
+ * sharded sample array; and entry points that take the reference's own arrays (numpy buffers of the .pyx files)
+ * and hand back the quantities the reference's loops produce, in the reference's conventions.  A Cython / C caller
+ * needs nothing else: no HIP calls, no torch, no knowledge of packs, tiles or workspaces.  Everything here is
+ * host-side C++ over the entry points of pmc_hip.h (pypmc_amd/csrc/pmc_ctx.hip); the kernels are the same.
+ *
+ * Conventions: every function returns 0 or a negative pmc_status (pmc_hip.h) and sets pmc_last_error(); calls are
+ * synchronous (the result arrays are filled on return); a context and its handles belong to one thread at a time;
+ * all arrays are C-contiguous fp64 (int64 where said).  With a communicator joined (pmc_ctx_join) every rank holds
+ * its shard of the samples and the K-sized results are those of ALL ranks' samples -- one all-reduce (sum) of the
+ * statistics buffer per call, identical on every rank, no gather and no broadcast (the reference:
+ * pypmc/tools/parallel_sampler.py:58-71 gathers the samples on the master, examples/pmc_mpi.py:119-131 broadcasts
+ * the proposal back).
+ */
+#ifndef PMC_CTX_H
+#define PMC_CTX_H
+
+#include "pmc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pmc_ctx pmc_ctx;
+typedef struct pmc_mix pmc_mix;
+typedef struct pmc_samples pmc_samples;
+
+/* ---- context ---------------------------------------------------------------------------------------- */
+/* One context per process and GPU: selects `device`, creates the stream every call of this header runs on. */
+int pmc_init(int device, pmc_ctx **out);
+/* Optional: join the ranks of a sharded run (collective; rank 0 draws the id with pmc_comm_unique_id and hands the
+   PMC_COMM_ID_BYTES bytes to the others by its own means -- MPI_Bcast in a pypmc process). */
+int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id);
+/* Frees the stream, the scratch and the communicator.  Handles made from the context must be freed first. */
+int pmc_shutdown(pmc_ctx *ctx);
+
+/* ---- mixture ------------------------------------------------------------------------------------------ */
+/*
+ * MixtureDensity of K Gauss (family PMC_KIND_GAUSS) or StudentT (PMC_KIND_STUDENT_T) components
+ * (pypmc/density/mixture.pyx:21-59) from the arrays the components hold:
+ *   h_w          K   weights (mixture.pyx:56; zeros = dead components, pmc.pyx:66)
+ *   h_mu         K x D
+ *   h_inv_sigma  K x D x D   (gauss.pyx:112, student_t.pyx:111)
+ *   h_log_norm   K   log_normalization (gauss.pyx:115, student_t.pyx:32-34)
+ *   h_dof        K   degrees of freedom (StudentT only, else NULL)
+ * The arrays are copied; the host stays authoritative: after component.update / a weight change call
+ * pmc_mixture_update with the new arrays.  PMC_ENOTPOSDEF names the component whose inv_sigma does not factorise.
+ */
+int pmc_mixture_create(pmc_ctx *ctx, int family, int K, int D, const double *h_w, const double *h_mu,
+                       const double *h_inv_sigma, const double *h_log_norm, const double *h_dof, pmc_mix **out);
+int pmc_mixture_update(pmc_mix *mix, const double *h_w, const double *h_mu, const double *h_inv_sigma,
+                       const double *h_log_norm, const double *h_dof);
+int pmc_mixture_destroy(pmc_mix *mix);
+
+/* ---- samples ------------------------------------------------------------------------------------------ */
+/* This rank's N x D block of the sample array, resident on the device until freed (History's samples[-1]). */
+int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_samples **out);
+/*
+ * MixtureDensity.propose(N, trace=True, shuffle=False) on the device (mixture.pyx:159-212): h_counts (K) are the
+ * component counts of the caller's generator (rng.multinomial, mixture.pyx:192 -- counts and origins stay
+ * bit-exact), the normal / chi-square numbers are Philox4x32-10 keyed by `seed` and counted from the GLOBAL sample
+ * index `first_sample` (shards of one logical run draw disjoint streams).  h_chol: K x D x D lower Cholesky factors of
+ * the covariances (component.cholesky_sigma), or NULL = derived from inv_sigma.  The origin (generating component per
+ * sample, sorted) stays with the handle: pmc_samples_origin copies it out, pmc_pmc_update_stats can use it as latent.
+ */
+int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol, const int64_t *h_counts,
+                         uint64_t seed, int64_t first_sample, pmc_samples **out);
+int64_t pmc_samples_count(const pmc_samples *s);
+int pmc_samples_download(const pmc_samples *s, double *h_x);
+int pmc_samples_origin(const pmc_samples *s, int64_t *h_origin);
+int pmc_samples_free(pmc_samples *s);
+
+/* ---- evaluation --------------------------------------------------------------------------------------- */
+/*
+ * MixtureDensity.multi_evaluate(x, out, individual) (mixture.pyx:112-156 with gauss.pyx:146-151 /
+ * student_t.pyx:154-164 and logsumexp2D, _regularize.pyx:57-84):  h_out N (or NULL), h_individual N x K row-major
+ * (or NULL).
+ */
+int pmc_mix_logpdf(const pmc_mix *mix, const pmc_samples *s, double *h_out, double *h_individual);
+/*
+ * ImportanceSampler._calculate_weights (pypmc/sampler/importance_sampling.py:197-215): w_n = exp(log P(x_n) -
+ * log q(x_n)).  log P either from the host (h_log_target, N: the user's target evaluated by the caller) or from a
+ * second mixture (`target`; then both densities are evaluated in one pass and h_log_target_out, if not NULL,
+ * receives log P -- the sampler's target_values).  h_w N (or NULL: the weights stay on the device only);
+ * h_sums[3] = sum w, sum w log w (zeros masked), sum w^2 over ALL ranks' samples: perp and ess
+ * (pypmc/tools/convergence.py:31-39, :67-72) follow from them.  The weights stay with the sample handle for
+ * pmc_pmc_update_stats(weights_on_device = 1).
+ */
+int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target, const pmc_mix *target,
+                   double *h_w, double *h_log_target_out, double *h_sums);
+
+/* ---- VB E-step ---------------------------------------------------------------------------------------- */
+/*
+ * GaussianInference.E_step (pypmc/mix_adapt/variational.pyx:116-127) for K components from the variational
+ * parameters the object holds --  h_m K x D, h_W K x D x D, h_nu, h_beta K, h_ln_pi = expectation_ln_pi K,
+ * h_ln_lambda = expectation_det_ln_lambda K (:759-772, :800-804) -- and optional sample weights h_sample_w (N, as
+ * the constructor normalised them, :86-100; NULL = unweighted).  Results in the reference's conventions, over ALL
+ * ranks' samples:
+ *   h_N_k   K          N_comp, zeros regularised to tiny (:699-709)
+ *   h_xbar  K x D      x_mean_comp (:806-853)
+ *   h_S     K x D x D  S, symmetric (:855-932)
+ *   h_elogqz 1         sum_n w_n sum_k r_nk log rho~_nk (:1003-1013)
+ *   h_r, h_log_rho     N x K row-major, this rank's rows (NULL: not materialised -- the E-step itself never needs them)
+ * The moments are taken in one pass about m_k (about h_shift, K x D, if given: the previous E-step's x_mean_comp
+ * makes x_mean_comp and S bit-stable as soon as r is) and repeated about the mean just found when that turns out
+ * more than 10 of the component's own standard deviations away (the reference takes the mean first, then the
+ * covariance about it).
+ */
+int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, int K, const double *h_m,
+                 const double *h_W, const double *h_nu, const double *h_beta, const double *h_ln_pi,
+                 const double *h_ln_lambda, const double *h_shift, double *h_N_k, double *h_xbar, double *h_S,
+                 double *h_elogqz, double *h_r, double *h_log_rho);
+
+/* ---- PMC update --------------------------------------------------------------------------------------- */
+/*
+ * The N-sized part of gaussian_pmc / student_t_pmc (pypmc/mix_adapt/pmc.pyx:120-246, :499-739) for the proposal
+ * `mix` and the samples it proposed: rho (Rao-Blackwellised, pmc.pyx:23-43, rb != 0) or the one-hot latent
+ * responsibilities (pmc.pyx:45-51, rb == 0; latent = h_latent, or the origin pmc_samples_generate left with the
+ * handle when h_latent is NULL), then the weighted sums of pmc.pyx:188-222 / :602-691, over ALL ranks' samples.
+ * Weights: h_w (N), or the importance weights pmc_is_weights left on the device (weights_on_device != 0), or none.
+ * Components with weight 0 are dead (pmc.pyx:66): they take part in the row maximum only and their rows of the
+ * outputs are not written.  Outputs (the host does component.update, brentq, mincount pruning and the renormalisation):
+ *   h_alpha     K          sum_n w rho / sum_n w                 (pmc.pyx:191-193, :612-617)
+ *   h_mu        K x D      new means       (:194-197; Student-t: weighted with gamma, :620-623)
+ *   h_sigma     K x D x D  new covariances (:198-204; Student-t: sum w rho gamma (x-mu)(x-mu)^T / sum w rho, :629-630)
+ *   h_dof_const K          Student-t only (else NULL): the constant c_k of the dof condition
+ *                          c_k + log(nu/2) - psi(nu/2) = 0 (:654-696; _DOFCondition :478-497)
+ *   h_loglik    1          sum_n w_n log q(x_n) of the proposal (:388-391), may be NULL
+ *   h_norm      1          sum_n w_n (N if unweighted), may be NULL
+ */
+int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s, const double *h_w,
+                         int weights_on_device, const int64_t *h_latent, int rb, double *h_alpha, double *h_mu,
+                         double *h_sigma, double *h_dof_const, double *h_loglik, double *h_norm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMC_CTX_H */

@@ -93,6 +93,29 @@ SIGNATURES = {
 
 
 
+# the handle layer (include/pmc_ctx.h): host pointers in and out; handles are opaque pointers
+_pp = C.POINTER(C.c_void_p)
+_ip = C.POINTER(C.c_int64)
+CTX_SIGNATURES = {
+    "pmc_init": (_int, [_int, _pp]),
+    "pmc_ctx_join": (_int, [_vp, _int, _int, _vp]),
+    "pmc_shutdown": (_int, [_vp]),
+    "pmc_mixture_create": (_int, [_vp, _int, _int, _int, _dp, _dp, _dp, _dp, _dp, _pp]),
+    "pmc_mixture_update": (_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
+    "pmc_mixture_destroy": (_int, [_vp]),
+    "pmc_samples_upload": (_int, [_vp, _dp, _i64, _int, _pp]),
+    "pmc_samples_generate": (_int, [_vp, _vp, _dp, _ip, C.c_uint64, _i64, _pp]),
+    "pmc_samples_count": (_i64, [_vp]),
+    "pmc_samples_download": (_int, [_vp, _dp]),
+    "pmc_samples_origin": (_int, [_vp, _ip]),
+    "pmc_samples_free": (_int, [_vp]),
+    "pmc_mix_logpdf": (_int, [_vp, _vp, _dp, _dp]),
+    "pmc_is_weights": (_int, [_vp, _vp, _dp, _vp, _dp, _dp, _dp]),
+    "pmc_vb_estep": (_int, [_vp, _vp, _dp, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "pmc_pmc_update_stats": (_int, [_vp, _vp, _vp, _dp, _int, _ip, _int, _dp, _dp, _dp, _dp, _dp, _dp]),
+}
+
+
 class Timing(C.Structure):
     """struct pmc_timing (include/pmc_hip.h)"""
     _fields_ = [("name", C.c_char * 48), ("calls", C.c_int), ("ms", C.c_double), ("flops", C.c_double),
@@ -120,7 +143,7 @@ def load():
         # do not see each other's devices, streams or allocations.
         import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(CTX_SIGNATURES.items()):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

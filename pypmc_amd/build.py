@@ -72,6 +72,9 @@ def build(jobs=None, force=False, verbose=False):
     headers.append(os.path.join(CSRC, "pmc_device.h"))
     asrc = os.path.join(CSRC, "pmc_api.hip")
     work = [(os.path.join(OBJ, "pmc_api.o"), asrc, [], [asrc] + headers, force)]
+    csrc = os.path.join(CSRC, "pmc_ctx.hip")           # the handle layer (include/pmc_ctx.h): host code only
+    ctx_h = os.path.join(os.path.dirname(HERE), "include", "pmc_ctx.h")
+    work.append((os.path.join(OBJ, "pmc_ctx.o"), csrc, [], [csrc, ctx_h, headers[2]], force))
     tsrc = os.path.join(CSRC, "pmc_tiles.hip")        # one unit for all dimensions (PMC_D is not used by it)
     work.append((os.path.join(OBJ, "pmc_tiles.o"), tsrc, ["-DPMC_D=1"], [tsrc] + headers, force))
     # the run-time-dimension unit (sample dimensions beyond the compiled ones): its own kernels plus the per-sample

@@ -722,6 +722,8 @@ extern "C" {
 
 int pmc_abi_version(void) { return PMC_ABI_VERSION; }
 const char *pmc_last_error(void) { return g_err; }
+// (not in the header: lets the handle layer, pmc_ctx.hip, report through the same thread-local message)
+int pmc_internal_fail(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
 
 int pmc_device_count(void)
 {

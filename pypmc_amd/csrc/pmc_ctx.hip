@@ -1,0 +1,742 @@
+// pmc_ctx.hip -- the handle layer (include/pmc_ctx.h): host pointers in, host pointers out, the reference's
+// conventions.  Host-side C++ over the kernel-level ABI of include/pmc_hip.h: it owns a stream, scratch buffers and
+// (optionally) the RCCL communicator, builds the parameter packs, runs the same entry points the Python front-end
+// runs, all-reduces the K-sized buffer and converts the shifted, un-normalised sums into N_comp / x_mean_comp / S
+// (variational.pyx:699-932) or alpha / mu / sigma / the dof constant (pmc.pyx:188-222, :602-696).  No kernels here.
+#include "../../include/pmc_ctx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <initializer_list>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+extern "C" int pmc_internal_fail(int code, const char *msg);       // pmc_api.hip: sets pmc_last_error()
+
+namespace {
+
+constexpr int NSC = 8;                                              // scalars in front of the statistics
+constexpr double TINY = 2.2250738585072014e-308;                    // numpy.finfo('d').tiny (_regularize.pyx:6-17)
+
+int failf(int code, const char *fmt, ...)
+{
+    char buf[400];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return pmc_internal_fail(code, buf);
+}
+int hipf(hipError_t e, const char *what) { return failf(PMC_EHIP, "%s: %s", what, hipGetErrorString(e)); }
+
+#define CK(call)                   \
+    do {                           \
+        const int rc_ = (call);    \
+        if (rc_ < 0) return rc_;   \
+    } while (0)
+#define HK(call, what)                            \
+    do {                                          \
+        const hipError_t e_ = (call);             \
+        if (e_ != hipSuccess) return hipf(e_, what); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PMC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        HK(hipMalloc(&p, want), "hipMalloc");
+        cap = want;
+        return PMC_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    double *d() const { return (double *)p; }
+};
+
+}  // namespace
+
+struct pmc_ctx {
+    int device;
+    hipStream_t stream;
+    pmc_comm *comm;
+    DevBuf ws, u, scratch, flat, pack, spack, aux, nk1, nk2, lat;
+};
+struct pmc_mix {
+    pmc_ctx *ctx;
+    int family, K, D;
+    std::vector<double> w, mu, inv_sigma, log_norm, dof;
+    DevBuf pack;                                                    // all K components, column k, weight w_k
+};
+struct pmc_samples {
+    pmc_ctx *ctx;
+    int64_t N;
+    int D;
+    DevBuf x, w, origin;
+    bool has_w, has_origin;
+};
+
+namespace {
+
+int use(const pmc_ctx *ctx)
+{
+    if (!ctx) return failf(PMC_EINVAL, "NULL context");
+    HK(hipSetDevice(ctx->device), "hipSetDevice");
+    return PMC_OK;
+}
+int h2d(pmc_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return PMC_OK;
+    HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync (host to device)");
+    HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");   // the source may be pageable and short-lived
+    return PMC_OK;
+}
+int d2h(pmc_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return PMC_OK;
+    HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync (device to host)");
+    HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return PMC_OK;
+}
+int workspace(pmc_ctx *ctx, int64_t N, int K, int D)
+{
+    const int64_t need = pmc_workspace_bytes(N > 0 ? N : 1, K, D);
+    if (need < 0) return (int)need;
+    return ctx->ws.ensure((size_t)need);
+}
+
+// psi(x) for x > 0: recurrence up to x >= 10, then the asymptotic series (|error| < 1e-15 there)
+double digamma(double x)
+{
+    double r = 0.0;
+    while (x < 10.0) {
+        r -= 1.0 / x;
+        x += 1.0;
+    }
+    const double f = 1.0 / (x * x);
+    const double t = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 + f * (-1.0 / 132.0 +
+                     f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+    return r + std::log(x) - 0.5 / x + t;
+}
+
+// lower Cholesky factor of a symmetric positive definite D x D matrix (row-major), in place in `a`'s lower triangle
+bool cholesky_lower(std::vector<double> &a, int D)
+{
+    for (int j = 0; j < D; ++j) {
+        double s = a[(size_t)j * D + j];
+        for (int k = 0; k < j; ++k) s -= a[(size_t)j * D + k] * a[(size_t)j * D + k];
+        if (!(s > 0.0) || !std::isfinite(s)) return false;
+        const double ljj = std::sqrt(s);
+        a[(size_t)j * D + j] = ljj;
+        for (int i = j + 1; i < D; ++i) {
+            double t = a[(size_t)i * D + j];
+            for (int k = 0; k < j; ++k) t -= a[(size_t)i * D + k] * a[(size_t)j * D + k];
+            a[(size_t)i * D + j] = t / ljj;
+        }
+        for (int i = 0; i < j; ++i) a[(size_t)i * D + j] = 0.0;
+    }
+    return true;
+}
+// lower Cholesky factor of sigma = inv(P) from the precision P
+bool chol_of_inverse(const double *P, int D, double *L)
+{
+    std::vector<double> g(P, P + (size_t)D * D);
+    if (!cholesky_lower(g, D)) return false;                        // P = G G^T
+    std::vector<double> gi((size_t)D * D, 0.0);                     // G^-1, lower
+    for (int j = 0; j < D; ++j) {
+        gi[(size_t)j * D + j] = 1.0 / g[(size_t)j * D + j];
+        for (int i = j + 1; i < D; ++i) {
+            double t = 0.0;
+            for (int k = j; k < i; ++k) t -= g[(size_t)i * D + k] * gi[(size_t)k * D + j];
+            gi[(size_t)i * D + j] = t / g[(size_t)i * D + i];
+        }
+    }
+    std::vector<double> s((size_t)D * D, 0.0);                      // sigma = G^-T G^-1
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double t = 0.0;
+            for (int k = i; k < D; ++k) t += gi[(size_t)k * D + i] * gi[(size_t)k * D + j];
+            s[(size_t)i * D + j] = s[(size_t)j * D + i] = t;
+        }
+    if (!cholesky_lower(s, D)) return false;
+    std::memcpy(L, s.data(), sizeof(double) * (size_t)D * D);
+    return true;
+}
+
+// pack of the components `sel` of a mixture (column = position in the mixture)
+int build_mix_pack(const pmc_mix *m, const std::vector<int> &sel, std::vector<double> &host)
+{
+    const int K = (int)sel.size(), D = m->D;
+    const int64_t stride = pmc_pack_stride(D);
+    if (stride < 0) return (int)stride;
+    std::vector<double> mu((size_t)K * D), prec((size_t)K * D * D), c0(K), c1(K, 0.0), c2(K, 0.0), c3(K, 0.0), w(K);
+    std::vector<int32_t> col(K);
+    for (int i = 0; i < K; ++i) {
+        const int k = sel[i];
+        std::memcpy(&mu[(size_t)i * D], &m->mu[(size_t)k * D], sizeof(double) * D);
+        std::memcpy(&prec[(size_t)i * D * D], &m->inv_sigma[(size_t)k * D * D], sizeof(double) * (size_t)D * D);
+        c0[i] = m->log_norm[k];
+        if (m->family == PMC_KIND_STUDENT_T) {
+            c1[i] = -.5 * (m->dof[k] + D);                          // student_t.pyx:116
+            c2[i] = 1. / m->dof[k];                                 // :117
+            c3[i] = m->dof[k];
+        }
+        w[i] = m->w[k];
+        col[i] = k;
+    }
+    host.assign((size_t)K * stride, 0.0);
+    return pmc_pack_components(K, D, mu.data(), prec.data(), c0.data(), c1.data(), c2.data(), c3.data(), w.data(),
+                               col.data(), host.data());
+}
+
+int load_mix(pmc_mix *m, const double *h_w, const double *h_mu, const double *h_inv_sigma, const double *h_log_norm,
+             const double *h_dof)
+{
+    const int K = m->K, D = m->D;
+    if (!h_w || !h_mu || !h_inv_sigma || !h_log_norm) return failf(PMC_EINVAL, "mixture: weights, means, inv_sigma and log_norm are required");
+    if (m->family == PMC_KIND_STUDENT_T && !h_dof) return failf(PMC_EINVAL, "mixture: StudentT components need h_dof");
+    m->w.assign(h_w, h_w + K);
+    m->mu.assign(h_mu, h_mu + (size_t)K * D);
+    m->inv_sigma.assign(h_inv_sigma, h_inv_sigma + (size_t)K * D * D);
+    m->log_norm.assign(h_log_norm, h_log_norm + K);
+    if (m->family == PMC_KIND_STUDENT_T) m->dof.assign(h_dof, h_dof + K);
+    std::vector<int> all(K);
+    for (int k = 0; k < K; ++k) all[k] = k;
+    std::vector<double> host;
+    CK(build_mix_pack(m, all, host));
+    CK(m->pack.ensure(host.size() * sizeof(double)));
+    return h2d(m->ctx, m->pack.p, host.data(), host.size() * sizeof(double));
+}
+
+// K x (1 + D + D(D+1)/2) statistics (pmc_sufficient_stats' layout) -> S0, M1, full symmetric M2
+void split_stats(const double *body, int K, int D, std::vector<double> &S0, std::vector<double> &M1, std::vector<double> &M2)
+{
+    const int T = D * (D + 1) / 2, PS = 1 + D + T;
+    S0.resize(K);
+    M1.resize((size_t)K * D);
+    M2.assign((size_t)K * D * D, 0.0);
+    for (int k = 0; k < K; ++k) {
+        const double *b = body + (size_t)k * PS;
+        S0[k] = b[0];
+        for (int i = 0; i < D; ++i) M1[(size_t)k * D + i] = b[1 + i];
+        int t = 0;
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j <= i; ++j, ++t)
+                M2[((size_t)k * D + i) * D + j] = M2[((size_t)k * D + j) * D + i] = b[1 + D + t];
+    }
+}
+
+// pypmc_amd/mix_adapt/_stats.py::shift_is_far (limit 100): does some component's weighted mean lie more than 10 of
+// its own standard deviations from the shift its one-pass moments were taken about?
+bool shift_is_far(const std::vector<double> &S0, const std::vector<double> &M1, const std::vector<double> &M2, int K, int D)
+{
+    double total = 0.0;
+    for (int k = 0; k < K; ++k)
+        if (std::isfinite(S0[k])) total += S0[k];
+    for (int k = 0; k < K; ++k) {
+        if (!std::isfinite(S0[k]) || !(S0[k] > 1e-200) || !(S0[k] > 1e-6 * total)) continue;
+        const double n = S0[k];
+        for (int i = 0; i < D; ++i) {
+            const double db = M1[(size_t)k * D + i] / n, dbar2 = db * db;
+            const double raw = M2[((size_t)k * D + i) * D + i] / n;
+            double var = raw - dbar2;
+            if (!(var > 1e-14 * raw)) var = 1e-14 * raw;
+            if (dbar2 > 100. * var) return true;
+        }
+    }
+    return false;
+}
+
+// _stats.py::centred_moments: mean = shift + M1 / reg(n_mean); cov = (M2 - n_mean dbar dbar^T) / reg(n_cov)
+void centred_moments(const double *n_mean_in, const double *n_cov_in, const std::vector<double> &M1,
+                     const std::vector<double> &M2, const double *shift, int K, int D, double *mean, double *cov)
+{
+    std::vector<double> dbar(D);
+    for (int k = 0; k < K; ++k) {
+        const double nm = n_mean_in[k] == 0.0 ? TINY : n_mean_in[k];
+        const double nc = n_cov_in[k] == 0.0 ? TINY : n_cov_in[k];
+        for (int i = 0; i < D; ++i) {
+            dbar[i] = M1[(size_t)k * D + i] / nm;
+            mean[(size_t)k * D + i] = shift[(size_t)k * D + i] + dbar[i];
+        }
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                const double prod = dbar[i] * dbar[j];
+                cov[((size_t)k * D + i) * D + j] = (M2[((size_t)k * D + i) * D + j] - nm * prod) / nc;
+            }
+    }
+}
+
+// shifts of a second pass: the mean just found where a component holds weight at all
+void new_shifts(const std::vector<double> &S0, const std::vector<double> &M1, int K, int D, std::vector<double> &shift)
+{
+    for (int k = 0; k < K; ++k) {
+        if (!(S0[k] > 1e-200)) continue;
+        const double n = S0[k] == 0.0 ? TINY : S0[k];
+        for (int i = 0; i < D; ++i) shift[(size_t)k * D + i] += M1[(size_t)k * D + i] / n;
+    }
+}
+
+int means_pack(pmc_ctx *ctx, const std::vector<double> &shift, int K, int D)
+{
+    const int64_t stride = pmc_pack_stride(D);
+    if (stride < 0) return (int)stride;
+    std::vector<double> host((size_t)K * stride);
+    CK(pmc_pack_means(K, D, shift.data(), host.data()));
+    CK(ctx->spack.ensure(host.size() * sizeof(double)));
+    return h2d(ctx, ctx->spack.p, host.data(), host.size() * sizeof(double));
+}
+
+int allreduce(pmc_ctx *ctx, double *d_buf, int64_t n)
+{
+    if (!ctx->comm) return PMC_OK;
+    return pmc_comm_allreduce_sum(ctx->comm, d_buf, n, ctx->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- context ----------------------------------------------------------------------------------------------
+int pmc_init(int device, pmc_ctx **out)
+{
+    if (!out) return failf(PMC_EINVAL, "pmc_init: NULL output");
+    const int n = pmc_device_count();
+    if (n < 0) return n;
+    if (device < 0 || device >= n) return failf(PMC_ENODEVICE, "pmc_init: device %d of %d", device, n);
+    HK(hipSetDevice(device), "hipSetDevice");
+    pmc_ctx *ctx = new pmc_ctx();
+    ctx->device = device;
+    ctx->comm = nullptr;
+    ctx->stream = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return hipf(e, "hipStreamCreateWithFlags");
+    }
+    *out = ctx;
+    return PMC_OK;
+}
+
+int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id)
+{
+    CK(use(ctx));
+    if (ctx->comm) return failf(PMC_EINVAL, "pmc_ctx_join: the context has a communicator already");
+    return pmc_comm_init(rank, world, h_id, ctx->device, &ctx->comm);
+}
+
+int pmc_shutdown(pmc_ctx *ctx)
+{
+    if (!ctx) return PMC_OK;
+    (void)hipSetDevice(ctx->device);
+    int rc = PMC_OK;
+    if (ctx->comm) rc = pmc_comm_destroy(ctx->comm);
+    for (DevBuf *b : {&ctx->ws, &ctx->u, &ctx->scratch, &ctx->flat, &ctx->pack, &ctx->spack, &ctx->aux, &ctx->nk1,
+                      &ctx->nk2, &ctx->lat})
+        b->release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return rc;
+}
+
+// ---- mixture ----------------------------------------------------------------------------------------------
+int pmc_mixture_create(pmc_ctx *ctx, int family, int K, int D, const double *h_w, const double *h_mu,
+                       const double *h_inv_sigma, const double *h_log_norm, const double *h_dof, pmc_mix **out)
+{
+    CK(use(ctx));
+    if (!out || K < 1 || D < 1) return failf(PMC_EINVAL, "pmc_mixture_create: bad K / D / output");
+    if (family != PMC_KIND_GAUSS && family != PMC_KIND_STUDENT_T)
+        return failf(PMC_EINVAL, "pmc_mixture_create: family must be PMC_KIND_GAUSS or PMC_KIND_STUDENT_T (got %d)", family);
+    if (pmc_padded_dim(D) < 0) return PMC_EINVAL;
+    pmc_mix *m = new pmc_mix();
+    m->ctx = ctx;
+    m->family = family;
+    m->K = K;
+    m->D = D;
+    const int rc = load_mix(m, h_w, h_mu, h_inv_sigma, h_log_norm, h_dof);
+    if (rc < 0) {
+        m->pack.release();
+        delete m;
+        return rc;
+    }
+    *out = m;
+    return PMC_OK;
+}
+
+int pmc_mixture_update(pmc_mix *mix, const double *h_w, const double *h_mu, const double *h_inv_sigma,
+                       const double *h_log_norm, const double *h_dof)
+{
+    if (!mix) return failf(PMC_EINVAL, "pmc_mixture_update: NULL mixture");
+    CK(use(mix->ctx));
+    return load_mix(mix, h_w, h_mu, h_inv_sigma, h_log_norm, h_dof);
+}
+
+int pmc_mixture_destroy(pmc_mix *mix)
+{
+    if (!mix) return PMC_OK;
+    (void)hipSetDevice(mix->ctx->device);
+    mix->pack.release();
+    delete mix;
+    return PMC_OK;
+}
+
+// ---- samples ----------------------------------------------------------------------------------------------
+int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_samples **out)
+{
+    CK(use(ctx));
+    if (!out || N < 0 || D < 1 || (N > 0 && !h_x)) return failf(PMC_EINVAL, "pmc_samples_upload: bad argument");
+    if (pmc_padded_dim(D) < 0) return PMC_EINVAL;
+    pmc_samples *s = new pmc_samples();
+    s->ctx = ctx;
+    s->N = N;
+    s->D = D;
+    s->has_w = s->has_origin = false;
+    int rc = s->x.ensure(sizeof(double) * (size_t)(N > 0 ? N : 1) * D);
+    if (rc == PMC_OK) rc = h2d(ctx, s->x.p, h_x, sizeof(double) * (size_t)N * D);
+    if (rc < 0) {
+        s->x.release();
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return PMC_OK;
+}
+
+int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol, const int64_t *h_counts,
+                         uint64_t seed, int64_t first_sample, pmc_samples **out)
+{
+    CK(use(ctx));
+    if (!out || !mix || !h_counts || mix->ctx != ctx) return failf(PMC_EINVAL, "pmc_samples_generate: bad argument");
+    const int K = mix->K, D = mix->D;
+    std::vector<int64_t> off(K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        if (h_counts[k] < 0) return failf(PMC_EINVAL, "pmc_samples_generate: negative count for component %d", k);
+        off[k + 1] = off[k] + h_counts[k];
+    }
+    const int64_t N = off[K];
+    std::vector<double> chol((size_t)K * D * D);
+    if (h_chol) {
+        std::memcpy(chol.data(), h_chol, sizeof(double) * chol.size());
+    } else {
+        for (int k = 0; k < K; ++k)
+            if (!chol_of_inverse(&mix->inv_sigma[(size_t)k * D * D], D, &chol[(size_t)k * D * D]))
+                return failf(PMC_ENOTPOSDEF, "pmc_samples_generate: inv_sigma of component %d is not positive definite", k);
+    }
+    // parameters: [mu K*D | chol K*D*D | dof K] doubles, then the K+1 offsets
+    const size_t nd = (size_t)K * D + (size_t)K * D * D + K;
+    CK(ctx->aux.ensure(nd * sizeof(double) + (K + 1) * sizeof(int64_t)));
+    double *d_mu = ctx->aux.d(), *d_chol = d_mu + (size_t)K * D, *d_dof = d_chol + (size_t)K * D * D;
+    int64_t *d_off = (int64_t *)(d_dof + K);
+    CK(h2d(ctx, d_mu, mix->mu.data(), sizeof(double) * (size_t)K * D));
+    CK(h2d(ctx, d_chol, chol.data(), sizeof(double) * chol.size()));
+    if (mix->family == PMC_KIND_STUDENT_T) CK(h2d(ctx, d_dof, mix->dof.data(), sizeof(double) * K));
+    CK(h2d(ctx, d_off, off.data(), sizeof(int64_t) * (K + 1)));
+    pmc_samples *s = new pmc_samples();
+    s->ctx = ctx;
+    s->N = N;
+    s->D = D;
+    s->has_w = false;
+    s->has_origin = true;
+    int rc = s->x.ensure(sizeof(double) * (size_t)(N > 0 ? N : 1) * D);
+    if (rc == PMC_OK) rc = s->origin.ensure(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    if (rc == PMC_OK && N > 0)
+        rc = pmc_propose(d_mu, d_chol, mix->family == PMC_KIND_STUDENT_T ? d_dof : nullptr, d_off, K, D, N, first_sample, seed,
+                         s->x.d(), (int64_t *)s->origin.p, ctx->stream);
+    if (rc == PMC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = failf(PMC_EHIP, "pmc_samples_generate: stream error");
+    if (rc < 0) {
+        s->x.release();
+        s->origin.release();
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return PMC_OK;
+}
+
+int64_t pmc_samples_count(const pmc_samples *s) { return s ? s->N : (int64_t)failf(PMC_EINVAL, "NULL samples"); }
+
+int pmc_samples_download(const pmc_samples *s, double *h_x)
+{
+    if (!s || !h_x) return failf(PMC_EINVAL, "pmc_samples_download: bad argument");
+    CK(use(s->ctx));
+    return d2h(s->ctx, h_x, s->x.p, sizeof(double) * (size_t)s->N * s->D);
+}
+
+int pmc_samples_origin(const pmc_samples *s, int64_t *h_origin)
+{
+    if (!s || !h_origin) return failf(PMC_EINVAL, "pmc_samples_origin: bad argument");
+    if (!s->has_origin) return failf(PMC_EINVAL, "pmc_samples_origin: these samples were uploaded, not generated");
+    CK(use(s->ctx));
+    return d2h(s->ctx, h_origin, s->origin.p, sizeof(int64_t) * (size_t)s->N);
+}
+
+int pmc_samples_free(pmc_samples *s)
+{
+    if (!s) return PMC_OK;
+    (void)hipSetDevice(s->ctx->device);
+    s->x.release();
+    s->w.release();
+    s->origin.release();
+    delete s;
+    return PMC_OK;
+}
+
+// ---- evaluation -------------------------------------------------------------------------------------------
+int pmc_mix_logpdf(const pmc_mix *mix, const pmc_samples *s, double *h_out, double *h_individual)
+{
+    if (!mix || !s || mix->ctx != s->ctx || mix->D != s->D) return failf(PMC_EINVAL, "pmc_mix_logpdf: mixture and samples do not belong together");
+    pmc_ctx *ctx = mix->ctx;
+    CK(use(ctx));
+    const int64_t N = s->N;
+    const int K = mix->K, D = mix->D;
+    if (N == 0) return PMC_OK;
+    CK(workspace(ctx, N, K, D));
+    CK(ctx->nk1.ensure(sizeof(double) * (size_t)N * (h_individual ? K + 1 : 1)));
+    double *d_out = ctx->nk1.d(), *d_ind = h_individual ? d_out + N : nullptr;
+    CK(pmc_mixture_logpdf(s->x.d(), N, D, mix->pack.d(), K, mix->family, 0, d_out, d_ind, K, nullptr, nullptr, nullptr,
+                          nullptr, ctx->ws.p, ctx->stream));
+    if (h_out) CK(d2h(ctx, h_out, d_out, sizeof(double) * (size_t)N));
+    if (h_individual) CK(d2h(ctx, h_individual, d_ind, sizeof(double) * (size_t)N * K));
+    return PMC_OK;
+}
+
+int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target, const pmc_mix *target, double *h_w,
+                   double *h_log_target_out, double *h_sums)
+{
+    if (!q || !s || q->ctx != s->ctx || q->D != s->D) return failf(PMC_EINVAL, "pmc_is_weights: proposal and samples do not belong together");
+    if ((h_log_target != nullptr) == (target != nullptr)) return failf(PMC_EINVAL, "pmc_is_weights: give h_log_target or a target mixture (one of them)");
+    if (target && (target->ctx != q->ctx || target->D != q->D)) return failf(PMC_EINVAL, "pmc_is_weights: target of another context / dimension");
+    pmc_ctx *ctx = q->ctx;
+    CK(use(ctx));
+    const int64_t N = s->N;
+    const int D = q->D, Kmax = target && target->K > q->K ? target->K : q->K;
+    CK(ctx->flat.ensure(sizeof(double) * NSC));
+    double *d_sc = ctx->flat.d();
+    HK(hipMemsetAsync(d_sc, 0, sizeof(double) * NSC, ctx->stream), "hipMemsetAsync");
+    if (N > 0) {
+        CK(workspace(ctx, N, Kmax, D));
+        CK(s->w.ensure(sizeof(double) * (size_t)N));
+        CK(ctx->nk1.ensure(sizeof(double) * (size_t)N));
+        if (target) {
+            CK(pmc_importance_weights(s->x.d(), N, D, q->pack.d(), q->K, q->family, target->pack.d(), target->K, target->family,
+                                      nullptr, h_log_target_out ? ctx->nk1.d() : nullptr, s->w.d(), nullptr, d_sc, ctx->ws.p,
+                                      ctx->stream));
+            if (h_log_target_out) CK(d2h(ctx, h_log_target_out, ctx->nk1.p, sizeof(double) * (size_t)N));
+        } else {
+            CK(h2d(ctx, ctx->nk1.p, h_log_target, sizeof(double) * (size_t)N));
+            CK(pmc_mixture_logpdf(s->x.d(), N, D, q->pack.d(), q->K, q->family, 0, nullptr, nullptr, q->K, ctx->nk1.d(), s->w.d(),
+                                  nullptr, d_sc, ctx->ws.p, ctx->stream));
+        }
+        s->has_w = true;
+        if (h_w) CK(d2h(ctx, h_w, s->w.p, sizeof(double) * (size_t)N));
+    }
+    CK(allreduce(ctx, d_sc, NSC));
+    double sc[NSC];
+    CK(d2h(ctx, sc, d_sc, sizeof(sc)));
+    if (sc[4] != 0.0) return failf(PMC_EINVAL, "pmc_is_weights: %g importance weights overflowed (math range error, importance_sampling.py:207)", sc[4]);
+    if (h_sums) {
+        h_sums[0] = sc[0];
+        h_sums[1] = sc[1];
+        h_sums[2] = sc[2];
+    }
+    return PMC_OK;
+}
+
+// ---- VB E-step --------------------------------------------------------------------------------------------
+int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, int K, const double *h_m, const double *h_W,
+                 const double *h_nu, const double *h_beta, const double *h_ln_pi, const double *h_ln_lambda,
+                 const double *h_shift, double *h_N_k, double *h_xbar, double *h_S, double *h_elogqz, double *h_r,
+                 double *h_log_rho)
+{
+    CK(use(ctx));
+    if (!s || s->ctx != ctx || K < 1 || !h_m || !h_W || !h_nu || !h_beta || !h_ln_pi || !h_ln_lambda || !h_N_k || !h_xbar || !h_S)
+        return failf(PMC_EINVAL, "pmc_vb_estep: bad argument");
+    const int64_t N = s->N;
+    const int D = s->D;
+    const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
+    if (stride < 0) return (int)stride;
+    // the posterior's pack (enum pmc_kind, PMC_KIND_VB): c0 = D / beta, c1 = nu, c2 = E[ln pi], c3 = E[ln|Lambda|] - D ln 2 pi
+    std::vector<double> c0(K), c3(K), host((size_t)K * stride);
+    const double dl2pi = D * std::log(2. * 3.14159265358979323846);
+    for (int k = 0; k < K; ++k) {
+        c0[k] = D / h_beta[k];
+        c3[k] = h_ln_lambda[k] - dl2pi;
+    }
+    CK(pmc_pack_components(K, D, h_m, h_W, c0.data(), h_nu, h_ln_pi, c3.data(), nullptr, nullptr, host.data()));
+    CK(ctx->pack.ensure(host.size() * sizeof(double)));
+    CK(h2d(ctx, ctx->pack.p, host.data(), host.size() * sizeof(double)));
+    const size_t nflat = NSC + (size_t)K * PS;
+    CK(ctx->flat.ensure(sizeof(double) * nflat));
+    double *d_flat = ctx->flat.d();
+    CK(workspace(ctx, N, K, D));
+    CK(ctx->u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, K)));
+    const double *d_sw = nullptr;
+    if (h_sample_w && N > 0) {
+        CK(ctx->aux.ensure(sizeof(double) * (size_t)N));
+        CK(h2d(ctx, ctx->aux.p, h_sample_w, sizeof(double) * (size_t)N));
+        d_sw = ctx->aux.d();
+    }
+    std::vector<double> shift(h_shift ? h_shift : h_m, (h_shift ? h_shift : h_m) + (size_t)K * D);
+    std::vector<double> flat(nflat), S0, M1, M2;
+    const bool want_nk = (h_r || h_log_rho) && N > 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool shifted = pass == 1 || h_shift != nullptr;
+        if (shifted) CK(means_pack(ctx, shift, K, D));
+        const double *d_spack = shifted ? ctx->spack.d() : nullptr;
+        if (want_nk && pass == 0) {
+            CK(ctx->nk1.ensure(sizeof(double) * (size_t)N * K));
+            CK(ctx->nk2.ensure(sizeof(double) * (size_t)N * K));
+            CK(pmc_responsibilities(s->x.d(), N, D, ctx->pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, ctx->u.d(),
+                                    nullptr, nullptr, h_r ? ctx->nk1.d() : nullptr, h_log_rho ? ctx->nk2.d() : nullptr, nullptr,
+                                    K, d_flat, ctx->ws.p, ctx->stream));
+            CK(pmc_sufficient_stats(s->x.d(), N, D, d_spack ? d_spack : ctx->pack.d(), K, ctx->u.d(), d_flat + NSC, ctx->ws.p,
+                                    ctx->stream));
+        } else {
+            CK(pmc_estep_about(s->x.d(), N, D, ctx->pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, ctx->u.d(), nullptr,
+                               nullptr, d_flat + NSC, d_flat, ctx->ws.p, d_spack, ctx->stream));
+        }
+        CK(allreduce(ctx, d_flat, (int64_t)nflat));
+        CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * nflat));
+        split_stats(flat.data() + NSC, K, D, S0, M1, M2);
+        if (pass == 1 || !shift_is_far(S0, M1, M2, K, D)) break;
+        new_shifts(S0, M1, K, D, shift);                              // second pass about the mean just found
+    }
+    for (int k = 0; k < K; ++k) h_N_k[k] = S0[k] == 0.0 ? TINY : S0[k];   // variational.pyx:699-709
+    centred_moments(h_N_k, h_N_k, M1, M2, shift.data(), K, D, h_xbar, h_S);
+    if (h_elogqz) *h_elogqz = flat[0];
+    if (want_nk) {
+        if (h_r) CK(d2h(ctx, h_r, ctx->nk1.p, sizeof(double) * (size_t)N * K));
+        if (h_log_rho) CK(d2h(ctx, h_log_rho, ctx->nk2.p, sizeof(double) * (size_t)N * K));
+    }
+    return PMC_OK;
+}
+
+// ---- PMC update -------------------------------------------------------------------------------------------
+int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s, const double *h_w, int weights_on_device,
+                         const int64_t *h_latent, int rb, double *h_alpha, double *h_mu, double *h_sigma,
+                         double *h_dof_const, double *h_loglik, double *h_norm)
+{
+    CK(use(ctx));
+    if (!mix || !s || mix->ctx != ctx || s->ctx != ctx || mix->D != s->D || !h_alpha || !h_mu || !h_sigma)
+        return failf(PMC_EINVAL, "pmc_pmc_update_stats: bad argument");
+    if (h_w && weights_on_device) return failf(PMC_EINVAL, "pmc_pmc_update_stats: h_w or weights_on_device, not both");
+    if (weights_on_device && !s->has_w) return failf(PMC_EINVAL, "pmc_pmc_update_stats: no importance weights on the device (pmc_is_weights first)");
+    if (!rb && !h_latent && !s->has_origin) return failf(PMC_EINVAL, "`rb` must be True if `latent` is not provided!");   // pmc.pyx:81-83
+    const bool student = mix->family == PMC_KIND_STUDENT_T;
+    if (student && !h_dof_const) return failf(PMC_EINVAL, "pmc_pmc_update_stats: StudentT components need h_dof_const");
+    const int64_t N = s->N;
+    const int K = mix->K, D = mix->D;
+    const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
+    std::vector<int> live;
+    for (int k = 0; k < K; ++k)
+        if (mix->w[k] != 0.0) live.push_back(k);                       // pmc.pyx:66
+    const int L = (int)live.size();
+    // weights and their local sum
+    const double *d_w = nullptr;
+    double local_norm = (double)N;
+    CK(ctx->flat.ensure(sizeof(double) * (NSC + (size_t)(L > 0 ? L : 1) * (PS + 2) + 1)));
+    double *d_flat = ctx->flat.d();
+    const size_t nstat = NSC + (size_t)L * PS + 2 * (size_t)L, nflat = nstat + 1;
+    CK(workspace(ctx, N, L > 0 ? L : 1, D));
+    if (h_w && N > 0) {
+        CK(ctx->aux.ensure(sizeof(double) * (size_t)N));
+        CK(h2d(ctx, ctx->aux.p, h_w, sizeof(double) * (size_t)N));
+        d_w = ctx->aux.d();
+        long double acc = 0.0L;
+        for (int64_t n = 0; n < N; ++n) acc += h_w[n];
+        local_norm = (double)acc;
+    } else if (weights_on_device && N > 0) {
+        d_w = s->w.d();
+        CK(pmc_weight_sums(d_w, N, d_flat, ctx->ws.p, ctx->stream));
+        double sc3[3];
+        CK(d2h(ctx, sc3, d_flat, sizeof(sc3)));
+        local_norm = sc3[0];
+    } else if (h_w || weights_on_device) {
+        local_norm = 0.0;
+    }
+    HK(hipMemsetAsync(d_flat, 0, sizeof(double) * nflat, ctx->stream), "hipMemsetAsync");
+    std::vector<double> shift((size_t)(L > 0 ? L : 1) * D, 0.0);
+    for (int i = 0; i < L; ++i) std::memcpy(&shift[(size_t)i * D], &mix->mu[(size_t)live[i] * D], sizeof(double) * D);
+    const int64_t *d_lat = nullptr;
+    if (!rb && N > 0) {
+        if (h_latent) {
+            CK(ctx->lat.ensure(sizeof(int64_t) * (size_t)N));
+            CK(h2d(ctx, ctx->lat.p, h_latent, sizeof(int64_t) * (size_t)N));
+            d_lat = (const int64_t *)ctx->lat.p;
+        } else {
+            d_lat = (const int64_t *)s->origin.p;
+        }
+    }
+    std::vector<double> flat(nflat, 0.0), S0, M1, M2;
+    if (L > 0) {
+        std::vector<double> host;
+        CK(build_mix_pack(mix, live, host));
+        CK(ctx->pack.ensure(host.size() * sizeof(double)));
+        CK(h2d(ctx, ctx->pack.p, host.data(), host.size() * sizeof(double)));
+        CK(ctx->u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, L)));
+        if (student) CK(ctx->scratch.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, L)));
+        const int mode = rb ? PMC_RESP_PMC_RB : PMC_RESP_PMC_LATENT;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) CK(means_pack(ctx, shift, L, D));
+            // dead components' all-zero columns take part in the row maximum (pmc.pyx:24-34)
+            CK(pmc_estep_about(s->x.d(), N, D, ctx->pack.d(), L, mix->family, mode, L < K ? 1 : 0, d_w, d_lat, ctx->u.d(),
+                               student ? ctx->scratch.d() : nullptr, student ? d_flat + NSC + (size_t)L * PS : nullptr,
+                               d_flat + NSC, d_flat, ctx->ws.p, pass == 1 ? ctx->spack.d() : nullptr, ctx->stream));
+            HK(hipMemcpyAsync(d_flat + nstat, &local_norm, sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+            HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+            CK(allreduce(ctx, d_flat, (int64_t)nflat));
+            CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * nflat));
+            split_stats(flat.data() + NSC, L, D, S0, M1, M2);
+            if (pass == 1 || !shift_is_far(S0, M1, M2, L, D)) break;
+            new_shifts(S0, M1, L, D, shift);
+        }
+    } else {
+        HK(hipMemcpyAsync(d_flat + nstat, &local_norm, sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
+        HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        CK(allreduce(ctx, d_flat, (int64_t)nflat));
+        CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * nflat));
+    }
+    const double norm = flat[nstat];
+    if (h_norm) *h_norm = norm;
+    if (h_loglik) *h_loglik = flat[3];
+    if (L == 0) return PMC_OK;
+    std::vector<double> mean((size_t)L * D), cov((size_t)L * D * D), V1(L), V2(L);
+    const double *vs = flat.data() + NSC + (size_t)L * PS;
+    for (int i = 0; i < L; ++i) {
+        V1[i] = vs[2 * i];
+        V2[i] = vs[2 * i + 1];
+    }
+    // Gauss: both normalised by sum w rho (pmc.pyx:194-204); Student-t: the mean by sum w rho gamma, the covariance by
+    // sum w rho (pmc.pyx:620-630)
+    centred_moments(S0.data(), student ? V1.data() : S0.data(), M1, M2, shift.data(), L, D, mean.data(), cov.data());
+    for (int i = 0; i < L; ++i) {
+        const int k = live[i];
+        const double wr = student ? V1[i] : S0[i];
+        h_alpha[k] = wr / norm;                                          // pmc.pyx:191-193, :612-617
+        std::memcpy(&h_mu[(size_t)k * D], &mean[(size_t)i * D], sizeof(double) * D);
+        std::memcpy(&h_sigma[(size_t)k * D * D], &cov[(size_t)i * D * D], sizeof(double) * (size_t)D * D);
+        if (student) {
+            // sum_n w_n (xi + delta)_nk of pmc.pyx:659-679 from the device sums (pypmc_amd/mix_adapt/pmc.py::student_t_pmc)
+            const double nu = mix->dof[k];
+            const double total = V2[i] - digamma(.5 * (D + nu)) * V1[i] + (norm - V1[i]) * (std::log(.5 * nu) - digamma(.5 * nu)) +
+                                 S0[i] + (norm - V1[i]);
+            h_dof_const[k] = 1. - total / norm;
+        }
+    }
+    return PMC_OK;
+}
+
+}  // extern "C"

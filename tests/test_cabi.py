@@ -11,8 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "pmc_hip.h")).read()
+def declared_symbols(header="pmc_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pmc_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +26,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libpmc_hip.so does not export " + name
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
     assert lib.pmc_abi_version() == 1
+    # the handle layer on top of it (include/pmc_ctx.h)
+    ctx_names = declared_symbols("pmc_ctx.h")
+    assert len(ctx_names) >= 16 and not set(ctx_names) & set(names)
+    for name in ctx_names:
+        assert hasattr(lib, name), "libpmc_hip.so does not export " + name
+    assert sorted(_lib.CTX_SIGNATURES) == ctx_names, "ctypes binding and pmc_ctx.h disagree"
+
+
+def test_handle_layer_fails_loudly_without_a_gpu():
+    """pmc_init on a box without a device: a status and a message, no crash, no fallback"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pypmc_amd import _lib
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    rc = lib.pmc_init(0, C.byref(ctx))
+    assert rc < 0 and not ctx.value and _lib.last_error()
+    assert lib.pmc_shutdown(None) == 0 and lib.pmc_mixture_destroy(None) == 0 and lib.pmc_samples_free(None) == 0
 
 
 def test_host_side_entry_points():

@@ -1,0 +1,381 @@
+"""The handle layer of the C ABI (include/pmc_ctx.h): host pointers in, host pointers out, the reference's conventions --
+what SURVEY section 8(b) lists as pmc_init / pmc_mixture_create / pmc_samples_upload / pmc_is_weights / pmc_vb_estep /
+pmc_pmc_update_stats.  Called through ctypes exactly as a .pyx binding would call it, checked against the oracle (the
+restated reference loops) and against the Python front-end on the same HIP kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.optimize import brentq
+from scipy.special import digamma
+
+pytestmark = pytest.mark.gpu
+
+dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+ip = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def mk(K, D, seed, spread=3.0):
+    rs = np.random.RandomState(seed)
+    mu = rs.normal(0, spread, size=(K, D))
+    A = rs.normal(size=(K, D, D))
+    cov = np.einsum('kij,klj->kil', A, A) / D + 0.5 * np.eye(D)
+    w = rs.uniform(0.5, 1.5, size=K)
+    return mu, cov, w / w.sum()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pypmc_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture()
+def ctx(lib):
+    h = C.c_void_p()
+    assert lib.pmc_init(0, C.byref(h)) == 0, lib.pmc_last_error()
+    yield h
+    assert lib.pmc_shutdown(h) == 0
+
+
+def make_mix(lib, ctx, mixture):
+    """pmc_mix handle from a front-end MixtureDensity: exactly the arrays its components hold"""
+    comps = mixture.components
+    K, D = len(comps), mixture.dim
+    student = hasattr(comps[0], "dof")
+    w = np.ascontiguousarray(mixture.weights, dtype=np.float64)
+    mu = np.ascontiguousarray([c.mu for c in comps], dtype=np.float64)
+    inv = np.ascontiguousarray([c.inv_sigma for c in comps], dtype=np.float64)
+    ln = np.ascontiguousarray([c.log_normalization for c in comps], dtype=np.float64)
+    dof = np.ascontiguousarray([c.dof for c in comps], dtype=np.float64) if student else None
+    h = C.c_void_p()
+    rc = lib.pmc_mixture_create(ctx, 1 if student else 0, K, D, dp(w), dp(mu), dp(inv), dp(ln), dp(dof), C.byref(h))
+    assert rc == 0, lib.pmc_last_error()
+    return h
+
+
+def upload(lib, ctx, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = C.c_void_p()
+    assert lib.pmc_samples_upload(ctx, dp(x), x.shape[0], x.shape[1], C.byref(h)) == 0, lib.pmc_last_error()
+    return h
+
+
+@pytest.mark.parametrize("student,D,K,N", [(False, 5, 3, 1000), (False, 20, 32, 70001), (True, 30, 8, 5003),
+                                           (False, 2, 1, 1), (True, 70, 4, 777)])
+def test_mix_logpdf_matches_oracle_and_front_end(lib, ctx, student, D, K, N):
+    from oracle import oracle as orc
+    from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture
+    mu, cov, w = mk(K, D, 3)
+    mixture = create_t_mixture(mu, cov, np.full(K, 6.5), w) if student else create_gaussian_mixture(mu, cov, w)
+    np.random.seed(4)
+    x = mixture.propose(N)
+    m, s = make_mix(lib, ctx, mixture), upload(lib, ctx, x)
+    assert lib.pmc_samples_count(s) == N
+    out, ind = np.empty(N), np.empty((N, K))
+    assert lib.pmc_mix_logpdf(m, s, dp(out), dp(ind)) == 0, lib.pmc_last_error()
+    ref_ind = np.empty((N, K))
+    ref = mixture.multi_evaluate(x, individual=ref_ind)
+    np.testing.assert_array_equal(out, ref)                       # the same kernels, the same pack
+    np.testing.assert_array_equal(ind, ref_ind)
+    comps = mixture.components
+    inv = np.array([c.inv_sigma for c in comps])
+    ln = np.array([c.log_normalization for c in comps])
+    if student:
+        o, _ = orc.mixture_multi_evaluate(1, x, mixture.weights, mu, inv, ln, prefactor=np.full(K, -.5 * (6.5 + D)),
+                                          inv_dof=np.full(K, 1. / 6.5))
+    else:
+        o, _ = orc.mixture_multi_evaluate(0, x, mixture.weights, mu, inv, ln)
+    assert np.max(np.abs(out - o) / np.abs(o)) < 1e-10
+    back = np.empty_like(x)
+    assert lib.pmc_samples_download(s, dp(back)) == 0
+    np.testing.assert_array_equal(back, x)
+    assert lib.pmc_samples_free(s) == 0 and lib.pmc_mixture_destroy(m) == 0
+
+
+def test_is_weights_both_target_forms(lib, ctx):
+    from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture
+    from pypmc_amd.tools.convergence import perp, ess
+    D, N = 12, 40001
+    prop = create_t_mixture(*mk(6, D, 1)[:2], np.full(6, 9.), mk(6, D, 1)[2])
+    tgt = create_gaussian_mixture(*mk(3, D, 2, spread=1.0))
+    np.random.seed(5)
+    x = prop.propose(N)
+    q, t, s = make_mix(lib, ctx, prop), make_mix(lib, ctx, tgt), upload(lib, ctx, x)
+    w1, lt, sums = np.empty(N), np.empty(N), np.empty(3)
+    assert lib.pmc_is_weights(q, s, None, t, dp(w1), dp(lt), dp(sums)) == 0, lib.pmc_last_error()
+    log_p, log_q = tgt.multi_evaluate(x), prop.multi_evaluate(x)
+    np.testing.assert_array_equal(lt, log_p)
+    ref = np.exp(log_p - log_q)                                    # importance_sampling.py:204-207
+    assert np.max(np.abs(w1 - ref) / ref) < 1e-10
+    np.testing.assert_allclose(sums, [ref.sum(), (ref * np.log(ref)).sum(), (ref ** 2).sum()], rtol=1e-10)
+    # perp / ess from the three sums (convergence.py:31-39, :67-72)
+    wn = ref / ref.sum()
+    assert abs(np.exp(-(sums[1] / sums[0] - np.log(sums[0]))) / N - perp(ref)) < 1e-10
+    assert abs(sums[0] ** 2 / sums[2] / N - 1. / (1. + np.mean((N * wn - 1) ** 2))) < 1e-10 and 0 < ess(ref) <= 1
+    # the caller's own target values
+    w2, sums2 = np.empty(N), np.empty(3)
+    assert lib.pmc_is_weights(q, s, dp(np.ascontiguousarray(log_p)), None, dp(w2), None, dp(sums2)) == 0
+    np.testing.assert_array_equal(w2, w1)
+    np.testing.assert_array_equal(sums2, sums)
+    assert lib.pmc_is_weights(q, s, None, None, dp(w2), None, None) < 0 and b"one of them" in lib.pmc_last_error()
+    for h in (q, t):
+        lib.pmc_mixture_destroy(h)
+    lib.pmc_samples_free(s)
+
+
+def vb_arrays(vb):
+    return [np.ascontiguousarray(a, dtype=np.float64) for a in
+            (vb.m, vb.W, vb.nu, vb.beta, vb.expectation_ln_pi, vb.expectation_det_ln_lambda)]
+
+
+@pytest.mark.parametrize("D,K,N,weighted", [(3, 4, 2000, False), (20, 32, 60000, True), (20, 8, 30011, False),
+                                            (40, 24, 20000, True)])
+def test_vb_estep_reference_conventions(lib, ctx, D, K, N, weighted):
+    from oracle import oracle as orc
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    mixture = create_gaussian_mixture(*mk(K, D, 7))
+    np.random.seed(8)
+    x = mixture.propose(N)
+    sw = np.random.uniform(0.5, 1.5, N) if weighted else None
+    vb = GaussianInference(x, initial_guess=mixture, weights=sw)     # its constructor runs the E-step
+    if weighted:
+        sw = np.ascontiguousarray(vb.weights, dtype=np.float64)      # as the constructor normalised them (variational.pyx:94)
+    m, W, nu, beta, ln_pi, ln_lam = vb_arrays(vb)
+    s = upload(lib, ctx, x)
+    Nk, xbar, S, elq = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(1)
+    r, lr = np.empty((N, K)), np.empty((N, K))
+    rc = lib.pmc_vb_estep(ctx, s, dp(sw), K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), None,
+                          dp(Nk), dp(xbar), dp(S), dp(elq), dp(r), dp(lr))
+    assert rc == 0, lib.pmc_last_error()
+    # against the oracle's two-pass loops (variational.pyx:699-932, :1003-1013)
+    o = orc.vb_estep(x, sw, m, W, beta, nu, ln_pi, ln_lam)
+    np.testing.assert_allclose(Nk, o["N_comp"], rtol=1e-10)
+    np.testing.assert_allclose(xbar, o["x_mean_comp"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(S, o["S"], rtol=1e-9, atol=1e-11)
+    assert abs(elq[0] - o["expectation_log_q_Z"]) <= 1e-9 * abs(o["expectation_log_q_Z"])
+    assert np.max(np.abs(r - o["r"]) / o["r"]) < 1e-10
+    # and the Python front-end, which runs the same kernels with the same shifts
+    np.testing.assert_allclose(Nk, vb.N_comp, rtol=1e-12)
+    np.testing.assert_allclose(xbar, vb.x_mean_comp, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(S, vb.S, rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(S, S.transpose(0, 2, 1))
+    np.testing.assert_array_equal(r, vb.r)
+    np.testing.assert_array_equal(lr, vb.log_rho)
+    # without the N x K matrices (the E-step proper) the K-sized results are the same to rounding
+    Nk2, xbar2, S2 = np.empty(K), np.empty((K, D)), np.empty((K, D, D))
+    assert lib.pmc_vb_estep(ctx, s, dp(sw), K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), None,
+                            dp(Nk2), dp(xbar2), dp(S2), None, None, None) == 0
+    np.testing.assert_allclose(Nk2, Nk, rtol=1e-11)
+    np.testing.assert_allclose(S2, S, rtol=1e-9, atol=1e-11)
+    # moments about the previous x_mean_comp: same numbers to rounding
+    assert lib.pmc_vb_estep(ctx, s, dp(sw), K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), dp(xbar),
+                            dp(Nk2), dp(xbar2), dp(S2), None, None, None) == 0
+    np.testing.assert_allclose(xbar2, xbar, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(S2, S, rtol=1e-9, atol=1e-11)
+    lib.pmc_samples_free(s)
+
+
+def test_vb_estep_far_start_values_take_the_second_pass(lib, ctx):
+    """start means 300 sigma off: one-pass moments about m_k would lose 1e-11; the layer repeats them about the mean"""
+    rs = np.random.RandomState(3)
+    D, K, N = 4, 2, 5000
+    x = np.ascontiguousarray(np.concatenate([rs.normal(0, 1, (N // 2, D)) + 300., rs.normal(0, 1, (N // 2, D)) - 300.]))
+    m = np.ascontiguousarray(np.array([[1.] * D, [-1.] * D]))
+    W = np.ascontiguousarray(np.array([np.eye(D) * 1e-2] * K))     # r = 1 / 1e-52: two clean blocks
+    nu, beta = np.full(K, D + 1.), np.full(K, 1.)
+    ln_pi, ln_lam = np.log(np.full(K, .5)), np.zeros(K)
+    s = upload(lib, ctx, x)
+    Nk, xbar, S = np.empty(K), np.empty((K, D)), np.empty((K, D, D))
+    assert lib.pmc_vb_estep(ctx, s, None, K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), None,
+                            dp(Nk), dp(xbar), dp(S), None, None, None) == 0, lib.pmc_last_error()
+    for k, blk in enumerate((x[:N // 2], x[N // 2:])):
+        np.testing.assert_allclose(Nk[k], N // 2, rtol=1e-12)
+        np.testing.assert_allclose(xbar[k], blk.mean(axis=0), rtol=1e-13)
+        c = blk - blk.mean(axis=0)
+        np.testing.assert_allclose(S[k], c.T @ c / (N // 2), rtol=2e-12, atol=1e-15)
+    lib.pmc_samples_free(s)
+
+
+@pytest.mark.parametrize("D,K,N,rb,dead", [(5, 4, 3000, True, False), (20, 32, 40000, True, True),
+                                           (8, 6, 9000, False, False)])
+def test_gaussian_pmc_update_stats(lib, ctx, D, K, N, rb, dead):
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+    mu, cov, w = mk(K, D, 11)
+    if dead:
+        w[2] = 0.
+        w /= w.sum()
+    proposal = create_gaussian_mixture(mu, cov, w)
+    np.random.seed(12)
+    x, origin = proposal.propose(N, trace=True, shuffle=False)
+    wts = np.random.uniform(0.2, 2.0, N)
+    latent = np.ascontiguousarray(origin, dtype=np.int64)
+    ref = gaussian_pmc(x, proposal, wts, latent=None if rb else latent, rb=rb, copy=True)
+    q, s = make_mix(lib, ctx, proposal), upload(lib, ctx, x)
+    alpha, nmu, nsig = np.zeros(K), np.array(mu), np.zeros((K, D, D))
+    ll, norm = np.empty(1), np.empty(1)
+    rc = lib.pmc_pmc_update_stats(ctx, q, s, dp(wts), 0, None if rb else ip(latent), int(rb), dp(alpha), dp(nmu), dp(nsig),
+                                  None, dp(ll), dp(norm))
+    assert rc == 0, lib.pmc_last_error()
+    assert abs(norm[0] - wts.sum()) <= 1e-12 * wts.sum()
+    live = [k for k in range(K) if w[k] != 0]
+    np.testing.assert_allclose(alpha[live] / alpha[live].sum(), ref.weights[live] / ref.weights[live].sum(), rtol=1e-11)
+    for k in live:
+        np.testing.assert_allclose(nmu[k], ref.components[k].mu, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(nsig[k], ref.components[k].sigma, rtol=1e-10, atol=1e-12)
+    if dead:
+        assert alpha[2] == 0. and not nsig[2].any()                 # rows of dead components are not written
+    if rb:
+        logq = proposal.multi_evaluate(x)
+        assert abs(ll[0] - (wts * logq).sum()) <= 1e-10 * abs((wts * logq).sum())
+    lib.pmc_mixture_destroy(q)
+    lib.pmc_samples_free(s)
+
+
+def test_student_t_pmc_update_stats_and_weights_on_device(lib, ctx):
+    from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture
+    from pypmc_amd.mix_adapt.pmc import student_t_pmc
+    D, K, N = 6, 5, 20000
+    mu, cov, w = mk(K, D, 21, spread=2.0)
+    dof = np.array([3., 5., 8., 13., 21.])
+    proposal = create_t_mixture(mu, cov, dof, w)
+    target = create_gaussian_mixture(*mk(3, D, 22, spread=1.5))
+    np.random.seed(23)
+    x = proposal.propose(N)
+    q, t, s = make_mix(lib, ctx, proposal), make_mix(lib, ctx, target), upload(lib, ctx, x)
+    wts, sums = np.empty(N), np.empty(3)
+    assert lib.pmc_is_weights(q, s, None, t, dp(wts), None, dp(sums)) == 0
+    ref = student_t_pmc(x, proposal, wts, rb=True, copy=True)
+    alpha, nmu, nsig, const = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D)), np.zeros(K)
+    norm = np.empty(1)
+    # the importance weights the weighting call left on the device: no N-sized array crosses the bus again
+    rc = lib.pmc_pmc_update_stats(ctx, q, s, None, 1, None, 1, dp(alpha), dp(nmu), dp(nsig), dp(const), None, dp(norm))
+    assert rc == 0, lib.pmc_last_error()
+    assert abs(norm[0] - sums[0]) <= 1e-12 * sums[0]
+    np.testing.assert_allclose(alpha, ref.weights, rtol=1e-10)
+    for k in range(K):
+        np.testing.assert_allclose(nmu[k], ref.components[k].mu, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(nsig[k], ref.components[k].sigma, rtol=1e-9, atol=1e-11)
+        nu = brentq(lambda v: const[k] + np.log(.5 * v) - digamma(.5 * v), 1e-5, 1e3, maxiter=100)   # pmc.pyx:478-497, :696
+        assert abs(nu - ref.components[k].dof) <= 1e-8 * ref.components[k].dof
+    # host weights give the same update
+    a2, m2, s2, c2 = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D)), np.zeros(K)
+    assert lib.pmc_pmc_update_stats(ctx, q, s, dp(wts), 0, None, 1, dp(a2), dp(m2), dp(s2), dp(c2), None, None) == 0
+    np.testing.assert_allclose(a2, alpha, rtol=1e-13)
+    np.testing.assert_allclose(s2, nsig, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(c2, const, rtol=1e-11, atol=1e-13)
+    assert lib.pmc_pmc_update_stats(ctx, q, s, dp(wts), 1, None, 1, dp(a2), dp(m2), dp(s2), dp(c2), None, None) < 0
+    for h in (q, t):
+        lib.pmc_mixture_destroy(h)
+    lib.pmc_samples_free(s)
+
+
+def test_generate_then_latent_update_and_mixture_update(lib, ctx):
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    D, K = 7, 4
+    mu, cov, w = mk(K, D, 31)
+    proposal = create_gaussian_mixture(mu, cov, w)
+    counts = np.array([3000, 0, 1201, 4999], dtype=np.int64)        # rng.multinomial of the caller (mixture.pyx:192)
+    N = int(counts.sum())
+    q = make_mix(lib, ctx, proposal)
+    chol = np.ascontiguousarray(np.linalg.cholesky(cov))
+    s1, s2, s3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.pmc_samples_generate(ctx, q, dp(chol), ip(counts), 99, 0, C.byref(s1)) == 0, lib.pmc_last_error()
+    assert lib.pmc_samples_generate(ctx, q, None, ip(counts), 99, 0, C.byref(s2)) == 0, lib.pmc_last_error()
+    assert lib.pmc_samples_generate(ctx, q, dp(chol), ip(counts), 100, 0, C.byref(s3)) == 0
+    assert lib.pmc_samples_count(s1) == N
+    x1, x2, x3, origin = np.empty((N, D)), np.empty((N, D)), np.empty((N, D)), np.empty(N, dtype=np.int64)
+    for h, out in ((s1, x1), (s2, x2), (s3, x3)):
+        assert lib.pmc_samples_download(h, dp(out)) == 0
+    assert lib.pmc_samples_origin(s1, ip(origin)) == 0
+    np.testing.assert_array_equal(origin, np.repeat(np.arange(K), counts))     # bit-exact counts and origins
+    np.testing.assert_allclose(x2, x1, rtol=1e-10, atol=1e-11)      # Cholesky factors derived from inv_sigma
+    assert np.abs(x3 - x1).max() > 0.1                              # another seed, other numbers
+    for k in (0, 2, 3):                                             # right distribution: whitened blocks ~ N(0, I)
+        z = np.linalg.solve(chol[k], (x1[origin == k] - mu[k]).T).T
+        assert np.abs(z.mean(axis=0)).max() < 5 / np.sqrt(counts[k]) and np.abs(np.cov(z.T) - np.eye(D)).max() < 0.15
+    # non-Rao-Blackwell update with the origin the handle kept as latent: component k's block mean / covariance
+    alpha, nmu, nsig = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D))
+    assert lib.pmc_pmc_update_stats(ctx, q, s1, None, 0, None, 0, dp(alpha), dp(nmu), dp(nsig), None, None, None) == 0, \
+        lib.pmc_last_error()
+    np.testing.assert_allclose(alpha, counts / N, rtol=1e-12)
+    for k in (0, 2, 3):
+        blk = x1[origin == k]
+        np.testing.assert_allclose(nmu[k], blk.mean(axis=0), rtol=1e-10, atol=1e-12)
+        c = blk - blk.mean(axis=0)
+        np.testing.assert_allclose(nsig[k], c.T @ c / counts[k], rtol=1e-9, atol=1e-11)
+    # uploaded samples carry no origin
+    up = upload(lib, ctx, x1)
+    assert lib.pmc_samples_origin(up, ip(origin)) < 0
+    assert lib.pmc_pmc_update_stats(ctx, q, up, None, 0, None, 0, dp(alpha), dp(nmu), dp(nsig), None, None, None) < 0
+    assert b"`rb` must be True" in lib.pmc_last_error()             # the reference's message (pmc.pyx:81-83)
+    # pmc_mixture_update: the handle follows the host's parameters
+    out1, out2 = np.empty(N), np.empty(N)
+    lib.pmc_mix_logpdf(q, up, dp(out1), None)
+    newp = create_gaussian_mixture(mu + 0.5, cov * 1.3, w[::-1].copy())
+    comps = newp.components
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in
+            (newp.weights, [c.mu for c in comps], [c.inv_sigma for c in comps], [c.log_normalization for c in comps])]
+    assert lib.pmc_mixture_update(q, dp(arrs[0]), dp(arrs[1]), dp(arrs[2]), dp(arrs[3]), None) == 0
+    lib.pmc_mix_logpdf(q, up, dp(out2), None)
+    np.testing.assert_array_equal(out2, newp.multi_evaluate(x1))
+    assert np.abs(out2 - out1).max() > 1e-3
+    # a precision matrix that does not factorise: the status and the component's number
+    bad = arrs[2].copy()
+    bad[1] = -np.eye(D)
+    assert lib.pmc_mixture_update(q, dp(arrs[0]), dp(arrs[1]), dp(bad), dp(arrs[3]), None) == -2
+    assert b"component 1" in lib.pmc_last_error()
+    for h in (s1, s2, s3, up):
+        lib.pmc_samples_free(h)
+    lib.pmc_mixture_destroy(q)
+
+
+def test_one_rank_communicator_changes_nothing(lib):
+    """pmc_ctx_join with a world of one: every K-sized result goes through ncclAllReduce on the context's stream"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    D, K, N = 10, 6, 15000
+    mixture = create_gaussian_mixture(*mk(K, D, 41))
+    np.random.seed(42)
+    x = mixture.propose(N)
+    wts = np.random.uniform(0.5, 1.5, N)
+    results = []
+    for joined in (False, True):
+        ctx = C.c_void_p()
+        assert lib.pmc_init(0, C.byref(ctx)) == 0
+        if joined:
+            uid = (C.c_char * 128)()
+            assert lib.pmc_comm_unique_id(uid) == 0, lib.pmc_last_error()
+            assert lib.pmc_ctx_join(ctx, 0, 1, uid) == 0, lib.pmc_last_error()
+            assert lib.pmc_ctx_join(ctx, 0, 1, uid) < 0              # once
+        q, s = make_mix(lib, ctx, mixture), upload(lib, ctx, x)
+        alpha, nmu, nsig, ll = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D)), np.empty(1)
+        assert lib.pmc_pmc_update_stats(ctx, q, s, dp(wts), 0, None, 1, dp(alpha), dp(nmu), dp(nsig), None, dp(ll), None) == 0, \
+            lib.pmc_last_error()
+        w, sums = np.empty(N), np.empty(3)
+        assert lib.pmc_is_weights(q, s, dp(np.zeros(N)), None, dp(w), None, dp(sums)) == 0
+        results.append((alpha, nmu, nsig, ll, sums))
+        lib.pmc_mixture_destroy(q)
+        lib.pmc_samples_free(s)
+        assert lib.pmc_shutdown(ctx) == 0
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_argument_errors(lib, ctx):
+    h = C.c_void_p()
+    assert lib.pmc_init(99, C.byref(h)) < 0 and not h.value
+    assert lib.pmc_samples_upload(ctx, None, 5, 3, C.byref(h)) < 0
+    assert lib.pmc_samples_upload(ctx, dp(np.zeros(3)), 1, 2000, C.byref(h)) < 0 and b"not supported" in lib.pmc_last_error()
+    x = np.zeros((4, 3))
+    s = upload(lib, ctx, x)
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    q = make_mix(lib, ctx, create_gaussian_mixture(*mk(2, 5, 1)))
+    assert lib.pmc_mix_logpdf(q, s, dp(np.empty(4)), None) < 0 and b"do not belong together" in lib.pmc_last_error()
+    assert lib.pmc_mixture_create(ctx, 2, 1, 3, dp(np.ones(1)), dp(np.zeros(3)), dp(np.eye(3)), dp(np.zeros(1)), None,
+                                  C.byref(h)) < 0
+    assert lib.pmc_mixture_create(ctx, 1, 1, 3, dp(np.ones(1)), dp(np.zeros(3)), dp(np.eye(3)), dp(np.zeros(1)), None,
+                                  C.byref(h)) < 0 and b"h_dof" in lib.pmc_last_error()
+    lib.pmc_mixture_destroy(q)
+    lib.pmc_samples_free(s)
