@@ -134,3 +134,19 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("oraclebackend", ""), os.path.join(dirpath, f)
+
+
+def test_ctx_demo_builds_with_plain_gcc(tmp_path):
+    """the handle layer needs nothing but a C compiler on the caller's side: examples/ctx_demo.c with gcc -std=c99,
+    pmc_ctx.h / pmc_hip.h as its only non-standard headers; run without a GPU it reports the missing device and exits"""
+    import subprocess
+    from pypmc_amd import _lib
+    exe = str(tmp_path / "ctx_demo")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-O2", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "ctx_demo.c"), "-L", libdir, "-lpmc_hip", "-Wl,-rpath," + libdir, "-lm",
+                    "-o", exe], check=True)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "10"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 3 and "pmc_init" in r.stderr
