@@ -123,6 +123,16 @@ int pmc_pack_components(int K, int D, const double *h_mu, const double *h_precis
  */
 int pmc_pack_means(int K, int D, const double *h_mu, double *h_pack);
 
+/* ---- streams ---------------------------------------------------------------------------------- */
+/*
+ * The library keeps 4.4 KB of device scratch per (device, stream) it has launched a finishing reduction on -- at most
+ * 256 such slots.  A caller that creates and destroys streams over its lifetime calls this (current device = the
+ * stream's) once the stream is idle, before destroying it: the slot is handed to the next new stream.  Needed for
+ * correctness too: a new stream may receive the handle value of a destroyed one.  Callers with a fixed set of streams
+ * (PyTorch's stream pool) never need it.
+ */
+int pmc_stream_release(void *stream);
+
 /* ---- workspace ------------------------------------------------------------------------------ */
 /* bytes of device scratch the calls below need for N samples, K components, dimension D */
 int64_t pmc_workspace_bytes(int64_t N, int K, int D);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "pmc_tile": (_int, []),
     "pmc_pack_components": (_int, [_int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i32, _dp]),
     "pmc_pack_means": (_int, [_int, _int, _dp, _dp]),
+    "pmc_stream_release": (_int, [_vp]),
     "pmc_workspace_bytes": (_i64, [_i64, _int, _int]),
     "pmc_tile_buffer_len": (_i64, [_i64, _int]),
     "pmc_stats_stride": (_i64, [_int]),

@@ -888,21 +888,34 @@ struct FinScratch {
     double *slices;
     unsigned *counter;
 };
+std::mutex g_fin_mutex;
+std::vector<FinScratch> g_fin_all;
+const hipStream_t FIN_FREE = (hipStream_t)(intptr_t)-1;         // a released slot (pmc_stream_release), memory kept
+
 FinScratch *fin_scratch(hipStream_t st)
 {
-    static std::mutex m;
-    static std::vector<FinScratch> all;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(m);
+    std::lock_guard<std::mutex> lock(g_fin_mutex);
+    std::vector<FinScratch> &all = g_fin_all;
     for (FinScratch &f : all)
         if (f.device == dev && f.stream == st) return &f;
+    const size_t bytes = sizeof(double) * FIN_GROUPS * PMC_NSCALARS + 256;
+    // hipMemset of device memory runs on the NULL stream and may return before it has run: a launch that follows on a
+    // NON-BLOCKING stream is not ordered behind it and could take its tickets from a counter that is zeroed under it
+    // (found with the handle layer's own stream: the last-ticket block never came and d_scalars was not written).
+    // Wait for it here, once per (device, stream).
+    for (FinScratch &f : all)
+        if (f.device == dev && f.stream == FIN_FREE) {          // a slot some released stream left behind
+            if (hipMemset(f.slices, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;
+            f.stream = st;
+            return &f;
+        }
     all.reserve(256);                                       // (pointers handed out stay valid)
     if (all.size() >= 256) return nullptr;                  // before anything is allocated
     void *p = nullptr;
-    const size_t bytes = sizeof(double) * FIN_GROUPS * PMC_NSCALARS + 256;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, bytes) != hipSuccess) {
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
         (void)hipFree(p);
         return nullptr;
     }
@@ -1287,6 +1300,17 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
                          const double *d_u, double *d_stats, void *d_workspace, void *stream)
 {
     return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, -1);
+}
+
+int pmc_stream_release(void *stream)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hipfail(e, "hipGetDevice");
+    std::lock_guard<std::mutex> lock(g_fin_mutex);
+    for (FinScratch &f : g_fin_all)
+        if (f.device == dev && f.stream == (hipStream_t)stream) f.stream = FIN_FREE;
+    return PMC_OK;
 }
 
 int pmc_configure(const char *key, double value)

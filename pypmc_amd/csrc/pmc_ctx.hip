@@ -347,7 +347,11 @@ int pmc_shutdown(pmc_ctx *ctx)
     for (DevBuf *b : {&ctx->ws, &ctx->u, &ctx->scratch, &ctx->flat, &ctx->pack, &ctx->spack, &ctx->aux, &ctx->nk1,
                       &ctx->nk2, &ctx->lat})
         b->release();
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)pmc_stream_release(ctx->stream);                     // the library's per-stream scratch slot
+        (void)hipStreamDestroy(ctx->stream);
+    }
     delete ctx;
     return rc;
 }

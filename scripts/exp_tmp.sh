@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_cabi_demo.py tests/test_gpu_ctx.py -x -q 2>&1 | tail -30
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8

@@ -379,3 +379,53 @@ def test_argument_errors(lib, ctx):
                                   C.byref(h)) < 0 and b"h_dof" in lib.pmc_last_error()
     lib.pmc_mixture_destroy(q)
     lib.pmc_samples_free(s)
+
+
+def test_many_contexts_in_sequence(lib):
+    """300 contexts, each with a stream of its own (non-blocking), each running a finishing reduction as its very first
+    launch: the library's per-stream scratch (at most 256 slots) is released with the context and re-used, and its
+    zeroing is complete before the first launch on the new stream (a race between the NULL stream's memset and a
+    non-blocking stream's kernel left the scalars unwritten now and then before)."""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    D, K, N = 6, 3, 4000
+    mixture = create_gaussian_mixture(*mk(K, D, 51))
+    np.random.seed(52)
+    x = mixture.propose(N)
+    lt = np.ascontiguousarray(np.random.normal(size=N))
+    first = None
+    for i in range(300):
+        ctx = C.c_void_p()
+        assert lib.pmc_init(0, C.byref(ctx)) == 0, lib.pmc_last_error()
+        q, s = make_mix(lib, ctx, mixture), upload(lib, ctx, x)
+        sums = np.empty(3)
+        assert lib.pmc_is_weights(q, s, dp(lt), None, None, None, dp(sums)) == 0, (i, lib.pmc_last_error())
+        if first is None:
+            first = sums.copy()
+            w = np.exp(lt - mixture.multi_evaluate(x))
+            np.testing.assert_allclose(first, [w.sum(), (w * np.log(w)).sum(), (w * w).sum()], rtol=1e-10)
+        np.testing.assert_array_equal(sums, first, err_msg="context %d" % i)
+        lib.pmc_mixture_destroy(q)
+        lib.pmc_samples_free(s)
+        assert lib.pmc_shutdown(ctx) == 0
+
+
+def test_first_launch_on_new_torch_streams(lib):
+    """the kernel-level ABI on streams it has never seen (PyTorch's pool streams are non-blocking): the scalars of the
+    first call on each are complete"""
+    import torch
+    from pypmc_amd.backend import HipBackend
+    from pypmc_amd.density.mixture import create_gaussian_mixture, component_set
+    be = HipBackend()
+    mixture = create_gaussian_mixture(*mk(4, 9, 61))
+    np.random.seed(62)
+    x = be.asdevice(mixture.propose(3000))
+    lt = be.asdevice(np.random.normal(size=3000))
+    cs = component_set(mixture.components, mixture.weights)
+    ref = be.tohost(be.logpdf(x, cs, log_target=lt, want_scalars=True)["scalars"])
+    torch.cuda.synchronize()
+    for _ in range(40):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            got = be.tohost(be.logpdf(x, cs, log_target=lt, want_scalars=True)["scalars"])
+        np.testing.assert_array_equal(got, ref)
+        assert lib.pmc_stream_release(C.c_void_p(st.cuda_stream)) == 0
