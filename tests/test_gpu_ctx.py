@@ -429,3 +429,76 @@ def test_first_launch_on_new_torch_streams(lib):
             got = be.tohost(be.logpdf(x, cs, log_target=lt, want_scalars=True)["scalars"])
         np.testing.assert_array_equal(got, ref)
         assert lib.pmc_stream_release(C.c_void_p(st.cuda_stream)) == 0
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_handle_layer_fuzz(lib, ctx, seed):
+    """random shapes through every handle-layer entry point against the Python front-end (same kernels underneath):
+    all compiled dimensions incl. padded ones and the run-time-dimension unit, K = 1 ..., ragged N, both families,
+    weights or none, a dead component now and then"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc, student_t_pmc
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    rs = np.random.RandomState(1000 + seed)
+    D = int(rs.choice([1, 2, 3, 5, 7, 8, 9, 11, 13, 16, 19, 20, 23, 29, 31, 32, 37, 48, 61, 64, 70, 100]))
+    K = int(rs.randint(1, 14))
+    N = int(rs.choice([1, 63, 64, 65, 700, 2999, 6001]))
+    student = bool(rs.randint(2))
+    mu, cov, w = mk(K, D, 2000 + seed, spread=2.0)
+    if K > 2 and rs.rand() < 0.4:
+        w[rs.randint(K)] = 0.
+        w /= w.sum()
+    dof = rs.uniform(2.5, 30., K)
+    mixture = create_t_mixture(mu, cov, dof, w) if student else create_gaussian_mixture(mu, cov, w)
+    np.random.seed(seed)
+    x = mixture.propose(N)
+    wts = rs.uniform(0.1, 3.0, N) if rs.rand() < 0.7 else None
+    q, s = make_mix(lib, ctx, mixture), upload(lib, ctx, x)
+    tag = "seed %d: D=%d K=%d N=%d student=%d weighted=%d" % (seed, D, K, N, student, wts is not None)
+    # log-pdf: bit-equal
+    out, ind = np.empty(N), np.empty((N, K))
+    assert lib.pmc_mix_logpdf(q, s, dp(out), dp(ind)) == 0, lib.pmc_last_error()
+    ref_ind = np.empty((N, K))
+    np.testing.assert_array_equal(out, mixture.multi_evaluate(x, individual=ref_ind), err_msg=tag)
+    np.testing.assert_array_equal(ind, ref_ind, err_msg=tag)
+    # PMC update
+    live = [k for k in range(K) if w[k] != 0]
+    alpha, nmu, nsig, const = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D)), np.zeros(K)
+    rc = lib.pmc_pmc_update_stats(ctx, q, s, dp(wts), 0, None, 1, dp(alpha), dp(nmu), dp(nsig), dp(const) if student else None,
+                                  None, None)
+    assert rc == 0, (tag, lib.pmc_last_error())
+    norm = wts.sum() if wts is not None else float(N)
+    from pypmc_amd.backend import get_backend
+    from pypmc_amd.density.mixture import component_set
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    be = get_backend(None)
+    cs = component_set(mixture.components, mixture.weights, live, K)
+    st = split_stats(be.tohost(be.estep(x, cs, 1, max_init_zero=len(live) < K, sample_w=wts)["stats"]), len(live), D)
+    shift = mu[live]
+    if student:
+        m_ref, c_ref = centred_moments(st[1], st[2], st[3], shift, S0_cov=st[4])
+        a_ref = st[4] / norm
+    else:
+        m_ref, c_ref = centred_moments(st[1], st[2], st[3], shift)
+        a_ref = st[1] / norm
+    from pypmc_amd.mix_adapt._stats import shift_is_far
+    if not shift_is_far(st[1], st[2], st[3]):                      # (else the layer took its second pass: checked elsewhere)
+        np.testing.assert_allclose(alpha[live], a_ref, rtol=1e-11, atol=1e-300, err_msg=tag)
+        np.testing.assert_allclose(nmu[live], m_ref, rtol=1e-10, atol=1e-12, err_msg=tag)
+        scale = np.abs(c_ref).max(axis=(1, 2))[:, None, None] + 1e-300
+        assert np.max(np.abs(nsig[live] - c_ref) / scale) < 1e-9, tag
+    # VB E-step (Gaussian posterior): against GaussianInference with the mixture as its guess
+    if not student and N >= K and len(live) == K:
+        vb = GaussianInference(x, initial_guess=mixture, weights=wts)
+        sw = np.ascontiguousarray(vb.weights) if wts is not None else None
+        m, W, nu, beta, ln_pi, ln_lam = vb_arrays(vb)
+        Nk, xbar, S, elq = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(1)
+        assert lib.pmc_vb_estep(ctx, s, dp(sw), K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), None,
+                                dp(Nk), dp(xbar), dp(S), dp(elq), None, None) == 0, (tag, lib.pmc_last_error())
+        np.testing.assert_allclose(Nk, vb.N_comp, rtol=1e-11, err_msg=tag)
+        np.testing.assert_allclose(xbar, vb.x_mean_comp, rtol=1e-10, atol=1e-12, err_msg=tag)
+        scale = np.abs(vb.S).max(axis=(1, 2))[:, None, None] + 1e-300
+        assert np.max(np.abs(S - vb.S) / scale) < 1e-9, tag
+        assert abs(elq[0] - vb._expectation_log_q_Z) <= 1e-10 * abs(vb._expectation_log_q_Z) + 1e-12, tag
+    lib.pmc_mixture_destroy(q)
+    lib.pmc_samples_free(s)
