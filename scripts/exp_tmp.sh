@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_ctx.py -x -q 2>&1 | tail -30
+timeout 600 python scripts/step_overheads.py 2>&1 | grep -v amdgpu.ids | tail -12
+timeout 600 python scripts/step_overheads.py 1250000 2>&1 | grep -v amdgpu.ids | tail -12
