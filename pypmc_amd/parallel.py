@@ -78,20 +78,22 @@ def init_from_env(force=False):
         return 0, 1, torch.cuda.current_device() if torch.cuda.is_available() else 0
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if not launched:
-        os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
     backend = os.environ.get("PMC_DIST_BACKEND", "nccl")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend != "nccl":
         local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if not dist.is_initialized():
+        # a forced one-rank group of a plain process meets itself through a file of its own: no TCP port to probe and
+        # lose to another process before it is bound; a launched group uses what the launcher set up (env://)
+        extra = {}
+        if not launched:
+            import tempfile
+            extra = dict(init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="pmc_rdzv_"), "store"), rank=0, world_size=1)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), **extra)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **extra)
     if os.environ.get("PMC_NATIVE_COLLECTIVE", "0") not in ("", "0"):
         enable_native_collective(local)
     return dist.get_rank(), dist.get_world_size(), local

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python scripts/step_overheads.py 2>&1 | grep -v amdgpu.ids | tail -12
-timeout 600 python scripts/step_overheads.py 1250000 2>&1 | grep -v amdgpu.ids | tail -12
+timeout 900 python -m pytest tests/test_gpu_nccl.py tests/test_gpu_distributed.py tests/test_gpu_ctx.py -q -x 2>&1 | grep -E "passed|failed|error|Error" | tail -5

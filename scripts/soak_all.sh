@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 fails=0
 for i in $(seq 1 ${1:-8}); do
-  r=$(timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -1)
+  r=$(timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|error" | tail -1)
   echo "suite run $i: $r"
   case "$r" in *failed*|*error*|*Error*) fails=$((fails+1));; esac
 done

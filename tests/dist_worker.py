@@ -99,6 +99,12 @@ def collectives(be=None):
     return out
 
 
+def _rendezvous(workdir):
+    """a file in the run's own temporary directory: no TCP port to pick and lose to another process before it is bound
+    (a full-suite run once died of EADDRINUSE on a port that had just been probed free)"""
+    return "file://" + os.path.join(workdir, "rendezvous")
+
+
 def run(rank, world, port, workdir, backend_kind="oracle", pg_backend="gloo"):
     import torch.distributed as dist
     if backend_kind == "hip":
@@ -106,10 +112,10 @@ def run(rank, world, port, workdir, backend_kind="oracle", pg_backend="gloo"):
         torch.cuda.set_device(0)                     # both ranks share the one GPU of the box
     if pg_backend == "nccl":                         # RCCL: one rank per device (a single rank on a one-GPU box)
         import torch
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+        dist.init_process_group("nccl", init_method=_rendezvous(workdir), rank=rank, world_size=world,
                                 device_id=torch.device("cuda", rank))
     else:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        dist.init_process_group("gloo", init_method=_rendezvous(workdir), rank=rank, world_size=world)
     try:
         from pypmc_amd import parallel
         if os.environ.get("PMC_NATIVE_COLLECTIVE", "0") not in ("", "0"):

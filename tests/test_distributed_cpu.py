@@ -18,6 +18,23 @@ def _free_port():
     return port
 
 
+def run_torchrun(nproc, script_args, env, timeout=900, attempts=4):
+    """`python -m torch.distributed.run --nproc-per-node nproc ...` on a port probed free, again on another one if the
+    port was taken between the probe and torchrun's bind (EADDRINUSE) -- other jobs share the node's port space"""
+    import subprocess
+    import sys
+    for attempt in range(attempts):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + list(script_args)
+        r = subprocess.run(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        if r.returncode != 0 and ("EADDRINUSE" in r.stderr or "address already in use" in r.stderr.lower()) \
+                and attempt + 1 < attempts:
+            continue
+        return r
+    return r
+
+
 def test_shard_bounds():
     from pypmc_amd.parallel import shard_bounds
     for N, world in ((10, 3), (7, 8), (1000, 8), (0, 2)):
@@ -109,7 +126,7 @@ def test_first_rows_spanning_ranks():
 
 def _first_rows_worker(rank, world, port, workdir):
     import torch.distributed as dist
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=dist_worker._rendezvous(workdir), rank=rank, world_size=world)
     try:
         from pypmc_amd import parallel
         from pypmc_amd.mix_adapt.variational import GaussianInference

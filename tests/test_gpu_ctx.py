@@ -502,3 +502,26 @@ def test_handle_layer_fuzz(lib, ctx, seed):
         assert abs(elq[0] - vb._expectation_log_q_Z) <= 1e-10 * abs(vb._expectation_log_q_Z) + 1e-12, tag
     lib.pmc_mixture_destroy(q)
     lib.pmc_samples_free(s)
+
+
+def test_vb_estep_large_batch_takes_the_fast_forms(lib, ctx):
+    """N large enough for the grouped responsibilities and the common-shift statistics (k_resp_groups + k_stats_gemm):
+    the handle layer issues the very call the front-end issues -- same numbers"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    D, K, N = 20, 32, 600_000
+    mixture = create_gaussian_mixture(*mk(K, D, 71))
+    np.random.seed(72)
+    x = mixture.propose(N)
+    vb = GaussianInference(x, initial_guess=mixture)
+    m, W, nu, beta, ln_pi, ln_lam = vb_arrays(vb)
+    s = upload(lib, ctx, x)
+    Nk, xbar, S, elq = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(1)
+    assert lib.pmc_vb_estep(ctx, s, None, K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), None,
+                            dp(Nk), dp(xbar), dp(S), dp(elq), None, None) == 0, lib.pmc_last_error()
+    np.testing.assert_array_equal(Nk, vb.N_comp)
+    np.testing.assert_array_equal(xbar, vb.x_mean_comp)
+    np.testing.assert_allclose(S, vb.S, rtol=1e-13, atol=1e-15)        # (numpy's einsum against the plain loop)
+    assert elq[0] == vb._expectation_log_q_Z
+    assert abs(Nk.sum() - N) < 1e-6
+    lib.pmc_samples_free(s)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import dist_worker
-from test_distributed_cpu import check_two_ranks, spawn_two_ranks, _free_port
+from test_distributed_cpu import check_two_ranks, spawn_two_ranks, run_torchrun
 
 pytestmark = pytest.mark.gpu
 
@@ -43,10 +43,8 @@ def test_two_ranks_vs_oracle():
 def test_bench_two_ranks_one_gpu():
     """bench.py --gpus 2 end to end (torch.distributed.run, 2 ranks on the one GPU via gloo)"""
     env = dict(os.environ, PMC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples-per-gpu", "300000"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    r = run_torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                         "--samples-per-gpu", "300000"], env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -60,9 +58,7 @@ def test_bench_two_ranks_one_gpu():
 def test_examples_under_torchrun(script, args):
     """the multi-rank examples end to end: 4 ranks sharing the one GPU (PMC_DIST_BACKEND=gloo)"""
     env = dict(os.environ, PMC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "examples", script)] + args
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    r = run_torchrun(4, [os.path.join(ROOT, "examples", script)] + args, env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     want = {"pmc_device_loop.py": "iteration 1", "variational.py": "converged after",
             "pmc_torchrun.py": "10 x 4000 samples on 4 rank(s)"}[script]

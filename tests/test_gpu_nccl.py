@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import dist_worker
-from test_distributed_cpu import check_collectives, spawn_ranks, _free_port
+from test_distributed_cpu import check_collectives, spawn_ranks, run_torchrun
 
 pytestmark = pytest.mark.gpu
 
@@ -51,10 +51,15 @@ def test_one_rank_through_the_librarys_own_communicator(monkeypatch):
 
 
 def _bench(launcher, extra, env=None):
-    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                      "--samples-per-gpu", "400000", "--no-cpu-baseline", "--no-configs"] + extra
-    r = subprocess.run(cmd, cwd=ROOT, env=env or dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, timeout=900)
+    """bench.py on a small batch: `launcher` = [python] for a plain process, "torchrun" for one rank under
+    torch.distributed.run (retried on another port should the probed one be taken in between)"""
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+            "--samples-per-gpu", "400000", "--no-cpu-baseline", "--no-configs"] + extra
+    if launcher == "torchrun":
+        r = run_torchrun(1, args, env or dict(os.environ), timeout=900)
+    else:
+        r = subprocess.run(launcher + args, cwd=ROOT, env=env or dict(os.environ), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -65,9 +70,7 @@ def _bench(launcher, extra, env=None):
 def test_bench_under_torchrun_one_rank_is_rccl(scaling):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.pop("PMC_DIST_BACKEND", None)
-    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
-    line = _bench(launcher, ["--scaling", scaling], env)
+    line = _bench("torchrun", ["--scaling", scaling], env)
     assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1
     assert line["dist"]["allreduce_ms"] > 0.0 and line["dist"]["allreduce_doubles"] > 0
     assert line["scaling"] == scaling and line["n_gpus"] == 1 and line["value"] > 0
