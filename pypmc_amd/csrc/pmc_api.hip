@@ -218,10 +218,15 @@ __global__ __launch_bounds__(256) void k_finish_scalars(const double *__restrict
     __syncthreads();
     if (ticket != FIN_GROUPS - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the 64 x 8 slices: fetched by all threads at once (two each) into LDS, then summed per scalar in the same ascending
+    // order as before (same bits) -- one thread per scalar walking 64 L2 round trips was most of this kernel's 10 us
+    __shared__ double sl[FIN_GROUPS * PMC_NSCALARS];
+    for (int q = threadIdx.x; q < FIN_GROUPS * PMC_NSCALARS; q += 256)
+        sl[q] = __hip_atomic_load(&slices[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (threadIdx.x < PMC_NSCALARS) {
         double t = 0.0;
-        for (int g = 0; g < FIN_GROUPS; ++g)
-            t += __hip_atomic_load(&slices[g * PMC_NSCALARS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int g = 0; g < FIN_GROUPS; ++g) t += sl[g * PMC_NSCALARS + threadIdx.x];
         scalars[threadIdx.x] = t;
     }
 }
@@ -289,8 +294,22 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const double *__restrict__ 
     __shared__ double red[4][64];
     const int k = blockIdx.y, m = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     double v = 0.0;
-    if (m < msp)
-        for (int ce = w; ce < nce; ce += 4) v += partials[((size_t)ce * K + k) * msp + m];
+    if (m < msp) {
+        // eight loads in flight, added in the same ascending order as one by one (same bits): the launch is a chain of
+        // dependent L2 round trips otherwise (20.6 us whatever N, a third of the statistics' finishing time at an
+        // 8-GPU shard size)
+        const double *p = partials + (size_t)k * msp + m;
+        const size_t step = (size_t)K * msp;
+        int ce = w;
+        for (; ce + 28 < nce; ce += 32) {
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = p[(size_t)(ce + 4 * q) * step];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += a[q];
+        }
+        for (; ce < nce; ce += 4) v += p[(size_t)ce * step];
+    }
     red[w][threadIdx.x & 63] = v;
     __syncthreads();
     if (w == 0 && m < msp) totals[(size_t)k * msp + m] = ((red[0][m & 63] + red[1][m & 63]) + red[2][m & 63]) + red[3][m & 63];
@@ -313,10 +332,15 @@ __global__ __launch_bounds__(256) void k_gemm_convert(const double *__restrict__
     double *out = stats + (size_t)k * PS;
     const double S0 = tk[0];
     __shared__ double wsum;
+    __shared__ double s0s[1024];
+    // the K weights: loaded side by side, summed by one thread in ascending order (same bits as a serial walk over global
+    // memory, without its K dependent round trips)
+    for (int q = threadIdx.x; q < K && q < 1024; q += 256) s0s[q] = totals[(size_t)q * msp];
+    __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int q = 0; q < K; ++q) {
-            const double s = totals[(size_t)q * msp];
+            const double s = q < 1024 ? s0s[q] : totals[(size_t)q * msp];
             if (s == s && fabs(s) <= 1.7976931348623157e308) t += s;
         }
         wsum = t;
