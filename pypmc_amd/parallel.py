@@ -16,6 +16,14 @@ bitwise the same everywhere.
 import numpy as np
 
 
+import os as _os
+
+# RCCL shares device memory between the ranks of a node through dmabuf IPC; the host driver of the MI355X boxes supports
+# only that mode, and without this switch `hipIpcGetMemHandle` fails with "invalid argument" as soon as a second rank
+# appears.  Set before the HIP runtime starts (it is read at initialisation); a value the launcher exported wins.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def _dist():
     try:
         import torch.distributed as dist
