@@ -1289,16 +1289,6 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
             e = hipGetLastError();
             if (e != hipSuccess) return hipfail(e, "k_gemm_convert launch");
         }
-        if (d_gscale) {
-            // should the form be refused, the per-component kernel below needs u complete
-            Timed t(T_STATS, st, 0.0, 0.0, 0);
-            const long long total_u = gg.ntiles * (long long)K * 64;
-            const long long blocks = ceil_div(total_u, 256);
-            hipLaunchKernelGGL(k_apply_scale, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (double *)d_u,
-                               d_gscale, gg.ntiles, K, (const int *)ctl);
-            e = hipGetLastError();
-            if (e != hipSuccess) return hipfail(e, "k_apply_scale launch");
-        }
         counted = 0;                                       // the launches below continue this call's record
     }
     PmcArgsB b;
@@ -1306,13 +1296,37 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
     b.x = d_x; b.N = N; b.dreal = D; b.pack = d_pack; b.K = K; b.u = d_u;
     b.partials = (double *)d_workspace; b.ntiles = g.ntiles; b.nchunks = g.nchunks;
     b.tiles_per_chunk = g.tiles_per_chunk; b.ngroups = g.ngroups; b.ctl = ctl;
+    const long long total = (long long)K * PS;
+    if (!counted) {
+        // behind the common-shift form: its fall-back -- the factors k_resp_groups left to the statistics kernel applied to
+        // u, the per-component-shift kernel, its finishing reduction -- three launches that return at once unless the
+        // control block asks for them, under ONE timing bracket (continuing the statistics' record): launches inside a
+        // bracket follow each other without a gap, every bracket of its own put ~10 us in front of its launch
+        // (profiles/r03_timeline_gaps_share.txt)
+        Timed t(T_STATS, st, 0.0, 0.0, 0);
+        if (d_gscale) {
+            const GemmGeom gg = gemm_geom(N, K, ks);
+            const long long total_u = gg.ntiles * (long long)K * 64;
+            const long long blocks = ceil_div(total_u, 256);
+            hipLaunchKernelGGL(k_apply_scale, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (double *)d_u,
+                               d_gscale, gg.ntiles, K, (const int *)ctl);
+            e = hipGetLastError();
+            if (e != hipSuccess) return hipfail(e, "k_apply_scale launch");
+        }
+        e = ks->stats(b, g.grid, st);
+        if (e != hipSuccess) return hipfail(e, "k_stats launch");
+        hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
+                           (const double *)d_workspace, g.nchunks, K, D, ks->dim, d_stats, (const int *)ctl);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hipfail(e, "k_finish_stats launch");
+        return PMC_OK;
+    }
     {
-        Timed t(T_STATS, st, counted ? flops_stats((double)N, K, D) : 0.0, counted ? 8.0 * N * (D + K) : 0.0, counted);
+        Timed t(T_STATS, st, flops_stats((double)N, K, D), 8.0 * N * (D + K));
         e = ks->stats(b, g.grid, st);
     }
     if (e != hipSuccess) return hipfail(e, "k_stats launch");
-    const long long total = (long long)K * PS;
-    Timed tf(T_FINISH, st, 0.0, 8.0 * g.nchunks * K * pmc_stats_stride_c(ks->dim), counted);
+    Timed tf(T_FINISH, st, 0.0, 8.0 * g.nchunks * K * pmc_stats_stride_c(ks->dim));
     hipLaunchKernelGGL(k_finish_stats, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
                        (const double *)d_workspace, g.nchunks, K, D, ks->dim, d_stats, (const int *)ctl);
     e = hipGetLastError();
