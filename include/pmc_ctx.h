@@ -109,7 +109,8 @@ int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target,
  * The moments are taken in one pass about m_k (about h_shift, K x D, if given: the previous E-step's x_mean_comp
  * makes x_mean_comp and S bit-stable as soon as r is) and repeated about the mean just found when that turns out
  * more than 10 of the component's own standard deviations away (the reference takes the mean first, then the
- * covariance about it).
+ * covariance about it).  Non-finite inputs come back as non-finite sums; the reference's checks of N_comp and S
+ * (variational.pyx:122-126) stay with the caller.
  */
 int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, int K, const double *h_m,
                  const double *h_W, const double *h_nu, const double *h_beta, const double *h_ln_pi,
@@ -130,7 +131,8 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
  *   h_sigma     K x D x D  new covariances (:198-204; Student-t: sum w rho gamma (x-mu)(x-mu)^T / sum w rho, :629-630)
  *   h_dof_const K          Student-t only (else NULL): the constant c_k of the dof condition
  *                          c_k + log(nu/2) - psi(nu/2) = 0 (:654-696; _DOFCondition :478-497)
- *   h_loglik    1          sum_n w_n log q(x_n) of the proposal (:388-391), may be NULL
+ *   h_loglik    1          sum_n w_n log q(x_n) of the proposal (:388-391; Rao-Blackwellised form only: the latent form
+ *                          does not evaluate the mixture), may be NULL
  *   h_norm      1          sum_n w_n (N if unweighted), may be NULL
  */
 int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s, const double *h_w,
