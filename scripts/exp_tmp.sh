@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-PMC_CTX_PIN_BYTES=0 timeout 600 python scripts/ctx_transfer_bench.py 10000000 child 2>&1 | grep -v amdgpu.ids
+timeout 900 python -m pytest tests/test_gpu_ctx_golden.py -x -q 2>&1 | tail -30
