@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_ctx_golden.py -x -q 2>&1 | tail -30
+timeout 900 python -m pytest tests/test_gpu_cython_binding.py -x -q 2>&1 | tail -20
