@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_cython_binding.py -x -q 2>&1 | tail -20
+for i in 1 2; do timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|error" | tail -2; done
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
