@@ -224,7 +224,9 @@ def main():
     for tag, K, D, N, seed, weighted, init in (("d2k3", 3, 2, 500, 61, False, "mixture"),
                                                ("d5k4w", 4, 5, 400, 62, True, "mixture"),
                                                ("d20k8", 8, 20, 300, 3, False, "mixture"),
-                                               ("d3k5first", 5, 3, 350, 63, True, "first")):
+                                               ("d3k5first", 5, 3, 350, 63, True, "first"),
+                                               # the headline's shape (BASELINE metric: K = 32, D = 20)
+                                               ("d20k32", 32, 20, 400, 64, False, "mixture")):
         mu, cov, w = mk(K, D, seed)
         gen = create_gaussian_mixture(mu, cov, w)
         np.random.seed(7)
@@ -242,6 +244,13 @@ def main():
         out.update(vb_state(vb, "e0_"))
         out["e0_bound"] = vb.likelihood_bound()
         out["e0_log_q_Z"] = vb._update_expectation_log_q_Z()
+        if tag == "d20k32":
+            # the headline's shape: the first E-step only, without the two N x K matrices the smaller fixtures cover
+            # (K x D x D arrays are 100 KB each here)
+            for k in ("e0_log_rho", "e0_expectation_gauss_exponent", "e0_log_det_W", "e0_inv_N_comp", "init_sigma", "W0", "m0"):
+                out.pop(k)
+            save("vb_" + tag, **out)
+            continue
         vb.update()
         out.update(vb_state(vb, "u1_"))
         out["u1_bound"] = vb.likelihood_bound()

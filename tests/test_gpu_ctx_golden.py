@@ -118,6 +118,44 @@ def test_vb_estep(lib, ctx, name, weighted):
     lib.pmc_samples_free(s)
 
 
+def test_vb_estep_headline_shape(lib, ctx):
+    """K = 32, D = 20: the reference's first E-step of the BASELINE metric's shape through the handle layer, and through
+    the kernel-level call the Python front-end makes"""
+    from pypmc_amd.backend import HipBackend, ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    g = load_golden("vb_d20k32")
+    x = c64(g["data"])
+    N, D = x.shape
+    p = lambda k: c64(g["e0_" + k])
+    K = len(p("nu"))
+    s = upload(lib, ctx, x)
+    Nk, xbar, S, elq, r = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(1), np.empty((N, K))
+    assert lib.pmc_vb_estep(ctx, s, None, K, dp(p("m")), dp(p("W")), dp(p("nu")), dp(p("beta")), dp(p("expectation_ln_pi")),
+                            dp(p("expectation_det_ln_lambda")), None, dp(Nk), dp(xbar), dp(S), dp(elq), dp(r), None) == 0, \
+        lib.pmc_last_error()
+    np.testing.assert_allclose(Nk, p("N_comp"), rtol=1e-10)
+    np.testing.assert_allclose(xbar, p("x_mean_comp"), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(S, p("S"), rtol=1e-10, atol=1e-12)
+    assert rel(r, p("r")) < 1e-10
+    assert abs(elq[0] - float(g["e0_log_q_Z"])) <= 1e-10 * abs(float(g["e0_log_q_Z"]))
+    lib.pmc_samples_free(s)
+    # the same step as HipBackend.estep issues it, with the common-shift statistics forced on at this small N
+    be = HipBackend()
+    cs = ComponentSet(2, p("m"), p("W"), c0=D / p("beta"), c1=p("nu"), c2=p("expectation_ln_pi"),
+                      c3=p("expectation_det_ln_lambda") - D * np.log(2. * np.pi))
+    be.configure("stats_common_shift_min_n", 0)
+    try:
+        flat = be.tohost(be.estep(x, cs, 0)["stats"])
+    finally:
+        be.configure("stats_common_shift_min_n", 524288)
+    sc, S0, M1, M2, _, _ = split_stats(flat, K, D)
+    xb, Sg = centred_moments(S0, M1, M2, p("m"))
+    np.testing.assert_allclose(S0, p("N_comp"), rtol=1e-10)
+    np.testing.assert_allclose(xb, p("x_mean_comp"), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(Sg, p("S"), rtol=1e-10, atol=1e-12)
+    assert abs(sc[0] - float(g["e0_log_q_Z"])) <= 1e-10 * abs(float(g["e0_log_q_Z"]))
+
+
 def _check_update(g, prefix, alpha, mu, sigma, live, what):
     ref_w = np.asarray(g[prefix + "weights"], dtype=float)
     np.testing.assert_allclose(alpha[live] / alpha[live].sum(), ref_w[live] / ref_w[live].sum(), rtol=1e-10, err_msg=what)

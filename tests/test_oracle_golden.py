@@ -127,6 +127,19 @@ def test_vb_estep(tag, stage):
         assert abs(res["expectation_log_q_Z"] - float(g[stage + "log_q_Z"])) <= 1e-12 * abs(float(g[stage + "log_q_Z"])) + 1e-12
 
 
+def test_vb_estep_headline_shape():
+    """K = 32, D = 20 (BASELINE's metric shape): the first E-step of the reference's GaussianInference, r bit for bit"""
+    g = load_golden("vb_d20k32")
+    p = lambda k: g["e0_" + k]
+    res = orc.vb_estep(g["data"], None, p("m"), p("W"), p("beta"), p("nu"), p("expectation_ln_pi"),
+                       p("expectation_det_ln_lambda"))
+    np.testing.assert_array_equal(res["r"], p("r"))
+    np.testing.assert_allclose(res["N_comp"], p("N_comp"), rtol=1e-13)
+    np.testing.assert_allclose(res["x_mean_comp"], p("x_mean_comp"), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(res["S"], p("S"), rtol=1e-11, atol=1e-13)
+    assert abs(res["expectation_log_q_Z"] - float(g["e0_log_q_Z"])) <= 1e-12 * abs(float(g["e0_log_q_Z"]))
+
+
 def _gauss_lognorm(log_det, D):
     return -0.5 * D * np.log(2 * np.pi) - 0.5 * log_det
 
