@@ -139,6 +139,18 @@ int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s,
                          int weights_on_device, const int64_t *h_latent, int rb, double *h_alpha, double *h_mu,
                          double *h_sigma, double *h_dof_const, double *h_loglik, double *h_norm);
 
+/* ---- weighted moments ---------------------------------------------------------------------------------- */
+/*
+ * calculate_mean / calculate_covariance (pypmc/sampler/importance_sampling.py:46-83) of this context's samples -- ALL
+ * ranks' with a communicator joined -- with the weights h_w (N), the importance weights pmc_is_weights left on the
+ * device (weights_on_device != 0), or none (w = 1):
+ *   h_mean  D        sum_n w_n x_n / sum_n w_n                                                        (:58-61)
+ *   h_cov   D x D    (sum w)^2 / ((sum w)^2 - sum w^2) * sum_n w_n (x_n - mean)(x_n - mean)^T / sum w   (:76-83), may be NULL
+ * One pass of the statistics kernel over the samples (moments about the first sample of rank 0's shard).
+ */
+int pmc_weighted_moments(pmc_ctx *ctx, const pmc_samples *s, const double *h_w, int weights_on_device, double *h_mean,
+                         double *h_cov);
+
 #ifdef __cplusplus
 }
 #endif

@@ -743,4 +743,64 @@ int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s,
     return PMC_OK;
 }
 
+// ---- weighted moments -------------------------------------------------------------------------------------
+int pmc_weighted_moments(pmc_ctx *ctx, const pmc_samples *s, const double *h_w, int weights_on_device, double *h_mean,
+                         double *h_cov)
+{
+    CK(use(ctx));
+    if (!s || s->ctx != ctx || !h_mean) return failf(PMC_EINVAL, "pmc_weighted_moments: bad argument");
+    if (h_w && weights_on_device) return failf(PMC_EINVAL, "pmc_weighted_moments: h_w or weights_on_device, not both");
+    if (weights_on_device && !s->has_w) return failf(PMC_EINVAL, "pmc_weighted_moments: no importance weights on the device (pmc_is_weights first)");
+    const int64_t N = s->N;
+    const int D = s->D;
+    const int64_t PS = pmc_stats_stride(D), stride = pmc_pack_stride(D);
+    if (stride < 0) return (int)stride;
+    // the shift: the first sample of rank 0 (every rank must take its moments about the same point)
+    std::vector<double> shift(D, 0.0);
+    int rank = 0;
+    if (ctx->comm) CK(pmc_comm_rank(ctx->comm, &rank, nullptr));
+    CK(ctx->flat.ensure(sizeof(double) * (size_t)(PS + NSC + D)));
+    double *d_flat = ctx->flat.d();                                    // [stats PS | sum w, sum w log w, sum w^2 ... (NSC) | shift D]
+    HK(hipMemsetAsync(d_flat, 0, sizeof(double) * (size_t)(PS + NSC + D), ctx->stream), "hipMemsetAsync");
+    if (rank == 0 && N > 0) HK(hipMemcpyAsync(d_flat + PS + NSC, s->x.p, sizeof(double) * D, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
+    CK(allreduce(ctx, d_flat + PS + NSC, D));
+    CK(d2h(ctx, shift.data(), d_flat + PS + NSC, sizeof(double) * D));
+    std::vector<double> hp((size_t)stride);
+    CK(pmc_pack_means(1, D, shift.data(), hp.data()));
+    CK(ctx->spack.ensure(hp.size() * sizeof(double)));
+    CK(h2d(ctx, ctx->spack.p, hp.data(), hp.size() * sizeof(double)));
+    CK(workspace(ctx, N, 1, D));
+    // u = the weights in the library's tile-major layout with K = 1: the weight vector itself, zero behind the samples
+    const size_t ulen = (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, 1);
+    CK(ctx->u.ensure(sizeof(double) * ulen));
+    HK(hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ulen, ctx->stream), "hipMemsetAsync");
+    if (N > 0) {
+        if (h_w) CK(h2d(ctx, ctx->u.p, h_w, sizeof(double) * (size_t)N));
+        else if (weights_on_device) HK(hipMemcpyAsync(ctx->u.p, s->w.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
+        else {
+            std::vector<double> ones((size_t)N, 1.0);
+            CK(h2d(ctx, ctx->u.p, ones.data(), sizeof(double) * (size_t)N));
+        }
+        CK(pmc_sufficient_stats(s->x.d(), N, D, ctx->spack.d(), 1, ctx->u.d(), d_flat, ctx->ws.p, ctx->stream));
+        CK(pmc_weight_sums(ctx->u.d(), N, d_flat + PS, ctx->ws.p, ctx->stream));
+    }
+    CK(allreduce(ctx, d_flat, PS + NSC));
+    std::vector<double> flat((size_t)(PS + NSC));
+    CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * flat.size()));
+    std::vector<double> S0, M1, M2;
+    split_stats(flat.data(), 1, D, S0, M1, M2);
+    const double sw = S0[0], q = flat[(size_t)PS + 2];
+    std::vector<double> dbar(D);
+    for (int i = 0; i < D; ++i) {
+        dbar[i] = M1[i] / sw;
+        h_mean[i] = shift[i] + dbar[i];                                   // importance_sampling.py:58-61
+    }
+    if (h_cov) {
+        const double corr = sw * sw / (sw * sw - q);                      // :76-83
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) h_cov[(size_t)i * D + j] = corr * (M2[(size_t)i * D + j] / sw - dbar[i] * dbar[j]);
+    }
+    return PMC_OK;
+}
+
 }  // extern "C"

@@ -525,3 +525,41 @@ def test_vb_estep_large_batch_takes_the_fast_forms(lib, ctx):
     assert elq[0] == vb._expectation_log_q_Z
     assert abs(Nk.sum() - N) < 1e-6
     lib.pmc_samples_free(s)
+
+
+@pytest.mark.parametrize("D,N,how", [(2, 1000, "host"), (20, 70001, "device"), (70, 333, "none"), (5, 1, "host")])
+def test_weighted_moments(lib, ctx, D, N, how):
+    """calculate_mean / calculate_covariance (importance_sampling.py:46-83) through the handle layer: against the
+    reference's formulas in numpy and against the front-end's functions"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.sampler.importance_sampling import calculate_mean, calculate_covariance
+    mixture = create_gaussian_mixture(*mk(3, D, 81))
+    np.random.seed(82)
+    x = mixture.propose(N) + 40.                                     # far from the origin: the shift matters
+    s = upload(lib, ctx, x)
+    if how == "host":
+        w = np.random.uniform(0.1, 2.0, N)
+        args = (dp(w), 0)
+    elif how == "device":                                            # the importance weights a weighting call left behind
+        q = make_mix(lib, ctx, mixture)
+        w = np.empty(N)
+        lt = np.ascontiguousarray(mixture.multi_evaluate(x) + np.random.normal(size=N))     # weights = exp(N(0, 1))
+        assert lib.pmc_is_weights(q, s, dp(lt), None, dp(w), None, None) == 0, lib.pmc_last_error()
+        lib.pmc_mixture_destroy(q)
+        args = (None, 1)
+    else:
+        w = np.ones(N)
+        args = (None, 0)
+    mean, cov = np.empty(D), np.empty((D, D))
+    assert lib.pmc_weighted_moments(ctx, s, args[0], args[1], dp(mean), dp(cov)) == 0, lib.pmc_last_error()
+    ref_mean = (w[:, None] * x).sum(axis=0) / w.sum()                # importance_sampling.py:58-61
+    np.testing.assert_allclose(mean, ref_mean, rtol=1e-12)
+    if N > 1:
+        c = x - ref_mean
+        sw, q2 = w.sum(), (w * w).sum()
+        ref_cov = sw / (sw * sw - q2) * np.einsum('n,ni,nj->ij', w, c, c)      # :76-83
+        np.testing.assert_allclose(cov, ref_cov, rtol=1e-9, atol=1e-12 * np.abs(ref_cov).max())
+        np.testing.assert_allclose(mean, calculate_mean(x, w), rtol=1e-13)
+        np.testing.assert_allclose(cov, calculate_covariance(x, w), rtol=1e-10, atol=1e-13 * np.abs(ref_cov).max())
+    assert lib.pmc_weighted_moments(ctx, s, dp(w), 1, dp(mean), dp(cov)) < 0
+    lib.pmc_samples_free(s)
