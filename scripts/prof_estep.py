@@ -25,3 +25,4 @@ for _ in range(50): vb.E_step()
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)

@@ -431,7 +431,7 @@ def test_first_launch_on_new_torch_streams(lib):
         assert lib.pmc_stream_release(C.c_void_p(st.cuda_stream)) == 0
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PMC_CTX_FUZZ_SEEDS", "16"))))   # (soak: more)
 def test_handle_layer_fuzz(lib, ctx, seed):
     """random shapes through every handle-layer entry point against the Python front-end (same kernels underneath):
     all compiled dimensions incl. padded ones and the run-time-dimension unit, K = 1 ..., ragged N, both families,
