@@ -151,6 +151,24 @@ int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s,
 int pmc_weighted_moments(pmc_ctx *ctx, const pmc_samples *s, const double *h_w, int weights_on_device, double *h_mean,
                          double *h_cov);
 
+/* ---- host-side conversion (no device involved) ----------------------------------------------------------- */
+/*
+ * The K-sized step between the statistics buffer of the kernel level (pmc_sufficient_stats' layout: per component
+ * sum u | sum u d (D) | sum u d d^T (lower triangle), d = x - shift_k) and the reference's conventions, for callers that
+ * run the kernel level themselves (pypmc_amd's front-end does):
+ *   h_S0    K          the raw sums (N_comp before its zeros are regularised, variational.pyx:699-709)
+ *   h_M1    K x D      the raw shifted first moments (NULL: not wanted)
+ *   h_mean  K x D      shift_k + M1_k / reg(S0_k)                                  (x_mean_comp, :806-853; pmc.pyx:194-197)
+ *   h_cov   K x D x D  (M2_k - reg(S0_k) dbar dbar^T) / reg(n_cov_k), symmetric    (S, :855-932; pmc.pyx:198-204, :629-630)
+ *                      h_n_cov (K) = the normalisation of the covariance when it is not S0 (Student-t PMC), else NULL
+ *   h_far   1          != 0 if some component holding more than a millionth of the weight has its mean more than 10 of
+ *                      its own standard deviations (in some coordinate) from its shift: the one-pass moments cancel, the
+ *                      caller repeats the statistics about the mean just found (pypmc_amd.mix_adapt._stats.shift_is_far)
+ * Same operations in the same order as the numpy code it replaces (bit-identical results).
+ */
+int pmc_host_convert_stats(int K, int D, const double *h_stats, const double *h_shift, const double *h_n_cov,
+                           double *h_S0, double *h_M1, double *h_mean, double *h_cov, int *h_far);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,7 @@ CTX_SIGNATURES = {
     "pmc_vb_estep": (_int, [_vp, _vp, _dp, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pmc_pmc_update_stats": (_int, [_vp, _vp, _vp, _dp, _int, _ip, _int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pmc_weighted_moments": (_int, [_vp, _vp, _dp, _int, _dp, _dp]),
+    "pmc_host_convert_stats": (_int, [_int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
 }
 
 

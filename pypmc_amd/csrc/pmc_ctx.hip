@@ -252,8 +252,8 @@ bool shift_is_far(const std::vector<double> &S0, const std::vector<double> &M1, 
         for (int i = 0; i < D; ++i) {
             const double db = M1[(size_t)k * D + i] / n, dbar2 = db * db;
             const double raw = M2[((size_t)k * D + i) * D + i] / n;
-            double var = raw - dbar2;
-            if (!(var > 1e-14 * raw)) var = 1e-14 * raw;
+            const double v = raw - dbar2, t = 1e-14 * raw;               // numpy.maximum(v, t): a NaN operand gives NaN,
+            const double var = (v != v || t != t) ? v + t : (v > t ? v : t);   // and the comparison below is false then
             if (dbar2 > 100. * var) return true;
         }
     }
@@ -800,6 +800,21 @@ int pmc_weighted_moments(pmc_ctx *ctx, const pmc_samples *s, const double *h_w, 
         for (int i = 0; i < D; ++i)
             for (int j = 0; j < D; ++j) h_cov[(size_t)i * D + j] = corr * (M2[(size_t)i * D + j] / sw - dbar[i] * dbar[j]);
     }
+    return PMC_OK;
+}
+
+// ---- host-side conversion ---------------------------------------------------------------------------------
+int pmc_host_convert_stats(int K, int D, const double *h_stats, const double *h_shift, const double *h_n_cov, double *h_S0,
+                           double *h_M1, double *h_mean, double *h_cov, int *h_far)
+{
+    if (K < 1 || D < 1 || !h_stats || !h_shift || !h_S0 || !h_mean || !h_cov)
+        return failf(PMC_EINVAL, "pmc_host_convert_stats: bad argument");
+    std::vector<double> S0, M1, M2;
+    split_stats(h_stats, K, D, S0, M1, M2);
+    std::memcpy(h_S0, S0.data(), sizeof(double) * K);
+    if (h_M1) std::memcpy(h_M1, M1.data(), sizeof(double) * (size_t)K * D);
+    if (h_far) *h_far = shift_is_far(S0, M1, M2, K, D) ? 1 : 0;
+    centred_moments(S0.data(), h_n_cov ? h_n_cov : S0.data(), M1, M2, h_shift, K, D, h_mean, h_cov);
     return PMC_OK;
 }
 

@@ -1,7 +1,10 @@
 """K-sized host conversions of the statistics vector produced by pmc_sufficient_stats
 (include/pmc_hip.h) into the reference's centred conventions."""
+import ctypes as _C
+
 import numpy as np
 
+from .. import _lib
 from .._lib import NSCALARS
 
 TINY = np.finfo('d').tiny
@@ -66,3 +69,29 @@ def shift_is_far(S0, M1, M2, limit=100.):
     with np.errstate(invalid='ignore'):
         return bool(np.any(dbar2 > limit * var))
 
+
+
+def convert_stats(flat, K, D, shift, n_cov=None):
+    """``split_stats`` + ``shift_is_far`` + ``centred_moments`` in one call of the library's host-side
+    ``pmc_host_convert_stats`` (include/pmc_ctx.h; the same operations in the same order: bit-identical to the numpy
+    functions above, a tenth of their time at K = 64, D = 20).  ``flat`` as ``split_stats`` takes it; ``n_cov`` (K): the
+    covariance's normalisation when it is not the first sum (``'vsum0'`` = the first Student-t sum of ``flat``).
+    Returns scalars, S0 (raw), M1, mean, cov, far, V1, V2."""
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    T = D * (D + 1) // 2
+    ps = 1 + D + T
+    scalars = flat[:NSCALARS].copy()
+    vs = flat[NSCALARS + K * ps:NSCALARS + K * ps + 2 * K].reshape(K, 2)
+    V1, V2 = vs[:, 0].copy(), vs[:, 1].copy()
+    if isinstance(n_cov, str):
+        n_cov = V1
+    shift = np.ascontiguousarray(shift, dtype=np.float64).reshape(K, D)
+    S0, M1 = np.empty(K), np.empty((K, D))
+    mean, cov = np.empty((K, D)), np.empty((K, D, D))
+    far = _C.c_int(0)
+    dp = lambda a: a.ctypes.data_as(_C.POINTER(_C.c_double))
+    body = flat[NSCALARS:NSCALARS + K * ps]
+    nc = None if n_cov is None else np.ascontiguousarray(n_cov, dtype=np.float64)
+    _lib.check(_lib.load().pmc_host_convert_stats(K, D, dp(body), dp(shift), None if nc is None else dp(nc), dp(S0), dp(M1),
+                                                  dp(mean), dp(cov), _C.byref(far)), "pmc_host_convert_stats")
+    return scalars, S0, M1, mean, cov, bool(far.value), V1, V2
