@@ -150,3 +150,33 @@ def test_ctx_demo_builds_with_plain_gcc(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "10"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 3 and "pmc_init" in r.stderr
+
+
+def test_host_convert_stats_is_bit_identical_to_numpy():
+    """pmc_host_convert_stats (the library's host code) against split_stats + shift_is_far + centred_moments of
+    pypmc_amd/mix_adapt/_stats.py: same operations in the same order, same bits -- zeros, NaN and inf included"""
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments, shift_is_far, convert_stats
+    rs = np.random.RandomState(0)
+    for trial in range(200):
+        K, D = int(rs.randint(1, 40)), int(rs.randint(1, 25))
+        ps = 1 + D + D * (D + 1) // 2
+        flat = rs.normal(size=8 + K * ps + 2 * K)
+        body = flat[8:8 + K * ps].reshape(K, ps)
+        body[:, 0] = np.abs(body[:, 0]) * rs.choice([1, 1, 1e-3, 1e3, 0], size=K)
+        body[:, 1:1 + D] *= rs.choice([1., 1e-2, 1e2])
+        if trial % 7 == 0:
+            flat[8 + rs.randint(K * ps)] = np.nan
+        if trial % 11 == 0:
+            flat[8 + rs.randint(K * ps)] = np.inf
+        vs = flat[8 + K * ps:].reshape(K, 2)
+        vs[:, 0] = np.abs(vs[:, 0]) + 0.1
+        shift = rs.normal(size=(K, D))
+        student = trial % 2 == 0
+        sc, S0, M1, M2, V1, V2 = split_stats(flat, K, D)
+        with np.errstate(all='ignore'):
+            far = shift_is_far(S0, M1, M2)
+            mean, cov = centred_moments(S0, M1, M2, shift, S0_cov=V1 if student else None)
+            got = convert_stats(flat, K, D, shift, n_cov='vsum0' if student else None)
+        for a, b in ((sc, got[0]), (S0, got[1]), (M1, got[2]), (mean, got[3]), (cov, got[4]), (V1, got[6]), (V2, got[7])):
+            assert np.array_equal(a, b, equal_nan=True), trial
+        assert far == got[5], trial
