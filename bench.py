@@ -207,8 +207,12 @@ def baseline_configs(be, reps=3, select=None):
     from pypmc_amd.mix_adapt.pmc import gaussian_pmc
 
     def timed(fn):
-        fn()                                             # warm-up (packs, scratch buffers)
+        fn()                                             # warm-up (packs, scratch buffers) ...
         torch.cuda.synchronize()
+        t_warm = time.perf_counter()                     # ... and clocks: the GPU has idled through the CPU baseline
+        while time.perf_counter() - t_warm < 0.15:
+            fn()
+            torch.cuda.synchronize()
         be.kernel_timings()
         be.kernel_timing(True)
         ts = []
