@@ -22,14 +22,14 @@ from ..backend import get_backend
 from ..density.gauss import Gauss
 from ..density.student_t import StudentT
 from ..density.mixture import MixtureDensity, component_set
-from ._stats import split_stats, centred_moments, shift_is_far, regularize
+from ._stats import convert_stats, split_stats, centred_moments, shift_is_far, regularize
 from ..tools._linalg import single_threaded_blas, chol_inv_det_batch
 
 logger = logging.getLogger(__name__)
 
 
 def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis=None,
-                        responsibilities=None):
+                        responsibilities=None, student=False):
     """Argument checks, live-component bookkeeping and the device pass
     (reference: pmc.pyx:53-118).  Returns density, live_components (after ``mincount`` pruning),
     the indices the statistics were computed for, the host statistics, the weight normalisation
@@ -125,9 +125,12 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
 
     flat, tail = exchange(flat)
     weight_normalization = float(tail[0])
-    stats = split_stats(flat, max(nlive, 1), D)
     shift = np.array([density.components[k].mu for k in stat_components]).reshape(len(stat_components), D)
-    if nlive and shift_is_far(stats[1], stats[2], stats[3]):
+    # split / far-shift test / centring in one host call of the library (_stats.convert_stats: the numpy functions'
+    # operations in their order); Student-t: the covariance is normalised by sum w rho, the mean by sum w rho gamma
+    n_cov = 'vsum0' if student else None
+    stats = convert_stats(flat, nlive, D, shift, n_cov) if nlive else None
+    if nlive and stats[5]:
         # a weighted mean far from its proposal component (the first iterations of a badly placed proposal): the
         # one-pass moments about mu_k would cancel; second pass about the mean just found -- the reference's own
         # order (mean first, then the covariance about it: pmc.pyx:188-222, :612-632).  Decided on the all-reduced
@@ -140,7 +143,7 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
             again = be.estep(samples, cs, mode, max_init_zero=len(live_components) < K, sample_w=weights,
                              latent=None if rb else latent, shift=shift)["stats"]
         flat, tail = exchange(again)
-        stats = split_stats(flat, max(nlive, 1), D)
+        stats = convert_stats(flat, nlive, D, shift, n_cov)
 
     if count is not None:
         count = tail[1:]
@@ -245,9 +248,8 @@ def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=
     density, live, stat_comps, stats, norm, renorm, shift = \
         _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis,
                             responsibilities)
-    _, S0, M1, M2, _, _ = stats
     if stat_comps:
-        mu, cov = centred_moments(S0, M1, M2, shift)             # pmc.pyx:194-204 / :213-222
+        _, S0, _, mu, cov, _, _, _ = stats                       # mu, cov: pmc.pyx:194-204 / :213-222 (_stats.centred_moments)
         alpha = S0 / norm                                         # :191-193
         pos = {k: i for i, k in enumerate(stat_comps)}
         new = {k: (alpha[pos[k]], (mu[pos[k]], cov[pos[k]])) for k in live}
@@ -274,14 +276,14 @@ def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solv
         samples = np.ascontiguousarray(samples, dtype=np.float64)
     density, live, stat_comps, stats, norm, renorm, shift = \
         _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis,
-                            responsibilities)
-    _, S0g, M1, M2, V1, V2 = stats        # S0g = sum w rho gamma, V1 = sum w rho
+                            responsibilities, student=True)
     D = density.dim
     new = {}
     if stat_comps:
+        # S0g = sum w rho gamma, V1 = sum w rho; mean: normalised by sum w rho gamma; covariance: by sum w rho
+        # (pmc.pyx:620-630; _stats.centred_moments with S0_cov = V1)
+        _, S0g, _, mu, cov, _, V1, V2 = stats
         old_dof = np.array([density.components[k].dof for k in stat_comps])
-        # mean: normalised by sum w rho gamma; covariance: by sum w rho   (pmc.pyx:620-630)
-        mu, cov = centred_moments(S0g, M1, M2, shift, S0_cov=V1)
         alpha = V1 / norm
         if dof_solver_steps:
             # sum_n w_n (xi + delta)_nk of pmc.pyx:659-679 assembled from the device sums:
