@@ -528,6 +528,36 @@ def main():
                                                   "sample": "%d samples, %.1f s, OpenMP over samples"
                                                             % (cb["all"]["n"], cb["all"]["seconds"])}}
         if world == 1 and not args.no_configs:
+            # what one GPU's share of a strong-scaled run of this batch over 8 GPUs costs (north_star: ">= 6x on the VB
+            # E-step at 8 GPUs"): the same step on the first N / 8 samples, after the headline's timed loop; the
+            # all-reduce of an 8-rank run comes on top (dist.allreduce_ms is one rank's)
+            n8 = N // 8
+            if n8 >= 64:
+                xs = x[:n8]
+                def share_step():
+                    be.importance_weights(xs, proposal, target, pack=p_prop, target_pack=p_tgt)
+                    e8 = be.estep(xs, posterior, 0, pack=p_vb, out=stats)
+                    return e8["stats"].cpu()
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 0.1:
+                    share_step()
+                torch.cuda.synchronize()
+                be.kernel_timings()
+                be.kernel_timing(True)
+                t_s = time.perf_counter()
+                for _ in range(20):
+                    share_step()
+                torch.cuda.synchronize()
+                share_ms = (time.perf_counter() - t_s) / 20 * 1e3
+                be.kernel_timing(False)
+                kt8 = {k_: v["ms"] / v["calls"] for k_, v in be.kernel_timings().items()}
+                e8_ms = kt8.get("k_resp", 0.0) + kt8.get("k_stats", 0.0) + kt8.get("k_estep_fused", 0.0)
+                ef_ms = kern.get("k_resp", 0.0) + kern.get("k_stats", 0.0) + kern.get("k_estep_fused", 0.0)
+                line["share_of_8"] = {"N": n8, "ms_per_step": share_ms, "kernel_ms": kt8,
+                                      "step_speedup_vs_full_batch": ms_per_step / share_ms,
+                                      "estep_kernels_speedup_vs_full_batch": ef_ms / e8_ms if e8_ms > 0 else None,
+                                      "note": "one GPU, N / 8 samples: a projection of strong scaling, not a measurement of it"}
+                del xs
             del x, r
             torch.cuda.empty_cache()
             line["configs"] = baseline_configs(be)
