@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 1
+#define PMC_ABI_VERSION 2
 
 enum pmc_status {
     PMC_OK = 0,
@@ -361,6 +361,42 @@ int pmc_importance_weights_emit(const double *d_x, int64_t N, int D, const doubl
                                 double *d_u, double *d_vsums, void *stream);
 int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, const double *d_u,
                      double *d_stats, void *d_workspace, void *stream);
+/*
+ * The grouped form of the same pair (ABI 2): the responsibilities are the product  u_nk = d_u[n, k] * d_gscale[n, k / 16]
+ * of a value per pair and a factor per (sample, group of 16 components) -- d_gscale: pmc_gscale_len(N, K) doubles,
+ * tile-major like d_u ((tile * ceil(K / 16) + group) * 64 + lane).  It lets the weighting pass write every d_u value
+ * ONCE, relative to its group's maximum, before the row's log-sum-exp is known; the statistics kernel (common-shift
+ * form) multiplies its weight operand with the factors.  From compiled D = 32 on (Gaussian proposal, N >= 32768,
+ * K a multiple of 32 up to ~20 % padding) the pass is then the matrix-product form of the Mahalanobis forms, see
+ * "maha_gemm_tolerance" below; everywhere else d_u is complete and the factors are ones.  pmc_estep_from_u_grouped may
+ * complete d_u IN PLACE (the factors become ones) when the statistics kernel that applies factors is not the one the
+ * shape gets or its a-posteriori test refuses the common shift: the pair (d_u, d_gscale) means the same u afterwards.
+ *
+ * The matrix-product form of the Mahalanobis forms (pypmc/tools/_linalg.pyx:10-39 called N K times), csrc/pmc_mgemm.hip:
+ *   maha_nk = sum_m theta_km z_nm,  z_n = the monomials of x_n - c up to degree 2 about ONE centre c (midrange of the
+ *   component means), theta_k from P_k = R_k^T R_k and mu_k - c -- a dense product on v_mfma_f64_16x16x4_f64 with the
+ *   per-sample epilogue fused behind it.  Its rounding error grows with |P| |x - c|^2 instead of maha, so every sample is
+ *   priced first: eps_g (Theta_1 |x - c|^2 + Theta_2 |x - c| + Theta_3) with the maxima over the components of
+ *   s_k |P_k|_F, 2 s_k |P_k (mu_k - c)|, s_k (mu_k - c)^T P_k (mu_k - c)  (s_k = |d a / d maha|), eps_g = 1e-15; a workgroup
+ *   (256 samples) that holds a sample beyond the tolerance, or a non-finite coordinate, is done by the exact kernel,
+ *   launched behind in the same call.  pmc_mixture_logpdf / pmc_importance_weights[_emit_grouped] / pmc_estep take the
+ *   form when they are given a workspace, no N x K output is asked for, and
+ *   pmc_configure("maha_gemm_tolerance", t) (default 5e-11, in units of a_nk; 0 = never) / ("maha_gemm_min_n", default
+ *   32768) allow it.
+ */
+int64_t pmc_gscale_len(int64_t N, int K);
+/* component tiles (of 16) per pass the matrix-product form would run this shape with; 0: the exact kernels */
+int pmc_maha_gemm_tiles(int64_t N, int K, int D);
+/* diagnostics of the last call that took the form with this workspace and shape (synchronises `stream`): the guard's
+ * norms Theta_1..3 (h_norms[3]), the number of workgroups of 256 samples it refused, and the number of workgroups */
+int pmc_maha_gemm_report(const void *d_workspace, int64_t N, int K, int D, void *stream, double *h_norms,
+                         int64_t *h_refused, int64_t *h_workgroups);
+int pmc_importance_weights_emit_grouped(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                                        const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                                        double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
+                                        double *d_u, double *d_gscale, double *d_vsums, void *stream);
+int pmc_estep_from_u_grouped(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, double *d_u,
+                             double *d_gscale, double *d_stats, void *d_workspace, void *stream);
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                             int max_init_zero, double *d_out, double *d_individual, int64_t ld,
                             const double *d_log_target, double *d_weights, const double *d_sample_w,

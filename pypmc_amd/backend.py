@@ -69,9 +69,21 @@ class Responsibilities(object):
     the update follows (``importance_weights(..., emit=True)``), together with what they belong to.
     ``gaussian_pmc(..., responsibilities=...)`` reduces them to the statistics without any responsibility kernel."""
 
-    def __init__(self, data, N, comps, weights, vsums=None):
+    def __init__(self, data, N, comps, weights, vsums=None, gscale=None):
         self.data, self.N, self.K, self.comps, self.weights = data, int(N), int(comps.K), comps, weights
         self.vsums = vsums            # Student-t: the 2 K sums of the degree-of-freedom condition (device)
+        self.gscale = gscale          # per-(sample, 16 components) factors u is still to be multiplied with (ABI 2)
+
+    def host_matrix(self, be):
+        """u as an N x K host array (the tile-major values times their groups' factors)"""
+        tile = be.tile
+        nt = (self.N + tile - 1) // tile
+        t = be.tohost(self.data)[:nt * self.K * tile].reshape(nt, self.K, tile)
+        if self.gscale is not None:
+            ng = (self.K + 15) // 16
+            f = be.tohost(self.gscale)[:nt * ng * tile].reshape(nt, ng, tile)
+            t = t * np.repeat(f, 16, axis=1)[:, :self.K, :]
+        return np.concatenate([t[i].T for i in range(nt)])[:self.N] if nt else np.zeros((0, self.K))
 
     def matches(self, comps_full, weights):
         """True for the very mixture (means, precisions, component weights, normalisations) and the very sample
@@ -158,6 +170,18 @@ class HipBackend(object):
         _lib.check(self.lib.pmc_get_timings(C.cast(buf, C.c_void_p), 16, C.byref(n)), "pmc_get_timings")
         return {buf[i].name.decode(): dict(calls=buf[i].calls, ms=buf[i].ms, flops=buf[i].flops, bytes=buf[i].bytes)
                 for i in range(min(n.value, 16))}
+
+    def maha_gemm_report(self, N, K, D):
+        """pmc_maha_gemm_report for the current stream's workspace: dict(norms, refused, workgroups) of the last call
+        that took the matrix-product form of the Mahalanobis forms with this shape (None: the shape does not take it)"""
+        if int(self.lib.pmc_maha_gemm_tiles(N, K, D)) <= 0:
+            return None
+        ws = self._workspace(N, K, D)
+        norms = np.zeros(3)
+        refused, wgs = C.c_int64(0), C.c_int64(0)
+        _lib.check(self.lib.pmc_maha_gemm_report(self._p(ws), N, K, D, self._stream(), _dptr(norms), C.byref(refused),
+                                                 C.byref(wgs)), "pmc_maha_gemm_report")
+        return dict(norms=norms, refused=int(refused.value), workgroups=int(wgs.value))
 
     def asdevice(self, a, dtype=None):
         """numpy array / torch tensor -> contiguous tensor on this device."""
@@ -257,7 +281,8 @@ class HipBackend(object):
         weights = self.empty(N) if lt is not None else None
         sw = self.asdevice(sample_w).reshape(N) if sample_w is not None else None
         scalars = self.zeros(NSCALARS) if want_scalars else None
-        ws = self._workspace(N, comps.K, D) if want_scalars else None
+        # (always a workspace: with it the library may take its matrix-product form of the Mahalanobis forms)
+        ws = self._workspace(N, comps.K, D)
         tiles = self._new_tiles(N, comps) if keep else None
         _lib.check(self._timed(
             "pmc_mixture_logpdf[K=%d]" % comps.K, self.lib.pmc_mixture_logpdf_keep,
@@ -313,14 +338,15 @@ class HipBackend(object):
         scalars = self.zeros(NSCALARS)
         ws = self._workspace(N, max(comps.K, target.K), D)
         u = self.empty(max(int(self.lib.pmc_tile_buffer_len(N, comps.K)), 1))      # the caller's: outlives this call
+        gscale = self.empty(max(int(self.lib.pmc_gscale_len(N, comps.K)), 1))
         vsums = self.zeros(2 * comps.K) if comps.kind == PMC_KIND_STUDENT_T else None
         _lib.check(self._timed(
-            "pmc_importance_weights_emit[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights_emit,
+            "pmc_importance_weights_emit[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights_emit_grouped,
             self._p(x), N, D, self._p(pack), comps.K, comps.kind, self._p(target_pack), target.K, target.kind,
-            self._p(out), self._p(lt), self._p(weights), self._p(scalars), self._p(ws), self._p(u), self._p(vsums),
-            self._stream()), "pmc_importance_weights_emit")
+            self._p(out), self._p(lt), self._p(weights), self._p(scalars), self._p(ws), self._p(u), self._p(gscale),
+            self._p(vsums), self._stream()), "pmc_importance_weights_emit_grouped")
         return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=None,
-                    responsibilities=Responsibilities(u, N, comps, weights, vsums))
+                    responsibilities=Responsibilities(u, N, comps, weights, vsums, gscale))
 
     def estep_from_u(self, x, comps, resp, out=None):
         """pmc_estep_from_u: the statistics of responsibilities a weighting pass left behind (``Responsibilities``).
@@ -336,10 +362,16 @@ class HipBackend(object):
         flat[:NSCALARS] = 0.
         if resp.vsums is not None:
             flat[NSCALARS + K * ps:] = resp.vsums
-        _lib.check(self._timed(
-            "pmc_estep_from_u", self.lib.pmc_estep_from_u, self._p(x), N, D, self._p(self.pack(comps)), K, comps.kind,
-            self._p(resp.data), self._p(flat[NSCALARS:]), self._p(self._workspace(N, K, D)), self._stream()),
-            "pmc_estep_from_u")
+        if resp.gscale is not None:
+            _lib.check(self._timed(
+                "pmc_estep_from_u", self.lib.pmc_estep_from_u_grouped, self._p(x), N, D, self._p(self.pack(comps)), K,
+                comps.kind, self._p(resp.data), self._p(resp.gscale), self._p(flat[NSCALARS:]),
+                self._p(self._workspace(N, K, D)), self._stream()), "pmc_estep_from_u_grouped")
+        else:
+            _lib.check(self._timed(
+                "pmc_estep_from_u", self.lib.pmc_estep_from_u, self._p(x), N, D, self._p(self.pack(comps)), K, comps.kind,
+                self._p(resp.data), self._p(flat[NSCALARS:]), self._p(self._workspace(N, K, D)), self._stream()),
+                "pmc_estep_from_u")
         return dict(stats=flat, r=None, log_rho=None, exponent=None)
 
     def weight_sums(self, w):

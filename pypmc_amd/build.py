@@ -84,7 +84,8 @@ def build(jobs=None, force=False, verbose=False):
         work.append((os.path.join(OBJ, "pmc_%s.o" % unit), src, ["-DPMC_D=0", "-DPMC_PADDED=0"], [src] + headers, force))
     for d, padded in dim_list():
         for p in ((0, 1) if padded else (0,)):
-            for unit in ("persample", "stats", "propose", "fused"):
+            # (mgemm: the Mahalanobis forms as one matrix product; one kernel serves the exact and the padded variant)
+            for unit in ("persample", "stats", "propose", "fused") + (("mgemm",) if p == 0 else ()):
                 src = os.path.join(CSRC, "pmc_%s.hip" % unit)
                 work.append((os.path.join(OBJ, "pmc_%s_d%d_p%d.o" % (unit, d, p)), src,
                              ["-DPMC_D=%d" % d, "-DPMC_PADDED=%d" % p], [src] + headers, force))

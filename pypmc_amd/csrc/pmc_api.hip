@@ -27,7 +27,11 @@
     extern "C" hipError_t pmc_launch_fused_d##d##_p##p(int, int, const PmcArgsF &, unsigned, hipStream_t); \
     extern "C" int pmc_fused_lds_bytes_d##d##_p##p(int, int);                                          \
     extern "C" hipError_t pmc_launch_stats_gemm_d##d##_p##p(const PmcArgsG &, unsigned, hipStream_t);   \
-    extern "C" void pmc_stats_gemm_config_d##d##_p##p(int *, int *, int *, int *);
+    extern "C" void pmc_stats_gemm_config_d##d##_p##p(int *, int *, int *, int *);          \
+    extern "C" hipError_t pmc_launch_mgemm_d##d##_p##p(int, const PmcArgsQ &, unsigned, hipStream_t);   \
+    extern "C" hipError_t pmc_launch_theta_d##d##_p##p(const double *, int, int, int, double *, double *, double *, \
+                                                       unsigned long long *, hipStream_t);               \
+    extern "C" void pmc_mgemm_config_d##d##_p##p(int *, int *);
 extern "C" hipError_t pmc_launch_resp_tiles(int, const PmcArgsT &, unsigned, hipStream_t);
 // the run-time-dimension unit (pmc_big.hip, pmc_persample.hip / pmc_propose.hip compiled with PMC_D = 0)
 extern "C" hipError_t pmc_launch_logpdf_d0_p0(int, int, const PmcArgsA &, unsigned, hipStream_t);
@@ -46,7 +50,8 @@ namespace {
     {d, p, 0, 0, &pmc_launch_logpdf_d##d##_p##p, &pmc_launch_resp_d##d##_p##p, &pmc_launch_resp_groups_d##d##_p##p, \
      &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p, \
      &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p, &pmc_launch_stats_gemm_d##d##_p##p, \
-     &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0, 0}
+     &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0, 0, &pmc_launch_mgemm_d##d##_p0, &pmc_launch_theta_d##d##_p0, \
+     &pmc_mgemm_config_d##d##_p0, 0, 0}
 struct DimEntry {
     int dim;
     bool has_padded;
@@ -157,6 +162,10 @@ const PmcKernelSet *big_kernels_for(int D)
     ks->stats_gemm = nullptr;
     ks->gemm_config = nullptr;
     ks->gemm_cols = ks->gemm_slices = ks->gemm_msp = ks->gemm_wgs = 0;
+    ks->mgemm = nullptr;
+    ks->theta = nullptr;
+    ks->mgemm_config = nullptr;
+    ks->mg_nstepp = ks->mg_nct_max = 0;
     sets.push_back(ks);
     return ks;
 }
@@ -171,6 +180,7 @@ const PmcKernelSet *kernels_for(int D)
         else continue;
         if (ks && ks->stats_nsub == 0) {                                                // idempotent
             ks->gemm_config(&ks->gemm_cols, &ks->gemm_slices, &ks->gemm_msp, &ks->gemm_wgs);
+            ks->mgemm_config(&ks->mg_nstepp, &ks->mg_nct_max);
             ks->config(&ks->stats_nsub, &ks->stats_waves);
         }
         return ks;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void k_gemm_convert(const double *__restrict__
 __global__ __launch_bounds__(256) void k_apply_scale(double *__restrict__ u, const double *__restrict__ gscale,
                                                      long long ntiles, int K, const int *__restrict__ ctl)
 {
-    if (ctl[PMC_CTL_REDO] == 0) return;                   // (a small grid: the launch is there in every call)
+    if (ctl && ctl[PMC_CTL_REDO] == 0) return;            // (a small grid: the launch is there in every call)
     const int G = (K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
     const long long total = ntiles * K * 64;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -389,6 +399,14 @@ __global__ __launch_bounds__(256) void k_apply_scale(double *__restrict__ u, con
         const int k = (int)(tk - tile * K);
         u[idx] *= gscale[(tile * G + k / PMC_RESP_GROUP) * 64 + (idx & 63)];
     }
+}
+
+// ... and the factors themselves become ones (a launch of its own: every factor serves 16 components' threads above), so
+// that a caller-owned pair (u, factors) -- pmc_importance_weights_emit_grouped -- still means the same u afterwards
+__global__ __launch_bounds__(256) void k_reset_scale(double *__restrict__ gscale, long long len, const int *__restrict__ ctl)
+{
+    if (ctl && ctl[PMC_CTL_REDO] == 0) return;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < len; idx += (long long)gridDim.x * 256) gscale[idx] = 1.0;
 }
 
 // N = 1, D = 1: stats[k] = (u_k, u_k d, u_k d^2), d = x - mu_k   (u tile-major: one tile, lane 0)
@@ -737,6 +755,106 @@ size_t gscale_offset(long long N, int K, const PmcKernelSet *ks)
     return a > b ? a : b;
 }
 
+// ---------------------------------------------------------------------------------------------
+// the Mahalanobis forms as one matrix product (pmc_mgemm.hip): selection, workspace region, launches
+// ---------------------------------------------------------------------------------------------
+// Tolerance of the guard in units of a_nk (0 switches the form off): a sample whose priced rounding error
+// eps_g (Theta_1 |d|^2 + Theta_2 |d| + Theta_3) exceeds it sends its workgroup to the exact kernel.  eps_g = 1e-15 is
+// three times the largest (difference to the exact kernel) / (Theta-sum) seen -- 3.4e-16, i.e. 1.5 ulp of the sum of the
+// terms' magnitudes (scripts/mgemm_check.py; tests/test_gpu_mgemm.py holds every case to it) -- and the tolerance
+// leaves a factor 2 to the contract's 1e-10 on responsibilities, i.e. on differences of a_nk.
+double g_mgemm_tol = 5e-11;
+constexpr double PMC_MGEMM_EPS = 1e-15;
+long long g_mgemm_min_n = 32768;                            // samples from which the form is tried at all
+// component tiles per pass (0: the exact kernels).  K is padded to a multiple of 16 NCT and a padded component costs
+// what a real one does; two tiles per pass cost 4.5 % more per pair than four (profiles/r03_maha_gemm_prototype.txt),
+// and the form as a whole is ~20 % ahead of the exact kernels, so more padding than that is not worth it.
+int mgemm_pick(const PmcKernelSet *ks, long long N, int K)
+{
+    if (!ks->mgemm || ks->mg_nstepp <= 0 || !(g_mgemm_tol > 0.0) || N < g_mgemm_min_n || K < 24) return 0;
+    int best = 0;
+    double bestc = 1.2 * K;
+    for (int nct = ks->mg_nct_max; nct >= 2; nct /= 2) {
+        const double c = (double)(ceil_div(K, 16 * nct) * 16 * nct) * (nct >= 4 ? 1.0 : 1.045);
+        if (c <= bestc) { bestc = c; best = nct; }
+    }
+    return best;
+}
+struct MgRegion {
+    size_t head, center, ctab, img, flags, lt, bytes;       // byte offsets from the region's start
+};
+MgRegion mgemm_region(long long N, int K, const PmcKernelSet *ks)
+{
+    MgRegion r;
+    const size_t kpad = (size_t)ceil_div(K, 64) * 64;       // (whatever NCT is picked)
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    r.head = 0;                                             // 3 guard norms (as doubles' bit patterns) | redo flag
+    r.center = 256;
+    r.ctab = r.center + up(sizeof(double) * 64);
+    r.img = r.ctab + up(sizeof(double) * kpad * 4);
+    r.flags = r.img + up(sizeof(double) * (kpad / 16) * (size_t)ks->mg_nstepp * 64);
+    const size_t nblocks = (size_t)ceil_div(ceil_div(N > 0 ? N : 1, PMC_TILE), PMC_A_WAVES);
+    r.lt = r.flags + up(sizeof(int) * nblocks);
+    r.bytes = r.lt + up(sizeof(double) * (size_t)(N > 0 ? N : 1));
+    return r;
+}
+size_t mgemm_bytes(long long N, int K, const PmcKernelSet *ks)
+{
+    return (ks->mgemm && ks->mg_nstepp > 0) ? mgemm_region(N, K, ks).bytes : 0;
+}
+size_t mgemm_offset(long long N, int K, const PmcKernelSet *ks)
+{
+    return (gscale_offset(N, K, ks) + gscale_bytes(N, K, ks) + 255) & ~(size_t)255;
+}
+// k_theta_build + k_mgemm on `a` (a.blockflag / a.redo are set here for the exact kernel the caller launches behind)
+hipError_t mgemm_run(const PmcKernelSet *ks, int nct, int kind, const PmcArgsA &a, PmcArgsA &fallback, void *d_workspace,
+                     hipStream_t st)
+{
+    const MgRegion r = mgemm_region(a.N, a.K, ks);
+    char *base = (char *)d_workspace + mgemm_offset(a.N, a.K, ks);
+    hipError_t e = hipMemsetAsync(base + r.head, 0, 64, st);
+    if (e != hipSuccess) return e;
+    const int kpad = (int)(ceil_div(a.K, 16 * nct) * 16 * nct);
+    PmcArgsQ q;
+    std::memset(&q, 0, sizeof(q));
+    q.kind = kind;
+    q.npass = kpad / (16 * nct);
+    q.img = (const double *)(base + r.img);
+    q.ctab = (const double *)(base + r.ctab);
+    q.center = (const double *)(base + r.center);
+    q.guard = (const double *)(base + r.head);
+    q.eps_tol = g_mgemm_tol / PMC_MGEMM_EPS;
+    q.blockflag = (int *)(base + r.flags);
+    q.redo = (int *)(base + r.head + 32);
+    e = ks->theta(a.pack, a.K, kpad, kind, (double *)(base + r.img), (double *)(base + r.ctab), (double *)(base + r.center),
+                  (unsigned long long *)(base + r.head), st);
+    if (e != hipSuccess) return e;
+    q.a = a;
+    e = ks->mgemm(nct, q, (unsigned)ceil_div(ceil_div(a.N, PMC_TILE), PMC_A_WAVES), st);
+    fallback.blockflag = q.blockflag;
+    fallback.redo = q.redo;
+    return e;
+}
+// diagnostics of the last such call in this workspace (synchronises the stream): the guard's three norms and the number
+// of workgroups it refused
+int mgemm_report(const PmcKernelSet *ks, const void *d_workspace, long long N, int K, hipStream_t st, double *norms,
+                 long long *refused, long long *nblocks_out)
+{
+    const MgRegion r = mgemm_region(N, K, ks);
+    const char *base = (const char *)d_workspace + mgemm_offset(N, K, ks);
+    const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    std::vector<int> flags((size_t)nblocks);
+    hipError_t e = hipMemcpyAsync(norms, base + r.head, 3 * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), base + r.flags, sizeof(int) * (size_t)nblocks, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hipfail(e, "pmc_maha_gemm_report");
+    long long c = 0;
+    for (int f : flags) c += f != 0;
+    *refused = c;
+    *nblocks_out = nblocks;
+    return PMC_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -804,7 +922,7 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
     if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
-    const size_t stats = gscale_offset(N, K, ks) + gscale_bytes(N, K, ks);
+    const size_t stats = mgemm_offset(N, K, ks) + mgemm_bytes(N, K, ks);
     const size_t scal = scalar_partials_bytes(N) +
                         (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
     size_t total = stats > scal ? stats : scal;
@@ -989,7 +1107,14 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K, D),
                 8.0 * N * (D + 1 + (d_individual ? K : 0) + (d_maha_tiles ? K : 0)));
-        hipError_t e = ks->padded == 2 ? big_logpdf(ks, kind, kind, a, D, st) : ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
+        // D >= 32: the forms of all components as one matrix product where its guard allows (pmc_mgemm.hip), the exact
+        // kernel behind it for the workgroups it refused
+        const int nct = (d_workspace && !d_individual && !d_maha_tiles && !max_init_zero && ks->padded != 2)
+                            ? mgemm_pick(ks, N, K) : 0;
+        hipError_t e = hipSuccess;
+        if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st);
+        if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
+        e = ks->padded == 2 ? big_logpdf(ks, kind, kind, a, D, st) : ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
@@ -1009,7 +1134,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
                                    const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                    double *d_log_target_out, double *d_weights, const double *d_sample_w,
                                    double *d_scalars, void *d_workspace, double *d_maha_tiles, double *d_u,
-                                   double *d_vsums, void *stream)
+                                   double *d_vsums, void *stream, double *d_gscale = nullptr)
 {
     if (N < 0 || K < 1 || K_target < 1 || !d_pack || !d_target_pack)
         return fail(PMC_EINVAL, "pmc_importance_weights: bad N/K/pack");
@@ -1030,10 +1155,30 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         a.out = d_out; a.weights = d_weights; a.sample_w = d_sample_w; a.atile = d_maha_tiles; a.u = d_u;
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         if (d_u && kind == PMC_KIND_STUDENT_T) a.vpartials = (double *)((char *)d_workspace + scalar_partials_bytes(N));
+        a.gscale = d_u ? d_gscale : nullptr;               // (the exact kernel's u is complete: it writes ones there)
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D),
                 8.0 * N * (D + 1 + (d_maha_tiles ? K : 0) + (d_u ? K : 0)));
-        hipError_t e = ks->padded == 2 ? big_logpdf(ks, kind, target_kind, a, D, st)
-                                       : ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
+        // D >= 32: the proposal's forms as one matrix product (pmc_mgemm.hip).  The target mixture -- a handful of
+        // components, which would pad a pass of 32 / 64 -- goes first, through the exact kernel, into log P; the matrix
+        // kernel reads it as given target values; the two-mixture exact kernel behind does the workgroups the guard refused.
+        const int nct = (d_workspace && !d_maha_tiles && ks->padded != 2 && (!d_u || (kind == PMC_KIND_GAUSS && d_gscale)))
+                            ? mgemm_pick(ks, N, K) : 0;
+        hipError_t e = hipSuccess;
+        if (nct) {
+            double *lt = d_log_target_out ? d_log_target_out
+                                          : (double *)((char *)d_workspace + mgemm_offset(N, K, ks) + mgemm_region(N, K, ks).lt);
+            PmcArgsA tg;
+            std::memset(&tg, 0, sizeof(tg));
+            tg.x = d_x; tg.N = N; tg.dreal = D; tg.pack = d_target_pack; tg.K = K_target; tg.ld = K_target; tg.out = lt;
+            e = ks->logpdf(target_kind, target_kind, tg, (unsigned)nblocks, st);
+            if (e != hipSuccess) return hipfail(e, "k_logpdf (target) launch");
+            PmcArgsA ga = a;
+            ga.pack2 = nullptr; ga.K2 = 0; ga.log_target_out = nullptr; ga.log_target = lt; ga.vpartials = nullptr;
+            e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st);
+            if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
+        }
+        e = ks->padded == 2 ? big_logpdf(ks, kind, target_kind, a, D, st)
+                            : ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_u && kind == PMC_KIND_STUDENT_T) {
@@ -1093,6 +1238,59 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
     if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T && kind != PMC_KIND_VB)
         return fail(PMC_EINVAL, "pmc_estep_from_u: unknown kind %d", kind);
     return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind);
+}
+
+int pmc_maha_gemm_tiles(int64_t N, int K, int D)
+{
+    if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_maha_gemm_tiles: bad N/K");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
+    return ks->padded == 2 ? 0 : mgemm_pick(ks, N, K);
+}
+
+int pmc_maha_gemm_report(const void *d_workspace, int64_t N, int K, int D, void *stream, double *h_norms,
+                         int64_t *h_refused, int64_t *h_workgroups)
+{
+    if (!d_workspace || !h_norms || !h_refused || !h_workgroups || N < 1 || K < 1)
+        return fail(PMC_EINVAL, "pmc_maha_gemm_report: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks || ks->padded == 2 || !mgemm_pick(ks, N, K))
+        return fail(PMC_EINVAL, "pmc_maha_gemm_report: the matrix-product form is not taken for this shape");
+    long long refused = 0, nb = 0;
+    const int rc = mgemm_report(ks, d_workspace, N, K, (hipStream_t)stream, h_norms, &refused, &nb);
+    *h_refused = refused;
+    *h_workgroups = nb;
+    return rc;
+}
+
+int64_t pmc_gscale_len(int64_t N, int K)
+{
+    if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_gscale_len: bad N/K");
+    return ceil_div(N, PMC_TILE) * (int64_t)ceil_div(K, PMC_RESP_GROUP) * PMC_TILE;
+}
+
+int pmc_importance_weights_emit_grouped(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
+                                        const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                                        double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
+                                        double *d_u, double *d_gscale, double *d_vsums, void *stream)
+{
+    if (!d_u || !d_gscale) return fail(PMC_EINVAL, "pmc_importance_weights_emit_grouped: d_u / d_gscale is NULL");
+    if (kind == PMC_KIND_STUDENT_T && (!d_vsums || !d_workspace))
+        return fail(PMC_EINVAL, "pmc_importance_weights_emit_grouped: Student-t needs d_vsums and d_workspace");
+    if (D > PMC_MAX_DIM)
+        return fail(PMC_EINVAL, "pmc_importance_weights_emit_grouped: compiled dimensions only (D <= %d)", PMC_MAX_DIM);
+    return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
+                                   d_log_target_out, d_weights, nullptr, d_scalars, d_workspace, nullptr, d_u, d_vsums, stream,
+                                   d_gscale);
+}
+
+int pmc_estep_from_u_grouped(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, double *d_u,
+                             double *d_gscale, double *d_stats, void *d_workspace, void *stream)
+{
+    if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T && kind != PMC_KIND_VB)
+        return fail(PMC_EINVAL, "pmc_estep_from_u_grouped: unknown kind %d", kind);
+    if (!d_gscale) return fail(PMC_EINVAL, "pmc_estep_from_u_grouped: d_gscale is NULL");
+    return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind, d_gscale);
 }
 
 int64_t pmc_maha_tiles_size(int64_t N, int K)
@@ -1254,8 +1452,22 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
     hipError_t e;
     int *ctl = nullptr;
     int counted = 1;
-    if (d_gscale && !gemm_selected(ks, N, K, kind)) return fail(PMC_EINVAL, "statistics: factors without the common-shift form");
-    if (gemm_selected(ks, N, K, kind)) {
+    const bool use_gemm = gemm_selected(ks, N, K, kind);  // (evaluated once: pmc_configure may run concurrently)
+    if (d_gscale && !use_gemm) {
+        // factors, but the statistics kernel that applies them is not the one this shape gets: complete u in place, the
+        // factors become ones (only a caller-owned pair gets here: pmc_estep decides both halves together)
+        const long long ntl = ceil_div(N, PMC_TILE), total_u = ntl * (long long)K * 64;
+        const long long glen = ntl * ceil_div(K, PMC_RESP_GROUP) * 64;
+        const long long blocks = ceil_div(total_u, 256), gblocks = ceil_div(glen, 256);
+        hipLaunchKernelGGL(k_apply_scale, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (double *)d_u,
+                           d_gscale, ntl, K, (const int *)nullptr);
+        hipLaunchKernelGGL(k_reset_scale, dim3((unsigned)(gblocks < 2048 ? gblocks : 2048)), dim3(256), 0, st,
+                           (double *)d_gscale, glen, (const int *)nullptr);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hipfail(e, "k_apply_scale launch");
+        d_gscale = nullptr;
+    }
+    if (use_gemm) {
         // The common-shift form first (k_stats_gemm, pmc_stats.hip); the per-component-shift kernel below then
         // returns at once unless the a-posteriori test of k_gemm_convert asks for it.
         if (((uintptr_t)d_u & 15u) != 0) return fail(PMC_EINVAL, "pmc_estep: d_u must be 16-byte aligned");
@@ -1310,6 +1522,10 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
             const long long blocks = ceil_div(total_u, 256);
             hipLaunchKernelGGL(k_apply_scale, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (double *)d_u,
                                d_gscale, gg.ntiles, K, (const int *)ctl);
+            const long long glen = gg.ntiles * ceil_div(K, PMC_RESP_GROUP) * 64;
+            const long long gblocks = ceil_div(glen, 256);
+            hipLaunchKernelGGL(k_reset_scale, dim3((unsigned)(gblocks < 2048 ? gblocks : 2048)), dim3(256), 0, st,
+                               (double *)d_gscale, glen, (const int *)ctl);
             e = hipGetLastError();
             if (e != hipSuccess) return hipfail(e, "k_apply_scale launch");
         }
@@ -1377,6 +1593,16 @@ int pmc_configure(const char *key, double value)
     if (std::strcmp(key, "stats_common_shift_min_n") == 0) {
         if (!(value >= 0.0 && value <= 9e18)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
         g_gemm_min_n = (long long)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "maha_gemm_tolerance") == 0) {
+        if (!(value >= 0.0 && value <= 1.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [0, 1]", key);
+        g_mgemm_tol = value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "maha_gemm_min_n") == 0) {
+        if (!(value >= 0.0 && value <= 9e18)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
+        g_mgemm_min_n = (long long)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "stats_common_shift_limit") == 0) {
@@ -1576,8 +1802,12 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
     }
     if (!fused_eligible(ks, K, kind, mode)) {
         if (!d_u) return fail(PMC_EINVAL, "pmc_estep: d_u is required unless pmc_estep_is_fused()");
-        if (ks->resp_groups && gemm_selected(ks, N, K, kind) && resp_groups_pays(ks->dim, K) &&
-            ((kind == PMC_KIND_VB && mode == PMC_RESP_VB) || (kind == PMC_KIND_GAUSS && mode == PMC_RESP_PMC_RB))) {
+        const bool groupable = ks->resp_groups && gemm_selected(ks, N, K, kind) &&
+                               ((kind == PMC_KIND_VB && mode == PMC_RESP_VB) || (kind == PMC_KIND_GAUSS && mode == PMC_RESP_PMC_RB));
+        // D >= 32: the forms of all components as one matrix product with the grouped epilogue fused behind it
+        // (pmc_mgemm.hip); k_resp_groups then only does the workgroups its guard refused
+        const int nct = groupable ? mgemm_pick(ks, N, K) : 0;
+        if (groupable && (nct || resp_groups_pays(ks->dim, K))) {
             // the statistics will run as the component x monomial product: responsibilities in groups of one row
             // block, written once, their per-(sample, group) factors left to that kernel (k_resp_groups)
             if (!d_x) return fail(PMC_EINVAL, "pmc_estep: d_x is NULL");
@@ -1592,7 +1822,10 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
             a.partials = (double *)d_workspace;
             {
                 Timed t(T_RESP, st, flops_pairs((double)N, K, D), 8.0 * N * (D + K + ceil_div(K, PMC_RESP_GROUP)));
-                hipError_t e = ks->resp_groups(kind, a, (unsigned)nblocks, st);
+                hipError_t e = hipSuccess;
+                if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st);
+                if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
+                e = ks->resp_groups(kind, a, (unsigned)nblocks, st);
                 if (e != hipSuccess) return hipfail(e, "k_resp_groups launch");
             }
             int rc = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);

@@ -103,6 +103,26 @@ struct PmcArgsA {
     double *r, *log_rho, *exponent;
     double *partials;     // gridDim.x * PMC_NSCALARS
     double *gscale;       // k_resp_groups: ntiles x ceil(K / 16) x 64 per-(sample, group of 16 components) factors
+                          // (k_logpdf's emitting epilogue writes ones there when it stands in for k_mgemm)
+    // the exact kernels as fall-back behind k_mgemm (pmc_mgemm.hip): a workgroup returns at once unless *redo != 0
+    // and blockflag[blockIdx.x] != 0 (both NULL: an ordinary launch)
+    const int *blockflag;
+    const int *redo;
+};
+
+// the Mahalanobis forms as one matrix product + the fused per-sample epilogues (pmc_mgemm.hip)
+struct PmcArgsQ {
+    PmcArgsA a;           // samples, outputs (out / weights with log_target / partials), sample_w; u + gscale: the grouped
+                          // responsibilities (k_resp_groups' form, one group per pass)
+    int kind;             // pmc_kind of the components
+    int npass;            // passes of 16 NCT components (K padded up to a multiple)
+    const double *img;    // [npass * NCT][NSTEPP][64] coefficient image (k_theta_build)
+    const double *ctab;   // [npass * NCT * 16][4] c0, c1, c2, c3-or-weight
+    const double *center; // [D] the common centre
+    const double *guard;  // Theta_1, Theta_2, Theta_3
+    double eps_tol;       // tolerance / eps_g: a sample with Theta_1 |d|^2 + Theta_2 |d| + Theta_3 beyond it flags its workgroup
+    int *blockflag;       // [gridDim.x] (output)
+    int *redo;            // set to 1 if any workgroup was flagged (zeroed by the caller)
 };
 constexpr int PMC_RESP_GROUP = 16;   // components per group of k_resp_groups = one row block of k_stats_gemm
 
@@ -228,4 +248,10 @@ struct PmcKernelSet {
     void (*gemm_config)(int *cols_per_wg, int *slices, int *msp, int *wgs_per_cu);
     int gemm_cols, gemm_slices, gemm_msp;   // monomial tiles (of 16) per workgroup, sample slices, partial row length
     int gemm_wgs;                           // workgroups of it that share a CU
+    // Mahalanobis forms as one matrix product (NULL / mg_nstepp == 0: this dimension has none)
+    hipError_t (*mgemm)(int nct, const PmcArgsQ &, unsigned grid, hipStream_t);
+    hipError_t (*theta)(const double *pack, int K, int Kpad, int kind, double *img, double *ctab, double *center,
+                        unsigned long long *guard, hipStream_t);
+    void (*mgemm_config)(int *nstepp, int *nct_max);
+    int mg_nstepp, mg_nct_max;
 };

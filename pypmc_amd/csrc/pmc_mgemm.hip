@@ -1,0 +1,558 @@
+// pmc_mgemm.hip -- the Mahalanobis forms of ALL components of a mixture as one matrix product on the fp64 matrix pipe,
+// with the per-sample epilogues of k_logpdf / k_resp_groups fused behind it (compiled dimensions 32, 40, 48):
+//
+//     maha_nk = (x_n - mu_k)^T P_k (x_n - mu_k) = sum_m theta_km z_nm,      P_k = R_k^T R_k,
+//     z_n = the (D + 1)(D + 2) / 2 monomials of d = x_n - c up to degree 2 about ONE centre c common to all components,
+//     theta_k = (P_ii | 2 P_ij, i < j | -2 (P delta)_i | delta^T P delta),   delta = mu_k - c
+//
+// on v_mfma_f64_16x16x4_f64: A = theta (16 components x 4 monomials), B = z (4 monomials x 16 samples).  It replaces
+// bilinear_sym (pypmc/tools/_linalg.pyx:10-39) called N K times by Gauss / StudentT.multi_evaluate
+// (density/gauss.pyx:146-151, student_t.pyx:154-164) and by the VB exponent (mix_adapt/variational.pyx:774-798).
+//
+// Why: from D = 32 on the per-sample kernels' engine (4 x 4 x 4 blocks of the triangular factor, pmc_persample.hip)
+// keeps the matrix pipe 67 % busy; this form is dense (97 % of the slots useful at D = 40), uses the instruction that
+// holds the highest clock, and shares every monomial product among NCT component tiles: 27 instead of 35 ps per pair
+// at D = 40, K = 128 (scripts/microbench/maha_gemm2.hip, profiles/r03_maha_gemm_prototype.txt).
+//
+// The price is numerical: the expanded form's rounding error is eps * sum_m |theta_km z_nm| -- it grows with
+// |P| |x - c|^2, not with maha.  A guard prices it per sample BEFORE any work is done,
+//     E_n = eps_g (Theta_1 |d_n|^2 + Theta_2 |d_n| + Theta_3),
+//     Theta_1 = max_k s_k |P_k|_F,  Theta_2 = max_k 2 s_k |P_k delta_k|,  Theta_3 = max_k s_k delta_k^T P_k delta_k
+// (s_k = |d a_nk / d maha_nk|: 1/2 Gauss, (nu + D) / (2 nu) Student-t, nu_k / 2 VB), and a workgroup with a sample
+// beyond the tolerance (or a non-finite coordinate) writes nothing but its flag: the exact kernel launched behind
+// (k_logpdf / k_resp_groups with PmcArgsA::blockflag) does exactly the flagged workgroups' samples.
+//
+// Work decomposition: workgroup = 4 wavefronts = 4 tiles of 64 samples (the per-sample kernels' blocks, so scalar
+// partials and flags line up).  The wavefront's samples sit in LDS as d[j][sample] with four views rotated by D / 4
+// coordinates, one per lane group g = lane >> 4, so that ONE compile-time pair of rows per step gives the four lane
+// groups four different monomials (pairs (a, a + delta), a < D / 4, delta = 0 ... D / 2; then D / 4 linear steps, one
+// constant step).  theta arrives by LDS-DMA in chunks of 16 steps, double buffered, shared by the four wavefronts.
+// Epilogue in the accumulator layout (lane (g, s) holds components g + 4 r of each tile for samples 16 t + s): the
+// pass's 16 NCT components are one group -- maximum and sums by two cross-lane steps, u' = [w_k] exp(a - M_pass)
+// written once (k_resp_groups' form with the pass as the group: the factor per (sample, group) is left to
+// k_stats_gemm) -- and lane l = sample l carries the row's running maximum / sum / bound term across the passes.
+#include "pmc_device.h"
+
+namespace {
+
+typedef double md4 __attribute__((ext_vector_type(4)));
+typedef double md2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void mg_gvoid_t;
+typedef __attribute__((address_space(3))) void mg_lvoid_t;
+
+template <int D> struct MgCfg {
+    static constexpr bool ENABLED = D == 32 || D == 40 || D == 48;
+    static constexpr int Q = D / 4;
+    static constexpr int ND = 2 * Q + 1;                   // deltas per a
+    static constexpr int NQ = Q * ND;                      // quadratic steps
+    static constexpr int NSTEP = NQ + Q + 1;
+    static constexpr int CH = 16;                          // steps per staged chunk of theta
+    static constexpr int NCH = (NSTEP + CH - 1) / CH;
+    static constexpr int NSTEPP = NCH * CH;
+    // row stride of the LDS image of d (doubles): >= 64 and Q RS = 16 mod 32, so that the two lane groups of a
+    // half-wavefront read 32 banks apart
+    static constexpr int RS = D == 32 ? 66 : (D == 40 ? 72 : (D == 48 ? 68 : 64));
+    // component tiles that share a monomial product: what the LDS holds next to the image of 256 samples
+    static constexpr int NCT_MAX = D <= 40 ? 4 : 2;
+    static constexpr size_t lds_bytes(int nct)
+    {
+        return sizeof(double) * (size_t)(2 * nct * CH * 64 + 4 * D * RS + 2 * nct * 64);
+    }
+};
+
+template <int IMM> __device__ __forceinline__ void mg_read64(double &v, unsigned addr)
+{
+    static_assert(IMM >= 0 && IMM < 65536 && IMM % 8 == 0, "ds_read_b64 offset");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+}
+__device__ __forceinline__ void mg_wait5(double &a, double &b, double &c, double &d, double &e)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+}
+__device__ __forceinline__ void mg_wait1(double &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+
+__device__ __forceinline__ double mg_xor16(double v) { return __shfl_xor(v, 16, 64); }
+__device__ __forceinline__ double mg_xor32(double v) { return __shfl_xor(v, 32, 64); }
+
+// ---------------------------------------------------------------------------------------------
+// k_theta_build: the coefficient image, the epilogue's constants, the centre and the guard's norms from the pack.
+// One workgroup per component (padding components up to a multiple of 16 NCT: zero coefficients, a value of -DBL_MAX).
+//   img[(k / 16) * NSTEPP + s][16 g + k % 16] = coefficient of component k for the monomial of lane group g in step s
+//   ctab[k][4] = c0, c1, c2, x3 (x3 = the component weight for the density kinds, c3 for VB)
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ pack, int K, int kind,
+                                                     double *__restrict__ img, double *__restrict__ ctab,
+                                                     double *__restrict__ center, unsigned long long *__restrict__ guard)
+{
+    using C = MgCfg<D>;
+    constexpr int STRIDE = pmc_pack_stride_c(D), T = pmc_tri(D), Q = C::Q, ND = C::ND, NQ = C::NQ;
+    __shared__ double cen[D], dlt[D], Pd[D], Rm[D][D + 1], Pm[D][D + 1], red[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    // the common centre: midrange of the component means per coordinate (every workgroup for itself, same bits)
+    if (tid < D) {
+        double lo = pack[tid], hi = lo;
+        for (int q = 1; q < K; ++q) {
+            const double m = pack[(size_t)q * STRIDE + tid];
+            lo = m < lo ? m : lo;
+            hi = m > hi ? m : hi;
+        }
+        const double c = 0.5 * lo + 0.5 * hi;
+        cen[tid] = (c == c && fabs(c) <= DBL_MAX) ? c : 0.0;
+        if (k == 0) center[tid] = cen[tid];
+    }
+    double *ik = img + ((size_t)(k / 16) * C::NSTEPP) * 64 + (k % 16);
+    if (k >= K) {                                          // padding: no coefficients, a value no maximum ever takes
+        for (int idx = tid; idx < C::NSTEPP * 4; idx += 256) ik[(size_t)(idx >> 2) * 64 + 16 * (idx & 3)] = 0.0;
+        if (tid < 4) ctab[(size_t)k * 4 + tid] = (tid == (kind == PMC_KIND_VB ? 2 : 0)) ? -DBL_MAX : 0.0;
+        return;
+    }
+    const double *pk = pack + (size_t)k * STRIDE;
+    for (int idx = tid; idx < D * D; idx += 256) {
+        const int i = idx / D, j = idx - i * D;
+        Rm[i][j] = j >= i ? pk[D + i * D - i * (i + 1) / 2 + j] : 0.0;
+    }
+    __syncthreads();
+    if (tid < D) dlt[tid] = pk[tid] - cen[tid];
+    // P = R^T R (symmetric; thread per element of the upper triangle)
+    double fro = 0.0;
+    for (int idx = tid; idx < D * D; idx += 256) {
+        const int i = idx / D, j = idx - i * D;
+        if (j < i) continue;
+        double s = 0.0;
+        for (int l = 0; l <= i; ++l) s = fma(Rm[l][i], Rm[l][j], s);
+        Pm[i][j] = s;
+        Pm[j][i] = s;
+        fro += (i == j ? 1.0 : 2.0) * s * s;
+    }
+    __syncthreads();
+    double pd2 = 0.0, cst = 0.0;
+    if (tid < D) {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) s = fma(Pm[tid][j], dlt[j], s);
+        Pd[tid] = s;
+        pd2 = s * s;
+        cst = s * dlt[tid];
+    }
+    __syncthreads();
+    // block sums of fro, pd2, cst in a fixed order
+    double sums[3];
+    const double vals[3] = {fro, pd2, cst};
+    for (int q = 0; q < 3; ++q) {
+        red[tid] = vals[q];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        sums[q] = red[0];
+        __syncthreads();
+    }
+    for (int idx = tid; idx < C::NSTEPP * 4; idx += 256) {
+        const int s = idx >> 2, g = idx & 3;
+        double v = 0.0;
+        if (s < NQ) {
+            const int a = s / ND, d = s - a * ND;
+            const int i = (a + g * Q) % D, j = (a + d + g * Q) % D;
+            if (d == 0) v = Pm[i][i];
+            else if (d == 2 * Q) v = g < 2 ? 2.0 * Pm[i][j] : 0.0;      // (i, i + D / 2): the pairs of groups 2, 3 repeat 0, 1
+            else v = 2.0 * Pm[i][j];
+        } else if (s < NQ + Q) {
+            v = -2.0 * Pd[(s - NQ + g * Q) % D];
+        } else if (s == NQ + Q) {
+            v = 0.25 * sums[2];
+        }
+        ik[(size_t)s * 64 + 16 * g] = v;
+    }
+    const double *c = pk + D + T;
+    if (tid == 0) {
+        double *o = ctab + (size_t)k * 4;
+        o[0] = c[0];
+        o[1] = c[1];
+        o[2] = c[2];
+        o[3] = kind == PMC_KIND_VB ? c[3] : c[4];
+        // |d a / d maha|
+        const double sk = kind == PMC_KIND_GAUSS ? 0.5 : (kind == PMC_KIND_STUDENT_T ? fabs(c[1] * c[2]) : 0.5 * fabs(c[1]));
+        const double th[3] = {sk * sqrt(sums[0]), 2.0 * sk * sqrt(sums[1]), sk * fabs(sums[2])};
+        for (int q = 0; q < 3; ++q) {
+            // non-negative doubles order like their bit patterns; a NaN's pattern lies above every number's, so it wins
+            // and the guard refuses every sample
+            const double t = th[q] == th[q] ? th[q] : __longlong_as_double(0x7ff8000000000000LL);
+            atomicMax(guard + q, (unsigned long long)__double_as_longlong(t));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mgemm
+// ---------------------------------------------------------------------------------------------
+template <int D, int NCT>
+__global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
+{
+    using C = MgCfg<D>;
+    constexpr int Q = C::Q, RS = C::RS, CH = C::CH, NCH = C::NCH, ND = C::ND, NQ = C::NQ, NSTEP = C::NSTEP;
+    static_assert(RS >= 64 && (Q * RS) % 32 == 16, "bank spread of the rotated views");
+    static_assert(NCH % 2 == 0, "the chunk's buffer is a compile-time constant of the step");
+    extern __shared__ double lds[];
+    double *th = lds;                                      // [2][NCT][CH * 64]
+    double *dl = lds + 2 * NCT * CH * 64;                  // [4][D][RS]
+    double *cts = dl + 4 * D * RS;                         // [2][NCT * 16][4]
+    __shared__ int s_flag;
+    const PmcArgsA &a = q.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s16 = lane & 15, g = lane >> 4;
+    const long long tile = blockIdx.x * 4LL + wave;
+    const long long n = tile * 64 + lane;
+    const bool valid = n < a.N;
+    const bool tile_live = tile * 64 < a.N;               // wave-uniform
+    const int K = a.K, kind = q.kind;
+    double *dw = dl + wave * D * RS;
+
+    // ---- the wavefront's samples minus the centre -> LDS, and the guard
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    {
+        const long long nc = valid ? n : a.N - 1;
+        const double *xr = a.x + nc * (long long)a.dreal;
+        double dsq = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < D; ++j) {
+            const double v = j < a.dreal ? xr[j] - q.center[j] : 0.0;
+            dw[j * RS + lane] = v;
+            dsq = fma(v, v, dsq);
+        }
+        const double dn = sqrt(dsq);
+        const double e = fma(fma(q.guard[0], dn, q.guard[1]), dn, q.guard[2]);
+        if (__any(!(e <= q.eps_tol)) && lane == 0) s_flag = 1;
+    }
+    __syncthreads();
+    const int flagged = s_flag;
+    if (tid == 0) {
+        q.blockflag[blockIdx.x] = flagged;
+        if (flagged) *q.redo = 1;                          // (benign race: every writer stores 1)
+    }
+    if (flagged) return;                                   // the exact kernel behind does this workgroup's samples
+
+    const unsigned dwa = (unsigned)(uintptr_t)(mg_lvoid_t *)dw, tha = (unsigned)(uintptr_t)(mg_lvoid_t *)th + 8u * lane;
+    unsigned base[4];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) base[jq] = dwa + 8u * (unsigned)((((jq + g) * Q) % D) * RS + s16);
+
+    const int npass = q.npass, nchunks = npass * NCH;
+    auto stage = [&](int cg) {                             // chunk cg = (pass, chunk of the pass) -> theta buffer cg & 1
+        const int pass = cg / NCH, ch = cg - pass * NCH;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const double *src = q.img + ((size_t)(pass * NCT + c) * NCH + ch) * CH * 64;
+            double *dst = th + ((cg & 1) * NCT + c) * CH * 64;
+#pragma unroll
+            for (int p = 0; p < (CH * 64 / 128 + 3) / 4; ++p) {
+                const int piece = wave + 4 * p;
+                if (piece < CH * 64 / 128)
+                    __builtin_amdgcn_global_load_lds((mg_gvoid_t *)(src + piece * 128 + 2 * lane),
+                                                     (mg_lvoid_t *)(dst + piece * 128), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_consts = [&](int pass) {                    // the pass's 16 NCT x 4 constants -> cts[pass & 1]
+        constexpr int PIECES = (NCT * 64 + 127) / 128;
+        if (wave < PIECES) {
+            const double *src = q.ctab + (size_t)pass * NCT * 64 + wave * 128;
+            int o = 2 * lane;
+            if (NCT * 64 < 128 && o > NCT * 64 - 2) o = NCT * 64 - 2;
+            __builtin_amdgcn_global_load_lds((mg_gvoid_t *)(src + o), (mg_lvoid_t *)(cts + (pass & 1) * NCT * 64 + wave * 128),
+                                             16, 0, 0);
+        }
+    };
+
+    // per-sample running state of the row (lane l = sample l of the tile): maximum, sum, VB bound term
+    double Mrun = -DBL_MAX, srun = 0.0, tbrun = 0.0;
+    const ExpConst EC;
+    const bool emit = a.u != nullptr;
+    const int G = (K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
+    double *ut = emit ? a.u + (size_t)(tile_live ? tile : 0) * K * 64 + s16 : nullptr;
+    double *gs = emit ? a.gscale + (size_t)(tile_live ? tile : 0) * G * 64 + lane : nullptr;
+
+    md4 acc[NCT][4];
+
+    // ---- epilogue of one pass: a_nk from the forms, the pass's maximum and sums, u'
+    auto epilogue = [&](int pass) {
+        const double *ct = cts + (pass & 1) * NCT * 64 + 4 * g;
+        double Mp[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+        // (the kind is a wave-uniform run-time value: one switch around each loop nest, not one per pair)
+        auto values = [&](auto KIND_) {
+            constexpr int KD = decltype(KIND_)::value;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const md2 c01 = *(const md2 *)(ct + (c * 16 + 4 * r) * 4), c23 = *(const md2 *)(ct + (c * 16 + 4 * r) * 4 + 2);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double m = acc[c][t][r];
+                        double v;
+                        if constexpr (KD == PMC_KIND_GAUSS) {
+                            v = fma(-0.5, m, c01[0]);                   // gauss.pyx:151
+                        } else if constexpr (KD == PMC_KIND_STUDENT_T) {
+                            double tt = m;                               // student_t.pyx:159-164
+                            tt *= c23[0];
+                            tt += 1.;
+                            tt = log_pos(tt);
+                            tt *= c01[1];
+                            tt += c01[0];
+                            v = tt;
+                        } else {
+                            const double expo = c01[0] + c01[1] * m;     // variational.pyx:798
+                            v = fma(0.5, c23[1] - expo, c23[0]);         // variational.pyx:691
+                        }
+                        acc[c][t][r] = v;
+                        Mp[t] = max_f64(v, Mp[t]);
+                    }
+                }
+        };
+        if (kind == PMC_KIND_GAUSS) values(ic<PMC_KIND_GAUSS>{});
+        else if (kind == PMC_KIND_STUDENT_T) values(ic<PMC_KIND_STUDENT_T>{});
+        else values(ic<PMC_KIND_VB>{});
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            Mp[t] = max_f64(Mp[t], mg_xor16(Mp[t]));
+            Mp[t] = max_f64(Mp[t], mg_xor32(Mp[t]));
+        }
+        double sp[4] = {0.0, 0.0, 0.0, 0.0}, tb[4] = {0.0, 0.0, 0.0, 0.0};
+        auto exps = [&](auto VB_) {
+            constexpr bool VB = decltype(VB_)::value != 0;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = (pass * NCT + c) * 16 + g + 4 * r;
+                    const double x3 = ct[(c * 16 + 4 * r) * 4 + 3];
+                    const bool st = emit && tile_live && kk < K;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double lr = max_f64(acc[c][t][r] - Mp[t], -1075.0);   // variational.pyx:741 / _regularize.pyx:79
+                        const double e = exp_clamped(lr, EC);
+                        double uo;
+                        if constexpr (VB) {
+                            tb[t] = fma(e, lr, tb[t]);
+                            sp[t] += e;
+                            uo = zero_to_tiny(e);                        // variational.pyx:751-753
+                        } else {
+                            uo = x3 * e;                                 // _regularize.pyx:79 / pmc.pyx:39
+                            sp[t] += uo;
+                        }
+                        if (st) ut[(size_t)kk * 64 + 16 * t] = uo;
+                    }
+                }
+        };
+        if (kind == PMC_KIND_VB) exps(ic<1>{});
+        else exps(ic<0>{});
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sp[t] += mg_xor16(sp[t]);
+            sp[t] += mg_xor32(sp[t]);
+        }
+        if (kind == PMC_KIND_VB) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                tb[t] += mg_xor16(tb[t]);
+                tb[t] += mg_xor32(tb[t]);
+            }
+        }
+        // lane l = sample l: the pass joins the row's running maximum / sum / bound term
+        const double Mo = g == 0 ? Mp[0] : (g == 1 ? Mp[1] : (g == 2 ? Mp[2] : Mp[3]));
+        const double so = g == 0 ? sp[0] : (g == 1 ? sp[1] : (g == 2 ? sp[2] : sp[3]));
+        const double to = g == 0 ? tb[0] : (g == 1 ? tb[1] : (g == 2 ? tb[2] : tb[3]));
+        const double Mn = max_f64(Mo, Mrun);
+        const double ar = max_f64(Mrun - Mn, -1075.0), ag = max_f64(Mo - Mn, -1075.0);
+        const double cr = exp_clamped(ar, EC), cg = exp_clamped(ag, EC);
+        if (kind == PMC_KIND_VB) tbrun = cr * fma(ar, srun, tbrun) + cg * fma(ag, so, to);
+        srun = cr * srun + cg * so;
+        Mrun = Mn;
+        if (emit && tile_live) {
+            // the pass's maximum waits in the factor's place (every group of 16 of the pass has the same)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+                if (pass * NCT + c < G) gs[(size_t)(pass * NCT + c) * 64] = Mo;
+        }
+    };
+
+    // ---- the passes
+    __syncthreads();
+    stage(0);
+    for (int kt = 0; kt <= npass; ++kt) {
+        if (kt < npass) {
+            // chunk (kt, 0) has landed, nobody reads the other buffer any more
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt * NCH + 1 < nchunks) stage(kt * NCH + 1);
+            stage_consts(kt);
+        }
+        if (kt > 0) epilogue(kt - 1);                      // (behind the barrier: its stores are old when the next one waits)
+        if (kt == npass) break;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[c][t] = md4{0.0, 0.0, 0.0, 0.0};
+        double ar[2][4], bv[2][4], tv[NCT][3], z[2][4];
+        // three stages, one step apart: fetch (LDS reads) -> mul (the monomials) -> the matrix instructions
+        auto fetch = [&](auto S_) {
+            constexpr int s = decltype(S_)::value, set = s & 1;
+            constexpr int ch = s / CH, i = s % CH;
+            static_for<0, NCT>([&](auto C_) {
+                constexpr int c = decltype(C_)::value;
+                constexpr int TH = 8 * ((((ch & 1) * NCT + c) * CH + i) * 64);
+                mg_read64<TH>(tv[c][s % 3], tha);
+            });
+            if constexpr (s < NQ) {
+                constexpr int aa = s / ND, dlt = s % ND, b = aa + dlt, jq = b / Q, br = b - jq * Q;
+                static_for<0, 4>([&](auto T_) {
+                    constexpr int t = decltype(T_)::value;
+                    if constexpr (dlt == 0) mg_read64<8 * (aa * RS + 16 * t)>(ar[aa & 1][t], base[0]);
+                    else mg_read64<8 * (br * RS + 16 * t)>(bv[set][t], base[jq]);
+                });
+            } else if constexpr (s < NQ + Q) {
+                constexpr int r = s - NQ;
+                static_for<0, 4>([&](auto T_) {
+                    constexpr int t = decltype(T_)::value;
+                    mg_read64<8 * (r * RS + 16 * t)>(bv[set][t], base[0]);
+                });
+            }
+        };
+        auto arrive = [&](auto S_) {
+            constexpr int s = decltype(S_)::value, set = s & 1;
+            if constexpr (s < NQ && s % ND == 0) {
+                constexpr int aa = s / ND;
+                mg_wait5(tv[0][s % 3], ar[aa & 1][0], ar[aa & 1][1], ar[aa & 1][2], ar[aa & 1][3]);
+            } else if constexpr (s < NQ + Q) mg_wait5(tv[0][s % 3], bv[set][0], bv[set][1], bv[set][2], bv[set][3]);
+            else mg_wait1(tv[0][s % 3]);
+            static_for<1, NCT>([&](auto C_) { mg_wait1(tv[decltype(C_)::value][s % 3]); });   // (already there: ties the registers)
+        };
+        auto mul = [&](auto S_, auto T_) {
+            constexpr int s = decltype(S_)::value, set = s & 1, t = decltype(T_)::value;
+            if constexpr (s < NQ) {
+                constexpr int aa = s / ND, dlt = s % ND;
+                z[set][t] = dlt == 0 ? ar[aa & 1][t] * ar[aa & 1][t] : ar[aa & 1][t] * bv[set][t];
+            } else if constexpr (s < NQ + Q) z[set][t] = bv[set][t];
+            else z[set][t] = 1.0;
+        };
+        auto boundary = [&](auto S_) {                     // in front of the first fetch of a chunk (not the pass's first)
+            constexpr int s = decltype(S_)::value;
+            if constexpr (s % CH == 0 && s > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int cg = kt * NCH + s / CH;
+                if (cg + 1 < nchunks) stage(cg + 1);
+            }
+        };
+        fetch(ic<0>{});
+        arrive(ic<0>{});
+        static_for<0, 4>([&](auto T_) { mul(ic<0>{}, T_); });
+        if constexpr (NSTEP > 1) {
+            boundary(ic<1>{});
+            fetch(ic<1>{});
+        }
+        static_for<0, NSTEP>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            if constexpr (s + 1 < NSTEP) arrive(ic<s + 1>{});
+            if constexpr (s + 2 < NSTEP) {
+                boundary(ic<s + 2>{});
+                fetch(ic<s + 2>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 4>([&](auto T_) {
+                constexpr int t = decltype(T_)::value;
+                static_for<0, NCT>([&](auto C_) {
+                    constexpr int c = decltype(C_)::value;
+                    acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[c][s % 3], z[s & 1][t], acc[c][t], 0, 0, 0);
+                });
+                if constexpr (s + 1 < NSTEP) mul(ic<s + 1>{}, T_);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    // ---- per sample (lane l = sample l): the row's log-sum-exp / normalisation, outputs, the groups' factors
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (kind == PMC_KIND_VB) {
+        // variational.pyx:748-755, :1003-1013
+        const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+        const double swv = valid ? sw : 0.0;
+        const double norm_inv = 1. / srun;
+        sc[0] = swv * fma(tbrun, norm_inv, log_any(norm_inv));
+        if (emit && tile_live) {
+            const double f = swv * norm_inv;
+            for (int gg = 0; gg < G; ++gg)
+                gs[(size_t)gg * 64] = f * exp_clamped(max_f64(gs[(size_t)gg * 64] - Mrun, -1075.0), EC);
+        }
+    } else {
+        const double lse = log_any(srun) + Mrun;          // _regularize.pyx:81
+        if (a.out != nullptr && valid) a.out[n] = lse;
+        double wn = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+        if (a.log_target != nullptr && valid) {
+            const double tmp = a.log_target[n] - lse;     // importance_sampling.py:204
+            const double w = exp(tmp);                    // :207
+            a.weights[n] = w;
+            sc[0] = w;
+            sc[1] = (w != 0.0) ? w * tmp : 0.0;           // convergence.py:35-36 (zeros masked)
+            sc[2] = w * w;
+            sc[4] = (isinf(w) && !isinf(tmp)) ? 1.0 : 0.0;
+            if (emit) wn = w;
+        }
+        if (valid) sc[3] = (a.sample_w != nullptr) ? a.sample_w[n] * lse : lse;   // pmc.pyx:388-391
+        if (emit && tile_live) {
+            // pmc.pyx:36-41: rho = exp(log q_k) w_k / (exp(lse) + tiny), times the sample's weight
+            const double f = valid ? wn / (exp(lse) + TINY) : 0.0;
+            for (int gg = 0; gg < G; ++gg) gs[(size_t)gg * 64] = f * exp(gs[(size_t)gg * 64]);
+        }
+    }
+    if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
+}
+
+}  // namespace
+
+// what the dispatcher needs: steps per component tile in the image (0: this dimension has no such kernel), the
+// largest number of component tiles per pass
+extern "C" void PMC_UNIT_NAME_X(pmc_mgemm_config_d, PMC_D, PMC_PADDED)(int *nstepp, int *nct_max)
+{
+    using C = MgCfg<D_>;
+    *nstepp = C::ENABLED ? C::NSTEPP : 0;
+    *nct_max = C::ENABLED ? C::NCT_MAX : 0;
+}
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_theta_d, PMC_D, PMC_PADDED)(const double *pack, int K, int Kpad, int kind,
+                                                                            double *img, double *ctab, double *center,
+                                                                            unsigned long long *guard, hipStream_t st)
+{
+    if constexpr (!MgCfg<D_>::ENABLED) return hipErrorNotSupported;
+    else {
+        hipLaunchKernelGGL((k_theta_build<D_>), dim3((unsigned)Kpad), dim3(256), 0, st, pack, K, kind, img, ctab, center, guard);
+        return hipGetLastError();
+    }
+}
+
+template <int NCT> static hipError_t mgemm_launch(const PmcArgsQ &q, unsigned grid, hipStream_t st)
+{
+    using C = MgCfg<D_>;
+    constexpr size_t lds = C::lds_bytes(NCT);
+    static_assert(lds + 512 <= 160 * 1024, "k_mgemm: the sample image and the theta buffers exceed the LDS");
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mgemm<D_, NCT>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (once != hipSuccess) return once;
+    hipLaunchKernelGGL((k_mgemm<D_, NCT>), dim3(grid), dim3(256), lds, st, q);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_mgemm_d, PMC_D, PMC_PADDED)(int nct, const PmcArgsQ &q, unsigned grid,
+                                                                            hipStream_t st)
+{
+    if constexpr (!MgCfg<D_>::ENABLED) return hipErrorNotSupported;
+    else {
+        if (nct == 2) return mgemm_launch<2>(q, grid, st);
+        if constexpr (MgCfg<D_>::NCT_MAX >= 4) {
+            if (nct == 4) return mgemm_launch<4>(q, grid, st);
+        }
+        return hipErrorInvalidValue;
+    }
+}

@@ -408,6 +408,8 @@ template <int D> __host__ __device__ constexpr int pmc_use_mfma() { return pmc_e
 template <int D, bool PADDED, int KIND, int KIND2>
 __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(const PmcArgsA a)
 {
+    // behind k_mgemm: only the workgroups its guard refused (block-uniform, in front of every barrier)
+    if (a.blockflag != nullptr && (*a.redo == 0 || a.blockflag[blockIdx.x] == 0)) return;
     const Dims<D> dm(a.dreal);
     const long long n = ((long long)blockIdx.x * PMC_A_WAVES * 64) + threadIdx.x;
     const bool valid = n < a.N;
@@ -478,6 +480,12 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         double *ut = a.u + (size_t)(n >> 6) * a.K * 64 + (threadIdx.x & 63);
         cdouble *pk = (cdouble *)a.pack + (size_t)(a.K - 1) * dm.STRIDE + dm.DT;
         double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)(n >> 6) * a.K * 2 : nullptr;
+        if (a.gscale != nullptr) {
+            // standing in for k_mgemm, which leaves a factor per (sample, group of 16 components) to the statistics
+            // kernel: this u is complete
+            const int G = (a.K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
+            for (int gq = 0; gq < G; ++gq) a.gscale[((size_t)(n >> 6) * G + gq) * 64 + (threadIdx.x & 63)] = 1.0;
+        }
         for (int k = a.K - 1; k >= 0; --k, pk -= dm.STRIDE) {               // last written first: still in L2
             double expo;
             const double maha = ut[(size_t)k * 64];
@@ -749,6 +757,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
 {
     static_assert(KIND == PMC_KIND_VB || KIND == PMC_KIND_GAUSS, "k_resp_groups: VB and Gaussian Rao-Blackwell PMC");
     constexpr int GS = PMC_RESP_GROUP;
+    if (a.blockflag != nullptr && (*a.redo == 0 || a.blockflag[blockIdx.x] == 0)) return;   // behind k_mgemm (see k_logpdf)
     const Dims<D> dm(a.dreal);
     const int lane = threadIdx.x & 63;
     const long long tile = (long long)blockIdx.x * PMC_A_WAVES +

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), "libpmc_hip.so does not export " + name
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert lib.pmc_abi_version() == 1
+    assert lib.pmc_abi_version() == 2
     # the handle layer on top of it (include/pmc_ctx.h)
     ctx_names = declared_symbols("pmc_ctx.h")
     assert len(ctx_names) >= 16 and not set(ctx_names) & set(names)

@@ -23,7 +23,7 @@ def test_cabi_demo_matches_oracle(tmp_path):
                     "-Wl,-rpath," + os.path.dirname(lib), "-o", exe], check=True)
     N = 1237
     res = subprocess.run([exe, str(N)], check=True, stdout=subprocess.PIPE, text=True).stdout.splitlines()
-    assert res[0].startswith("abi 1 arch gfx950")
+    assert res[0].startswith("abi 2 arch gfx950")
     D, K = 4, 3
     mu = np.array([[0, 0, 0, 0], [2, -1, 0.5, 1], [-3, 2, 1, -1]], dtype=float)
     var = np.array([[1, 2, 0.5, 1], [0.3, 0.7, 1.1, 2.0], [1.5, 0.4, 0.9, 1.2]])

@@ -44,7 +44,7 @@ def test_emit_matches_oracle_and_the_kept_forms(be, orc, D, K, N):
     # u = w rho against the oracle's rho (pmc.pyx:23-43) and the weights just formed
     wts = be.tohost(em["weights"])
     rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
-    u = untile(be, resp.data, N, K)
+    u = resp.host_matrix(be)
     ref = wts[:, None] * rho
     normal = ref > 1e-290
     assert_rel(u[normal], ref[normal], rtol=1e-10, what="u = w rho")
