@@ -78,7 +78,8 @@ __device__ __forceinline__ double mg_xor32(double v) { return __shfl_xor(v, 32, 
 // k_theta_build: the coefficient image, the epilogue's constants, the centre and the guard's norms from the pack.
 // One workgroup per component (padding components up to a multiple of 16 NCT: zero coefficients, a value of -DBL_MAX).
 //   img[(k / 16) * NSTEPP + s][16 g + k % 16] = coefficient of component k for the monomial of lane group g in step s
-//   ctab[k][4] = c0, c1, c2, x3 (x3 = the component weight for the density kinds, c3 for VB)
+//   ctab[k][4] = c0 + log w_k, c1, 0, 0 (what the Student-t epilogue needs behind the product; the other kinds' constants
+//                are folded into the image)
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ pack, int K, int kind,
@@ -104,7 +105,11 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
     double *ik = img + ((size_t)(k / 16) * C::NSTEPP) * 64 + (k % 16);
     if (k >= K) {                                          // padding: no coefficients, a value no maximum ever takes
         for (int idx = tid; idx < C::NSTEPP * 4; idx += 256) ik[(size_t)(idx >> 2) * 64 + 16 * (idx & 3)] = 0.0;
-        if (tid < 4) ctab[(size_t)k * 4 + tid] = (tid == (kind == PMC_KIND_VB ? 2 : 0)) ? -DBL_MAX : 0.0;
+        // (Gauss / VB: the value is the constant monomial, 4 x a quarter; Student-t: log 1 = 0 times c1 = 0, plus c0)
+        __syncthreads();
+        if (kind != PMC_KIND_STUDENT_T && tid < 4) ik[(size_t)(NQ + Q) * 64 + 16 * tid] = -0.25 * DBL_MAX;
+        if (kind == PMC_KIND_STUDENT_T && tid < 4) ik[(size_t)(NQ + Q) * 64 + 16 * tid] = 0.25;
+        if (tid < 4) ctab[(size_t)k * 4 + tid] = tid == 0 ? -DBL_MAX : 0.0;
         return;
     }
     const double *pk = pack + (size_t)k * STRIDE;
@@ -148,32 +153,44 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
         sums[q] = red[0];
         __syncthreads();
     }
+    // What the product returns is the component's value itself where that is affine in the form (one instruction less
+    // per pair, no constants in the epilogue):
+    //   Gauss      a + log w = (c0 + log w) - maha / 2                          (gauss.pyx:151, the weight of logsumexp2D folded in)
+    //   VB         a = c2 + (c3 - c0) / 2 - c1 maha / 2                         (variational.pyx:798, :691)
+    //   Student-t  t = 1 + c2 maha, then a + log w = (c0 + log w) + c1 log t    (student_t.pyx:159-164)
+    // i.e. every coefficient times `scale`, the constant monomial plus `shift`.
+    const double *c = pk + D + T;
+    const bool vb = kind == PMC_KIND_VB;
+    const double logw = vb ? 0.0 : log(c[4]);
+    const double scale = kind == PMC_KIND_GAUSS ? -0.5 : (vb ? -0.5 * c[1] : c[2]);
+    const double shift = kind == PMC_KIND_GAUSS ? c[0] + logw : (vb ? c[2] + 0.5 * (c[3] - c[0]) : 1.0);
     for (int idx = tid; idx < C::NSTEPP * 4; idx += 256) {
         const int s = idx >> 2, g = idx & 3;
         double v = 0.0;
         if (s < NQ) {
             const int a = s / ND, d = s - a * ND;
             const int i = (a + g * Q) % D, j = (a + d + g * Q) % D;
-            if (d == 0) v = Pm[i][i];
-            else if (d == 2 * Q) v = g < 2 ? 2.0 * Pm[i][j] : 0.0;      // (i, i + D / 2): the pairs of groups 2, 3 repeat 0, 1
-            else v = 2.0 * Pm[i][j];
+            if (d == 0) v = scale * Pm[i][i];
+            else if (d == 2 * Q) v = g < 2 ? scale * (2.0 * Pm[i][j]) : 0.0;   // (i, i + D / 2): the pairs of groups 2, 3 repeat 0, 1
+            else v = scale * (2.0 * Pm[i][j]);
         } else if (s < NQ + Q) {
-            v = -2.0 * Pd[(s - NQ + g * Q) % D];
+            v = scale * (-2.0 * Pd[(s - NQ + g * Q) % D]);
         } else if (s == NQ + Q) {
-            v = 0.25 * sums[2];
+            v = 0.25 * (scale * sums[2] + shift);
         }
         ik[(size_t)s * 64 + 16 * g] = v;
     }
-    const double *c = pk + D + T;
     if (tid == 0) {
-        double *o = ctab + (size_t)k * 4;
-        o[0] = c[0];
+        double *o = ctab + (size_t)k * 4;                  // (read by the Student-t epilogue only)
+        o[0] = c[0] + logw;
         o[1] = c[1];
-        o[2] = c[2];
-        o[3] = kind == PMC_KIND_VB ? c[3] : c[4];
+        o[2] = o[3] = 0.0;
         // |d a / d maha|
         const double sk = kind == PMC_KIND_GAUSS ? 0.5 : (kind == PMC_KIND_STUDENT_T ? fabs(c[1] * c[2]) : 0.5 * fabs(c[1]));
-        const double th[3] = {sk * sqrt(sums[0]), 2.0 * sk * sqrt(sums[1]), sk * fabs(sums[2])};
+        double th[3] = {sk * sqrt(sums[0]), 2.0 * sk * sqrt(sums[1]), sk * fabs(sums[2])};
+        // A component without weight takes part in the reference's row maximum (logsumexp2D, _regularize.pyx:73-77) but
+        // has no logarithm to fold in: such mixtures stay with the exact kernels (a NaN norm refuses every sample)
+        if (!vb && !(c[4] > 0.0 && c[4] <= DBL_MAX)) th[0] = __longlong_as_double(0x7ff8000000000000LL);
         for (int q = 0; q < 3; ++q) {
             // non-negative doubles order like their bit patterns; a NaN's pattern lies above every number's, so it wins
             // and the guard refuses every sample
@@ -280,40 +297,29 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
     auto epilogue = [&](int pass) {
         const double *ct = cts + (pass & 1) * NCT * 64 + 4 * g;
         double Mp[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
-        // (the kind is a wave-uniform run-time value: one switch around each loop nest, not one per pair)
-        auto values = [&](auto KIND_) {
-            constexpr int KD = decltype(KIND_)::value;
+        // The product already is the component's value a_nk [+ log w_k] for the Gauss and VB kinds (k_theta_build folds
+        // their constants into the image); Student-t: t = 1 + maha / nu came out, a = (c0 + log w) + c1 log t
+        if (kind == PMC_KIND_STUDENT_T) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const md2 c01 = *(const md2 *)(ct + (c * 16 + 4 * r) * 4), c23 = *(const md2 *)(ct + (c * 16 + 4 * r) * 4 + 2);
+                    const md2 c01 = *(const md2 *)(ct + (c * 16 + 4 * r) * 4);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const double m = acc[c][t][r];
-                        double v;
-                        if constexpr (KD == PMC_KIND_GAUSS) {
-                            v = fma(-0.5, m, c01[0]);                   // gauss.pyx:151
-                        } else if constexpr (KD == PMC_KIND_STUDENT_T) {
-                            double tt = m;                               // student_t.pyx:159-164
-                            tt *= c23[0];
-                            tt += 1.;
-                            tt = log_pos(tt);
-                            tt *= c01[1];
-                            tt += c01[0];
-                            v = tt;
-                        } else {
-                            const double expo = c01[0] + c01[1] * m;     // variational.pyx:798
-                            v = fma(0.5, c23[1] - expo, c23[0]);         // variational.pyx:691
-                        }
-                        acc[c][t][r] = v;
-                        Mp[t] = max_f64(v, Mp[t]);
+                        double tt = log_pos(acc[c][t][r]);               // student_t.pyx:161-164
+                        tt *= c01[1];
+                        tt += c01[0];
+                        acc[c][t][r] = tt;
                     }
                 }
-        };
-        if (kind == PMC_KIND_GAUSS) values(ic<PMC_KIND_GAUSS>{});
-        else if (kind == PMC_KIND_STUDENT_T) values(ic<PMC_KIND_STUDENT_T>{});
-        else values(ic<PMC_KIND_VB>{});
+        }
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Mp[t] = max_f64(acc[c][t][r], Mp[t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             Mp[t] = max_f64(Mp[t], mg_xor16(Mp[t]));
@@ -327,7 +333,6 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kk = (pass * NCT + c) * 16 + g + 4 * r;
-                    const double x3 = ct[(c * 16 + 4 * r) * 4 + 3];
                     const bool st = emit && tile_live && kk < K;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -339,8 +344,8 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
                             sp[t] += e;
                             uo = zero_to_tiny(e);                        // variational.pyx:751-753
                         } else {
-                            uo = x3 * e;                                 // _regularize.pyx:79 / pmc.pyx:39
-                            sp[t] += uo;
+                            uo = e;                                      // w_k exp(a - M): _regularize.pyx:79 / pmc.pyx:39
+                            sp[t] += e;
                         }
                         if (st) ut[(size_t)kk * 64 + 16 * t] = uo;
                     }
