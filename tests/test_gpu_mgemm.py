@@ -1,0 +1,376 @@
+"""The matrix-product form of the Mahalanobis forms (csrc/pmc_mgemm.hip; compiled D = 32, 40, 48): against the oracle
+(bilinear_sym -> multi_evaluate -> logsumexp2D, pypmc/tools/_linalg.pyx:10-39, density/gauss.pyx:146-151,
+student_t.pyx:154-164, tools/_regularize.pyx:57-84; rho, pmc.pyx:23-43; the VB E-step, variational.pyx:675-1013),
+against the exact kernels it stands in for, and on the cases its guard exists for -- means 30 sigma from the centre,
+cond(Sigma) = 1e10, one far outlier per workgroup, NaN / inf coordinates, zero-weight components."""
+import numpy as np
+import pytest
+from scipy.special import digamma
+
+from test_gpu_kernels import mk, draw, gauss_set, student_set, assert_rel
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-11          # the library's default "maha_gemm_tolerance"
+EPS_G = 1e-15        # the guard's error constant (csrc/pmc_api.hip)
+
+
+@pytest.fixture(scope="module")
+def be():
+    from pypmc_amd.backend import HipBackend
+    b = HipBackend()
+    yield b
+    b.configure("maha_gemm_tolerance", TOL)
+    b.configure("maha_gemm_min_n", 32768)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture()
+def small(be):
+    """the form from 1000 samples on (its default threshold is 32768: below, its fixed cost does not pay)"""
+    be.configure("maha_gemm_min_n", 1000)
+    be.configure("maha_gemm_tolerance", TOL)
+    yield
+    be.configure("maha_gemm_min_n", 32768)
+    be.configure("maha_gemm_tolerance", TOL)
+
+
+def exact(be, fn):
+    be.configure("maha_gemm_tolerance", 0.0)
+    try:
+        return fn()
+    finally:
+        be.configure("maha_gemm_tolerance", TOL)
+
+
+def report(be, N, K, D):
+    rep = be.maha_gemm_report(N, K, D)
+    assert rep is not None, "the shape does not take the matrix-product form"
+    return rep
+
+
+def guard_bound(rep, mu, x):
+    cen = 0.5 * (mu.min(axis=0) + mu.max(axis=0))
+    dn = np.linalg.norm(x - cen, axis=1)
+    return EPS_G * (rep["norms"][0] * dn ** 2 + rep["norms"][1] * dn + rep["norms"][2])
+
+
+CASES = [(32, 32, 3000), (32, 64, 2049), (31, 32, 1500), (40, 128, 2500), (40, 32, 1111), (40, 96, 1300), (37, 64, 1290),
+         (48, 32, 1500), (48, 64, 1027), (44, 96, 1100), (40, 28, 1200), (40, 120, 1100)]
+
+
+@pytest.mark.parametrize("D,K,N", CASES)
+def test_gauss_logpdf_vs_oracle(be, orc, small, D, K, N):
+    mu, cov, w = mk(K, D, 300 + D + K)
+    x, _ = draw(mu, cov, w, N, 17)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    ref, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+    rep = report(be, N, K, D)
+    assert rep["refused"] == 0, "the guard refused healthy data: %r" % rep
+    assert_rel(got, ref, what="log q through the matrix product")
+    # the guard's price covers what the form really costs (the difference to the exact kernel), with room to spare
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    assert_rel(ex, ref, rtol=1e-12, what="exact kernel")
+    ratio = (np.abs(got - ex) / guard_bound(rep, mu, x)).max()
+    assert ratio < 0.75, "difference / bound = %.3f" % ratio
+
+
+@pytest.mark.parametrize("D,K,N,dof", [(32, 32, 2000, 8.), (40, 64, 1500, 3.), (40, 128, 1100, 50.), (48, 32, 1200, 5.),
+                                       (36, 32, 1300, 1.5)])
+def test_student_logpdf_vs_oracle(be, orc, small, D, K, N, dof):
+    mu, cov, w = mk(K, D, 400 + D + K)
+    x, _ = draw(mu, cov * 1.3, w, N, 18)
+    dofs = np.full(K, dof) + 0.25 * (np.arange(K) % 7)
+    cs, inv, ln, pf, idf = student_set(mu, cov, w, dofs)
+    ref, _ = orc.mixture_multi_evaluate(1, x, w, mu, inv, ln, pf, idf)
+    be.configure("maha_gemm_tolerance", 1e-9)             # (the Student-t slope (nu + D) / 2 nu prices small dof out by default)
+    got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+    rep = report(be, N, K, D)
+    be.configure("maha_gemm_tolerance", TOL)
+    assert rep["refused"] == 0
+    assert_rel(got, ref, what="Student-t log q through the matrix product")
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    assert (np.abs(got - ex) / guard_bound(rep, mu, x)).max() < 0.75
+
+
+@pytest.mark.parametrize("D,K,N", [(32, 32, 2500), (40, 128, 1500), (40, 64, 1100), (48, 64, 1300), (35, 32, 1200)])
+def test_importance_weights_and_emitted_responsibilities(be, orc, small, D, K, N):
+    """configuration 5's pair of calls: weights + u = w rho (grouped: values x factors) + the statistics"""
+    mu, cov, w = mk(K, D, 500 + D + K)
+    x, _ = draw(mu, cov, w, N, 19)
+    tmu, tcov, tw = mk(4, D, 78)
+    prop, inv, ln = gauss_set(mu, cov, w)
+    target, tinv, tln = gauss_set(0.5 * tmu, tcov, tw)
+    logq, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    logp, _ = orc.mixture_multi_evaluate(0, x, tw, 0.5 * tmu, tinv, tln)
+    em = be.importance_weights(x, prop, target, want_out=True, want_log_target=True, emit=True)
+    rep = report(be, N, K, D)
+    assert rep["refused"] == 0
+    assert_rel(be.tohost(em["out"]), logq, what="log q")
+    assert_rel(be.tohost(em["log_target"]), logp, what="log P")
+    wts = be.tohost(em["weights"])
+    assert_rel(wts, orc.is_weights(logp, logq), what="importance weights")
+    sc = be.tohost(em["scalars"])
+    assert_rel(sc[:3], [wts.sum(), (wts * np.log(wts)).sum(), (wts ** 2).sum()], rtol=1e-11, what="weight sums")
+    resp = em["responsibilities"]
+    assert resp.gscale is not None
+    rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+    u, ref = resp.host_matrix(be), wts[:, None] * rho
+    normal = ref > 1e-290
+    assert_rel(u[normal], ref[normal], what="u = w rho")
+    assert np.all(u[~normal] <= 1e-280)
+    # the statistics of these responsibilities against the exact pair of calls
+    a = be.tohost(be.estep_from_u(x, prop, resp)["stats"])
+    b = exact(be, lambda: be.tohost(be.estep_from_u(x, prop, be.importance_weights(x, prop, target, emit=True)["responsibilities"])
+                                    ["stats"]))
+    ps = 1 + D + D * (D + 1) // 2
+    a, b = a[8:8 + K * ps].reshape(K, ps), b[8:8 + K * ps].reshape(K, ps)
+    assert (np.abs(a - b) / (np.abs(b).max(axis=1, keepdims=True) + 1e-300)).max() < 1e-11
+    # ... and used twice (the far-shift second pass of an update does that): the pair (u, factors) still means the same u
+    a2 = be.tohost(be.estep_from_u(x, prop, resp)["stats"])[8:8 + K * ps].reshape(K, ps)
+    assert (np.abs(a2 - a) / (np.abs(a).max(axis=1, keepdims=True) + 1e-300)).max() < 1e-12
+    np.testing.assert_allclose(resp.host_matrix(be), u, rtol=1e-14, atol=0)
+
+
+def vb_set(mu, cov, D, K, seed):
+    from pypmc_amd.backend import ComponentSet
+    rs = np.random.RandomState(seed)
+    inv = np.linalg.inv(cov)
+    inv = 0.5 * (inv + inv.transpose(0, 2, 1))
+    nu, beta, alpha = D + 2. + rs.uniform(0, 3, K), 1. + rs.uniform(0, 3, K), 1. + rs.uniform(0, 3, K)
+    W = inv / nu[:, None, None]
+    ln_lambda = sum(digamma(0.5 * (nu + 1. - i)) for i in range(1, D + 1)) + D * np.log(2.) + np.linalg.slogdet(W)[1]
+    ln_pi = digamma(alpha) - digamma(alpha.sum())
+    cs = ComponentSet(2, mu, W, c0=D / beta, c1=nu, c2=ln_pi, c3=ln_lambda - D * np.log(2. * np.pi))
+    return cs, W, beta, nu, ln_pi, ln_lambda
+
+
+@pytest.mark.parametrize("D,K,N,weighted", [(32, 32, 20000, False), (40, 64, 17000, True), (40, 128, 16500, False),
+                                            (48, 32, 18000, True)])
+def test_estep_vs_oracle(be, orc, small, D, K, N, weighted):
+    """pmc_estep (VB and Gaussian Rao-Blackwell PMC): k_mgemm's grouped responsibilities + the common-shift statistics.
+    Overlapping components (responsibilities that are not one-hot), so that the soft-max itself is tested."""
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    mu, cov, w = mk(K, D, 600 + D + K)
+    mu = 0.2 * mu
+    x, _ = draw(mu, cov, w, N, 21)
+    sw = np.random.RandomState(5).uniform(0.5, 1.5, N) if weighted else None
+    cs, W, beta, nu, ln_pi, ln_lambda = vb_set(mu, cov, D, K, 3)
+    o = orc.vb_estep(x, sw, mu, W, beta, nu, ln_pi, ln_lambda, mt=True)
+    assert (o["r"].max(axis=1) < 0.999).mean() > 0.05, "the test data should not be one-hot"
+    be.configure("stats_common_shift_min_n", 0)
+    try:
+        e = be.tohost(be.estep(x, cs, 0, sample_w=sw)["stats"])
+        rep = report(be, N, K, D)
+        assert rep["refused"] == 0
+        sc, S0, M1, M2, _, _ = split_stats(e, K, D)
+        xbar, S = centred_moments(S0, M1, M2, mu)
+        assert_rel(S0, o["N_comp"], what="N_k")
+        assert abs(sc[0] - o["expectation_log_q_Z"]) <= 1e-10 * abs(o["expectation_log_q_Z"])
+        np.testing.assert_allclose(xbar, o["x_mean_comp"], rtol=1e-10, atol=1e-11)
+        dg = np.sqrt(np.einsum('kii->ki', o["S"]))
+        assert (np.abs(S - o["S"]) / (dg[:, :, None] * dg[:, None, :])).max() < 1e-10
+        # Gaussian Rao-Blackwell PMC through the same kernel
+        gs, inv, ln = gauss_set(mu, cov, w)
+        eg = be.tohost(be.estep(x, gs, 1, sample_w=sw)["stats"])
+        ex = exact(be, lambda: be.tohost(be.estep(x, gs, 1, sample_w=sw)["stats"]))
+        ps = 1 + D + D * (D + 1) // 2
+        a, b = eg[8:8 + K * ps].reshape(K, ps), ex[8:8 + K * ps].reshape(K, ps)
+        assert (np.abs(a - b) / (np.abs(b).max(axis=1, keepdims=True) + 1e-300)).max() < 1e-11
+        assert abs(eg[3] - ex[3]) <= 1e-11 * abs(ex[3])      # sum of sample_w log q
+        rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+        wr = rho if sw is None else sw[:, None] * rho
+        assert_rel(a[:, 0], wr.sum(axis=0), what="sum w rho")
+    finally:
+        be.configure("stats_common_shift_min_n", 524288)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the guard
+# ---------------------------------------------------------------------------------------------------------------
+def test_far_outliers_send_their_workgroups_to_the_exact_kernel(be, orc, small):
+    """one far outlier per wavefront in some workgroups: exactly those workgroups fall back (bit for bit the exact
+    kernel's numbers there), the others keep the matrix product"""
+    D, K, N = 40, 64, 256 * 12 + 100
+    mu, cov, w = mk(K, D, 777)
+    x, _ = draw(mu, cov, w, N, 23)
+    bad_blocks = [1, 4, 5, 11]
+    for b in bad_blocks:
+        for wave in range(4):
+            x[256 * b + 64 * wave + 7 * wave + 3] += 4000.0 * (1 + wave)
+    x[256 * 12 + 5] -= 1e5                                 # ... and one in the ragged last workgroup
+    bad_blocks.append(12)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    ref, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    lt = np.random.RandomState(1).normal(size=N)
+    res = be.logpdf(x, cs, want_scalars=True, log_target=lt)
+    rep = report(be, N, K, D)
+    assert rep["refused"] == len(bad_blocks) and rep["workgroups"] == 13
+    got = be.tohost(res["out"])
+    assert_rel(got, ref, what="log q with outliers")
+    ex = exact(be, lambda: be.logpdf(x, cs, want_scalars=True, log_target=lt))
+    exo = be.tohost(ex["out"])
+    inbad = np.zeros(N, dtype=bool)
+    for b in bad_blocks:
+        inbad[256 * b:256 * (b + 1)] = True
+    np.testing.assert_array_equal(got[inbad], exo[inbad])
+    assert (got[~inbad] != exo[~inbad]).any()
+    np.testing.assert_array_equal(be.tohost(res["weights"])[inbad], be.tohost(ex["weights"])[inbad])
+    assert_rel(be.tohost(res["scalars"])[:4], be.tohost(ex["scalars"])[:4], rtol=1e-11, what="scalar sums across both kernels")
+    # the emitting pass and the E-step with the same outliers: complete u (factors one) in the refused workgroups
+    target = gauss_set(*mk(3, D, 79))[0]
+    em = be.importance_weights(x, cs, target, emit=True)
+    assert report(be, N, K, D)["refused"] == len(bad_blocks)
+    eme = exact(be, lambda: be.importance_weights(x, cs, target, emit=True))
+    np.testing.assert_array_equal(be.tohost(em["weights"])[inbad], be.tohost(eme["weights"])[inbad])
+    u, ue = em["responsibilities"].host_matrix(be), eme["responsibilities"].host_matrix(be)
+    np.testing.assert_array_equal(u[inbad], ue[inbad])
+    big = ue > 1e-250
+    assert (np.abs(u - ue)[big] / ue[big]).max() < 1e-10
+    f = be.tohost(em["responsibilities"].gscale).reshape(-1, (K + 15) // 16, 64)
+    assert np.all(f[4 * 4:4 * 6] == 1.0) and not np.all(f[0:4] == 1.0)
+    st = be.tohost(be.estep_from_u(x, cs, em["responsibilities"])["stats"])
+    ste = exact(be, lambda: be.tohost(be.estep_from_u(x, cs, eme["responsibilities"])["stats"]))
+    ps = 1 + D + D * (D + 1) // 2
+    a, b = st[8:8 + K * ps].reshape(K, ps), ste[8:8 + K * ps].reshape(K, ps)
+    assert (np.abs(a - b) / (np.abs(b).max(axis=1, keepdims=True) + 1e-300)).max() < 1e-10
+
+
+def test_means_30_sigma_from_the_centre(be, orc, small):
+    """components 30 sigma and more from the common centre: either the guard prices every sample out (then the numbers
+    are the exact kernel's) or what it lets through holds the contract"""
+    D, K, N = 40, 32, 3000
+    mu, cov, w = mk(K, D, 31)
+    mu = mu * 12.0                                        # |mu_k - c| ~ 36 sigma per coordinate
+    x, _ = draw(mu, cov, w, N, 5)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    ref, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+    rep = report(be, N, K, D)
+    assert_rel(got, ref, what="30 sigma")
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    bound = guard_bound(rep, mu, x)
+    assert rep["refused"] == rep["workgroups"] == 12 and bound.min() > TOL
+    np.testing.assert_array_equal(got, ex)
+    # the same mixture with the tolerance opened wide: the form runs, and its error stays inside its price
+    be.configure("maha_gemm_tolerance", 1e-6)
+    wide = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+    assert report(be, N, K, D)["refused"] == 0
+    be.configure("maha_gemm_tolerance", TOL)
+    assert (np.abs(wide - ex) / bound).max() < 0.75
+
+
+def test_condition_number_1e10(be, orc, small):
+    D, K, N = 32, 32, 2000
+    mu, cov, w = mk(K, D, 41)
+    rs = np.random.RandomState(2)
+    for k in range(K):
+        q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+        cov[k] = (q * np.logspace(-5, 5, D)).dot(q.T)
+        cov[k] = 0.5 * (cov[k] + cov[k].T)
+    x, _ = draw(mu, cov, w, N, 6)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+    rep = report(be, N, K, D)
+    assert rep["refused"] == rep["workgroups"], "precisions of norm 1e5 and more cannot be priced in"
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    np.testing.assert_array_equal(got, ex)
+
+
+def test_non_finite_coordinates_and_zero_weights(be, orc, small):
+    D, K, N = 40, 32, 1500
+    mu, cov, w = mk(K, D, 51)
+    x, _ = draw(mu, cov, w, N, 7)
+    x[300, 3] = np.nan
+    x[800, 17] = np.inf
+    cs, inv, ln = gauss_set(mu, cov, w)
+    got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+    rep = report(be, N, K, D)
+    assert rep["refused"] == 2
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    assert np.isnan(got[300]) and np.array_equal(np.isnan(got), np.isnan(ex))
+    np.testing.assert_array_equal(got[256:512], ex[256:512])
+    np.testing.assert_array_equal(got[768:1024], ex[768:1024])
+    ref, _ = orc.mixture_multi_evaluate(0, x[:256], w, mu, inv, ln)
+    assert_rel(got[:256], ref, what="the clean workgroups")
+    # a component without weight takes part in the reference's row maximum (_regularize.pyx:73-77): no logarithm to fold
+    # into the image -- the whole call stays with the exact kernel
+    w0 = w.copy()
+    w0[5] = 0.0
+    cs0 = gauss_set(mu, cov, w0)[0]
+    xc, _ = draw(mu, cov, w, N, 8)
+    got0 = be.tohost(be.logpdf(xc, cs0, want_scalars=True)["out"])
+    rep0 = report(be, N, K, D)
+    assert rep0["refused"] == rep0["workgroups"]
+    np.testing.assert_array_equal(got0, exact(be, lambda: be.tohost(be.logpdf(xc, cs0, want_scalars=True)["out"])))
+
+
+def test_bitwise_determinism_and_selection(be, small):
+    D, K, N = 40, 128, 5000
+    mu, cov, w = mk(K, D, 61)
+    x, _ = draw(mu, cov, w, N, 9)
+    x[1000] += 1e4                                        # (a refused workgroup in the mix)
+    cs = gauss_set(mu, cov, w)[0]
+    target = gauss_set(*mk(4, D, 62))[0]
+    xd = be.asdevice(x)
+    first = None
+    for _ in range(6):
+        em = be.importance_weights(xd, cs, target, want_out=True, emit=True)
+        st = be.estep_from_u(xd, cs, em["responsibilities"])
+        cur = [be.tohost(t).copy() for t in (em["out"], em["weights"], em["scalars"], em["responsibilities"].data,
+                                            em["responsibilities"].gscale, st["stats"])]
+        if first is None:
+            first = cur
+        for a, b in zip(first, cur):
+            np.testing.assert_array_equal(a, b)
+    # which shapes take the form: compiled D = 32, 40, 48 (padded 31 ... 48), K within ~20 % of a multiple of 32 / 64,
+    # N from the threshold on
+    lib = be.lib
+    assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 40) == 2
+    assert lib.pmc_maha_gemm_tiles(N, 96, 33) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 48) == 2
+    assert lib.pmc_maha_gemm_tiles(N, 100, 40) == 0 and lib.pmc_maha_gemm_tiles(N, 16, 40) == 0
+    assert lib.pmc_maha_gemm_tiles(N, 128, 30) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 64) == 0
+    assert lib.pmc_maha_gemm_tiles(N, 128, 72) == 0 and lib.pmc_maha_gemm_tiles(999, 128, 40) == 0
+    be.configure("maha_gemm_min_n", 32768)
+    assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(32768, 128, 40) == 4
+
+
+def test_front_end_iteration_takes_the_form(be):
+    """ImportanceSampler.run_device(prepare_update=True) + gaussian_pmc at D = 40, K = 64, N above the default threshold:
+    the update equals the one computed with the exact kernels to 1e-10"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.sampler.importance_sampling import ImportanceSampler
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+    D, K, N = 40, 64, 40000
+    tmu, tcov, tw = mk(4, D, 11)
+    tmu /= 3.0
+    target = create_gaussian_mixture(tmu, tcov, tw)
+    which = np.arange(K) % 4
+
+    def run(tol):
+        be.configure("maha_gemm_tolerance", tol)
+        try:
+            proposal = create_gaussian_mixture(tmu[which] + np.random.RandomState(5).normal(0, 0.15, (K, D)), 1.5 * tcov[which])
+            np.random.seed(100)
+            sampler = ImportanceSampler(target.evaluate, proposal)
+            r = sampler.run_device(N, trace_sort=True, prepare_update=True)
+            new = gaussian_pmc(r["samples"], sampler.proposal, r["weights"], r["origin"], mincount=0, rb=True, copy=True,
+                               mahalanobis=r["mahalanobis"], responsibilities=r["responsibilities"])
+            return (np.array(new.weights), np.array([c.mu for c in new.components]),
+                    np.array([c.sigma for c in new.components]), be.tohost(r["weights"]))
+        finally:
+            be.configure("maha_gemm_tolerance", TOL)
+    a = run(TOL)
+    from pypmc_amd.backend import get_backend
+    assert report(get_backend(), N, K, D)["refused"] == 0     # (the front-end's own backend object and workspace)
+    b = run(0.0)
+    assert_rel(a[3], b[3], what="importance weights")
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-10)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-10, atol=1e-12)
+    dg = np.sqrt(np.einsum('kii->ki', b[2]))
+    assert (np.abs(a[2] - b[2]) / (dg[:, :, None] * dg[:, None, :])).max() < 1e-10
