@@ -214,13 +214,17 @@ def vb_estep(data, weights, m, W, beta, nu, ln_pi, det_ln_lambda, mt=False):
 
 
 # ----------------------------------------------------------------------------- PMC
-def rho_rb(family, samples, weights, mu, inv_sigma, log_norm, prefactor, inv_dof, live):
-    """calculate_rho_rb (pmc.pyx:23-43)."""
+def rho_rb(family, samples, weights, mu, inv_sigma, log_norm, prefactor, inv_dof, live, mt=False):
+    """calculate_rho_rb (pmc.pyx:23-43).  ``mt`` (every component live only): the component densities on all host
+    cores, sample chunks in parallel, same per-pair arithmetic."""
     x = np.ascontiguousarray(samples, dtype=np.float64)
     K = len(weights)
     rho = np.zeros((len(x), K))
-    mixture_multi_evaluate(family, x, weights, mu, inv_sigma, log_norm, prefactor, inv_dof,
-                           components=live, individual=rho)
+    if mt and list(live) == list(range(K)):
+        mixture_multi_evaluate(family, x, weights, mu, inv_sigma, log_norm, prefactor, inv_dof, individual=rho, mt=True)
+    else:
+        mixture_multi_evaluate(family, x, weights, mu, inv_sigma, log_norm, prefactor, inv_dof,
+                               components=live, individual=rho)
     w, wp = _d(weights)
     lv, lvp = _i(list(live))
     lib().orc_rho_rb_finish(rho.ctypes.data_as(_dp), _sz(len(x)), _sz(K), wp, lvp, _sz(len(lv)))
@@ -250,8 +254,9 @@ def student_t_gamma(samples, mu, inv_sigma, dof, live):
     return gamma
 
 
-def pmc_reductions(samples, rho, gamma, weights, live):
-    """alpha (unnormalised), mu, cov of gaussian_pmc / student_t_pmc."""
+def pmc_reductions(samples, rho, gamma, weights, live, mt=False):
+    """alpha (unnormalised), mu, cov of gaussian_pmc / student_t_pmc.  ``mt``: the components spread over the host's
+    cores (bit-identical results: every component's sums keep their order)."""
     x, xp = _d(samples)
     N, D = x.shape
     rho, rp = _d(rho)
@@ -262,7 +267,7 @@ def pmc_reductions(samples, rho, gamma, weights, live):
     alpha = np.empty(K)
     mu = np.empty((K, D))
     cov = np.zeros((K, D, D))
-    lib().orc_pmc_reductions(xp, _sz(N), _sz(D), _sz(K), rp, gp, wp, lvp, _sz(len(lv)),
+    (lib().orc_pmc_reductions_mt if mt else lib().orc_pmc_reductions)(xp, _sz(N), _sz(D), _sz(K), rp, gp, wp, lvp, _sz(len(lv)),
                              alpha.ctypes.data_as(_dp), mu.ctypes.data_as(_dp),
                              cov.ctypes.data_as(_dp))
     return alpha, mu, cov

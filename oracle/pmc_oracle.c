@@ -632,6 +632,66 @@ void orc_pmc_reductions(const double *samples, size_t N, size_t dim, size_t K, c
 }
 
 /*
+ * orc_pmc_reductions with the COMPONENTS spread over the host's cores (a checker for full-size GPU runs; not a
+ * statement about the reference, which has no threading).  Every component's sums are taken over the samples in the
+ * same order as above, so the results are bit-identical to orc_pmc_reductions.
+ */
+void orc_pmc_reductions_mt(const double *samples, size_t N, size_t dim, size_t K, const double *rho,
+                           const double *gamma /* or NULL */, const double *weights /* or NULL */,
+                           const int *live, size_t nlive, double *alpha_unnorm, double *mu, double *cov)
+{
+    long kq;
+#pragma omp parallel for schedule(dynamic)
+    for (kq = 0; kq < (long)K; ++kq) {
+        size_t k = (size_t)kq, n, i, j, kk;
+        double norm = 0.0, nk;
+        double *d = (double *)malloc(sizeof(double) * (dim ? dim : 1));
+        int is_live = 0;
+        alpha_unnorm[k] = 0.0;
+        for (i = 0; i < dim; ++i)
+            mu[k * dim + i] = 0.0;
+        for (n = 0; n < N; ++n) {
+            double w = weights ? weights[n] * rho[n * K + k] : rho[n * K + k];
+            double wg;
+            alpha_unnorm[k] += w;
+            if (gamma)
+                wg = (rho[n * K + k] != 0.0) ? w * gamma[n * K + k] : 0.0;
+            else
+                wg = w;
+            norm += wg;
+            for (i = 0; i < dim; ++i)
+                mu[k * dim + i] += wg * samples[n * dim + i];
+        }
+        nk = norm == 0.0 ? ORC_TINY : norm;
+        for (i = 0; i < dim; ++i)
+            mu[k * dim + i] *= 1. / nk;
+        for (kk = 0; kk < nlive; ++kk)
+            if ((size_t)live[kk] == k)
+                is_live = 1;
+        if (is_live) {
+            double inv_alpha;
+            double *ck = cov + k * dim * dim;
+            for (i = 0; i < dim * dim; ++i)
+                ck[i] = 0.0;
+            for (n = 0; n < N; ++n) {
+                double w = weights ? weights[n] * rho[n * K + k] : rho[n * K + k];
+                if (gamma)
+                    w *= gamma[n * K + k];
+                for (i = 0; i < dim; ++i)
+                    d[i] = samples[n * dim + i] - mu[k * dim + i];
+                for (i = 0; i < dim; ++i)
+                    for (j = 0; j < dim; ++j)
+                        ck[i * dim + j] += w * d[i] * d[j];
+            }
+            inv_alpha = 1. / (alpha_unnorm[k] == 0.0 ? ORC_TINY : alpha_unnorm[k]);
+            for (i = 0; i < dim * dim; ++i)
+                ck[i] *= inv_alpha;
+        }
+        free(d);
+    }
+}
+
+/*
  * pmc.pyx:654-691  the N-sized part of the degree-of-freedom condition:
  * for live k:  c_k = 1 - (sum_n [w_n] (xi+delta)_nk) / weight_normalization   with
  * (xi+delta)_nk = rho (log(.5 (b+nu)) - psi(.5 (D+nu))) + (1-rho)(log(.5 nu) - psi(.5 nu))

@@ -175,6 +175,83 @@ def test_cfg4_vb_estep_1e7(be, orc, K, N):
     assert np.max(np.abs(res["r"].cpu().numpy().sum(axis=1) - 1)) < 1e-13
 
 
+def _moment_errors(xbar, S, ref_xbar, ref_S):
+    """errors of means and second moments on the components' own scale: a mean against its standard deviation, S_ij
+    against sqrt(S_ii S_jj) -- the reference's normalisation (both are divided by N_k / the weight sum)"""
+    sd = np.sqrt(np.einsum('kii->ki', ref_S))
+    return (float(np.max(np.abs(xbar - ref_xbar) / sd)),
+            float(np.max(np.abs(S - ref_S) / (sd[:, :, None] * sd[:, None, :]))))
+
+
+@pytest.mark.parametrize("K,spread", [(64, 1.0), (32, 1.0), (64, 0.25)])
+def test_cfg4_statistics_vs_oracle_1e6(be, orc, K, spread):
+    """The statistics the headline runs -- responsibilities in groups (k_resp_groups) + the common-shift matrix product
+    (k_stats_gemm), which only engage from N * ceil(K / 32) >= 524288 on -- against the oracle's loops
+    (variational.pyx:699-709, :806-932, :1003-1013) on ALL host cores at N = 1e6: N_k, x-bar, S, E[log q(Z)] at 1e-10.
+    spread 0.25: overlapping components (responsibilities far from one-hot)."""
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    D, N = 20, 1_000_000
+    mu, cov, w = mk(K, D, 3)
+    mu = spread * mu
+    x, _ = device_samples(be, mu, cov, w, N, 9)
+    xh = x.cpu().numpy()
+    cs, (W, beta, nu, ln_pi, ln_lambda) = _vb_set(mu, cov, w, N, D)
+    sw = np.random.RandomState(4).uniform(0.5, 1.5, N)
+    sw *= N / sw.sum()                                   # variational.pyx:86-100
+    for weights in (None, sw):
+        ref = orc.vb_estep(xh, weights, mu, W, beta, nu, ln_pi, ln_lambda, mt=True)
+        if spread < 1:
+            assert (ref["r"].max(axis=1) < 0.99).mean() > 0.3
+        flat = be.estep(x, cs, 0, sample_w=weights)["stats"].cpu().numpy()
+        sc, S0, M1, M2, _, _ = split_stats(flat, K, D)
+        assert rel(S0, ref["N_comp"]) < 1e-10
+        xbar, S = centred_moments(S0, M1, M2, mu)
+        e1, e2 = _moment_errors(xbar, S, ref["x_mean_comp"], ref["S"])
+        assert e1 < 1e-10 and e2 < 1e-10, (e1, e2)
+        elq = ref["expectation_log_q_Z"]
+        assert abs(sc[0] - elq) <= 1e-10 * abs(elq) + 1e-14 * N, (sc[0], elq)
+        del ref
+
+
+@pytest.mark.parametrize("emit", [False, True])
+def test_cfg5_update_vs_oracle_2e5(be, orc, emit):
+    """alpha / mu / Sigma of configuration 5's Rao-Blackwell update (pmc.pyx:188-222) at N = 2e5, D = 40, K = 128 against
+    the oracle on all host cores, at 1e-10 in the reference's normalisation -- through pmc_estep (the responsibilities'
+    matrix-product form + the common-shift statistics) and through the emitting weighting pass + pmc_estep_from_u"""
+    import torch
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    K, D, N = 128, 40, 200_000
+    tmu, tcov, tw = mk(4, D, 11)
+    tmu /= 3.0
+    which = np.arange(K) % 4
+    mu = tmu[which] + np.random.RandomState(5).normal(0, 0.15, (K, D))
+    cov = 1.5 * tcov[which]
+    w = np.full(K, 1. / K)
+    x, _ = device_samples(be, mu, cov, w, N, 10)
+    xh = x.cpu().numpy()
+    inv = prec(cov)
+    ln = -0.5 * D * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(cov)[1]
+    cs = ComponentSet(0, mu, inv, c0=ln, weight=w)
+    rho = orc.rho_rb(0, xh, w, mu, inv, ln, None, None, list(range(K)), mt=True)
+    if emit:
+        tcs = ComponentSet(0, tmu, prec(tcov), c0=-0.5 * D * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(tcov)[1], weight=tw)
+        em = be.importance_weights(x, cs, tcs, emit=True)
+        assert em["responsibilities"] is not None and be.maha_gemm_report(N, K, D)["refused"] == 0
+        iw = em["weights"].cpu().numpy()
+        flat = be.estep_from_u(x, cs, em["responsibilities"])["stats"].cpu().numpy()
+    else:
+        iw = np.random.RandomState(6).uniform(0.5, 1.5, N)
+        flat = be.estep(x, cs, 1, sample_w=iw)["stats"].cpu().numpy()
+        assert be.maha_gemm_report(N, K, D)["refused"] == 0
+    alpha, o_mu, o_cov = orc.pmc_reductions(xh, rho, None, iw, list(range(K)), mt=True)
+    sc, S0, M1, M2, _, _ = split_stats(flat, K, D)
+    assert rel(S0, alpha) < 1e-10
+    mean, sigma = centred_moments(S0, M1, M2, mu)
+    e1, e2 = _moment_errors(mean, sigma, o_mu, o_cov)
+    assert e1 < 1e-10 and e2 < 1e-10, (e1, e2)
+
+
 def test_cfg5_pmc_update_d40_k128(be, orc):
     """PMC Rao-Blackwell update D=40, K=128 (one GPU's share of N=1e8 / 8)"""
     import torch

@@ -236,3 +236,28 @@ def test_combine_weights_both_branches():
         got = np.concatenate([orc.combine_weights_run(q_matrix(samples[t]), counts, t, omegas[t], n_total, log_scale)
                               for t in range(2)])
         np.testing.assert_allclose(got, g[key], rtol=9e-16, atol=0)
+
+
+def test_multithreaded_checkers_are_bit_identical_to_the_loops():
+    """orc_pmc_reductions_mt / rho_rb(mt=True) (full-size GPU tests run them on all host cores) keep every
+    component's summation order: same bits as the single-threaded restatement of pmc.pyx:23-43, :188-222"""
+    from oracle import oracle as orc
+    rs = np.random.RandomState(3)
+    K, D, N = 7, 5, 9000
+    mu = rs.normal(0, 2, (K, D))
+    A = rs.normal(size=(K, D, D))
+    cov = np.einsum('kij,klj->kil', A, A) / D + 0.5 * np.eye(D)
+    inv = np.linalg.inv(cov)
+    inv = 0.5 * (inv + inv.transpose(0, 2, 1))
+    ln = -0.5 * D * np.log(2 * np.pi) - 0.5 * np.linalg.slogdet(cov)[1]
+    w = rs.uniform(0.5, 1.5, K)
+    w /= w.sum()
+    x = mu[rs.choice(K, N)] + rs.normal(size=(N, D))
+    live = list(range(K))
+    r1 = orc.rho_rb(0, x, w, mu, inv, ln, None, None, live)
+    r2 = orc.rho_rb(0, x, w, mu, inv, ln, None, None, live, mt=True)
+    np.testing.assert_array_equal(r1, r2)
+    sw = rs.uniform(0.5, 1.5, N)
+    for lv in (live, [0, 2, 3, 6]):
+        for a, b in zip(orc.pmc_reductions(x, r1, None, sw, lv), orc.pmc_reductions(x, r1, None, sw, lv, mt=True)):
+            np.testing.assert_array_equal(a, b)
