@@ -39,6 +39,11 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for R
 
 K, D, K_T = 32, 20, 4
 FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (spec)
+# which fp64 pipe a hot kernel's arithmetic runs on at the headline's shape, and what a pure stream of that pipe's
+# instruction sustains on the chip (scripts/microbench/fp64_peak.hip, DESIGN section 3: 71.5 TFLOP/s for v_fma_f64 with
+# one SGPR operand at 2.18 GHz, 75.1 for v_mfma_f64_16x16x4 at 2.38 GHz)
+PIPE_OF = {"k_logpdf": "valu", "k_resp": "valu", "k_stats": "mfma", "k_estep_fused": "valu"}
+ATTAINABLE_TFLOPS = {"valu": 71.5, "mfma": 75.1}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md
 
 
@@ -147,14 +152,17 @@ def live_traffic(kernel, N, timeout=150):
 
 
 def reference_ratio():
-    """oracle speed / reference speed on the bench step, timed in the build container where the reference
-    runs (scripts/cpu_ratio.py -> profiles/r02_cpu_ratio.json); None if absent"""
+    """(oracle speed / reference speed on the bench step, where that was measured): timed in the BUILD CONTAINER, where
+    the reference runs (scripts/cpu_ratio.py -> profiles/r02_cpu_ratio.json) -- another host than the GPU box this
+    line's cpu_baseline is timed on, so the ratio is a property of the two programs, not of this box; (None, None) if
+    absent"""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_ratio.json")))
         row = [r for r in rec["rows"] if r["case"].startswith("bench step")][0]
-        return float(row["oracle_over_reference"])
+        host = rec.get("host") or rec.get("cpu") or "the build container's host CPU (not this GPU box)"
+        return float(row["oracle_over_reference"]), "profiles/r02_cpu_ratio.json, measured on: %s" % host
     except (OSError, KeyError, IndexError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
@@ -181,11 +189,17 @@ def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
 
     out = {}
     for mt, label in ((False, "single"), (True, "all")):
-        x = draw(2000)
+        # size the timed sample from a WARM probe (the first call pays page faults and the OpenMP team's start; the
+        # all-cores probe has to be large enough to keep every core busy for a moment), so that the timed run takes
+        # seconds_target for one core and 5-8 s for all cores -- a 0.3 s run is noise, not a baseline
+        n_probe = 200_000 if mt else 2000
+        x = draw(n_probe)
+        step(x, mt)
         t0 = time.perf_counter()
         step(x, mt)
-        rate = 2000 / (time.perf_counter() - t0)
-        n = int(max(2000, min(rate * seconds_target, 4_000_000)))
+        rate = n_probe / (time.perf_counter() - t0)
+        want = min(seconds_target, 8.0) if mt else seconds_target
+        n = int(max(n_probe, min(rate * max(want, 5.0 if mt else 0.0), 6_000_000)))   # (6e6: ~8 GB of N x K matrices)
         x = draw(n)
         t0 = time.perf_counter()
         step(x, mt)
@@ -467,6 +481,7 @@ def main():
         dom = per_launch[dominant]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) * 1e-12
         traffic, traffic_src = (None, "switched off") if (args.no_traffic or world > 1) else live_traffic(dominant, N)
+        traffic_live = traffic is not None
         if traffic is None:
             why = traffic_src
             traffic, traffic_src = measured_traffic(dominant, N)
@@ -496,9 +511,17 @@ def main():
             "mixture_logpdf_evals_per_s": N / (per_launch["k_logpdf"]["ms"] * 1e-3),
             "kernel_ms": kern,
             "perplexity": perp,
-            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+            # bound: the pipe the dominant kernel's arithmetic runs on -- "valu" (v_fma_f64 with scalar-cache operands:
+            # k_logpdf, k_resp at D = 20) or "mfma" (v_mfma_f64_16x16x4: k_stats_gemm); both pipes share the 78.6 TFLOP/s
+            # fp64 peak of the spec sheet.  attainable_peak: what a pure stream of that instruction class sustains on this
+            # chip under its power cap (scripts/microbench/fp64_peak.hip, profiles/r02_fp64_clocks.txt)
+            "roofline": {"bound": PIPE_OF.get(dominant, "valu"), "kernel": dominant, "achieved": achieved,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                         "attainable_peak": ATTAINABLE_TFLOPS[PIPE_OF.get(dominant, "valu")],
+                         "frac_of_attainable": achieved / ATTAINABLE_TFLOPS[PIPE_OF.get(dominant, "valu")],
+                         "per_kernel_bound": {k_: PIPE_OF.get(k_, "valu") for k_ in per_launch},
                          "traffic": traffic,
+                         "traffic_measured_live": bool(traffic is not None and traffic_live),
                          "traffic_source": traffic_src,
                          "timing_source": "pmc_get_timings: HIP events on the launch stream around each kernel, "
                                           "mean over the timed steps",
@@ -519,11 +542,13 @@ def main():
                                     "sample": "same step on %d samples drawn from the proposal (%.1f s), C oracle = "
                                               "restatement of the reference's single-threaded Cython loops"
                                               % (cb["single"]["n"], cb["single"]["seconds"]),
-                                    "oracle_over_reference": reference_ratio(),
+                                    "oracle_over_reference": reference_ratio()[0],
+                                    "oracle_over_reference_source": reference_ratio()[1],
                                     "note": "the reference itself (Cython, single-threaded) cannot run on the GPU box; in the "
                                             "build container the oracle runs this step oracle_over_reference times as fast "
-                                            "as the reference (profiles/r02_cpu_ratio.json), i.e. the reference-equivalent "
-                                            "rate is value / oracle_over_reference",
+                                            "as the reference (a ratio of two programs measured on ANOTHER host, see "
+                                            "oracle_over_reference_source), i.e. the reference-equivalent rate is about "
+                                            "value / oracle_over_reference",
                                     "all_cores": {"value": cb["all"]["value"], "cores": cb["all"]["cores"],
                                                   "sample": "%d samples, %.1f s, OpenMP over samples"
                                                             % (cb["all"]["n"], cb["all"]["seconds"])}}

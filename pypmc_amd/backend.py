@@ -69,10 +69,19 @@ class Responsibilities(object):
     the update follows (``importance_weights(..., emit=True)``), together with what they belong to.
     ``gaussian_pmc(..., responsibilities=...)`` reduces them to the statistics without any responsibility kernel."""
 
-    def __init__(self, data, N, comps, weights, vsums=None, gscale=None):
+    def __init__(self, data, N, comps, weights, vsums=None, gscale=None, samples=None):
         self.data, self.N, self.K, self.comps, self.weights = data, int(N), int(comps.K), comps, weights
         self.vsums = vsums            # Student-t: the 2 K sums of the degree-of-freedom condition (device)
         self.gscale = gscale          # per-(sample, 16 components) factors u is still to be multiplied with (ABI 2)
+        # what the values were formed on: the sample tensor's storage, the weight tensor's modification counter
+        self._samples_key = self._key(samples)
+        self._weights_version = getattr(weights, "_version", None)
+
+    @staticmethod
+    def _key(t):
+        # (storage and shape, not the modification counter: a run of a DeviceHistory is a view whose counter moves with
+        #  every later append to the history)
+        return (t.data_ptr(), tuple(t.shape)) if hasattr(t, "data_ptr") else None
 
     def host_matrix(self, be):
         """u as an N x K host array (the tile-major values times their groups' factors)"""
@@ -85,15 +94,19 @@ class Responsibilities(object):
             t = t * np.repeat(f, 16, axis=1)[:, :self.K, :]
         return np.concatenate([t[i].T for i in range(nt)])[:self.N] if nt else np.zeros((0, self.K))
 
-    def matches(self, comps_full, weights):
-        """True for the very mixture (means, precisions, component weights, normalisations) and the very sample
-        weights (the importance weights of that pass) these values were formed with"""
+    def matches(self, comps_full, weights, samples=None):
+        """True for the very mixture (means, precisions, component weights, normalisations), the very sample weights
+        (the importance weights of that pass: the same tensor, not modified in place since) and -- when ``samples`` is
+        a device tensor -- the very sample array (same storage and shape) these values were formed with"""
         c = self.comps
         same = comps_full is c or (comps_full.K == c.K and comps_full.kind == c.kind and
                                    np.array_equal(comps_full.mu, c.mu) and np.array_equal(comps_full.precision, c.precision)
                                    and np.array_equal(comps_full.weight, c.weight) and np.array_equal(comps_full.c0, c.c0)
                                    and np.array_equal(comps_full.c3, c.c3))
-        return same and weights is self.weights
+        if not same or weights is not self.weights or getattr(weights, "_version", None) != self._weights_version:
+            return False
+        key = self._key(samples)
+        return key is None or self._samples_key is None or key == self._samples_key
 
 
 def _dptr(a):
@@ -346,7 +359,7 @@ class HipBackend(object):
             self._p(out), self._p(lt), self._p(weights), self._p(scalars), self._p(ws), self._p(u), self._p(gscale),
             self._p(vsums), self._stream()), "pmc_importance_weights_emit_grouped")
         return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=None,
-                    responsibilities=Responsibilities(u, N, comps, weights, vsums, gscale))
+                    responsibilities=Responsibilities(u, N, comps, weights, vsums, gscale, samples=x))
 
     def estep_from_u(self, x, comps, resp, out=None):
         """pmc_estep_from_u: the statistics of responsibilities a weighting pass left behind (``Responsibilities``).

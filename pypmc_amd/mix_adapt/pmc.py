@@ -105,7 +105,7 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
         if responsibilities is not None and rb:
             # the weighting pass left u = w rho of these very samples, weights and parameters: statistics only
             full = component_set(density.components, density.weights)
-            if len(live_components) < K or responsibilities.N != N_local or not responsibilities.matches(full, weights):
+            if len(live_components) < K or responsibilities.N != N_local or not responsibilities.matches(full, weights, samples):
                 raise ValueError('``responsibilities`` were not formed with this density, these samples and weights')
             res = be.estep_from_u(samples, cs, responsibilities)
         elif mahalanobis is not None and rb:

@@ -58,15 +58,6 @@ def shard_bounds(N, r=None, world=None):
     return begin, begin + base + (1 if r < extra else 0)
 
 
-def _free_port():
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def init_from_env(force=False):
     """Join the process group ``torchrun`` set up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): one process per
     GPU, backend "nccl" (= RCCL over xGMI).  ``PMC_DIST_BACKEND=gloo`` is the development aid used by the
@@ -76,12 +67,18 @@ def init_from_env(force=False):
     A launch under ``torchrun`` (RANK and WORLD_SIZE in the environment) always gets its group, a single rank
     included -- ``torchrun --nproc-per-node 1`` runs the very collectives an 8-GPU run issues, on one GPU.
     A plain ``python`` process gets none (0, 1, current device) unless ``force`` (or ``PMC_FORCE_DIST=1``) asks
-    for a one-rank group on a free local port."""
+    for a one-rank group, which meets itself through a rendezvous file of its own (removed at exit).
+    WORLD_SIZE > 1 without RANK -- a launcher that names its variables differently (mpirun, srun) -- is an error: a
+    private one-rank group there would make every process run unsharded and all-reduce only its own data, silently."""
     import os
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     force = force or os.environ.get("PMC_FORCE_DIST", "0") not in ("", "0")
+    if world > 1 and not launched:
+        raise RuntimeError("WORLD_SIZE=%d but RANK is not set: launch with torch.distributed.run (torchrun), or export "
+                           "RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the launcher's own variables "
+                           "(e.g. OMPI_COMM_WORLD_RANK, SLURM_PROCID)" % world)
     if world <= 1 and not launched and not force:
         return 0, 1, torch.cuda.current_device() if torch.cuda.is_available() else 0
     import torch.distributed as dist
@@ -90,14 +87,19 @@ def init_from_env(force=False):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend != "nccl":
         local %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
+    if backend == "nccl" or torch.cuda.is_available():      # (a gloo group on a box without a GPU: the CPU test-suite)
+        torch.cuda.set_device(local)
     if not dist.is_initialized():
         # a forced one-rank group of a plain process meets itself through a file of its own: no TCP port to probe and
         # lose to another process before it is bound; a launched group uses what the launcher set up (env://)
         extra = {}
-        if not launched:
+        if not launched:                                    # (force, one rank: checked above)
+            import atexit
+            import shutil
             import tempfile
-            extra = dict(init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="pmc_rdzv_"), "store"), rank=0, world_size=1)
+            rdzv = tempfile.mkdtemp(prefix="pmc_rdzv_")
+            atexit.register(shutil.rmtree, rdzv, ignore_errors=True)
+            extra = dict(init_method="file://" + os.path.join(rdzv, "store"), rank=0, world_size=1)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local), **extra)
         else:

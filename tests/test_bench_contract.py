@@ -6,10 +6,13 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _line():
+def _path():
     import glob
-    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_with_cpu_baseline.json")))[-1]
-    return json.load(open(path))
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_with_cpu_baseline.json")))[-1]
+
+
+def _line():
+    return json.load(open(_path()))
 
 
 def test_recorded_line_has_the_contract_fields():
@@ -23,7 +26,8 @@ def test_recorded_line_has_the_contract_fields():
     assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    # ("valu": compute-bound on the fp64 vector pipe, which shares the matrix pipe's peak -- verdict r3 weak 8c)
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
@@ -43,11 +47,19 @@ def test_flop_and_traffic_helpers():
     t, src = bench.measured_traffic("k_stats", 10_000_000)
     assert t is None or (1e9 < t < 2e10 and src.startswith("profiles/"))
     assert bench.measured_traffic("no_such_kernel", 1) == (None, None)
-    ratio = bench.reference_ratio()
-    assert ratio is None or 1.0 < ratio < 5.0
+    ratio, where = bench.reference_ratio()
+    assert ratio is None or (1.0 < ratio < 5.0 and "measured on" in where)
+    assert set(bench.PIPE_OF.values()) <= set(bench.ATTAINABLE_TFLOPS) and all(
+        v < bench.FP64_PEAK_TFLOPS for v in bench.ATTAINABLE_TFLOPS.values())
 
 
 def test_recorded_line_names_its_sources():
     r = _line()["roofline"]
     assert "timing_source" in r and "pmc_get_timings" in r["timing_source"]
-    assert r["traffic"] is None or "measured in this run" in r["traffic_source"]     # live, or says that it is not
+    if "traffic_measured_live" in r:                     # (lines from round 4 on: an explicit flag, not a substring)
+        assert isinstance(r["traffic_measured_live"], bool)
+        assert r["traffic_measured_live"] == (r["traffic"] is not None and r["traffic_source"].startswith("measured in this run"))
+        assert r["bound"] == r["per_kernel_bound"][r["kernel"]] and r["attainable_peak"] < r["peak"]
+        assert abs(r["frac_of_attainable"] - r["achieved"] / r["attainable_peak"]) < 1e-12
+    else:
+        assert _path().split(os.sep)[-1] < "r04"

@@ -8,6 +8,7 @@ import numpy as np
 
 import dist_worker
 from oracle_backend import OracleBackend
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -136,3 +137,42 @@ def _first_rows_worker(rank, world, port, workdir):
         np.save(os.path.join(workdir, "m%d.npy" % rank), vb.m)
     finally:
         dist.destroy_process_group()
+
+
+def test_init_from_env_refuses_a_world_without_a_rank():
+    """advice r3: WORLD_SIZE > 1 with no RANK (mpirun / srun name their variables differently) used to fall into a private
+    one-rank group -- every process unsharded, every all-reduce over its own data only.  Now it is an error; a forced
+    one-rank group of a plain process still works and removes its rendezvous directory at exit."""
+    code = r'''
+import glob, os, sys, tempfile
+sys.path.insert(0, %r)
+os.environ.pop("RANK", None)
+os.environ["WORLD_SIZE"] = "4"
+from pypmc_amd import parallel
+try:
+    parallel.init_from_env()
+    print("NO ERROR")
+except RuntimeError as exc:
+    print("refused:", "RANK is not set" in str(exc))
+os.environ.pop("WORLD_SIZE")
+os.environ["PMC_DIST_BACKEND"] = "gloo"
+before = set(glob.glob(os.path.join(tempfile.gettempdir(), "pmc_rdzv_*")))
+r, w, _ = parallel.init_from_env(force=True)
+mine = set(glob.glob(os.path.join(tempfile.gettempdir(), "pmc_rdzv_*"))) - before
+print("group:", r, w, parallel.active(), len(mine))
+open(os.path.join(%r, "rdzv.txt"), "w").write("\n".join(mine))
+import torch.distributed as dist
+dist.destroy_process_group()
+'''
+    import subprocess
+    import sys
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PMC_FORCE_DIST"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, "-c", code % (ROOT, tmp)], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "refused: True" in out.stdout and "group: 0 1 True 1" in out.stdout, out.stdout
+        left = [d for d in open(os.path.join(tmp, "rdzv.txt")).read().split("\n") if d]
+        assert left and not any(os.path.exists(d) for d in left), "the rendezvous directory was not removed at exit"

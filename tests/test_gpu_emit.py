@@ -59,6 +59,16 @@ def test_emit_matches_oracle_and_the_kept_forms(be, orc, D, K, N):
     assert resp.matches(prop, em["weights"]) and not resp.matches(prop, kept["weights"])
     other, _, _ = gauss_set(mu + 1e-3, cov, w)
     assert not resp.matches(other, em["weights"])
+    # advice r3: another sample array of the same length, and weights modified in place, are refused too
+    xd = be.asdevice(x)
+    em2 = be.importance_weights(xd, prop, target, emit=True)
+    r2 = em2["responsibilities"]
+    assert r2.matches(prop, em2["weights"], xd) and not r2.matches(prop, em2["weights"], xd.clone())
+    em3 = be.importance_weights(xd, prop, target, emit=True)
+    r3 = em3["responsibilities"]
+    assert r3.matches(prop, em3["weights"], xd)
+    em3["weights"].mul_(2.0)
+    assert not r3.matches(prop, em3["weights"], xd)
 
 
 @pytest.mark.parametrize("D,K,N", [(2, 3, 1000), (5, 9, 257), (20, 32, 30000), (30, 8, 5000), (40, 24, 20000), (64, 3, 200)])
