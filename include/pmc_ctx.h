@@ -10,8 +10,11 @@
  * host-side C++ over the entry points of pmc_hip.h (pypmc_amd/csrc/pmc_ctx.hip); the kernels are the same.
  *
  * Conventions: every function returns 0 or a negative pmc_status (pmc_hip.h) and sets pmc_last_error(); calls are
- * synchronous (the result arrays are filled on return); a context and its handles belong to one thread at a time;
- * all arrays are C-contiguous fp64 (int64 where said).  With a communicator joined (pmc_ctx_join) every rank holds
+ * synchronous (the result arrays are filled on return).  Threads: any thread may call into a context and its handles;
+ * the calls of ONE context are serialised inside the library (a mutex per context), different contexts run side by
+ * side -- each on its own stream, with its own scratch, its own options (pmc_ctx_configure) and its own timing record
+ * (pmc_ctx_get_timings).  Destroying a handle while another thread still uses it is the caller's error.
+ * All arrays are C-contiguous fp64 (int64 / int32 where said).  With a communicator joined (pmc_ctx_join) every rank holds
  * its shard of the samples and the K-sized results are those of ALL ranks' samples -- one all-reduce (sum) of the
  * statistics buffer per call, identical on every rank, no gather and no broadcast (the reference:
  * pypmc/tools/parallel_sampler.py:58-71 gathers the samples on the master, examples/pmc_mpi.py:119-131 broadcasts
@@ -38,6 +41,19 @@ int pmc_init(int device, pmc_ctx **out);
 int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id);
 /* Frees the stream, the scratch and the communicator.  Handles made from the context must be freed first. */
 int pmc_shutdown(pmc_ctx *ctx);
+/*
+ * Library options for THIS context's calls (keys and values as pmc_configure, pmc_hip.h: "stats_common_shift_limit",
+ * "maha_gemm_tolerance", ...).  A context starts from a copy of the process-wide options as they stand at pmc_init;
+ * pmc_configure afterwards does not reach it, and this call changes nothing outside the context.
+ */
+int pmc_ctx_configure(pmc_ctx *ctx, const char *key, double value);
+/*
+ * Kernel timing of this context's launches only (HIP events on the context's stream around every hot kernel, see
+ * pmc_get_timings in pmc_hip.h for the entries' meaning): enable, run calls, read.  Independent of the process-wide
+ * pmc_timing_enable / pmc_get_timings, which never see a context's records while its own timing is on.
+ */
+int pmc_ctx_timing_enable(pmc_ctx *ctx, int on);
+int pmc_ctx_get_timings(pmc_ctx *ctx, pmc_timing *h_out, int max_entries, int *n_entries);
 
 /* ---- mixture ------------------------------------------------------------------------------------------ */
 /*
@@ -82,6 +98,14 @@ int pmc_samples_free(pmc_samples *s);
  * (or NULL).
  */
 int pmc_mix_logpdf(const pmc_mix *mix, const pmc_samples *s, double *h_out, double *h_individual);
+/*
+ * The subset mode of the same method, multi_evaluate(x, individual=..., components=[...]) (mixture.pyx:153-156; its
+ * caller: calculate_rho_rb on the live components, pmc.pyx:27): only the listed components are evaluated and only their
+ * columns of h_individual (N x K row-major, K = the mixture's component count) are written; every other column keeps
+ * what the caller had there, and there is no `out` (the reference returns None in this mode).
+ */
+int pmc_mix_logpdf_components(const pmc_mix *mix, const pmc_samples *s, const int32_t *h_components, int ncomponents,
+                              double *h_individual);
 /*
  * ImportanceSampler._calculate_weights (pypmc/sampler/importance_sampling.py:197-215): w_n = exp(log P(x_n) -
  * log q(x_n)).  log P either from the host (h_log_target, N: the user's target evaluated by the caller) or from a

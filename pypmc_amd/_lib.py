@@ -117,6 +117,10 @@ CTX_SIGNATURES = {
     "pmc_samples_origin": (_int, [_vp, _ip]),
     "pmc_samples_free": (_int, [_vp]),
     "pmc_mix_logpdf": (_int, [_vp, _vp, _dp, _dp]),
+    "pmc_mix_logpdf_components": (_int, [_vp, _vp, _i32, _int, _dp]),
+    "pmc_ctx_configure": (_int, [_vp, C.c_char_p, C.c_double]),
+    "pmc_ctx_timing_enable": (_int, [_vp, _int]),
+    "pmc_ctx_get_timings": (_int, [_vp, _vp, _int, C.POINTER(C.c_int)]),
     "pmc_is_weights": (_int, [_vp, _vp, _dp, _vp, _dp, _dp, _dp]),
     "pmc_vb_estep": (_int, [_vp, _vp, _dp, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pmc_pmc_update_stats": (_int, [_vp, _vp, _vp, _dp, _int, _ip, _int, _dp, _dp, _dp, _dp, _dp, _dp]),

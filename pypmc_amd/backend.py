@@ -317,8 +317,7 @@ class HipBackend(object):
         q (``comps``) in one pass over ``x``.  Returns dict(weights, scalars, out, log_target[, tiles | responsibilities]).
         ``emit`` (Gauss / Student-t proposal, compiled dimensions, every component alive): the pass also leaves
         u = w rho [gamma] for the update (``Responsibilities``; pmc_importance_weights_emit)."""
-        if emit and not keep and sample_w is None and comps.kind in (PMC_KIND_GAUSS, PMC_KIND_STUDENT_T) \
-                and comps.D <= 64 and comps.ld == comps.K and bool((comps.weight != 0).all()):
+        if emit and not keep and sample_w is None and self.can_emit(comps):
             return self._importance_weights_emit(x, comps, target, want_out, want_log_target, pack, target_pack)
         x = self.asdevice(x)
         N, D = x.shape
@@ -338,6 +337,14 @@ class HipBackend(object):
             self._p(out), self._p(lt), self._p(weights), self._p(sw), self._p(scalars), self._p(ws),
             self._p(tiles.data) if keep else None, self._stream()), "pmc_importance_weights")
         return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=tiles)
+
+    @staticmethod
+    def can_emit(comps):
+        """does the emitting form of the weighting pass apply to this proposal?  (Gauss / Student-t, a compiled
+        dimension, the complete mixture, every component alive) -- callers that need the update's inputs either way
+        ask BEFORE the pass and keep the Mahalanobis forms instead where it does not"""
+        return comps.kind in (PMC_KIND_GAUSS, PMC_KIND_STUDENT_T) and comps.D <= 64 and comps.ld == comps.K \
+            and bool((comps.weight != 0).all())
 
     def _importance_weights_emit(self, x, comps, target, want_out, want_log_target, pack, target_pack):
         x = self.asdevice(x)

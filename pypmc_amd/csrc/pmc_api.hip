@@ -86,6 +86,7 @@ enum { T_LOGPDF = 0, T_RESP, T_STATS, T_FUSED, T_PROPOSE, T_FINISH, T_COUNT };
 const char *const g_timing_names[T_COUNT] = {"k_logpdf", "k_resp", "k_stats", "k_estep_fused", "k_propose",
                                              "finishing reductions"};
 struct TimingRec {
+    hipStream_t st;       // the stream the launch went to (the handle layer reads its own context's records)
     int id;
     int calls;            // 1, or 0 for a bracket that continues the previous launch of the same kernel
     hipEvent_t a, b;
@@ -94,6 +95,13 @@ struct TimingRec {
 std::mutex g_timing_mutex;
 bool g_timing_on = false;
 std::vector<TimingRec> g_timing_recs;
+std::vector<hipStream_t> g_timing_streams;                  // streams whose launches are timed for their context only
+bool timing_stream_on(hipStream_t st)                      // (g_timing_mutex held)
+{
+    for (hipStream_t q : g_timing_streams)
+        if (q == st) return true;
+    return false;
+}
 std::vector<hipEvent_t> g_timing_pool;
 constexpr size_t PMC_TIMING_MAX_RECORDS = 1 << 16;
 
@@ -117,7 +125,8 @@ struct Timed {
     Timed(int id, hipStream_t st_, double flops, double bytes, int calls = 1) : st(st_), on(false)
     {
         std::lock_guard<std::mutex> lock(g_timing_mutex);
-        if (!g_timing_on || g_timing_recs.size() >= PMC_TIMING_MAX_RECORDS) return;
+        if (!(g_timing_on || timing_stream_on(st)) || g_timing_recs.size() >= PMC_TIMING_MAX_RECORDS) return;
+        rec.st = st;
         rec.id = id; rec.calls = calls; rec.flops = flops; rec.bytes = bytes;
         rec.a = timing_event();
         rec.b = timing_event();
@@ -270,22 +279,61 @@ __global__ __launch_bounds__(256) void k_finish_stats(const double *__restrict__
 // Library options (pmc_configure): the form is tried for K >= g_gemm_min_k when the compiled dimension has the
 // kernel; a component whose weighted mean lies further than sqrt(limit) of its own standard deviations (in some
 // coordinate) from the common shift sends the call back to the per-component-shift kernel.
-int g_gemm_min_k = 17;
-double g_gemm_limit = 1000.0;
+// The options live in one struct: the process-wide instance pmc_configure() writes, and -- for the handle layer,
+// include/pmc_ctx.h -- one instance per context (pmc_ctx_configure), installed for the calling thread while a call of
+// that context runs.  Every public entry point takes ONE snapshot when it starts (TuneScope) and everything below it
+// reads that snapshot: a pmc_configure() from another thread cannot change the selection between the two halves of a
+// call (advice r3).
+struct PmcTuning {
+    int gemm_min_k = 17;
+    double gemm_limit = 1000.0;
+    long long gemm_min_n = 524288;
+    double gemm_min_fill = 0.63;
+    int resp_groups = 1;
+    size_t big_scratch_bytes = 256u << 20;
+    double mgemm_tol = 5e-11;
+    long long mgemm_min_n = 32768;
+};
+PmcTuning g_tuning;
+std::mutex g_tuning_mutex;
+thread_local const PmcTuning *t_tuning = nullptr;
+PmcTuning tun()
+{
+    if (t_tuning) return *t_tuning;
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    return g_tuning;
+}
+struct TuneScope {
+    PmcTuning snap;
+    bool mine;
+    TuneScope() : mine(t_tuning == nullptr)
+    {
+        if (mine) {
+            snap = tun();
+            t_tuning = &snap;
+        }
+    }
+    ~TuneScope()
+    {
+        if (mine) t_tuning = nullptr;
+    }
+};
+#define g_gemm_min_k (tun().gemm_min_k)
+#define g_gemm_limit (tun().gemm_limit)
 // ... and from g_gemm_min_n samples per 32 components on: the form costs three launches more (reduce, re-centre, the
 // skipped fallback pair) and its own prologue, ~35 us that pay back at 6.7e-8 ms per sample and 32 components
 // (scripts/gemm_crossover.py, D = 20: N = 262144, K = 32: 0.133 against 0.110 ms; N = 4e6: 1.09 against 1.32)
-long long g_gemm_min_n = 524288;
+#define g_gemm_min_n (tun().gemm_min_n)
 // ... and only if the groups of 32 components are filled well enough: a group costs the same whether it holds 1 or 32
 // (one row block is no cheaper than two: the B operands dominate then), so K = 33 ... 40 runs 4-11 % slower than the
 // per-component kernel at D = 20 and K = 41 36 % faster (scripts/gemm_crossover.py ksweep, profiles/r03_gemm_crossover.txt)
-double g_gemm_min_fill = 0.63;
+#define g_gemm_min_fill (tun().gemm_min_fill)
 // pmc_estep's responsibilities in groups of 16 with their factors left to k_stats_gemm (k_resp_groups): 0 never,
 // 1 where it pays, 2 wherever the common-shift statistics run.  Where it pays (scripts/resp_groups_ab.py matrix,
 // profiles/r03_resp_groups.txt; responsibilities + statistics, per 2e6 samples): compiled D <= 16 at any K (-2 ... -19 %),
 // D = 20, 32, 40 from K = 64 on (-2 ... -6 %: the parked traffic of k_resp costs clock there); it loses at D = 24, 30, 48,
 // 64 (+2 ... +14 %: 25-40 more registers than k_resp) and is neutral at D = 20, K = 32.
-int g_resp_groups = 1;
+#define g_resp_groups (tun().resp_groups)
 bool resp_groups_pays(int dim, int K)
 {
     if (g_resp_groups != 1) return g_resp_groups == 2;
@@ -697,7 +745,7 @@ struct StreamScratch {
 // bytes, 10 GB at N = 1e7, K = 128, outside pmc_workspace_bytes and outside the caller's allocator): the samples go in
 // chunks of a multiple of 256 (one workgroup of the per-sample kernels, so block indices and tile buffers line up),
 // each chunk = k_big_maha [x 2] + k_logpdf<0> on pointers moved to the chunk.
-size_t g_big_scratch_bytes = 256u << 20;                  // pmc_configure("big_dim_scratch_bytes")
+#define g_big_scratch_bytes (tun().big_scratch_bytes)     // pmc_configure("big_dim_scratch_bytes")
 hipError_t big_logpdf(const PmcKernelSet *ks, int kind, int kind2, const PmcArgsA &full, int D, hipStream_t st)
 {
     const bool keep = full.atile != nullptr;
@@ -763,9 +811,9 @@ size_t gscale_offset(long long N, int K, const PmcKernelSet *ks)
 // three times the largest (difference to the exact kernel) / (Theta-sum) seen -- 3.4e-16, i.e. 1.5 ulp of the sum of the
 // terms' magnitudes (scripts/mgemm_check.py; tests/test_gpu_mgemm.py holds every case to it) -- and the tolerance
 // leaves a factor 2 to the contract's 1e-10 on responsibilities, i.e. on differences of a_nk.
-double g_mgemm_tol = 5e-11;
+#define g_mgemm_tol (tun().mgemm_tol)                     // default 5e-11
 constexpr double PMC_MGEMM_EPS = 1e-15;
-long long g_mgemm_min_n = 32768;                            // samples from which the form is tried at all
+#define g_mgemm_min_n (tun().mgemm_min_n)                 // default 32768: samples from which the form is tried at all
 // component tiles per pass (0: the exact kernels).  K is padded to a multiple of 16 NCT and a padded component costs
 // what a real one does; two tiles per pass cost 4.5 % more per pair than four (profiles/r03_maha_gemm_prototype.txt),
 // and the form as a whole is ~20 % ahead of the exact kernels, so more padding than that is not worth it.
@@ -1087,6 +1135,7 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
                             const double *d_log_target, double *d_weights, const double *d_sample_w,
                             double *d_scalars, void *d_workspace, double *d_maha_tiles, void *stream)
 {
+    TuneScope options;                                     // one snapshot of the options for the whole call
     if (N < 0 || K < 1 || !d_pack) return fail(PMC_EINVAL, "pmc_mixture_logpdf: bad N/K/pack");
     if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T)
         return fail(PMC_EINVAL, "pmc_mixture_logpdf: kind must be GAUSS or STUDENT_T (got %d)", kind);
@@ -1136,6 +1185,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
                                    double *d_scalars, void *d_workspace, double *d_maha_tiles, double *d_u,
                                    double *d_vsums, void *stream, double *d_gscale = nullptr)
 {
+    TuneScope options;                                     // one snapshot of the options for the whole call
     if (N < 0 || K < 1 || K_target < 1 || !d_pack || !d_target_pack)
         return fail(PMC_EINVAL, "pmc_importance_weights: bad N/K/pack");
     if ((kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T) ||
@@ -1235,6 +1285,7 @@ int pmc_importance_weights_emit(const double *d_x, int64_t N, int D, const doubl
 int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, const double *d_u,
                      double *d_stats, void *d_workspace, void *stream)
 {
+    TuneScope options;                                     // one snapshot of the options for the whole call
     if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T && kind != PMC_KIND_VB)
         return fail(PMC_EINVAL, "pmc_estep_from_u: unknown kind %d", kind);
     return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, kind);
@@ -1287,6 +1338,7 @@ int pmc_importance_weights_emit_grouped(const double *d_x, int64_t N, int D, con
 int pmc_estep_from_u_grouped(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, double *d_u,
                              double *d_gscale, double *d_stats, void *d_workspace, void *stream)
 {
+    TuneScope options;                                     // one snapshot of the options for the whole call
     if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T && kind != PMC_KIND_VB)
         return fail(PMC_EINVAL, "pmc_estep_from_u_grouped: unknown kind %d", kind);
     if (!d_gscale) return fail(PMC_EINVAL, "pmc_estep_from_u_grouped: d_gscale is NULL");
@@ -1553,6 +1605,7 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
 int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pack, int K,
                          const double *d_u, double *d_stats, void *d_workspace, void *stream)
 {
+    TuneScope options;                                     // one snapshot of the options for the whole call
     return sufficient_stats_impl(d_x, N, D, d_pack, K, d_u, d_stats, d_workspace, stream, -1);
 }
 
@@ -1567,51 +1620,72 @@ int pmc_stream_release(void *stream)
     return PMC_OK;
 }
 
-int pmc_configure(const char *key, double value)
+static int configure_into(PmcTuning &t, const char *key, double value)
 {
     if (!key) return fail(PMC_EINVAL, "pmc_configure: NULL key");
     if (std::strcmp(key, "stats_common_shift_min_k") == 0) {
         if (!(value >= 1.0 && value <= 1e9)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 1", key);
-        g_gemm_min_k = (int)value;
+        t.gemm_min_k = (int)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "big_dim_scratch_bytes") == 0) {
         if (!(value >= 1.0 && value <= 1e15)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 1", key);
-        g_big_scratch_bytes = (size_t)value;
+        t.big_scratch_bytes = (size_t)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "estep_grouped_responsibilities") == 0) {
         if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(PMC_EINVAL, "pmc_configure: %s is 0, 1 or 2", key);
-        g_resp_groups = (int)value;
+        t.resp_groups = (int)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "stats_common_shift_min_fill") == 0) {
         if (!(value >= 0.0 && value <= 1.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [0, 1]", key);
-        g_gemm_min_fill = value;
+        t.gemm_min_fill = value;
         return PMC_OK;
     }
     if (std::strcmp(key, "stats_common_shift_min_n") == 0) {
         if (!(value >= 0.0 && value <= 9e18)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
-        g_gemm_min_n = (long long)value;
+        t.gemm_min_n = (long long)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "maha_gemm_tolerance") == 0) {
         if (!(value >= 0.0 && value <= 1.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [0, 1]", key);
-        g_mgemm_tol = value;
+        t.mgemm_tol = value;
         return PMC_OK;
     }
     if (std::strcmp(key, "maha_gemm_min_n") == 0) {
         if (!(value >= 0.0 && value <= 9e18)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
-        g_mgemm_min_n = (long long)value;
+        t.mgemm_min_n = (long long)value;
         return PMC_OK;
     }
     if (std::strcmp(key, "stats_common_shift_limit") == 0) {
         if (!(value >= 0.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
-        g_gemm_limit = value;
+        t.gemm_limit = value;
         return PMC_OK;
     }
     return fail(PMC_EINVAL, "pmc_configure: unknown key '%s'", key);
 }
+
+int pmc_configure(const char *key, double value)
+{
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    return configure_into(g_tuning, key, value);
+}
+
+// per-context options of the handle layer (pmc_ctx.hip; not in the public header): a context starts from a copy of the
+// process-wide options, changes only its copy, and installs it for the calling thread around each of its calls
+void *pmc_internal_tuning_new(void)
+{
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    return new PmcTuning(g_tuning);
+}
+void pmc_internal_tuning_free(void *t) { delete (PmcTuning *)t; }
+int pmc_internal_tuning_set(void *t, const char *key, double value)
+{
+    if (!t) return fail(PMC_EINVAL, "NULL options");
+    return configure_into(*(PmcTuning *)t, key, value);
+}
+void pmc_internal_tuning_use(const void *t) { t_tuning = (const PmcTuning *)t; }
 
 // ---- RCCL, opened at run time -------------------------------------------------------------------------
 // (the few declarations of rccl.h the library needs; values as in NCCL's public header)
@@ -1726,13 +1800,20 @@ int pmc_timing_enable(int on)
     return PMC_OK;
 }
 
-int pmc_get_timings(pmc_timing *h_out, int max_entries, int *n_entries)
+// stream == FIN_FREE: the records of every stream that is not timed for a context of its own (pmc_get_timings);
+// else: the records of that stream (pmc_ctx_get_timings)
+static int collect_timings(hipStream_t stream, pmc_timing *h_out, int max_entries, int *n_entries)
 {
     if (!n_entries || (max_entries > 0 && !h_out)) return fail(PMC_EINVAL, "pmc_get_timings: bad argument");
     std::vector<TimingRec> recs;
     {
         std::lock_guard<std::mutex> lock(g_timing_mutex);
-        recs.swap(g_timing_recs);
+        std::vector<TimingRec> keep;
+        for (const TimingRec &r : g_timing_recs) {
+            const bool take = stream == FIN_FREE ? !timing_stream_on(r.st) : r.st == stream;
+            (take ? recs : keep).push_back(r);
+        }
+        g_timing_recs.swap(keep);
     }
     pmc_timing acc[T_COUNT];
     std::memset(acc, 0, sizeof(acc));
@@ -1767,6 +1848,27 @@ int pmc_get_timings(pmc_timing *h_out, int max_entries, int *n_entries)
     return rc;
 }
 
+int pmc_get_timings(pmc_timing *h_out, int max_entries, int *n_entries)
+{
+    return collect_timings(FIN_FREE, h_out, max_entries, n_entries);
+}
+// the handle layer's per-context timing (pmc_ctx.hip: pmc_ctx_timing_enable / pmc_ctx_get_timings)
+int pmc_internal_timing_stream(void *stream, int on)
+{
+    std::lock_guard<std::mutex> lock(g_timing_mutex);
+    for (size_t i = 0; i < g_timing_streams.size(); ++i)
+        if (g_timing_streams[i] == (hipStream_t)stream) {
+            if (!on) g_timing_streams.erase(g_timing_streams.begin() + (long)i);
+            return PMC_OK;
+        }
+    if (on) g_timing_streams.push_back((hipStream_t)stream);
+    return PMC_OK;
+}
+int pmc_internal_get_timings(void *stream, pmc_timing *h_out, int max_entries, int *n_entries)
+{
+    return collect_timings((hipStream_t)stream, h_out, max_entries, n_entries);
+}
+
 int pmc_estep_is_fused(int K, int D, int kind, int mode)
 {
     const PmcKernelSet *ks = kernels_for(D);
@@ -1788,6 +1890,7 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
                     double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
                     const double *d_shift_pack, void *stream)
 {
+    TuneScope options;                                     // one snapshot of the options for the whole call
     const double *d_spack = d_shift_pack ? d_shift_pack : d_pack;      // whose means the moments are taken about
     if (N < 0 || K < 1 || !d_pack || !d_stats || !d_scalars || !d_workspace)
         return fail(PMC_EINVAL, "pmc_estep: bad N/K/pack/stats/scalars/workspace");
@@ -1876,6 +1979,7 @@ int pmc_estep_from_tiles(const double *d_x, int64_t N, int D, const double *d_pa
                          double *d_u, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
                          void *stream)
 {
+    TuneScope options;                                     // one snapshot of the options for the whole call
     if (N < 0 || K < 1 || K_tiles < 1 || !d_pack || !d_stats || !d_scalars || !d_workspace)
         return fail(PMC_EINVAL, "pmc_estep_from_tiles: bad N/K/pack/stats/scalars/workspace");
     if (kind != PMC_KIND_GAUSS && kind != PMC_KIND_STUDENT_T)

@@ -13,9 +13,18 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 extern "C" int pmc_internal_fail(int code, const char *msg);       // pmc_api.hip: sets pmc_last_error()
+// (pmc_api.hip, not in the public headers) a context's own copy of the library options, installed for the calling thread
+// while one of its calls runs; its launches' timing records
+extern "C" void *pmc_internal_tuning_new(void);
+extern "C" void pmc_internal_tuning_free(void *);
+extern "C" int pmc_internal_tuning_set(void *, const char *key, double value);
+extern "C" void pmc_internal_tuning_use(const void *);
+extern "C" int pmc_internal_timing_stream(void *stream, int on);
+extern "C" int pmc_internal_get_timings(void *stream, pmc_timing *h_out, int max_entries, int *n_entries);
 
 namespace {
 
@@ -73,6 +82,8 @@ struct pmc_ctx {
     int device;
     hipStream_t stream;
     pmc_comm *comm;
+    std::recursive_mutex mu;      // calls of one context are serialised here: any thread may call, one at a time
+    void *tuning;                 // this context's copy of the library options (pmc_ctx_configure)
     DevBuf ws, u, scratch, flat, pack, spack, aux, nk1, nk2, lat;
 };
 struct pmc_mix {
@@ -90,6 +101,24 @@ struct pmc_samples {
 };
 
 namespace {
+
+// Scope of one call of a context: its mutex held, its options installed for this thread (the kernel-level entry points
+// below read them instead of the process-wide ones)
+struct CtxCall {
+    pmc_ctx *c;
+    explicit CtxCall(pmc_ctx *c_) : c(c_)
+    {
+        c->mu.lock();
+        pmc_internal_tuning_use(c->tuning);
+    }
+    ~CtxCall()
+    {
+        pmc_internal_tuning_use(nullptr);
+        c->mu.unlock();
+    }
+    CtxCall(const CtxCall &) = delete;
+    CtxCall &operator=(const CtxCall &) = delete;
+};
 
 int use(const pmc_ctx *ctx)
 {
@@ -322,8 +351,10 @@ int pmc_init(int device, pmc_ctx **out)
     ctx->device = device;
     ctx->comm = nullptr;
     ctx->stream = nullptr;
+    ctx->tuning = pmc_internal_tuning_new();
     const hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
+        pmc_internal_tuning_free(ctx->tuning);
         delete ctx;
         return hipf(e, "hipStreamCreateWithFlags");
     }
@@ -334,6 +365,7 @@ int pmc_init(int device, pmc_ctx **out)
 int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id)
 {
     CK(use(ctx));
+    CtxCall call_(ctx);
     if (ctx->comm) return failf(PMC_EINVAL, "pmc_ctx_join: the context has a communicator already");
     return pmc_comm_init(rank, world, h_id, ctx->device, &ctx->comm);
 }
@@ -343,15 +375,19 @@ int pmc_shutdown(pmc_ctx *ctx)
     if (!ctx) return PMC_OK;
     (void)hipSetDevice(ctx->device);
     int rc = PMC_OK;
+    ctx->mu.lock();                                                 // (a call still running in another thread finishes first)
     if (ctx->comm) rc = pmc_comm_destroy(ctx->comm);
     for (DevBuf *b : {&ctx->ws, &ctx->u, &ctx->scratch, &ctx->flat, &ctx->pack, &ctx->spack, &ctx->aux, &ctx->nk1,
                       &ctx->nk2, &ctx->lat})
         b->release();
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
+        (void)pmc_internal_timing_stream(ctx->stream, 0);
         (void)pmc_stream_release(ctx->stream);                     // the library's per-stream scratch slot
         (void)hipStreamDestroy(ctx->stream);
     }
+    pmc_internal_tuning_free(ctx->tuning);
+    ctx->mu.unlock();
     delete ctx;
     return rc;
 }
@@ -361,6 +397,7 @@ int pmc_mixture_create(pmc_ctx *ctx, int family, int K, int D, const double *h_w
                        const double *h_inv_sigma, const double *h_log_norm, const double *h_dof, pmc_mix **out)
 {
     CK(use(ctx));
+    CtxCall call_(ctx);
     if (!out || K < 1 || D < 1) return failf(PMC_EINVAL, "pmc_mixture_create: bad K / D / output");
     if (family != PMC_KIND_GAUSS && family != PMC_KIND_STUDENT_T)
         return failf(PMC_EINVAL, "pmc_mixture_create: family must be PMC_KIND_GAUSS or PMC_KIND_STUDENT_T (got %d)", family);
@@ -385,6 +422,7 @@ int pmc_mixture_update(pmc_mix *mix, const double *h_w, const double *h_mu, cons
 {
     if (!mix) return failf(PMC_EINVAL, "pmc_mixture_update: NULL mixture");
     CK(use(mix->ctx));
+    CtxCall call_(mix->ctx);
     return load_mix(mix, h_w, h_mu, h_inv_sigma, h_log_norm, h_dof);
 }
 
@@ -392,6 +430,7 @@ int pmc_mixture_destroy(pmc_mix *mix)
 {
     if (!mix) return PMC_OK;
     (void)hipSetDevice(mix->ctx->device);
+    CtxCall call_(mix->ctx);
     mix->pack.release();
     delete mix;
     return PMC_OK;
@@ -401,6 +440,7 @@ int pmc_mixture_destroy(pmc_mix *mix)
 int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_samples **out)
 {
     CK(use(ctx));
+    CtxCall call_(ctx);
     if (!out || N < 0 || D < 1 || (N > 0 && !h_x)) return failf(PMC_EINVAL, "pmc_samples_upload: bad argument");
     if (pmc_padded_dim(D) < 0) return PMC_EINVAL;
     pmc_samples *s = new pmc_samples();
@@ -423,6 +463,7 @@ int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol,
                          uint64_t seed, int64_t first_sample, pmc_samples **out)
 {
     CK(use(ctx));
+    CtxCall call_(ctx);
     if (!out || !mix || !h_counts || mix->ctx != ctx) return failf(PMC_EINVAL, "pmc_samples_generate: bad argument");
     const int K = mix->K, D = mix->D;
     std::vector<int64_t> off(K + 1, 0);
@@ -476,6 +517,7 @@ int pmc_samples_download(const pmc_samples *s, double *h_x)
 {
     if (!s || !h_x) return failf(PMC_EINVAL, "pmc_samples_download: bad argument");
     CK(use(s->ctx));
+    CtxCall call_(s->ctx);
     return d2h(s->ctx, h_x, s->x.p, sizeof(double) * (size_t)s->N * s->D);
 }
 
@@ -484,6 +526,7 @@ int pmc_samples_origin(const pmc_samples *s, int64_t *h_origin)
     if (!s || !h_origin) return failf(PMC_EINVAL, "pmc_samples_origin: bad argument");
     if (!s->has_origin) return failf(PMC_EINVAL, "pmc_samples_origin: these samples were uploaded, not generated");
     CK(use(s->ctx));
+    CtxCall call_(s->ctx);
     return d2h(s->ctx, h_origin, s->origin.p, sizeof(int64_t) * (size_t)s->N);
 }
 
@@ -491,6 +534,7 @@ int pmc_samples_free(pmc_samples *s)
 {
     if (!s) return PMC_OK;
     (void)hipSetDevice(s->ctx->device);
+    CtxCall call_(s->ctx);
     s->x.release();
     s->w.release();
     s->origin.release();
@@ -504,6 +548,7 @@ int pmc_mix_logpdf(const pmc_mix *mix, const pmc_samples *s, double *h_out, doub
     if (!mix || !s || mix->ctx != s->ctx || mix->D != s->D) return failf(PMC_EINVAL, "pmc_mix_logpdf: mixture and samples do not belong together");
     pmc_ctx *ctx = mix->ctx;
     CK(use(ctx));
+    CtxCall call_(ctx);
     const int64_t N = s->N;
     const int K = mix->K, D = mix->D;
     if (N == 0) return PMC_OK;
@@ -517,6 +562,74 @@ int pmc_mix_logpdf(const pmc_mix *mix, const pmc_samples *s, double *h_out, doub
     return PMC_OK;
 }
 
+int pmc_mix_logpdf_components(const pmc_mix *mix, const pmc_samples *s, const int32_t *h_components, int ncomponents,
+                              double *h_individual)
+{
+    if (!mix || !s || mix->ctx != s->ctx || mix->D != s->D) return failf(PMC_EINVAL, "pmc_mix_logpdf_components: mixture and samples do not belong together");
+    if (!h_components || ncomponents < 1 || !h_individual) return failf(PMC_EINVAL, "pmc_mix_logpdf_components: components and h_individual are required");
+    pmc_ctx *ctx = mix->ctx;
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    const int64_t N = s->N;
+    const int K = mix->K, D = mix->D, n = ncomponents;
+    std::vector<int> sel(n);
+    for (int i = 0; i < n; ++i) {
+        if (h_components[i] < 0 || h_components[i] >= K) return failf(PMC_EINVAL, "pmc_mix_logpdf_components: component %d of %d", (int)h_components[i], K);
+        sel[i] = h_components[i];
+    }
+    if (N == 0) return PMC_OK;
+    // the listed components as a pack of their own whose output columns are 0 ... n-1: an N x n matrix comes back and
+    // is scattered into the listed columns of the caller's N x K array (every other column stays as it is)
+    pmc_mix view;
+    view.ctx = ctx; view.family = mix->family; view.K = n; view.D = D;
+    view.w.resize(n); view.mu.resize((size_t)n * D); view.inv_sigma.resize((size_t)n * D * D); view.log_norm.resize(n);
+    if (mix->family == PMC_KIND_STUDENT_T) view.dof.resize(n);
+    std::vector<int> all(n);
+    for (int i = 0; i < n; ++i) {
+        const int k = sel[i];
+        all[i] = i;
+        view.w[i] = mix->w[k];
+        view.log_norm[i] = mix->log_norm[k];
+        if (mix->family == PMC_KIND_STUDENT_T) view.dof[i] = mix->dof[k];
+        std::memcpy(&view.mu[(size_t)i * D], &mix->mu[(size_t)k * D], sizeof(double) * D);
+        std::memcpy(&view.inv_sigma[(size_t)i * D * D], &mix->inv_sigma[(size_t)k * D * D], sizeof(double) * (size_t)D * D);
+    }
+    std::vector<double> host;
+    CK(build_mix_pack(&view, all, host));
+    CK(ctx->pack.ensure(host.size() * sizeof(double)));
+    CK(h2d(ctx, ctx->pack.p, host.data(), host.size() * sizeof(double)));
+    CK(workspace(ctx, N, n, D));
+    CK(ctx->nk1.ensure(sizeof(double) * (size_t)N * n));
+    CK(pmc_mixture_logpdf(s->x.d(), N, D, ctx->pack.d(), n, mix->family, 0, nullptr, ctx->nk1.d(), n, nullptr, nullptr, nullptr,
+                          nullptr, ctx->ws.p, ctx->stream));
+    std::vector<double> cols((size_t)N * n);
+    CK(d2h(ctx, cols.data(), ctx->nk1.p, sizeof(double) * cols.size()));
+    for (int64_t r = 0; r < N; ++r)
+        for (int i = 0; i < n; ++i) h_individual[(size_t)r * K + sel[i]] = cols[(size_t)r * n + i];
+    return PMC_OK;
+}
+
+int pmc_ctx_configure(pmc_ctx *ctx, const char *key, double value)
+{
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    return pmc_internal_tuning_set(ctx->tuning, key, value);
+}
+
+int pmc_ctx_timing_enable(pmc_ctx *ctx, int on)
+{
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    return pmc_internal_timing_stream(ctx->stream, on);
+}
+
+int pmc_ctx_get_timings(pmc_ctx *ctx, pmc_timing *h_out, int max_entries, int *n_entries)
+{
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    return pmc_internal_get_timings(ctx->stream, h_out, max_entries, n_entries);
+}
+
 int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target, const pmc_mix *target, double *h_w,
                    double *h_log_target_out, double *h_sums)
 {
@@ -525,6 +638,7 @@ int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target,
     if (target && (target->ctx != q->ctx || target->D != q->D)) return failf(PMC_EINVAL, "pmc_is_weights: target of another context / dimension");
     pmc_ctx *ctx = q->ctx;
     CK(use(ctx));
+    CtxCall call_(ctx);
     const int64_t N = s->N;
     const int D = q->D, Kmax = target && target->K > q->K ? target->K : q->K;
     CK(ctx->flat.ensure(sizeof(double) * NSC));
@@ -566,6 +680,7 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
                  double *h_log_rho)
 {
     CK(use(ctx));
+    CtxCall call_(ctx);
     if (!s || s->ctx != ctx || K < 1 || !h_m || !h_W || !h_nu || !h_beta || !h_ln_pi || !h_ln_lambda || !h_N_k || !h_xbar || !h_S)
         return failf(PMC_EINVAL, "pmc_vb_estep: bad argument");
     const int64_t N = s->N;
@@ -634,6 +749,7 @@ int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s,
                          double *h_dof_const, double *h_loglik, double *h_norm)
 {
     CK(use(ctx));
+    CtxCall call_(ctx);
     if (!mix || !s || mix->ctx != ctx || s->ctx != ctx || mix->D != s->D || !h_alpha || !h_mu || !h_sigma)
         return failf(PMC_EINVAL, "pmc_pmc_update_stats: bad argument");
     if (h_w && weights_on_device) return failf(PMC_EINVAL, "pmc_pmc_update_stats: h_w or weights_on_device, not both");
@@ -748,6 +864,7 @@ int pmc_weighted_moments(pmc_ctx *ctx, const pmc_samples *s, const double *h_w, 
                          double *h_cov)
 {
     CK(use(ctx));
+    CtxCall call_(ctx);
     if (!s || s->ctx != ctx || !h_mean) return failf(PMC_EINVAL, "pmc_weighted_moments: bad argument");
     if (h_w && weights_on_device) return failf(PMC_EINVAL, "pmc_weighted_moments: h_w or weights_on_device, not both");
     if (weights_on_device && !s->has_w) return failf(PMC_EINVAL, "pmc_weighted_moments: no importance weights on the device (pmc_is_weights first)");

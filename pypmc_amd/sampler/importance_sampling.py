@@ -142,13 +142,12 @@ class ImportanceSampler(object):
         prop_set = component_set(self.proposal.components, self.proposal.weights)
         if isinstance(tgt, MixtureDensity):
             # mixture target: log P, log q, the weights and the perplexity sums in one pass over x
+            # prepare_update: the pass leaves u = w rho itself where that form applies, else it keeps the Mahalanobis
+            # forms for the update -- decided BEFORE the pass (advice r3: it used to run twice in the second case)
+            emit = prepare_update and not keep_mahalanobis and getattr(be, "can_emit", lambda c: True)(prop_set)
             res = be.importance_weights(x, prop_set, component_set(tgt.components, tgt.weights),
                                         want_log_target=store and self.target_values is not None,
-                                        keep=keep_mahalanobis, emit=prepare_update and not keep_mahalanobis)
-            if prepare_update and res.get("responsibilities") is None and res.get("tiles") is None:
-                # the emitting form does not apply here: keep the Mahalanobis forms instead (second pass over them)
-                res = be.importance_weights(x, prop_set, component_set(tgt.components, tgt.weights),
-                                            want_log_target=store and self.target_values is not None, keep=True)
+                                        keep=keep_mahalanobis or (prepare_update and not emit), emit=emit)
             log_target = res["log_target"]
         else:
             log_target = be.asdevice(self._target_values(be.tohost(x), N))

@@ -563,3 +563,82 @@ def test_weighted_moments(lib, ctx, D, N, how):
         np.testing.assert_allclose(cov, calculate_covariance(x, w), rtol=1e-10, atol=1e-13 * np.abs(ref_cov).max())
     assert lib.pmc_weighted_moments(ctx, s, dp(w), 1, dp(mean), dp(cov)) < 0
     lib.pmc_samples_free(s)
+
+
+def test_two_contexts_two_threads_with_their_own_options(lib):
+    """re-entrant per context, serialised per context.  Two contexts in two threads run the same large E-step
+    at once, one with the common-shift statistics switched off for ITS context (pmc_ctx_configure), the other with the
+    defaults; a third thread hammers the process-wide pmc_configure meanwhile.  Each context's numbers are, bit for bit,
+    what it gives alone -- and the two differ (different kernels), so a shared global would show."""
+    import threading
+    from pypmc_amd import _lib
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    D, K, N = 20, 32, 300_000
+    mixture = create_gaussian_mixture(*mk(K, D, 81))
+    np.random.seed(82)
+    x = mixture.propose(N)
+    vb = GaussianInference(x[:2000], initial_guess=mixture)
+    m, W, nu, beta, ln_pi, ln_lam = vb_arrays(vb)
+
+    def make(limit):
+        h = C.c_void_p()
+        assert lib.pmc_init(0, C.byref(h)) == 0, lib.pmc_last_error()
+        assert lib.pmc_ctx_configure(h, b"stats_common_shift_min_n", 0.0) == 0
+        if limit is not None:
+            assert lib.pmc_ctx_configure(h, b"stats_common_shift_limit", limit) == 0
+        assert lib.pmc_ctx_configure(h, b"no_such_option", 1.0) < 0
+        assert lib.pmc_ctx_timing_enable(h, 1) == 0
+        return h, upload(lib, h, x)
+
+    def estep(h, s):
+        Nk, xbar, S, elq = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(1)
+        rc = lib.pmc_vb_estep(h, s, None, K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), None,
+                              dp(Nk), dp(xbar), dp(S), dp(elq), None, None)
+        assert rc == 0, lib.pmc_last_error()
+        return np.concatenate([Nk, xbar.ravel(), S.ravel(), elq])
+
+    (ha, sa), (hb, sb) = make(0.0), make(None)
+    alone_a, alone_b = estep(ha, sa), estep(hb, sb)
+    assert not np.array_equal(alone_a, alone_b), "the two contexts should run different statistics kernels"
+    np.testing.assert_allclose(alone_a, alone_b, rtol=1e-9, atol=1e-9)
+    errors, stop = [], threading.Event()
+
+    def worker(h, s, ref):
+        try:
+            for _ in range(12):
+                if not np.array_equal(estep(h, s), ref):
+                    errors.append("a context's result changed under concurrency")
+        except Exception as exc:                           # noqa: BLE001
+            errors.append(repr(exc))
+
+    def meddler():
+        flip = 0
+        while not stop.is_set():
+            lib.pmc_configure(b"stats_common_shift_limit", 0.0 if flip else 1000.0)
+            flip ^= 1
+    threads = [threading.Thread(target=worker, args=(ha, sa, alone_a)), threading.Thread(target=worker, args=(hb, sb, alone_b)),
+               threading.Thread(target=worker, args=(hb, sb, alone_b))]       # (two threads on ONE context: serialised inside)
+    med = threading.Thread(target=meddler)
+    med.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stop.set()
+    med.join()
+    lib.pmc_configure(b"stats_common_shift_limit", 1000.0)
+    assert not errors, errors
+    # each context's own timing record: context a ran 13 E-steps, context b 25; the process-wide record saw none of them
+    buf = (_lib.Timing * 16)()
+    n = C.c_int(0)
+    calls = {}
+    for name, h in (("a", ha), ("b", hb)):
+        assert lib.pmc_ctx_get_timings(h, C.cast(buf, C.c_void_p), 16, C.byref(n)) == 0
+        calls[name] = {buf[i].name.decode(): buf[i].calls for i in range(n.value)}
+    assert calls["a"]["k_resp"] == 13 and calls["b"]["k_resp"] == 25, calls
+    assert calls["a"]["k_stats"] == 13 and calls["b"]["k_stats"] == 25, calls
+    assert lib.pmc_get_timings(C.cast(buf, C.c_void_p), 16, C.byref(n)) == 0 and n.value == 0
+    for h, s in ((ha, sa), (hb, sb)):
+        lib.pmc_samples_free(s)
+        assert lib.pmc_shutdown(h) == 0
