@@ -35,7 +35,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL (see pypmc_amd/parallel.py); before HIP starts
+# dmabuf IPC for RCCL: with the legacy mode hipIpcGetMemHandle fails between two processes on these boxes
+# (profiles/r04_ipc_mode.txt, pypmc_amd/parallel.py); a setdefault, before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 K, D, K_T = 32, 20, 4
 FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector = fp64 matrix peak (spec)

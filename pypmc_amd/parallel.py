@@ -18,9 +18,12 @@ import numpy as np
 
 import os as _os
 
-# RCCL shares device memory between the ranks of a node through dmabuf IPC; the host driver of the MI355X boxes supports
-# only that mode, and without this switch `hipIpcGetMemHandle` fails with "invalid argument" as soon as a second rank
-# appears.  Set before the HIP runtime starts (it is read at initialisation); a value the launcher exported wins.
+# RCCL shares device memory between the ranks of a node through hipIpcGetMemHandle / hipIpcOpenMemHandle; the host driver
+# of the MI355X boxes supports only the dmabuf IPC mode, and with the legacy mode (this variable unset or 1) the first of
+# the two calls fails with "invalid argument" as soon as a second process is involved -- measured on a box of the pool
+# with two processes sharing one allocation: profiles/r04_ipc_mode.txt (scripts/ipc_mode_probe.py).  The image exports
+# the variable already; this is a setdefault (a value the launcher exported wins) for ranks started from an environment
+# that lost it, and it has to happen before the HIP runtime starts (it is read at initialisation).
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
