@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpmc_hip.so")
+# (PMC_HIP_LIBRARY: development aid -- an A/B variant of the library built by `PMC_VARIANT=... python -m pypmc_amd.build`)
+LIB_PATH = os.environ.get("PMC_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libpmc_hip.so")
 
 PMC_KIND_GAUSS, PMC_KIND_STUDENT_T, PMC_KIND_VB = 0, 1, 2
 PMC_RESP_VB, PMC_RESP_PMC_RB, PMC_RESP_PMC_LATENT = 0, 1, 2

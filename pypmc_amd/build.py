@@ -19,6 +19,14 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpmc_hip.so")
+# Development aid for A/B measurements: PMC_VARIANT=<name> builds lib/libpmc_hip_<name>.so from a copy of the main
+# build's objects in which the units listed in PMC_VARIANT_UNITS (comma separated object stems, e.g.
+# "pmc_persample_d20_p0,pmc_stats_d20_p0") are recompiled with PMC_EXTRA_FLAGS; PMC_HIP_LIBRARY=<path> makes
+# pypmc_amd._lib load it.  The product is always lib/libpmc_hip.so.
+VARIANT = os.environ.get("PMC_VARIANT", "")
+if VARIANT:
+    OBJ = os.path.join(CSRC, "build_" + VARIANT)
+    LIB = os.path.join(LIBDIR, "libpmc_hip_%s.so" % VARIANT)
 ARCH = "gfx950"
 
 HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -52,6 +60,15 @@ def _newer(target, sources):
 
 def _compile(job):
     out, src, defs, deps, force = job
+    if VARIANT:
+        stem = os.path.splitext(os.path.basename(out))[0]
+        main = os.path.join(CSRC, "build", os.path.basename(out))
+        if stem not in os.environ.get("PMC_VARIANT_UNITS", "").split(","):
+            if not os.path.exists(main):
+                raise RuntimeError("variant build: %s is missing (build the product first)" % main)
+            shutil.copy2(main, out)
+            return out, 0.0
+        force = True
     if not force and _newer(out, deps):
         return out, 0.0
     import time

@@ -774,8 +774,13 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
     } else {
         Engine engine;
         engine.load(a, tile, lane);
+#ifdef PMC_AB_NO_U_STORE                                  // (A/B switch, timing only: the same instruction stream, but every
+        double *ut = a.u + (size_t)(tile & 63) * K * 64 + lane;    //  workgroup's u lands in the same few tiles: L2 absorbs it)
+        double *gs = a.gscale + (size_t)(tile & 63) * G * 64 + lane;
+#else
         double *ut = a.u + (size_t)tile * K * 64 + lane;
         double *gs = a.gscale + (size_t)tile * G * 64 + lane;
+#endif
         double *pl = dyn_lds + Engine::LDS_DOUBLES + (size_t)(threadIdx.x >> 6) * GS * 64 + lane;
         const ExpConst EC;
         double poison = 0.0;                              // NaN if a component value of the row is NaN

@@ -672,7 +672,11 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
                     *(gd2 *)(ubuf + q * UT + 16 * UPIECE + 2 * lane) = gd2{0.0, 0.0};
                     continue;
                 }
+#ifdef PMC_AB_CONST_U
+                long long o = (0 * gtot + 2 * group) * 64;
+#else
                 long long o = ((t + q) * gtot + 2 * group) * 64;                     // wave-uniform
+#endif
                 // the array's very last group has no successor: its second half re-reads the group itself (rows discarded)
                 const int gl = o >= glen - 64 ? (2 * lane) & 63 : 2 * lane;
                 if (o > glen - 64) o = glen - 64;
@@ -692,7 +696,11 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
                     *(gd2 *)(ubuf + q * UT + p * UPIECE + 2 * lane) = gd2{0.0, 0.0};
                     continue;
                 }
+#ifdef PMC_AB_CONST_U                                     // (A/B switch, timing only: u from ONE tile, i.e. out of L2)
+                const long long tile = 0;
+#else
                 const long long tile = t + q;
+#endif
                 // lane -> 16-byte chunk (component 2 p + (lane >> 5), sample pair lane & 31 with bits 2 and 3 swapped)
                 long long o = (tile * b.K + kmin + 2 * p) * 64;                      // wave-uniform
                 // components beyond K read the next tile's (finite values, rows discarded); past the array's very
