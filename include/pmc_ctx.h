@@ -193,6 +193,21 @@ int pmc_weighted_moments(pmc_ctx *ctx, const pmc_samples *s, const double *h_w, 
 int pmc_host_convert_stats(int K, int D, const double *h_stats, const double *h_shift, const double *h_n_cov,
                            double *h_S0, double *h_M1, double *h_mean, double *h_cov, int *h_far);
 
+/*
+ * chol_inv_det (pypmc/tools/_linalg.pyx:41-95: potrf, potri, symmetrised inverse, log det) of a stack of K symmetric
+ * D x D matrices -- the K-sized host step of every proposal / posterior update (pmc.pyx:227-244, variational.pyx:934-946)
+ * -- as ONE call (the per-matrix interpreter overhead and array glue of the Python loop it replaces were most of its
+ * time; PMC_HOST_THREADS > 1 spreads the matrices over threads for a LAPACK that takes concurrent calls, which scipy's
+ * OpenBLAS does not).  dpotrf / dpotri: the addresses of the LAPACK routines to use
+ * (Fortran convention `void f(char *uplo, int *n, double *a, int *lda, int *info)`; from Python:
+ * scipy.linalg.cython_lapack.__pyx_capi__), so the results are bit for bit what the reference's scipy calls give.
+ * h_lower K x D x D (L with m = L L^T, upper triangle zero), h_inverse K x D x D (symmetric), h_log_det K, h_failed K
+ * (LAPACK's info per matrix, -1 for a non-finite determinant; may be NULL).  PMC_ENOTPOSDEF if any matrix fails (the
+ * arrays of the others are still filled).
+ */
+int pmc_host_chol_inv_det_batch(int K, int D, const double *h_m, void *dpotrf, void *dpotri, double *h_lower,
+                                double *h_inverse, double *h_log_det, int *h_failed);
+
 #ifdef __cplusplus
 }
 #endif

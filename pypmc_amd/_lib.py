@@ -127,6 +127,7 @@ CTX_SIGNATURES = {
     "pmc_pmc_update_stats": (_int, [_vp, _vp, _vp, _dp, _int, _ip, _int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pmc_weighted_moments": (_int, [_vp, _vp, _dp, _int, _dp, _dp]),
     "pmc_host_convert_stats": (_int, [_int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
+    "pmc_host_chol_inv_det_batch": (_int, [_int, _int, _dp, _vp, _vp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
 }
 
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------
@@ -991,8 +992,14 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     const int Dp = ks->dim, Tp = pmc_tri(Dp), stride = pmc_pack_stride_c(Dp);
+    // The K factorisations are independent: from ~1e6 multiply-adds on they are spread over a few host threads (K = 128,
+    // D = 40: 0.45 -> 0.1 ms; part of every iteration's host share at an 8-GPU shard size).  A component that does not
+    // factorise is reported as before: the lowest such index, its pivot and its value.
+    struct Bad { int k, i; double s; };
+    std::vector<Bad> bad_of;                                   // one slot per worker
+    auto range = [&](int k0, int k1, Bad *bad) {
     std::vector<double> R((size_t)D * D);
-    for (int k = 0; k < K; ++k) {
+    for (int k = k0; k < k1; ++k) {
         double *pk = pack + (size_t)k * stride;
         std::memset(pk, 0, sizeof(double) * stride);
         for (int j = 0; j < D; ++j) pk[j] = mu[(size_t)k * D + j];
@@ -1003,10 +1010,10 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
                 double s = A[(size_t)i * D + j];
                 for (int l = 0; l < i; ++l) s -= R[(size_t)l * D + i] * R[(size_t)l * D + j];
                 if (j == i) {
-                    if (!(s > 0.0) || !std::isfinite(s))
-                        return fail(PMC_ENOTPOSDEF,
-                                    "precision matrix of component %d is not positive definite "
-                                    "(pivot %d = %g)", k, i, s);
+                    if (!(s > 0.0) || !std::isfinite(s)) {
+                        *bad = Bad{k, i, s};
+                        return;
+                    }
                     R[(size_t)i * D + i] = std::sqrt(s);
                 } else {
                     R[(size_t)i * D + j] = s / R[(size_t)i * D + i];
@@ -1047,6 +1054,27 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
         const long long col = column ? (long long)column[k] : (long long)k;
         std::memcpy(&c[5], &col, sizeof(col));
     }
+    };
+    int nt = 1;
+    if ((double)K * D * D * D / 6.0 >= 1e6) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        nt = (int)(hw ? hw : 1);
+        if (nt > 8) nt = 8;
+        if (nt > K / 4) nt = K / 4;
+        if (nt < 1) nt = 1;
+    }
+    bad_of.assign((size_t)nt, Bad{-1, 0, 0.0});
+    if (nt == 1) {
+        range(0, K, &bad_of[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back(range, (int)((long long)K * t / nt), (int)((long long)K * (t + 1) / nt), &bad_of[(size_t)t]);
+        for (std::thread &t : th) t.join();
+    }
+    for (const Bad &b : bad_of)                                 // (workers hold ascending ranges: the first hit is the lowest index)
+        if (b.k >= 0)
+            return fail(PMC_ENOTPOSDEF, "precision matrix of component %d is not positive definite (pivot %d = %g)", b.k, b.i, b.s);
     return PMC_OK;
 }
 

@@ -12,8 +12,10 @@
 #include <initializer_list>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 extern "C" int pmc_internal_fail(int code, const char *msg);       // pmc_api.hip: sets pmc_last_error()
@@ -933,6 +935,74 @@ int pmc_host_convert_stats(int K, int D, const double *h_stats, const double *h_
     if (h_far) *h_far = shift_is_far(S0, M1, M2, K, D) ? 1 : 0;
     centred_moments(S0.data(), h_n_cov ? h_n_cov : S0.data(), M1, M2, h_shift, K, D, h_mean, h_cov);
     return PMC_OK;
+}
+
+// ---- K-sized host linear algebra ------------------------------------------------------------------------------
+// chol_inv_det (pypmc/tools/_linalg.pyx:41-95) of a stack of K symmetric D x D matrices: potrf, potri of the lower
+// factor, the inverse mirrored, log det = 2 sum log L_ii summed left to right -- the SAME LAPACK routines the reference
+// calls through scipy, handed in by address (scipy.linalg.cython_lapack's dpotrf / dpotri: Fortran calling convention,
+// column-major), so the numbers are scipy's own.  A symmetric matrix reads the same row- and column-major, the factor
+// comes back transposed and is turned here.
+// h_failed (K ints, may be NULL): potrf's / potri's info per matrix (0 = fine), or -1 for a non-finite log det.
+typedef void (*pmc_lapack_fn)(char *uplo, int *n, double *a, int *lda, int *info);
+int pmc_host_chol_inv_det_batch(int K, int D, const double *h_m, void *dpotrf, void *dpotri, double *h_lower,
+                                double *h_inverse, double *h_log_det, int *h_failed)
+{
+    if (K < 1 || D < 1 || !h_m || !dpotrf || !dpotri || !h_lower || !h_inverse || !h_log_det)
+        return failf(PMC_EINVAL, "pmc_host_chol_inv_det_batch: bad argument");
+    const pmc_lapack_fn potrf = (pmc_lapack_fn)dpotrf, potri = (pmc_lapack_fn)dpotri;
+    std::vector<int> info((size_t)K, 0);
+    auto work = [&](int k0, int k1) {
+        std::vector<double> a((size_t)D * D);
+        char lo = 'L';
+        for (int k = k0; k < k1; ++k) {
+            int n = D, lda = D, inf = 0;
+            std::memcpy(a.data(), h_m + (size_t)k * D * D, sizeof(double) * (size_t)D * D);
+            potrf(&lo, &n, a.data(), &lda, &inf);
+            if (inf != 0) {
+                info[k] = inf;
+                continue;
+            }
+            // column-major lower factor: element (i, j), i >= j, at a[j * D + i]
+            double *L = h_lower + (size_t)k * D * D;
+            double ld = 0.0;
+            for (int i = 0; i < D; ++i) {
+                for (int j = 0; j < D; ++j) L[(size_t)i * D + j] = j <= i ? a[(size_t)j * D + i] : 0.0;
+                ld += std::log(a[(size_t)i * D + i]);                // left to right, as the reference sums
+            }
+            ld *= 2.0;
+            h_log_det[k] = ld;
+            if (!std::isfinite(ld)) info[k] = -1;
+            potri(&lo, &n, a.data(), &lda, &inf);
+            if (inf != 0) {
+                info[k] = inf;
+                continue;
+            }
+            double *I = h_inverse + (size_t)k * D * D;
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j <= i; ++j) I[(size_t)i * D + j] = I[(size_t)j * D + i] = a[(size_t)j * D + i];
+        }
+    };
+    // On the calling thread unless PMC_HOST_THREADS asks for more: scipy's OpenBLAS serialises calls that arrive from
+    // several threads at once (measured: K = 128, D = 40: 2.6 ms on one thread, 4.2 ms on 2 ... 8), so spreading the
+    // matrices only pays with a LAPACK that does not.  The gain over the numpy loop this replaces (6.4 ms on the same
+    // host) is the glue: no per-matrix Python call, no transposed copies, no triangle masks.
+    int nt = 1;
+    if (const char *e = std::getenv("PMC_HOST_THREADS")) nt = std::atoi(e);
+    if (nt > K / 8) nt = K / 8;                                     // (a thread is worth starting for eight 40 x 40 matrices)
+    if ((size_t)D * D * K < 20000 || nt < 2) {
+        work(0, K);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, (int)((long long)K * t / nt), (int)((long long)K * (t + 1) / nt));
+        for (std::thread &t : th) t.join();
+    }
+    int bad = 0;
+    for (int k = 0; k < K; ++k) {
+        if (h_failed) h_failed[k] = info[k];
+        bad += info[k] != 0;
+    }
+    return bad ? failf(PMC_ENOTPOSDEF, "pmc_host_chol_inv_det_batch: %d of %d matrices do not factorise", bad, K) : PMC_OK;
 }
 
 }  // extern "C"

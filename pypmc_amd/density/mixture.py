@@ -36,6 +36,8 @@ def component_set(components, weights, columns=None, ld=None):
     if first not in (Gauss, StudentT) or any(type(c) is not first for c in comps):
         return None
     idx = list(range(len(comps))) if columns is None else list(columns)
+    if columns is not None and idx == list(range(len(comps))) and ld in (None, len(comps)):
+        columns = None                                       # every component, in order: the complete mixture (cached)
     sel = [comps[k] for k in idx]
     mu = np.array([c.mu for c in sel], dtype=np.float64).reshape(len(sel), -1)
     wts = np.asarray(weights, dtype=np.float64)[idx]

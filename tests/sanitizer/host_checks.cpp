@@ -257,6 +257,7 @@ int main()
     kernel_level(32, 20, 20000, 4);
     kernel_level(64, 40, 40000, 5);                       // k_mgemm + its fall-back launches
     kernel_level(33, 37, 33000, 6);
+    kernel_level(128, 40, 40000, 14);                     // (pack building on several host threads)
     kernel_level(4, 70, 600, 7);                          // pmc_big.hip's unit (chunked scratch)
     kernel_level(32, 20, 600000, 8);                      // k_resp_groups + k_stats_gemm
     kernel_level(1, 1, 1, 9);
