@@ -349,6 +349,17 @@ __device__ __forceinline__ void block_scalars(double (&sc)[NS], double *partials
 }
 
 
+// store of a responsibility value: written once, read by the NEXT kernel -- far more than the L2 holds in between
+// (-DPMC_NT_STORES: with the non-temporal hint, an A/B switch)
+__device__ __forceinline__ void store_u(double *p, double v)
+{
+#ifdef PMC_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 constexpr int D_ = PMC_D;
 constexpr bool P_ = PMC_PADDED != 0;
 

@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
                             uo = e;                                      // w_k exp(a - M): _regularize.pyx:79 / pmc.pyx:39
                             sp[t] += e;
                         }
-                        if (st) ut[(size_t)kk * 64 + 16 * t] = uo;
+                        // (non-temporal: 8 K bytes per sample stream out while every workgroup re-reads the coefficient
+                        //  image out of L2 -- k_mgemm -1.2 % at D = 40, K = 128; no effect on k_resp_groups at D = 20)
+                        if (st) __builtin_nontemporal_store(uo, ut + (size_t)kk * 64 + 16 * t);
                     }
                 }
         };

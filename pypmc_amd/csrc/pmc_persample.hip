@@ -807,11 +807,11 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 if constexpr (KIND == PMC_KIND_VB) {
                     tbg = fma(e, lr, tbg);
                     sg += e;
-                    ut[(size_t)(kb + j) * 64] = zero_to_tiny(e);
+                    store_u(ut + (size_t)(kb + j) * 64, zero_to_tiny(e));
                 } else {
                     const double we = ((cdouble *)a.pack + (size_t)(kb + j) * dm.STRIDE)[dm.DT + 4] * e;
                     sg += we;
-                    ut[(size_t)(kb + j) * 64] = we;
+                    store_u(ut + (size_t)(kb + j) * 64, we);
                 }
             };
             descend(kn, 0, [&](int j) { return pl[j * 64]; }, expstep);
