@@ -200,13 +200,15 @@ def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
         t0 = time.perf_counter()
         step(x, mt)
         rate = n_probe / (time.perf_counter() - t0)
-        want = min(seconds_target, 8.0) if mt else seconds_target
-        n = int(max(n_probe, min(rate * max(want, 5.0 if mt else 0.0), 6_000_000)))   # (6e6: ~8 GB of N x K matrices)
+        want = max(min(seconds_target, 8.0), 5.0) if mt else seconds_target
+        n = int(max(n_probe, min(rate * want, 4_000_000)))      # (4e6: ~5 GB of N x K matrices in the oracle)
+        reps = max(1, int(np.ceil(rate * want / n)))            # ... and the step repeated on them until `want` seconds
         x = draw(n)
         t0 = time.perf_counter()
-        step(x, mt)
+        for _ in range(reps):
+            step(x, mt)
         dt = time.perf_counter() - t0
-        out[label] = dict(value=n / dt, n=n, seconds=dt, cores=orc.num_threads() if mt else 1)
+        out[label] = dict(value=reps * n / dt, n=reps * n, seconds=dt, cores=orc.num_threads() if mt else 1)
     return out
 
 

@@ -434,6 +434,30 @@ int pmc_comm_rank(const pmc_comm *comm, int *rank, int *world);
 int pmc_comm_allreduce_sum(pmc_comm *comm, double *d_buf, int64_t n, void *stream);
 int pmc_comm_destroy(pmc_comm *comm);
 
+/* ---- the exchange without a ring: one-shot all-gather + ordered local sum (ranks of one node) ---- */
+/*
+ * The statistics vector of an update is small (7 464 doubles at K = 32, D = 20; 110 336 at K = 128, D = 40): a ring
+ * all-reduce is 2 (G - 1) dependent hops of pure latency.  Here every rank owns a mailbox in its device memory that its
+ * peers map through HIP IPC; pmc_p2p_allreduce_sum writes the rank's vector into its slot of EVERY mailbox (peer stores
+ * over xGMI) followed by a flag, waits for the G flags of its own mailbox and adds the G slots in RANK ORDER: one hop, and
+ * the same bits on every rank and from run to run.  Bootstrap like pmc_comm_*: every rank calls pmc_p2p_create (its
+ * mailbox holds vectors of up to max_doubles), hands its PMC_P2P_HANDLE_BYTES bytes (pmc_p2p_handle) to all ranks by the
+ * caller's own means (MPI_Allgather, a file, torch.distributed), and calls pmc_p2p_connect with the world x
+ * PMC_P2P_HANDLE_BYTES bytes of all ranks in rank order.  The ranks must call pmc_p2p_allreduce_sum in the same order
+ * with the same n; launches are asynchronous on `stream`.  A rank whose peers do not arrive within PMC_P2P_TIMEOUT_S
+ * seconds (environment, default 20) gives up without a result; pmc_p2p_status (synchronises) reports it.
+ * world <= 16; one node (HIP IPC); the processes need HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts with dmabuf IPC only.
+ * Replaces nothing by default: pmc_comm_allreduce_sum (RCCL) stays the default exchange.
+ */
+#define PMC_P2P_HANDLE_BYTES 64
+typedef struct pmc_p2p pmc_p2p;
+int pmc_p2p_create(int rank, int world, int64_t max_doubles, int device, pmc_p2p **out);
+int pmc_p2p_handle(const pmc_p2p *p, void *h_handle);
+int pmc_p2p_connect(pmc_p2p *p, const void *h_handles);
+int pmc_p2p_allreduce_sum(pmc_p2p *p, double *d_buf, int64_t n, void *stream);
+int pmc_p2p_status(pmc_p2p *p, void *stream);
+int pmc_p2p_destroy(pmc_p2p *p);
+
 /* ---- kernel timing ----------------------------------------------------------------------------- */
 /*
  * Roofline numbers for callers without a profiler.  While timing is enabled every launch of a hot kernel

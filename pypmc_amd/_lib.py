@@ -74,6 +74,12 @@ SIGNATURES = {
     "pmc_comm_rank": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pmc_comm_allreduce_sum": (_int, [_vp, _vp, _i64, _vp]),
     "pmc_comm_destroy": (_int, [_vp]),
+    "pmc_p2p_create": (_int, [_int, _int, _i64, _int, C.POINTER(_vp)]),
+    "pmc_p2p_handle": (_int, [_vp, _vp]),
+    "pmc_p2p_connect": (_int, [_vp, _vp]),
+    "pmc_p2p_allreduce_sum": (_int, [_vp, _vp, _i64, _vp]),
+    "pmc_p2p_status": (_int, [_vp, _vp]),
+    "pmc_p2p_destroy": (_int, [_vp]),
     "pmc_timing_enable": (_int, [_int]),
     "pmc_get_timings": (_int, [_vp, _int, C.POINTER(C.c_int)]),
     "pmc_configure": (_int, [C.c_char_p, C.c_double]),
