@@ -203,21 +203,28 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 // k_mgemm
 // ---------------------------------------------------------------------------------------------
-template <int D, int NCT>
-__global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
+// NCT: component tiles per wavefront and pass.  HW = 1: four wavefronts, one per 64-sample tile, all tiles of a pass.
+// HW = 2: EIGHT wavefronts, two per SIMD -- wavefront (tile, half) takes tiles 2 half, 2 half + 1 of the pass's four on its
+// tile's samples: each forms its own monomial products (one v_mul_f64 per two matrix instructions instead of one per
+// four), but the two wavefronts of a SIMD cover each other's LDS waits, multiplies and epilogues, which one wavefront
+// per SIMD leaves exposed (matrix pipe 78 % busy at D = 40, K = 128).  The halves of a sample row meet in LDS at the end.
+template <int D, int NCT, int HW>
+__global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
 {
+    constexpr int NTP = NCT * HW;                          // component tiles per pass
     using C = MgCfg<D>;
     constexpr int Q = C::Q, RS = C::RS, CH = C::CH, NCH = C::NCH, ND = C::ND, NQ = C::NQ, NSTEP = C::NSTEP;
     static_assert(RS >= 64 && (Q * RS) % 32 == 16, "bank spread of the rotated views");
     static_assert(NCH % 2 == 0, "the chunk's buffer is a compile-time constant of the step");
     extern __shared__ double lds[];
-    double *th = lds;                                      // [2][NCT][CH * 64]
-    double *dl = lds + 2 * NCT * CH * 64;                  // [4][D][RS]
-    double *cts = dl + 4 * D * RS;                         // [2][NCT * 16][4]
+    double *th = lds;                                      // [2][NTP][CH * 64]
+    double *dl = lds + 2 * NTP * CH * 64;                  // [4][D][RS]
+    double *cts = dl + 4 * D * RS;                         // [2][NTP * 16][4]
     __shared__ int s_flag;
     const PmcArgsA &a = q.a;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, half = wave8 >> 2;         // sample tile of the workgroup, half of the pass's tiles
     const int s16 = lane & 15, g = lane >> 4;
     const long long tile = blockIdx.x * 4LL + wave;
     const long long n = tile * 64 + lane;
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
     // ---- the wavefront's samples minus the centre -> LDS, and the guard
     if (tid == 0) s_flag = 0;
     __syncthreads();
-    {
+    if (half == 0) {                                       // (wave-uniform: a tile's image is written once)
         const long long nc = valid ? n : a.N - 1;
         const double *xr = a.x + nc * (long long)a.dreal;
         double dsq = 0.0;
@@ -251,7 +258,8 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
     }
     if (flagged) return;                                   // the exact kernel behind does this workgroup's samples
 
-    const unsigned dwa = (unsigned)(uintptr_t)(mg_lvoid_t *)dw, tha = (unsigned)(uintptr_t)(mg_lvoid_t *)th + 8u * lane;
+    const unsigned dwa = (unsigned)(uintptr_t)(mg_lvoid_t *)dw;
+    const unsigned tha = (unsigned)(uintptr_t)(mg_lvoid_t *)th + 8u * lane + 8u * (unsigned)(half * NCT * CH * 64);
     unsigned base[4];
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq) base[jq] = dwa + 8u * (unsigned)((((jq + g) * Q) % D) * RS + s16);
@@ -260,12 +268,12 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
     auto stage = [&](int cg) {                             // chunk cg = (pass, chunk of the pass) -> theta buffer cg & 1
         const int pass = cg / NCH, ch = cg - pass * NCH;
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            const double *src = q.img + ((size_t)(pass * NCT + c) * NCH + ch) * CH * 64;
-            double *dst = th + ((cg & 1) * NCT + c) * CH * 64;
+        for (int c = 0; c < NTP; ++c) {
+            const double *src = q.img + ((size_t)(pass * NTP + c) * NCH + ch) * CH * 64;
+            double *dst = th + ((cg & 1) * NTP + c) * CH * 64;
 #pragma unroll
-            for (int p = 0; p < (CH * 64 / 128 + 3) / 4; ++p) {
-                const int piece = wave + 4 * p;
+            for (int p = 0; p < (CH * 64 / 128 + 4 * HW - 1) / (4 * HW); ++p) {
+                const int piece = wave8 + 4 * HW * p;
                 if (piece < CH * 64 / 128)
                     __builtin_amdgcn_global_load_lds((mg_gvoid_t *)(src + piece * 128 + 2 * lane),
                                                      (mg_lvoid_t *)(dst + piece * 128), 16, 0, 0);
@@ -273,12 +281,12 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
         }
     };
     auto stage_consts = [&](int pass) {                    // the pass's 16 NCT x 4 constants -> cts[pass & 1]
-        constexpr int PIECES = (NCT * 64 + 127) / 128;
-        if (wave < PIECES) {
-            const double *src = q.ctab + (size_t)pass * NCT * 64 + wave * 128;
+        constexpr int PIECES = (NTP * 64 + 127) / 128;
+        if (wave8 < PIECES) {
+            const double *src = q.ctab + (size_t)pass * NTP * 64 + wave8 * 128;
             int o = 2 * lane;
-            if (NCT * 64 < 128 && o > NCT * 64 - 2) o = NCT * 64 - 2;
-            __builtin_amdgcn_global_load_lds((mg_gvoid_t *)(src + o), (mg_lvoid_t *)(cts + (pass & 1) * NCT * 64 + wave * 128),
+            if (NTP * 64 < 128 && o > NTP * 64 - 2) o = NTP * 64 - 2;
+            __builtin_amdgcn_global_load_lds((mg_gvoid_t *)(src + o), (mg_lvoid_t *)(cts + (pass & 1) * NTP * 64 + wave8 * 128),
                                              16, 0, 0);
         }
     };
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
 
     // ---- epilogue of one pass: a_nk from the forms, the pass's maximum and sums, u'
     auto epilogue = [&](int pass) {
-        const double *ct = cts + (pass & 1) * NCT * 64 + 4 * g;
+        const double *ct = cts + (pass & 1) * NTP * 64 + half * NCT * 64 + 4 * g;
         double Mp[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
         // The product already is the component's value a_nk [+ log w_k] for the Gauss and VB kinds (k_theta_build folds
         // their constants into the image); Student-t: t = 1 + maha / nu came out, a = (c0 + log w) + c1 log t
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kk = (pass * NCT + c) * 16 + g + 4 * r;
+                    const int kk = (pass * NTP + half * NCT + c) * 16 + g + 4 * r;
                     const bool st = emit && tile_live && kk < K;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
             // the pass's maximum waits in the factor's place (every group of 16 of the pass has the same)
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
-                if (pass * NCT + c < G) gs[(size_t)(pass * NCT + c) * 64] = Mo;
+                if (pass * NTP + half * NCT + c < G) gs[(size_t)(pass * NTP + half * NCT + c) * 64] = Mo;
         }
     };
 
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
             constexpr int ch = s / CH, i = s % CH;
             static_for<0, NCT>([&](auto C_) {
                 constexpr int c = decltype(C_)::value;
-                constexpr int TH = 8 * ((((ch & 1) * NCT + c) * CH + i) * 64);
+                constexpr int TH = 8 * ((((ch & 1) * NTP + c) * CH + i) * 64);
                 mg_read64<TH>(tv[c][s % 3], tha);
             });
             if constexpr (s < NQ) {
@@ -480,41 +488,101 @@ __global__ __launch_bounds__(256) void k_mgemm(const PmcArgsQ q)
         });
     }
 
-    // ---- per sample (lane l = sample l): the row's log-sum-exp / normalisation, outputs, the groups' factors
-    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (kind == PMC_KIND_VB) {
-        // variational.pyx:748-755, :1003-1013
-        const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
-        const double swv = valid ? sw : 0.0;
-        const double norm_inv = 1. / srun;
-        sc[0] = swv * fma(tbrun, norm_inv, log_any(norm_inv));
-        if (emit && tile_live) {
-            const double f = swv * norm_inv;
-            for (int gg = 0; gg < G; ++gg)
-                gs[(size_t)gg * 64] = f * exp_clamped(max_f64(gs[(size_t)gg * 64] - Mrun, -1075.0), EC);
+    // ---- HW = 2: the two halves of a sample row meet -- half 1 hands its running maximum / sum / bound term to half 0
+    // through LDS (the theta buffers: behind the barrier nobody reads them any more)
+    double *xch = th;                                      // [4 tiles][64][4]
+    if constexpr (HW == 2) {
+        __syncthreads();
+        double *mine = xch + (size_t)(wave * 64 + lane) * 4;
+        if (half == 1) {
+            mine[0] = Mrun;
+            mine[1] = srun;
+            mine[2] = tbrun;
         }
-    } else {
-        const double lse = log_any(srun) + Mrun;          // _regularize.pyx:81
-        if (a.out != nullptr && valid) a.out[n] = lse;
-        double wn = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
-        if (a.log_target != nullptr && valid) {
-            const double tmp = a.log_target[n] - lse;     // importance_sampling.py:204
-            const double w = exp(tmp);                    // :207
-            a.weights[n] = w;
-            sc[0] = w;
-            sc[1] = (w != 0.0) ? w * tmp : 0.0;           // convergence.py:35-36 (zeros masked)
-            sc[2] = w * w;
-            sc[4] = (isinf(w) && !isinf(tmp)) ? 1.0 : 0.0;
-            if (emit) wn = w;
-        }
-        if (valid) sc[3] = (a.sample_w != nullptr) ? a.sample_w[n] * lse : lse;   // pmc.pyx:388-391
-        if (emit && tile_live) {
-            // pmc.pyx:36-41: rho = exp(log q_k) w_k / (exp(lse) + tiny), times the sample's weight
-            const double f = valid ? wn / (exp(lse) + TINY) : 0.0;
-            for (int gg = 0; gg < G; ++gg) gs[(size_t)gg * 64] = f * exp(gs[(size_t)gg * 64]);
+        __syncthreads();
+        if (half == 0) {
+            const double Mo = mine[0], so = mine[1], to = mine[2];
+            const double Mn = max_f64(Mo, Mrun);
+            const double ar = max_f64(Mrun - Mn, -1075.0), ag = max_f64(Mo - Mn, -1075.0);
+            const double cr = exp_clamped(ar, EC), cg = exp_clamped(ag, EC);
+            if (kind == PMC_KIND_VB) tbrun = cr * fma(ar, srun, tbrun) + cg * fma(ag, so, to);
+            srun = cr * srun + cg * so;
+            Mrun = Mn;
         }
     }
-    if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
+
+    // ---- per sample (lane l = sample l, half 0): the row's log-sum-exp / normalisation, outputs, the factor's row part
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double f = 0.0;                                        // VB: w_n / s (times exp(M_g - M) per group); else w_n / (exp(lse) + tiny)
+    if (half == 0) {
+        if (kind == PMC_KIND_VB) {
+            // variational.pyx:748-755, :1003-1013
+            const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+            const double swv = valid ? sw : 0.0;
+            const double norm_inv = 1. / srun;
+            sc[0] = swv * fma(tbrun, norm_inv, log_any(norm_inv));
+            f = swv * norm_inv;
+        } else {
+            const double lse = log_any(srun) + Mrun;      // _regularize.pyx:81
+            if (a.out != nullptr && valid) a.out[n] = lse;
+            double wn = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+            if (a.log_target != nullptr && valid) {
+                const double tmp = a.log_target[n] - lse; // importance_sampling.py:204
+                const double w = exp(tmp);                // :207
+                a.weights[n] = w;
+                sc[0] = w;
+                sc[1] = (w != 0.0) ? w * tmp : 0.0;       // convergence.py:35-36 (zeros masked)
+                sc[2] = w * w;
+                sc[4] = (isinf(w) && !isinf(tmp)) ? 1.0 : 0.0;
+                if (emit) wn = w;
+            }
+            if (valid) sc[3] = (a.sample_w != nullptr) ? a.sample_w[n] * lse : lse;   // pmc.pyx:388-391
+            // pmc.pyx:36-41: rho = exp(log q_k) w_k / (exp(lse) + tiny), times the sample's weight
+            if (emit) f = valid ? wn / (exp(lse) + TINY) : 0.0;
+        }
+    }
+    if (emit) {
+        if constexpr (HW == 2) {                           // (the row's part of the factors travels back to half 1)
+            double *mine = xch + (size_t)(wave * 64 + lane) * 4;
+            __syncthreads();
+            if (half == 0) {
+                mine[0] = f;
+                mine[1] = Mrun;
+            }
+            __syncthreads();
+            f = mine[0];
+            Mrun = mine[1];
+        }
+        if (tile_live) {
+            // every wavefront completes the factors of the groups it parked its maxima for
+            for (int gg = 0; gg < G; ++gg) {
+                if (HW == 2 && ((gg % NTP) / NCT) != half) continue;
+                if (kind == PMC_KIND_VB) gs[(size_t)gg * 64] = f * exp_clamped(max_f64(gs[(size_t)gg * 64] - Mrun, -1075.0), EC);
+                else gs[(size_t)gg * 64] = f * exp(gs[(size_t)gg * 64]);
+            }
+        }
+    }
+    if (a.partials != nullptr) {
+        if constexpr (HW == 1) {
+            block_scalars<5>(sc, a.partials);
+        } else {
+            __shared__ double red2[4][PMC_NSCALARS];       // (block_scalars' tree over the four half-0 wavefronts)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double v = wave_sum(sc[i]);
+                if (half == 0 && lane == 0) red2[wave][i] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < PMC_NSCALARS) {
+                double v = 0.0;
+                if (threadIdx.x < 5) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red2[w][threadIdx.x];
+                }
+                a.partials[(size_t)blockIdx.x * PMC_NSCALARS + threadIdx.x] = v;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -539,15 +607,15 @@ extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_theta_d, PMC_D, PMC_PADDED)(con
     }
 }
 
-template <int NCT> static hipError_t mgemm_launch(const PmcArgsQ &q, unsigned grid, hipStream_t st)
+template <int NCT, int HW> static hipError_t mgemm_launch(const PmcArgsQ &q, unsigned grid, hipStream_t st)
 {
     using C = MgCfg<D_>;
-    constexpr size_t lds = C::lds_bytes(NCT);
-    static_assert(lds + 512 <= 160 * 1024, "k_mgemm: the sample image and the theta buffers exceed the LDS");
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mgemm<D_, NCT>),
+    constexpr size_t lds = C::lds_bytes(NCT * HW);
+    static_assert(lds + 1024 <= 160 * 1024, "k_mgemm: the sample image and the theta buffers exceed the LDS");
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mgemm<D_, NCT, HW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (once != hipSuccess) return once;
-    hipLaunchKernelGGL((k_mgemm<D_, NCT>), dim3(grid), dim3(256), lds, st, q);
+    hipLaunchKernelGGL((k_mgemm<D_, NCT, HW>), dim3(grid), dim3(256 * HW), lds, st, q);
     return hipGetLastError();
 }
 
@@ -556,9 +624,15 @@ extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_mgemm_d, PMC_D, PMC_PADDED)(int
 {
     if constexpr (!MgCfg<D_>::ENABLED) return hipErrorNotSupported;
     else {
-        if (nct == 2) return mgemm_launch<2>(q, grid, st);
+        // nct = component tiles per PASS: 2 (one wavefront per SIMD, both tiles) or 4 -- as two wavefronts per SIMD with
+        // two tiles each (PMC_MGEMM_ONE_WAVE: one wavefront with all four, the A/B alternative)
+        if (nct == 2) return mgemm_launch<2, 1>(q, grid, st);
         if constexpr (MgCfg<D_>::NCT_MAX >= 4) {
-            if (nct == 4) return mgemm_launch<4>(q, grid, st);
+#ifdef PMC_MGEMM_ONE_WAVE
+            if (nct == 4) return mgemm_launch<4, 1>(q, grid, st);
+#else
+            if (nct == 4) return mgemm_launch<2, 2>(q, grid, st);
+#endif
         }
         return hipErrorInvalidValue;
     }
