@@ -39,6 +39,15 @@ int pmc_init(int device, pmc_ctx **out);
 /* Optional: join the ranks of a sharded run (collective; rank 0 draws the id with pmc_comm_unique_id and hands the
    PMC_COMM_ID_BYTES bytes to the others by its own means -- MPI_Bcast in a pypmc process). */
 int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id);
+/*
+ * The same sharded run with the one-shot exchange of pmc_hip.h (pmc_p2p_*: the ranks of ONE node; every rank writes its
+ * statistics vector into every peer's mailbox through HIP IPC and adds them in rank order) instead of the RCCL
+ * communicator: pmc_ctx_p2p_open creates this rank's mailbox (vectors of up to max_doubles: 8 + K (1 + D + D (D + 1) / 2)
+ * + 2 K for the largest K, D the context will see) and returns its PMC_P2P_HANDLE_BYTES bytes; the caller gathers all
+ * ranks' bytes in rank order (MPI_Allgather) and hands them to pmc_ctx_p2p_connect.  Collective; instead of pmc_ctx_join.
+ */
+int pmc_ctx_p2p_open(pmc_ctx *ctx, int rank, int world, int64_t max_doubles, void *h_handle);
+int pmc_ctx_p2p_connect(pmc_ctx *ctx, const void *h_handles);
 /* Frees the stream, the scratch and the communicator.  Handles made from the context must be freed first. */
 int pmc_shutdown(pmc_ctx *ctx);
 /*

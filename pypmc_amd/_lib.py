@@ -113,6 +113,8 @@ _ip = C.POINTER(C.c_int64)
 CTX_SIGNATURES = {
     "pmc_init": (_int, [_int, _pp]),
     "pmc_ctx_join": (_int, [_vp, _int, _int, _vp]),
+    "pmc_ctx_p2p_open": (_int, [_vp, _int, _int, _i64, _vp]),
+    "pmc_ctx_p2p_connect": (_int, [_vp, _vp]),
     "pmc_shutdown": (_int, [_vp]),
     "pmc_mixture_create": (_int, [_vp, _int, _int, _int, _dp, _dp, _dp, _dp, _dp, _pp]),
     "pmc_mixture_update": (_int, [_vp, _dp, _dp, _dp, _dp, _dp]),

@@ -84,6 +84,7 @@ struct pmc_ctx {
     int device;
     hipStream_t stream;
     pmc_comm *comm;
+    pmc_p2p *p2p;                 // the one-shot exchange (pmc_ctx_p2p_open / _connect) instead of the RCCL communicator
     std::recursive_mutex mu;      // calls of one context are serialised here: any thread may call, one at a time
     void *tuning;                 // this context's copy of the library options (pmc_ctx_configure)
     DevBuf ws, u, scratch, flat, pack, spack, aux, nk1, nk2, lat;
@@ -333,6 +334,7 @@ int means_pack(pmc_ctx *ctx, const std::vector<double> &shift, int K, int D)
 
 int allreduce(pmc_ctx *ctx, double *d_buf, int64_t n)
 {
+    if (ctx->p2p) return pmc_p2p_allreduce_sum(ctx->p2p, d_buf, n, ctx->stream);
     if (!ctx->comm) return PMC_OK;
     return pmc_comm_allreduce_sum(ctx->comm, d_buf, n, ctx->stream);
 }
@@ -352,6 +354,7 @@ int pmc_init(int device, pmc_ctx **out)
     pmc_ctx *ctx = new pmc_ctx();
     ctx->device = device;
     ctx->comm = nullptr;
+    ctx->p2p = nullptr;
     ctx->stream = nullptr;
     ctx->tuning = pmc_internal_tuning_new();
     const hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -372,6 +375,23 @@ int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id)
     return pmc_comm_init(rank, world, h_id, ctx->device, &ctx->comm);
 }
 
+int pmc_ctx_p2p_open(pmc_ctx *ctx, int rank, int world, int64_t max_doubles, void *h_handle)
+{
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    if (ctx->comm || ctx->p2p) return failf(PMC_EINVAL, "pmc_ctx_p2p_open: the context has an exchange already");
+    CK(pmc_p2p_create(rank, world, max_doubles, ctx->device, &ctx->p2p));
+    return pmc_p2p_handle(ctx->p2p, h_handle);
+}
+
+int pmc_ctx_p2p_connect(pmc_ctx *ctx, const void *h_handles)
+{
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    if (!ctx->p2p) return failf(PMC_EINVAL, "pmc_ctx_p2p_connect: call pmc_ctx_p2p_open first");
+    return pmc_p2p_connect(ctx->p2p, h_handles);
+}
+
 int pmc_shutdown(pmc_ctx *ctx)
 {
     if (!ctx) return PMC_OK;
@@ -379,6 +399,7 @@ int pmc_shutdown(pmc_ctx *ctx)
     int rc = PMC_OK;
     ctx->mu.lock();                                                 // (a call still running in another thread finishes first)
     if (ctx->comm) rc = pmc_comm_destroy(ctx->comm);
+    if (ctx->p2p) (void)pmc_p2p_destroy(ctx->p2p);
     for (DevBuf *b : {&ctx->ws, &ctx->u, &ctx->scratch, &ctx->flat, &ctx->pack, &ctx->spack, &ctx->aux, &ctx->nk1,
                       &ctx->nk2, &ctx->lat})
         b->release();

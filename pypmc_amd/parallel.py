@@ -109,6 +109,8 @@ def init_from_env(force=False):
             dist.init_process_group(backend, **extra)
     if os.environ.get("PMC_NATIVE_COLLECTIVE", "0") not in ("", "0"):
         enable_native_collective(local)
+    if os.environ.get("PMC_P2P_COLLECTIVE", "0") not in ("", "0"):
+        enable_p2p_collective(device=local)
     return dist.get_rank(), dist.get_world_size(), local
 
 
@@ -156,10 +158,12 @@ def disable_native_collective():
 
 def collective_name():
     """what sums the statistics buffer over the ranks: None (no group), 'nccl' / 'gloo' (torch.distributed's
-    backend) or 'rccl:libpmc_hip' (the library's own communicator)"""
+    backend), 'rccl:libpmc_hip' (the library's own RCCL communicator) or 'p2p:libpmc_hip' (its one-shot exchange)"""
     d = _dist()
     if d is None:
         return None
+    if _p2p is not None:
+        return "p2p:libpmc_hip"                          # (device buffers that fit the mailbox; the rest as below)
     return "rccl:libpmc_hip" if _native is not None else d.get_backend()
 
 
@@ -172,6 +176,64 @@ def _native_all_reduce(t):
     assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     _lib.check(lib.pmc_comm_allreduce_sum(comm, C.c_void_p(t.data_ptr()), t.numel(), stream), "pmc_comm_allreduce_sum")
+
+
+# ---- the one-shot exchange among the ranks of a node (include/pmc_hip.h: pmc_p2p_*), optional --------------------
+_p2p = None               # (ctypes handle of the pmc_p2p, the library, capacity in doubles)
+
+
+def enable_p2p_collective(max_doubles=1 << 18, device=None):
+    """Run the path's all-reduce of DEVICE buffers of up to ``max_doubles`` doubles as the library's one-shot exchange
+    (``pmc_p2p_allreduce_sum``: every rank writes its vector into a mailbox of every peer through HIP IPC and adds the
+    G vectors in rank order -- one hop instead of a ring's 2 (G - 1), bit-identical on all ranks and from run to run).
+    The ranks of ONE node; the existing process group only carries the 64-byte mailbox handles at set-up.  Opt-in
+    (``PMC_P2P_COLLECTIVE=1`` makes ``init_from_env`` call this): tested with several processes on one GPU; RCCL stays
+    the default for multi-GPU runs until a box with more than one GPU has timed both."""
+    global _p2p
+    d = _dist()
+    if d is None:
+        raise RuntimeError("enable_p2p_collective needs an initialised torch.distributed process group")
+    if _p2p is not None:
+        return
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    world, me = d.get_world_size(), d.get_rank()
+    h = C.c_void_p()
+    _lib.check(lib.pmc_p2p_create(me, world, int(max_doubles), dev, C.byref(h)), "pmc_p2p_create")
+    mine = (C.c_char * 64)()
+    _lib.check(lib.pmc_p2p_handle(h, C.cast(mine, C.c_void_p)), "pmc_p2p_handle")
+    where = torch.device("cuda", dev) if d.get_backend() == "nccl" else torch.device("cpu")
+    allh = torch.zeros(world * 64, dtype=torch.float64, device=where)      # (a sum all-reduce: every backend has one)
+    allh[me * 64:(me + 1) * 64] = torch.tensor(list(bytes(mine)), dtype=torch.float64, device=where)
+    d.all_reduce(allh, op=d.ReduceOp.SUM)
+    raw = bytes(int(v) for v in allh.cpu().tolist())
+    buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+    _lib.check(lib.pmc_p2p_connect(h, C.cast(buf, C.c_void_p)), "pmc_p2p_connect")
+    d.barrier()                                          # every mailbox is mapped everywhere before the first round
+    _p2p = (h, lib, int(max_doubles))
+
+
+def disable_p2p_collective():
+    global _p2p
+    if _p2p is not None:
+        h, lib, _ = _p2p
+        _p2p = None
+        d = _dist()
+        if d is not None:
+            d.barrier()                                  # nobody unmaps a mailbox a peer may still write to
+        lib.pmc_p2p_destroy(h)
+
+
+def _p2p_all_reduce(t):
+    import ctypes as C
+    import torch
+    from . import _lib
+    h, lib, _ = _p2p
+    stream = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    _lib.check(lib.pmc_p2p_allreduce_sum(h, C.c_void_p(t.data_ptr()), t.numel(), stream), "pmc_p2p_allreduce_sum")
 
 
 def _collective_device(d):
@@ -192,6 +254,10 @@ def all_reduce_sum(buf):
     if d is None:
         return buf
     import torch
+    if _p2p is not None and not isinstance(buf, np.ndarray) and buf.is_cuda and buf.is_contiguous() \
+            and buf.dtype == torch.float64 and buf.numel() <= _p2p[2]:
+        _p2p_all_reduce(buf)                            # the one-shot exchange (device buffers that fit the mailbox)
+        return buf
     if _native is not None:                             # the library's own communicator: always on the device
         cuda = torch.device("cuda", torch.cuda.current_device())
         if isinstance(buf, np.ndarray):

@@ -120,6 +120,8 @@ def run(rank, world, port, workdir, backend_kind="oracle", pg_backend="gloo"):
         from pypmc_amd import parallel
         if os.environ.get("PMC_NATIVE_COLLECTIVE", "0") not in ("", "0"):
             parallel.enable_native_collective(0)
+        if os.environ.get("PMC_P2P_COLLECTIVE", "0") not in ("", "0"):
+            parallel.enable_p2p_collective(device=0)
         if backend_kind == "hip":
             from pypmc_amd.backend import HipBackend
             be = HipBackend(0)
@@ -138,4 +140,5 @@ def run(rank, world, port, workdir, backend_kind="oracle", pg_backend="gloo"):
     finally:
         from pypmc_amd import parallel as _p
         _p.disable_native_collective()
+        _p.disable_p2p_collective()
         dist.destroy_process_group()

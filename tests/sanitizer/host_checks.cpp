@@ -299,6 +299,33 @@ int main()
         c.join();
         pmc_configure("stats_common_shift_limit", 1000.0);
     }
+    // the one-shot exchange: two "ranks" in this process (the stand-in's IPC handle carries the pointer), through the
+    // kernel-level entry points and through two contexts
+    {
+        pmc_p2p *a = nullptr, *b = nullptr;
+        unsigned char h[2 * PMC_P2P_HANDLE_BYTES];
+        EXPECT(pmc_p2p_create(0, 2, 1000, 0, &a) == PMC_OK && pmc_p2p_create(1, 2, 1000, 0, &b) == PMC_OK);
+        EXPECT(pmc_p2p_create(2, 2, 1000, 0, &b) == PMC_EINVAL && pmc_p2p_create(0, 17, 1000, 0, &b) == PMC_EINVAL);
+        EXPECT(pmc_p2p_handle(a, h) == PMC_OK && pmc_p2p_handle(b, h + PMC_P2P_HANDLE_BYTES) == PMC_OK);
+        Dev v(8 * 1000);
+        EXPECT(pmc_p2p_allreduce_sum(a, v.d(), 10, nullptr) == PMC_EINVAL);       // not connected
+        EXPECT(pmc_p2p_connect(a, h) == PMC_OK && pmc_p2p_connect(b, h) == PMC_OK && pmc_p2p_connect(b, h) == PMC_EINVAL);
+        EXPECT(pmc_p2p_allreduce_sum(a, v.d(), 1000, nullptr) == PMC_OK && pmc_p2p_allreduce_sum(b, v.d(), 1000, nullptr) == PMC_OK);
+        EXPECT(pmc_p2p_allreduce_sum(a, v.d(), 1025, nullptr) == PMC_EINVAL);
+        EXPECT(pmc_p2p_status(a, nullptr) == PMC_OK);
+        EXPECT(pmc_p2p_destroy(a) == PMC_OK && pmc_p2p_destroy(b) == PMC_OK && pmc_p2p_destroy(nullptr) == PMC_OK);
+        pmc_ctx *c0 = nullptr, *c1 = nullptr;
+        EXPECT(pmc_init(0, &c0) == PMC_OK && pmc_init(0, &c1) == PMC_OK);
+        EXPECT(pmc_ctx_p2p_connect(c0, h) == PMC_EINVAL);
+        EXPECT(pmc_ctx_p2p_open(c0, 0, 2, 5000, h) == PMC_OK && pmc_ctx_p2p_open(c1, 1, 2, 5000, h + PMC_P2P_HANDLE_BYTES) == PMC_OK);
+        EXPECT(pmc_ctx_p2p_open(c0, 0, 2, 5000, h) == PMC_EINVAL);
+        EXPECT(pmc_ctx_p2p_connect(c0, h) == PMC_OK && pmc_ctx_p2p_connect(c1, h) == PMC_OK);
+        double xs[6] = {0, 1, 2, 3, 4, 5}, wv[3] = {1, 1, 1}, mean[2];
+        pmc_samples *s0 = nullptr;
+        EXPECT(pmc_samples_upload(c0, xs, 3, 2, &s0) == PMC_OK);
+        EXPECT(pmc_weighted_moments(c0, s0, wv, 0, mean, nullptr) == PMC_OK);        // (its all-reduce goes through the mailboxes)
+        EXPECT(pmc_samples_free(s0) == PMC_OK && pmc_shutdown(c0) == PMC_OK && pmc_shutdown(c1) == PMC_OK);
+    }
     EXPECT(pmc_stub_leaked_streams() == 0);
     if (g_fail) {
         std::fprintf(stderr, "host_checks: %d check(s) failed\n", g_fail);
