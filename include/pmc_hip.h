@@ -340,8 +340,10 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
  * PMC_RB) of the SAME samples in the SAME order, with a_nk, rho [gamma and the dof sums] formed from the kept
  * values instead of new quadratic forms: d_pack describes the components to update (any subset of the
  * proposal's, its `column` entries naming their positions in the kept tiles, K_tiles = the proposal's
- * component count) and must hold the parameters the tiles were made with.  Results equal pmc_estep's
- * two-kernel path bit for bit.  d_u (K*ceil(N/64)*64 doubles) is required, d_vsums (2 K) for Student-t;
+ * component count) and must hold the parameters the tiles were made with.  The responsibilities equal those of
+ * pmc_responsibilities bit for bit, and so do the statistics wherever pmc_estep runs k_resp + the per-component
+ * statistics kernel; where pmc_estep takes its large-batch forms (grouped responsibilities, common-shift statistics,
+ * the matrix-product Mahalanobis forms) the two agree to rounding (1e-11 of each component's largest sum).  d_u (K*ceil(N/64)*64 doubles) is required, d_vsums (2 K) for Student-t;
  * d_stats, d_scalars, d_workspace as for pmc_estep.
  *
  * pmc_importance_weights_emit goes one step further for a proposal whose update is known to follow (every

@@ -374,3 +374,46 @@ def test_front_end_iteration_takes_the_form(be):
     np.testing.assert_allclose(a[1], b[1], rtol=1e-10, atol=1e-12)
     dg = np.sqrt(np.einsum('kii->ki', b[2]))
     assert (np.abs(a[2] - b[2]) / (dg[:, :, None] * dg[:, None, :])).max() < 1e-10
+
+
+def test_grouped_pair_completed_in_place_bit_for_bit(be, small):
+    """advice r3: a bitwise regression for the path behind grouped responsibilities.  When the statistics kernel that
+    applies the per-(sample, group) factors is not the one the shape gets, pmc_estep_from_u_grouped completes u in place
+    (k_apply_scale), sets the factors to one (k_reset_scale) and runs the per-component kernel: bit for bit the statistics
+    of pmc_sufficient_stats on the product u' f formed on the host (one multiplication per pair either way)."""
+    import ctypes as C
+    from pypmc_amd import _lib
+    D, K, N = 40, 64, 3000
+    mu, cov, w = mk(K, D, 91)
+    x, _ = draw(mu, cov, w, N, 10)
+    prop = gauss_set(mu, cov, w)[0]
+    target = gauss_set(*mk(3, D, 92))[0]
+    em = be.importance_weights(x, prop, target, emit=True)
+    assert report(be, N, K, D)["refused"] == 0
+    resp = em["responsibilities"]
+    tile, nt, ng = be.tile, (N + 63) // 64, (K + 15) // 16
+    vals = be.tohost(resp.data)[:nt * K * tile].reshape(nt, K, tile)
+    fac = be.tohost(resp.gscale)[:nt * ng * tile].reshape(nt, ng, tile)
+    assert not np.all(fac == 1.0)
+    complete = vals * np.repeat(fac, 16, axis=1)[:, :K, :]          # u = u' f, the same single product the kernel forms
+    ps = 1 + D + D * (D + 1) // 2
+    xd = be.asdevice(x)
+    ref = be.zeros(K * ps)
+    ud = be.asdevice(complete.reshape(-1))
+    _lib.check(be.lib.pmc_sufficient_stats(be._p(xd), N, D, be._p(be.pack(prop)), K, be._p(ud), be._p(ref),
+                                           be._p(be._workspace(N, K, D)), be._stream()), "pmc_sufficient_stats")
+    be.configure("stats_common_shift_min_k", 1e9)          # the common-shift statistics off: factors without their consumer
+    try:
+        got = be.tohost(be.estep_from_u(xd, prop, resp)["stats"])[8:8 + K * ps]
+    finally:
+        be.configure("stats_common_shift_min_k", 17)
+    np.testing.assert_array_equal(got, be.tohost(ref))
+    np.testing.assert_array_equal(be.tohost(resp.data)[:nt * K * tile].reshape(nt, K, tile), complete)
+    assert np.all(be.tohost(resp.gscale)[:nt * ng * tile] == 1.0)
+    # ... and a second use of the (now complete) pair gives the same bits
+    be.configure("stats_common_shift_min_k", 1e9)
+    try:
+        again = be.tohost(be.estep_from_u(xd, prop, resp)["stats"])[8:8 + K * ps]
+    finally:
+        be.configure("stats_common_shift_min_k", 17)
+    np.testing.assert_array_equal(again, got)
