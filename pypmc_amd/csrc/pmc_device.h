@@ -123,6 +123,80 @@ template <int D> __device__ __forceinline__ double mahalanobis(const double (&xv
     return maha;
 }
 
+// The same product with the scalar loads scheduled by hand (-DPMC_SP_GROUP=G, G = 1 or 2 lines of 8 coefficients per
+// group): a group's s_load_dwordx16 are issued one group ahead of their use into the other half of 2 G SGPR buffers.
+// Left to itself the compiler gives k_logpdf's first loop two or three buffers, but k_resp_groups' (and the target
+// mixture's) loop ONE: load, s_waitcnt, eight multiply-adds, load, ... -- every scalar-cache hit's latency in the open,
+// 29 times per component.  Scalar loads return out of order, so lgkmcnt(0) is the only wait there is and the distance
+// between issue and wait is what one group computes.  Same operations in the same order: same bits.
+typedef double sgpr8d __attribute__((ext_vector_type(8)));
+template <int BYTES> __device__ __forceinline__ void sp_issue(sgpr8d &r, cdouble *p)
+{
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(r) : "s"(p), "n"(BYTES));
+}
+__device__ __forceinline__ void sp_wait(sgpr8d &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+__device__ __forceinline__ void sp_wait(sgpr8d &a, sgpr8d &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+// `touch`: pull the component's lines into the scalar cache first (touch_component above) -- here with the first
+// group's loads already on their way and ONE wait for both (the register the touch loads land in stays reserved up to
+// that wait).
+template <int D, int G> __device__ __forceinline__ double mahalanobis_sp(const double (&xv)[D], cdouble *pk, bool touch)
+{
+    static_assert(G == 1 || G == 2, "one or two lines per group");
+    constexpr int T = D + D * (D + 1) / 2, NC = (T + 7) / 8, NG = (NC + G - 1) / G;
+    sgpr8d b[2][G];
+    auto issue = [&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        static_for<0, G>([&](auto E) {
+            constexpr int e = decltype(E)::value, c = g * G + e;
+            if constexpr (c < NC) sp_issue<c * 64>(b[g & 1][e], pk);
+        });
+    };
+    int landing = 0;
+    auto arrive = [&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        if constexpr (g == 0) {
+            if constexpr (G == 2 && 1 < NC)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0][0]), "+s"(b[0][1]), "+s"(landing));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0][0]), "+s"(landing));
+        } else if constexpr (G == 2 && g * G + 1 < NC) sp_wait(b[g & 1][0], b[g & 1][1]);
+        else sp_wait(b[g & 1][0]);
+    };
+    // coefficient number idx of the component (compile-time): waits for its group at the group's first element and
+    // sends the next group on its way
+    auto coef = [&](auto IDX) -> double {
+        constexpr int idx = decltype(IDX)::value, c = idx / 8, g = c / G;
+        if constexpr (idx % (8 * G) == 0) {
+            // (nothing crosses: the asm statements have no latency the scheduler knows of, and it would let the
+            //  arithmetic of a group drift behind the next wait)
+            __builtin_amdgcn_sched_barrier(0);
+            arrive(std::integral_constant<int, g>{});
+            if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return b[g & 1][c % G][idx % 8];
+    };
+    issue(std::integral_constant<int, 0>{});
+    if (touch) {                                          // workgroup-uniform
+        constexpr int LINES = pmc_pack_stride_c(D) * 8 / 64;
+        asm volatile(".set pmc_touch_i, 0\n .rept %2\n s_load_dword %0, %1, pmc_touch_i*64\n .set pmc_touch_i, pmc_touch_i+1\n .endr"
+                     : "+s"(landing) : "s"(pk), "n"(LINES) : "memory");
+    }
+    double d[D];
+    static_for<0, D>([&](auto J) { constexpr int j = decltype(J)::value; d[j] = xv[j] - coef(J); });
+    double maha = 0.0;
+    static_for<0, D>([&](auto I) {
+        constexpr int i = decltype(I)::value, base = D + i * D - i * (i - 1) / 2 - i;
+        double y = 0.0;
+        static_for<i, D>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            y = fma(coef(std::integral_constant<int, base + j>{}), d[j], y);
+        });
+        maha = fma(y, y, maha);
+    });
+    return maha;
+}
+
 // acc += coef[lane N of this lane's 16-lane row] * d  -- v_fmac_f64 with a DPP row broadcast on its first
 // source: a coefficient held ONCE per row in a VGPR feeds the FMA of all 64 lanes like an SGPR operand
 // would, at the full fp64 rate (scripts/microbench/dpp_f64.hip: 73 TFLOP/s against 68 with plain VGPR

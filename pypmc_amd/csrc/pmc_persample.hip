@@ -100,6 +100,18 @@ template <int D, bool PADDED, int ENGINE> struct MahaEngine {
     }
     __device__ __forceinline__ double eval(cdouble *pk, int)
     {
+        // D >= 8: the scalar loads scheduled by hand, one group of lines ahead (mahalanobis_sp, pmc_device.h).  ms per 4e6
+        // samples, responsibilities of K = 32 / 64 components, [compiler's schedule] -> one line ahead -> two lines:
+        //   D =  8  0.50 / 0.90 -> 0.50 / 0.87 -> 0.49 / 0.875      D = 20  1.285 / 2.455 -> 1.21 / 2.325 -> 1.23 / 2.31
+        //   D = 12  0.69 / 1.26 -> 0.665 / 1.18 -> 0.67 / 1.20      D = 24  1.76 / 3.75 -> 1.68 / 3.49 -> 1.64 / 3.43
+        //   D = 16  0.955 / 1.91 -> 0.895 / 1.75 -> 0.90 / 1.67     D = 30  2.68 / 5.48 -> 2.68 / 5.47 -> 2.41 / 5.05
+#ifndef PMC_SP_GROUP
+#define PMC_SP_GROUP ((D <= 12 || D == 20) ? 1 : 2)
+#endif
+        if constexpr (D >= 8 && PMC_SP_GROUP != 0) {
+            if (!resident && sync) component_sync();      // workgroup-uniform
+            return mahalanobis_sp<D, (PMC_SP_GROUP != 0 ? PMC_SP_GROUP : 1)>(xv, pk, !resident);
+        }
         if (!resident) {                                  // workgroup-uniform
             if (sync) component_sync();
             touch_component<D>(pk);
