@@ -4,7 +4,7 @@ of libpmc_hip.so (include/pmc_ctx.h) declared `cdef extern`, and the bodies of t
 call each, on the typed memoryviews the .pyx files already hold.
 
     GaussianInference.E_step                    pypmc/mix_adapt/variational.pyx:116-127
-    MixtureDensity.multi_evaluate               pypmc/density/mixture.pyx:112-156
+    MixtureDensity.multi_evaluate               pypmc/density/mixture.pyx:112-156 (and its `components=` mode, :153-156)
     gaussian_pmc (its N-sized part)             pypmc/mix_adapt/pmc.pyx:188-222
 
 Built and run by tests/test_gpu_cython_binding.py (cythonize + gcc, no HIP headers, no torch):
@@ -25,6 +25,8 @@ cdef extern from "pmc_ctx.h":
     int pmc_samples_upload(pmc_ctx *ctx, const double *x, long long N, int D, pmc_samples **out)
     int pmc_samples_free(pmc_samples *s)
     int pmc_mix_logpdf(const pmc_mix *mix, const pmc_samples *s, double *out, double *individual)
+    int pmc_mix_logpdf_components(const pmc_mix *mix, const pmc_samples *s, const int *components, int ncomponents,
+                                  double *individual)
     int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *sample_w, int K, const double *m, const double *W,
                      const double *nu, const double *beta, const double *ln_pi, const double *ln_lambda,
                      const double *shift, double *N_k, double *xbar, double *S, double *elogqz, double *r, double *log_rho)
@@ -104,6 +106,22 @@ def multi_evaluate(DeviceSamples x, double[::1] weights, double[:, ::1] mu, doub
     finally:
         pmc_mixture_destroy(mix)
     return np.asarray(out), np.asarray(individual)
+
+
+def multi_evaluate_components(DeviceSamples x, double[::1] weights, double[:, ::1] mu, double[:, :, ::1] inv_sigma,
+                              double[::1] log_norm, double[:, ::1] individual, int[::1] components):
+    """multi_evaluate(x, individual=individual, components=[...]) (mixture.pyx:153-156): only the listed components'
+    columns of ``individual`` are written, in place; returns None as the reference does in this mode"""
+    cdef int K = mu.shape[0], D = mu.shape[1]
+    cdef pmc_mix *mix = NULL
+    if individual.shape[0] != x.N or individual.shape[1] != K:
+        raise ValueError("individual must be N x K")
+    _check(pmc_mixture_create(_context(), 0, K, D, &weights[0], &mu[0, 0], &inv_sigma[0, 0, 0], &log_norm[0], NULL, &mix))
+    try:
+        _check(pmc_mix_logpdf_components(mix, x.handle, &components[0] if components.shape[0] else NULL,
+                                         <int>components.shape[0], &individual[0, 0]))
+    finally:
+        pmc_mixture_destroy(mix)
 
 
 def gaussian_pmc_sums(DeviceSamples x, double[::1] weights, double[:, ::1] mu, double[:, :, ::1] inv_sigma,

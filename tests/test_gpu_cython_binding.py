@@ -57,6 +57,14 @@ def test_binding_reproduces_the_reference(tmp_path):
         out, ind = b.multi_evaluate(x, c64(g["weights"]), c64(g["mu"]), c64(g["inv_sigma"]), c64(g["log_norm"]))
         assert np.max(np.abs(out - g["out"]) / np.abs(g["out"])) < 1e-10
         assert np.max(np.abs(ind - g["individual"]) / np.abs(g["individual"])) < 1e-10
+        # ... and its subset mode: the listed columns are written, the others keep the caller's values
+        sub = np.full_like(g["individual"], -7.25)
+        which = np.array([1, 5, 6, 15], dtype=np.int32)
+        assert b.multi_evaluate_components(x, c64(g["weights"]), c64(g["mu"]), c64(g["inv_sigma"]), c64(g["log_norm"]),
+                                           sub, which) is None
+        assert np.max(np.abs(sub[:, which] - g["individual"][:, which]) / np.abs(g["individual"][:, which])) < 1e-10
+        rest = np.setdiff1d(np.arange(sub.shape[1]), which)
+        assert (sub[:, rest] == -7.25).all()
         # gaussian_pmc
         g = load_golden("pmc_gauss_d5k4")
         x = b.DeviceSamples(c64(g["samples"]))
