@@ -131,7 +131,7 @@ def live_traffic(kernel, N, timeout=150):
             out = os.path.join(work, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--n", str(N),
-                   "--no-cpu-baseline", "--no-configs", "--no-traffic"]
+                   "--no-cpu-baseline", "--no-configs", "--no-traffic", "--prewarm", "0"]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE, text=True, timeout=timeout)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -332,6 +332,8 @@ def main():
     ap.add_argument("--n", "--samples-per-gpu", dest="n", type=int, default=10_000_000, help="samples per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm", type=int, default=25,
+                    help="untimed steps in front of the --warmup steps (the chip's clock settles in ~50 ms of load)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --n samples per GPU; strong: --n samples in total, sharded over the ranks")
     ap.add_argument("--force-dist", action="store_true",
@@ -435,6 +437,12 @@ def main():
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
+    # Clocks first: the chip needs ~50 ms of this load before its clock settles (under rocprofv3 the first calls of
+    # k_logpdf take 3.75, 3.57, 3.43, 3.39, 3.33 ms, from the sixth on 3.23-3.30: profiles/r04_bench_n1_kernel_stats.csv),
+    # so a short warm-up would put the ramp into the timed steps.  Untimed, the same step, reported as `prewarm_steps`.
+    # (a COUNT, not a duration: every rank must enter the step's collective the same number of times)
+    for _ in range(args.prewarm):
+        step()
     for _ in range(args.warmup):
         step()
     if grouped:
@@ -496,7 +504,7 @@ def main():
             "metric": "IS samples/sec + VB E-step samples/sec at N=1e7, K=32, D=20",
             "value": n_total / (ms_per_step * 1e-3),
             "unit": "samples/s through one IS weighting pass plus one VB E-step",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": args.prewarm, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "IS weights (K=32 Gauss proposal, K_t=4 Gauss target, perplexity/ESS sums) "

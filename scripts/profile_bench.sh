@@ -12,6 +12,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats"
     python "$R/bench.py" --no-cpu-baseline --no-traffic --no-configs > "$OUT/bench_profiled_stdout.json" 2> "$OUT/bench_profiled_stderr.log"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -o t -- \
-        python "$R/bench.py" --no-cpu-baseline --no-configs --no-traffic --steps 3 --warmup 1 > /dev/null 2> "$OUT/pmc_$c.log"
+        python "$R/bench.py" --no-cpu-baseline --no-configs --no-traffic --steps 3 --warmup 1 --prewarm 0 > /dev/null 2> "$OUT/pmc_$c.log"
 done
 find "$OUT" -name "*.csv" | head -20

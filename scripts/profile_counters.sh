@@ -10,6 +10,6 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_V
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
     i=$((i+1))
     timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pass$i" -o t -- \
-        python "$R/bench.py" --no-cpu-baseline --no-configs --no-traffic --steps 3 --warmup 1 > /dev/null 2> "$OUT/pass$i.log"
+        python "$R/bench.py" --no-cpu-baseline --no-configs --no-traffic --steps 3 --warmup 1 --prewarm 0 > /dev/null 2> "$OUT/pass$i.log"
     echo "pass $i rc=$?"
 done
