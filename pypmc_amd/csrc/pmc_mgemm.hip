@@ -268,7 +268,11 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
         double dsq = 0.0;
 #pragma unroll 8
         for (int j = 0; j < D; ++j) {
+#ifndef PMC_MG_AB_NOPRO
             const double v = j < a.dreal ? xr[j] - q.center[j] : 0.0;
+#else
+            const double v = 1e-3 * (double)(j + lane);
+#endif
             dw[j * RS + lane] = v;
             dsq = fma(v, v, dsq);
         }
@@ -430,7 +434,18 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
             if (kt * NCH + 1 < nchunks) stage(kt * NCH + 1);
             stage_consts(kt);
         }
+#ifndef PMC_MG_AB_NOEPI                                    // (A/B switches, timing only: scripts/mgemm_ab.sh)
         if (kt > 0) epilogue(kt - 1);                      // (behind the barrier: its stores are old when the next one waits)
+#else
+        if (kt > 0) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) srun += acc[c][t][r];
+        }
+#endif
         if (kt == npass) break;
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
@@ -441,12 +456,21 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
         auto fetch = [&](auto S_) {
             constexpr int s = decltype(S_)::value, set = s & 1;
             constexpr int ch = s / CH, i = s % CH;
+#ifdef PMC_MG_AB_NOTHREAD
+            if constexpr (s < 3)
+#endif
             static_for<0, NCT>([&](auto C_) {
                 constexpr int c = decltype(C_)::value;
                 constexpr int TH = 8 * ((((ch & 1) * NTP + c) * CH + i) * 64);
                 mg_read64<TH>(tv[c][s % 3], tha);
             });
-            if constexpr (s < NQ) {
+#ifdef PMC_MG_AB_NODREAD
+            constexpr bool dread = s < 2;
+#else
+            constexpr bool dread = true;
+#endif
+            if constexpr (!dread) {
+            } else if constexpr (s < NQ) {
                 constexpr int aa = s / ND, dlt = s % ND, b = aa + dlt, jq = b / Q, br = b - jq * Q;
                 static_for<0, 4>([&](auto T_) {
                     constexpr int t = decltype(T_)::value;
@@ -474,13 +498,21 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
             constexpr int s = decltype(S_)::value, set = s & 1, t = decltype(T_)::value;
             if constexpr (s < NQ) {
                 constexpr int aa = s / ND, dlt = s % ND;
+#ifdef PMC_MG_AB_NOMUL
+                z[set][t] = dlt == 0 ? ar[aa & 1][t] : bv[set][t];
+#else
                 z[set][t] = dlt == 0 ? ar[aa & 1][t] * ar[aa & 1][t] : ar[aa & 1][t] * bv[set][t];
+#endif
             } else if constexpr (s < NQ + Q) z[set][t] = bv[set][t];
             else z[set][t] = 1.0;
         };
         auto boundary = [&](auto S_) {                     // in front of the first fetch of a chunk (not the pass's first)
             constexpr int s = decltype(S_)::value;
+#ifdef PMC_MG_AB_NOBAR
+            if constexpr (false) {
+#else
             if constexpr (s % CH == 0 && s > 0) {
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 const int cg = kt * NCH + s / CH;
@@ -502,14 +534,28 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                 fetch(ic<s + 2>{});
             }
             __builtin_amdgcn_sched_barrier(0);
+            // The next step's four products in ONE block in front of this step's matrix instructions, not one behind every
+            // pair of them: v_mul_f64 runs on the units the fp64 matrix instructions run on, and every change between
+            // the two streams costs more than the multiply itself (D = 40, K = 128: 28.5 -> 27.1 ps per pair; behind the
+            // block of matrix instructions 27.5; without any products 26.0 -- scripts/mgemm_ab.sh).
+#if !defined(PMC_MG_MUL_INTERLEAVED) && !defined(PMC_MG_MUL_AFTER)
+            if constexpr (s + 1 < NSTEP) static_for<0, 4>([&](auto T_) { mul(ic<s + 1>{}, T_); });
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             static_for<0, 4>([&](auto T_) {
                 constexpr int t = decltype(T_)::value;
                 static_for<0, NCT>([&](auto C_) {
                     constexpr int c = decltype(C_)::value;
                     acc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[c][s % 3], z[s & 1][t], acc[c][t], 0, 0, 0);
                 });
+#if defined(PMC_MG_MUL_INTERLEAVED)
                 if constexpr (s + 1 < NSTEP) mul(ic<s + 1>{}, T_);
+#endif
             });
+#if defined(PMC_MG_MUL_AFTER)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s + 1 < NSTEP) static_for<0, 4>([&](auto T_) { mul(ic<s + 1>{}, T_); });
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     }
