@@ -231,14 +231,17 @@ def baseline_configs(be, reps=3, select=None):
         while time.perf_counter() - t_warm < 0.15:
             fn()
             torch.cuda.synchronize()
-        be.kernel_timings()
-        be.kernel_timing(True)
         ts = []
-        for _ in range(reps):
+        for _ in range(reps):                            # the wall time: without the library's event records ...
             t0 = time.perf_counter()
             fn()
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
+        be.kernel_timings()
+        be.kernel_timing(True)                           # ... the kernels' own times in a loop of their own
+        for _ in range(reps):
+            fn()
+            torch.cuda.synchronize()
         be.kernel_timing(False)
         kern = {k_: v["ms"] / reps for k_, v in be.kernel_timings().items()}
         return float(np.median(ts)), kern
@@ -579,13 +582,16 @@ def main():
                 while time.perf_counter() - t_w < 0.1:
                     share_step()
                 torch.cuda.synchronize()
-                be.kernel_timings()
-                be.kernel_timing(True)
                 t_s = time.perf_counter()
-                for _ in range(20):
+                for _ in range(20):                      # the wall time: without the library's event records ...
                     share_step()
                 torch.cuda.synchronize()
                 share_ms = (time.perf_counter() - t_s) / 20 * 1e3
+                be.kernel_timings()
+                be.kernel_timing(True)                   # ... the kernels' own times in a loop of their own
+                for _ in range(10):
+                    share_step()
+                torch.cuda.synchronize()
                 be.kernel_timing(False)
                 kt8 = {k_: v["ms"] / v["calls"] for k_, v in be.kernel_timings().items()}
                 e8_ms = kt8.get("k_resp", 0.0) + kt8.get("k_stats", 0.0) + kt8.get("k_estep_fused", 0.0)
