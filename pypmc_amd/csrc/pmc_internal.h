@@ -5,7 +5,13 @@
 
 constexpr int PMC_TILE = 64;       // samples per tile = one wavefront
 constexpr int PMC_NSCALARS = 8;    // per-launch scalar reductions
-constexpr int PMC_A_WAVES = 4;     // wavefronts (tiles) per workgroup in the per-sample kernels
+// (overridable for A/B builds of the whole library.  With the hand-scheduled scalar loads of round 4, ms at the headline
+//  for k_logpdf / k_resp_groups: 2 wavefronts 3.69 / 3.39, 4: 3.20 / 2.97, 8: 3.47 / 3.33 -- four share a scalar-cache
+//  fill behind one barrier per component; config 3: 9.2 / 6.7 / 9.0)
+#ifndef PMC_A_WAVES_N
+#define PMC_A_WAVES_N 4
+#endif
+constexpr int PMC_A_WAVES = PMC_A_WAVES_N;     // wavefronts (tiles) per workgroup in the per-sample kernels
 // k_resp parks its first components in LDS between its passes (pmc_resp_klds below) and the rest in the output buffer
 // fused small-D E-step (pmc_fused.hip): wavefronts per workgroup, components per wavefront in its
 // responsibility phase (so K <= PMC_F_WAVES / 2 * PMC_F_KQMAX = 32), largest compiled dimension
