@@ -966,11 +966,10 @@ int64_t pmc_stats_stride(int D)
     return pmc_stats_stride_c(D);
 }
 
-int64_t pmc_workspace_bytes(int64_t N, int K, int D)
+// bytes one call with exactly K components lays out (the regions' offsets are functions of (N, K): stats_geom / gemm_geom
+// halve their chunk counts where ceil(K / 32) steps up, so this is NOT monotone in K)
+static size_t workspace_bytes_exact(long long N, int K, const PmcKernelSet *ks)
 {
-    if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
-    const PmcKernelSet *ks = kernels_for(D);
-    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     const size_t stats = mgemm_offset(N, K, ks) + mgemm_bytes(N, K, ks);
     const size_t scal = scalar_partials_bytes(N) +
                         (size_t)ceil_div(N > 0 ? N : 1, PMC_TILE) * K * 2 * sizeof(double);
@@ -981,7 +980,29 @@ int64_t pmc_workspace_bytes(int64_t N, int K, int D)
                               (size_t)f.grid * f.tpr * K * 2) * sizeof(double);        // + Student-t dof sums
         if (fused > total) total = fused;
     }
-    return (int64_t)((total + 255) & ~(size_t)255);
+    return total;
+}
+
+// The documented contract sizes ONE workspace for the largest component count of a call ("workspace for max(K,
+// K_target)", pmc_importance_weights) while every launch places its regions by its own K: the size is therefore the
+// running maximum over all K' <= K (advice r4: D = 40, N = 2e5 laid out 62.1 MB for K = 32 and 36.3 MB for K = 33; a
+// proposal of 32 components weighted against a target of 33 wrote 25 MB past a workspace sized by the contract).
+int64_t pmc_workspace_bytes(int64_t N, int K, int D)
+{
+    if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_workspace_bytes: bad N/K");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
+    // (front-ends ask once per call: the last answer of this thread is kept; the options a geometry depends on are
+    //  compile-time tables of the kernel set, not pmc_configure's)
+    static thread_local struct { int64_t N; int K, D; int64_t bytes; } last = {-1, 0, 0, 0};
+    if (last.N == N && last.K == K && last.D == D) return last.bytes;
+    size_t total = 0;
+    for (int k = 1; k <= K; ++k) {
+        const size_t b = workspace_bytes_exact(N, k, ks);
+        if (b > total) total = b;
+    }
+    last = {N, K, D, (int64_t)((total + 255) & ~(size_t)255)};
+    return last.bytes;
 }
 
 int pmc_pack_components(int K, int D, const double *mu, const double *prec, const double *c0,

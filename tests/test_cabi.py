@@ -94,6 +94,19 @@ def test_host_side_entry_points():
     assert "component 1" in _lib.last_error()
 
 
+def test_workspace_bytes_is_monotone_in_the_component_count():
+    """One workspace serves every launch of a call that involves up to K components (a proposal and a larger target,
+    pmc_importance_weights): its size must not shrink when K grows (advice r4: the chunk counts of the statistics kernels
+    halve where ceil(K / 32) steps up, and the regions of a K = 32 launch did not fit the workspace of K = 33)."""
+    from pypmc_amd import _lib
+    lib = _lib.load()
+    for D in (2, 5, 20, 24, 32, 40, 48, 64, 70):
+        for N in (1, 1000, 65536, 200000, 10 ** 6):
+            sizes = [lib.pmc_workspace_bytes(N, K, D) for K in range(1, 140)]
+            assert all(s > 0 for s in sizes)
+            assert all(b >= a for a, b in zip(sizes, sizes[1:])), (D, N)
+
+
 def test_evaluate_once_entry_points_check_their_arguments():
     """pmc_maha_tiles_size and the argument checks of pmc_estep_from_tiles (they return before any launch)."""
     from pypmc_amd import _lib

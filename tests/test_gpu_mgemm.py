@@ -417,3 +417,37 @@ def test_grouped_pair_completed_in_place_bit_for_bit(be, small):
     finally:
         be.configure("stats_common_shift_min_k", 17)
     np.testing.assert_array_equal(again, got)
+
+
+@pytest.mark.parametrize("D,K,Kt,N", [(40, 32, 33, 200000), (32, 32, 40, 65536), (48, 64, 65, 70000), (40, 32, 33, 40000)])
+def test_target_with_more_components_than_the_proposal_on_a_fresh_workspace(orc, D, K, Kt, N):
+    """advice r4: the workspace is sized for max(K, K_target) while the matrix-product form places its region by the
+    PROPOSAL's K, and the layout was not monotone in K (K = 32 needed 62 MB, K = 33 36 MB at D = 40, N = 2e5): 25 MB were
+    written past the allocation.  A fresh backend (a workspace of exactly the contract's size) with a poisoned fence
+    behind it: nothing beyond pmc_workspace_bytes(N, max(K, K_target), D) may be touched, and the weights are right."""
+    import torch
+    from pypmc_amd.backend import HipBackend
+    b = HipBackend()
+    need = int(b.lib.pmc_workspace_bytes(N, max(K, Kt), D))
+    assert need >= int(b.lib.pmc_workspace_bytes(N, K, D))
+    fence = 1 << 20
+    raw = torch.full((need + fence,), 0x5a, dtype=torch.uint8, device=b.device)
+    key = torch.cuda.current_stream(b.device).cuda_stream
+    b._ws[key] = raw[:need]                              # the workspace the calls below get: exactly the contract's size
+    mu, cov, w = mk(K, D, 900 + D + K)
+    x, _ = draw(mu, cov, w, N, 23)
+    tmu, tcov, tw = mk(Kt, D, 91)
+    prop, inv, ln = gauss_set(mu, cov, w)
+    target, tinv, tln = gauss_set(0.5 * tmu, tcov, tw)
+    res = b.importance_weights(x, prop, target, want_out=True, want_log_target=True)
+    torch.cuda.synchronize()
+    assert b._ws[key].data_ptr() == raw.data_ptr(), "the backend replaced the workspace"
+    assert bool((raw[need:] == 0x5a).all()), "bytes behind the workspace were written"
+    rep = b.maha_gemm_report(N, K, D)
+    assert rep is not None and rep["refused"] == 0
+    sub = slice(0, N, max(N // 3000, 1))
+    logq, _ = orc.mixture_multi_evaluate(0, x[sub], w, mu, inv, ln)
+    logp, _ = orc.mixture_multi_evaluate(0, x[sub], tw, 0.5 * tmu, tinv, tln)
+    assert_rel(b.tohost(res["out"])[sub], logq, what="log q")
+    assert_rel(b.tohost(res["log_target"])[sub], logp, what="log P")
+    assert_rel(b.tohost(res["weights"])[sub], orc.is_weights(logp, logq), what="weights")
