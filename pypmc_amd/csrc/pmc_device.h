@@ -244,8 +244,18 @@ __device__ __forceinline__ double zero_to_tiny(double r)
 // degree-7 minimax R of the freely distributable fdlibm e_log.c (error < 1 ulp), the division as a reciprocal with
 // two Newton steps and one residual correction.  38 vector instructions; the device library's log is a
 // double-double evaluation of 88 (most of what a Student-t pair costs beyond a Gaussian one: D = 8 +75 %, D = 20
-// +28 % before).  t = inf gives NaN where log gives inf (a Mahalanobis form beyond 1e308), NaN stays NaN.
+// +28 % before).  t = +inf (a Mahalanobis form beyond 1e308: the reference's log gives +inf and the component's value
+// -inf, student_t.pyx:159-164) falls through the reduction as NaN and is put right behind it: one v_cmp_class per call,
+// the select only in a wavefront that holds such a lane.  NaN stays NaN.
+__device__ __forceinline__ double log_pos_finite(double t);
 __device__ __forceinline__ double log_pos(double t)
+{
+    double r = log_pos_finite(t);
+    const bool pinf = __builtin_amdgcn_class(t, 0x200);                 // +infinity
+    if (__builtin_expect(__any(pinf), 0)) r = pinf ? t : r;
+    return r;
+}
+__device__ __forceinline__ double log_pos_finite(double t)
 {
 #ifdef PMC_LIBM_LOG
     return log(t);
@@ -280,7 +290,7 @@ __device__ __forceinline__ double log_pos(double t)
 // positive normal number -- the rule; the library's otherwise (a row sum that underflowed to 0 must give -inf).
 __device__ __forceinline__ double log_any(double t)
 {
-    if (__all(t >= 2.2250738585072014e-308 && t <= DBL_MAX)) return log_pos(t);      // (a NaN fails the test)
+    if (__all(t >= 2.2250738585072014e-308 && t <= DBL_MAX)) return log_pos_finite(t);      // (a NaN fails the test)
     return log(t);
 }
 

@@ -66,7 +66,7 @@ __device__ __forceinline__ void normal_pair(const Philox &g, unsigned long long 
 #else
     // u1 is a positive normal number (>= 2^-53): the lean log; the angle 2 pi u2 as a multiple of pi needs no
     // range reduction against pi at all
-    const double rad = sqrt(-2.0 * log_pos(u1));
+    const double rad = sqrt(-2.0 * log_pos_finite(u1));
     double s, c;
     sincospi(2.0 * u2, &s, &c);
 #endif

@@ -792,3 +792,34 @@ def test_many_components(be, orc, D, K, N):
     assert_rel(got[normal], rho[normal], what="rho")
     S0 = split_stats(be.tohost(be.estep(x, cs, 1, sample_w=iw)["stats"]), K, D)[1]
     np.testing.assert_allclose(S0, (iw[:, None] * rho).sum(axis=0), rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("D,K", [(1, 2), (4, 3), (20, 4), (30, 8), (40, 5), (70, 2)])
+def test_student_t_component_whose_mahalanobis_form_overflows(be, orc, D, K):
+    """verdict r4: a point 1e160 from a Student-t component -- maha = 1e320 = inf, log(1 + maha / nu) = +inf, the
+    component's value -inf (student_t.pyx:159-164), the mixture's value -inf when every component's form overflows
+    (_regularize.pyx:72-81).  ONE far coordinate per such row: the reference's bilinear form (_linalg.pyx:32-37) then
+    adds finite cross terms to an infinite square and overflows cleanly (with two far coordinates it multiplies
+    inf by M_ij and subtracts infinities -- NaN, an artefact of its summation that |R d|^2 does not share, and not
+    compared here).  Against the oracle, -inf for -inf."""
+    rs = np.random.RandomState(50 + D)
+    mu, cov, w = mk(K, D, 60 + D)
+    dof = rs.uniform(2., 9., K)
+    cs, inv, ln, pf, idf = student_set(mu, cov, w, dof)
+    x, _ = draw(mu, cov, w, 300, 3)
+    far = np.arange(0, 300, 7)
+    x[far, rs.randint(0, D, len(far))] = 1e160 * rs.choice([-1., 1.], len(far))
+    with np.errstate(all="ignore"):
+        ref, ref_ind = orc.mixture_multi_evaluate(1, x, w, mu, inv, ln, pf, idf)
+    assert np.isneginf(ref_ind[far]).all() and np.isneginf(ref[far]).all() and not np.isnan(ref_ind).any()
+    res = be.logpdf(x, cs, want_individual=True)
+    ind, out = be.tohost(res["individual"]), be.tohost(res["out"])
+    assert_rel(ind, ref_ind, what="a_nk with overflowing forms")
+    assert_rel(out, ref, what="log q with overflowing forms")
+    assert np.isneginf(out[far]).all()
+    # importance weights of the all-overflow rows: exp(log P - (-inf)) = inf; the finite rows are untouched
+    lt = rs.normal(size=300)
+    wts = be.tohost(be.logpdf(x, cs, log_target=lt, want_scalars=True)["weights"])
+    ok = np.isfinite(ref)
+    assert_rel(wts[ok], np.exp(lt[ok] - ref[ok]), what="weights of the finite rows")
+    assert np.isposinf(wts[~ok]).all()
