@@ -34,8 +34,29 @@ typedef struct pmc_mix pmc_mix;
 typedef struct pmc_samples pmc_samples;
 
 /* ---- context ---------------------------------------------------------------------------------------- */
-/* One context per process and GPU: selects `device`, creates the stream every call of this header runs on. */
+/*
+ * a context over the GPUs of one node for ONE host process -- the way pypmc's callers run (a single
+ * Python process, pypmc/examples/pmc.py:53-73, examples/variational.py:54-61; its only multi-process code gathers whole
+ * sample histories over MPI, pypmc/tools/parallel_sampler.py:58-66).
+ *   n_devices, device_ids   the devices, in the order their shares are summed; n_devices = 0: the list in the
+ *                           environment variable PMC_HIP_DEVICES ("0,1,2,3"), or every visible device.  The same
+ *                           ordinal may appear more than once: virtual shards on one GPU, each with its own stream and
+ *                           scratch (how the sharded path is tested and profiled on a one-GPU box).
+ * The context owns one stream, one scratch set and one host thread per device.  pmc_samples_upload / _generate split
+ * the rows into contiguous blocks (sizes differ by at most one, device order = row order; the library owns them);
+ * pmc_mixture_create / _update copy the pack to every device; every N-sized call runs on all devices at once and the
+ * K-sized vectors are added IN DEVICE ORDER -- each device's vector is copied into its slot on the first device (peer
+ * copy over xGMI) and one kernel forms ((v_0 + v_1) + v_2) + ... -- so the result is bit-reproducible, and equal to the
+ * ordered sum of the per-shard results of one-device contexts.  No IPC, no RCCL, no second process.  pmc_ctx_join on
+ * top of it sums over the ranks of a multi-node run as before (the first device holds the communicator).
+ * pmc_init(device, &ctx) is pmc_init_devices(1, &device, &ctx).
+ * PMC_HIP_LOG=1: one line per N-sized call on stderr (samples, devices, milliseconds, samples per second).
+ */
+int pmc_init_devices(int n_devices, const int *device_ids, pmc_ctx **out);
 int pmc_init(int device, pmc_ctx **out);
+/* number of parts of the context; their device ordinals (returns the count, writes at most max_ids) */
+int pmc_ctx_device_count(const pmc_ctx *ctx);
+int pmc_ctx_devices(const pmc_ctx *ctx, int *h_device_ids, int max_ids);
 /* Optional: join the ranks of a sharded run (collective; rank 0 draws the id with pmc_comm_unique_id and hands the
    PMC_COMM_ID_BYTES bytes to the others by its own means -- MPI_Bcast in a pypmc process). */
 int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id);
@@ -47,6 +68,8 @@ int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id);
  * ranks' bytes in rank order (MPI_Allgather) and hands them to pmc_ctx_p2p_connect.  Collective; instead of pmc_ctx_join.
  */
 int pmc_ctx_p2p_open(pmc_ctx *ctx, int rank, int world, int64_t max_doubles, void *h_handle);
+/* (a negative status -- no peer path, another host, a failed self-test, pmc_hip.h -- leaves the context WITHOUT an exchange:
+   join an RCCL communicator instead, on all ranks) */
 int pmc_ctx_p2p_connect(pmc_ctx *ctx, const void *h_handles);
 /* Frees the stream, the scratch and the communicator.  Handles made from the context must be freed first. */
 int pmc_shutdown(pmc_ctx *ctx);
@@ -60,6 +83,8 @@ int pmc_ctx_configure(pmc_ctx *ctx, const char *key, double value);
  * Kernel timing of this context's launches only (HIP events on the context's stream around every hot kernel, see
  * pmc_get_timings in pmc_hip.h for the entries' meaning): enable, run calls, read.  Independent of the process-wide
  * pmc_timing_enable / pmc_get_timings, which never see a context's records while its own timing is on.
+ * A context of several devices merges its parts' records by kernel name: calls, flops and bytes added, ms = the slowest
+ * part's (the parts run side by side).
  */
 int pmc_ctx_timing_enable(pmc_ctx *ctx, int on);
 int pmc_ctx_get_timings(pmc_ctx *ctx, pmc_timing *h_out, int max_entries, int *n_entries);
@@ -83,7 +108,8 @@ int pmc_mixture_update(pmc_mix *mix, const double *h_w, const double *h_mu, cons
 int pmc_mixture_destroy(pmc_mix *mix);
 
 /* ---- samples ------------------------------------------------------------------------------------------ */
-/* This rank's N x D block of the sample array, resident on the device until freed (History's samples[-1]). */
+/* This rank's N x D block of the sample array, resident on the device(s) until freed (History's samples[-1]); a context
+   of several devices holds contiguous blocks of it, device order = row order (pmc_samples_shard). */
 int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_samples **out);
 /*
  * MixtureDensity.propose(N, trace=True, shuffle=False) on the device (mixture.pyx:159-212): h_counts (K) are the
@@ -96,6 +122,8 @@ int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_sa
 int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol, const int64_t *h_counts,
                          uint64_t seed, int64_t first_sample, pmc_samples **out);
 int64_t pmc_samples_count(const pmc_samples *s);
+/* rows [*begin, *begin + *count) live on part `part` of the context; returns that part's device ordinal */
+int pmc_samples_shard(const pmc_samples *s, int part, int64_t *begin, int64_t *count);
 int pmc_samples_download(const pmc_samples *s, double *h_x);
 int pmc_samples_origin(const pmc_samples *s, int64_t *h_origin);
 int pmc_samples_free(pmc_samples *s);

@@ -307,6 +307,19 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *                                Rao-Blackwell PMC).  0 never, 1 where it is faster (compiled D <= 16, 20, 32, 40;
  *                                D = 24 from K = 128 on), 2 always.  The workspace holds the factors (8 ceil(K/16) bytes per sample).
  * pmc_sufficient_stats itself always takes its moments about the pack's own shifts.
+ *
+ * Two things a caller should know about these large-batch forms (verdict r4):
+ *   1. The selection depends on the BATCH SIZE (grouped responsibilities / common-shift statistics from
+ *      N * ceil(K / 32) >= 524288, the matrix-product Mahalanobis forms from N >= 32768), and each form agrees with the
+ *      exact kernels to ~1e-11 relative, not bit for bit.  Results are bit-reproducible from run to run for the SAME
+ *      shard sizes; a rank or device count that moves a shard across a threshold changes low-order bits of the
+ *      statistics (well inside the 1e-10 contract).  pmc_configure can pin either form on or off if bit-identity
+ *      across different shardings matters more than speed.
+ *   2. The grouped responsibilities do not materialise r_nk, and with that the reference's clamp r == 0 -> tiny
+ *      (variational.pyx:751-753) is applied only to a pair whose exp underflows within its OWN group of 16; a pair that
+ *      underflows only against the row maximum of another group contributes 0 instead of 2.2e-308 to N_k / x-bar_k / S_k
+ *      (at most N * 2.2e-308 per sum -- far below one ulp of any sum that matters).  pmc_responsibilities -- the
+ *      form that writes r -- applies the clamp exactly as the reference does.
  */
 int pmc_configure(const char *key, double value);
 int pmc_estep_is_fused(int K, int D, int kind, int mode);
@@ -446,18 +459,30 @@ int pmc_comm_destroy(pmc_comm *comm);
  * mailbox holds vectors of up to max_doubles), hands its PMC_P2P_HANDLE_BYTES bytes (pmc_p2p_handle) to all ranks by the
  * caller's own means (MPI_Allgather, a file, torch.distributed), and calls pmc_p2p_connect with the world x
  * PMC_P2P_HANDLE_BYTES bytes of all ranks in rank order.  The ranks must call pmc_p2p_allreduce_sum in the same order
- * with the same n; launches are asynchronous on `stream`.  A rank whose peers do not arrive within PMC_P2P_TIMEOUT_S
- * seconds (environment, default 20) gives up without a result; pmc_p2p_status (synchronises) reports it.
+ * with the same n; launches are asynchronous on `stream`.
+ *
+ * Safety (round 5).  The mailbox is fine-grained device memory (coherent while kernels of several devices run; uncached
+ * or coarse-grained memory only where the runtime refuses it for IPC, or by PMC_P2P_MEMORY); the handle carries the
+ * owner's host and PCI bus id, and pmc_p2p_connect -- collective -- refuses peers on another host or without a peer path
+ * (hipDeviceCanAccessPeer), closes whatever it mapped when it fails, and ends with a SELF-TEST round (a known pattern per
+ * rank, the rank-ordered sum compared bit for bit; PMC_P2P_SELFTEST=0 skips it).  A failure is a negative status with the
+ * reason in pmc_last_error(): the caller then uses pmc_comm_* (RCCL) -- on ALL ranks, so the ranks must agree on the
+ * outcome by their own means (pypmc_amd.parallel: one min all-reduce of the ok flags).
+ * A rank whose peers do not arrive within PMC_P2P_TIMEOUT_S seconds (environment, default 20; values that are not
+ * positive numbers are ignored) fills d_buf with NaN -- never its own unreduced numbers -- and raises the exchange's error
+ * word (host memory): pmc_p2p_status (synchronises the stream) and the next pmc_p2p_allreduce_sum report it, and the
+ * exchange refuses all further rounds.  pmc_p2p_info: "memory=finegrained world=4 ... selftest=passed".
  * world <= 16; one node (HIP IPC); the processes need HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts with dmabuf IPC only.
  * Replaces nothing by default: pmc_comm_allreduce_sum (RCCL) stays the default exchange.
  */
-#define PMC_P2P_HANDLE_BYTES 64
+#define PMC_P2P_HANDLE_BYTES 128
 typedef struct pmc_p2p pmc_p2p;
 int pmc_p2p_create(int rank, int world, int64_t max_doubles, int device, pmc_p2p **out);
 int pmc_p2p_handle(const pmc_p2p *p, void *h_handle);
 int pmc_p2p_connect(pmc_p2p *p, const void *h_handles);
 int pmc_p2p_allreduce_sum(pmc_p2p *p, double *d_buf, int64_t n, void *stream);
 int pmc_p2p_status(pmc_p2p *p, void *stream);
+int pmc_p2p_info(const pmc_p2p *p, char *buf, size_t buflen);
 int pmc_p2p_destroy(pmc_p2p *p);
 
 /* ---- kernel timing ----------------------------------------------------------------------------- */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pmc_p2p_connect": (_int, [_vp, _vp]),
     "pmc_p2p_allreduce_sum": (_int, [_vp, _vp, _i64, _vp]),
     "pmc_p2p_status": (_int, [_vp, _vp]),
+    "pmc_p2p_info": (_int, [_vp, C.c_char_p, C.c_size_t]),
     "pmc_p2p_destroy": (_int, [_vp]),
     "pmc_timing_enable": (_int, [_int]),
     "pmc_get_timings": (_int, [_vp, _int, C.POINTER(C.c_int)]),
@@ -112,6 +113,10 @@ _pp = C.POINTER(C.c_void_p)
 _ip = C.POINTER(C.c_int64)
 CTX_SIGNATURES = {
     "pmc_init": (_int, [_int, _pp]),
+    "pmc_init_devices": (_int, [_int, C.POINTER(C.c_int), _pp]),
+    "pmc_ctx_device_count": (_int, [_vp]),
+    "pmc_ctx_devices": (_int, [_vp, C.POINTER(C.c_int), _int]),
+    "pmc_samples_shard": (_int, [_vp, _int, _ip, _ip]),
     "pmc_ctx_join": (_int, [_vp, _int, _int, _vp]),
     "pmc_ctx_p2p_open": (_int, [_vp, _int, _int, _i64, _vp]),
     "pmc_ctx_p2p_connect": (_int, [_vp, _vp]),

@@ -8,13 +8,17 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
+#include <functional>
 #include <initializer_list>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -27,11 +31,14 @@ extern "C" int pmc_internal_tuning_set(void *, const char *key, double value);
 extern "C" void pmc_internal_tuning_use(const void *);
 extern "C" int pmc_internal_timing_stream(void *stream, int on);
 extern "C" int pmc_internal_get_timings(void *stream, pmc_timing *h_out, int max_entries, int *n_entries);
+// (pmc_p2p.hip) out[i] = ((slot_0[i] + slot_1[i]) + slot_2[i]) + ...: the sum over a context's devices, in device order
+extern "C" int pmc_internal_ordered_sum(const double *d_slots, int nslots, int64_t stride, int64_t n, double *d_out, void *stream);
 
 namespace {
 
 constexpr int NSC = 8;                                              // scalars in front of the statistics
 constexpr double TINY = 2.2250738585072014e-308;                    // numpy.finfo('d').tiny (_regularize.pyx:6-17)
+constexpr int MAX_PARTS = 64;
 
 int failf(int code, const char *fmt, ...)
 {
@@ -78,29 +85,73 @@ struct DevBuf {
     double *d() const { return (double *)p; }
 };
 
+// One device's share of a context: its stream and scratch.  A context over several devices (pmc_init_devices) gives
+// every part a host thread of its own that issues that part's copies and launches ("one host thread per
+// device"): a single thread issuing to eight devices would start the last one ~0.4 ms after the first, a quarter of an
+// E-step at the 8-way shard size.  The same device may appear more than once (virtual shards, each with its own stream
+// and scratch): that is how the sharded path is tested on a one-GPU box.
+struct Part {
+    int index = 0, device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf ws, u, scratch, flat, pack, spack, aux, nk1, nk2, lat;
+    // the worker (multi-part contexts only)
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    const std::function<int(Part &)> *job = nullptr;
+    bool pending = false, quit = false;
+    int rc = PMC_OK;
+    std::string err;
+    const void *tuning = nullptr;
+    void release_buffers()
+    {
+        for (DevBuf *b : {&ws, &u, &scratch, &flat, &pack, &spack, &aux, &nk1, &nk2, &lat}) b->release();
+    }
+};
+
+void worker_main(Part *p)
+{
+    (void)hipSetDevice(p->device);                                  // (the current device is a per-thread setting)
+    std::unique_lock<std::mutex> lk(p->m);
+    for (;;) {
+        p->cv.wait(lk, [p] { return p->pending || p->quit; });
+        if (p->quit) return;
+        pmc_internal_tuning_use(p->tuning);
+        int rc = (*p->job)(*p);
+        if (rc < 0) p->err = pmc_last_error();
+        pmc_internal_tuning_use(nullptr);
+        p->rc = rc;
+        p->pending = false;
+        p->cv.notify_all();
+    }
+}
+
 }  // namespace
 
 struct pmc_ctx {
-    int device;
-    hipStream_t stream;
-    pmc_comm *comm;
-    pmc_p2p *p2p;                 // the one-shot exchange (pmc_ctx_p2p_open / _connect) instead of the RCCL communicator
+    std::vector<Part *> parts;    // parts[0] holds the exchange with other ranks and the sum over this context's devices
+    pmc_comm *comm = nullptr;
+    pmc_p2p *p2p = nullptr;       // the one-shot exchange (pmc_ctx_p2p_open / _connect) instead of the RCCL communicator
     std::recursive_mutex mu;      // calls of one context are serialised here: any thread may call, one at a time
-    void *tuning;                 // this context's copy of the library options (pmc_ctx_configure)
-    DevBuf ws, u, scratch, flat, pack, spack, aux, nk1, nk2, lat;
+    void *tuning = nullptr;       // this context's copy of the library options (pmc_ctx_configure)
+    DevBuf slots;                 // on parts[0]'s device: one statistics vector per part, summed in part order
+    int log = 0;                  // PMC_HIP_LOG: one line per N-sized call on stderr (samples per second)
+    int nparts() const { return (int)parts.size(); }
 };
 struct pmc_mix {
     pmc_ctx *ctx;
     int family, K, D;
     std::vector<double> w, mu, inv_sigma, log_norm, dof;
-    DevBuf pack;                                                    // all K components, column k, weight w_k
+    std::vector<DevBuf> pack;                                       // per part: all K components, column k, weight w_k
 };
 struct pmc_samples {
     pmc_ctx *ctx;
     int64_t N;
     int D;
-    DevBuf x, w, origin;
+    std::vector<int64_t> begin;                                     // nparts + 1: part p holds rows [begin[p], begin[p + 1])
+    std::vector<DevBuf> x, w, origin;                               // per part
     bool has_w, has_origin;
+    int64_t n(int p) const { return begin[p + 1] - begin[p]; }
 };
 
 namespace {
@@ -123,31 +174,114 @@ struct CtxCall {
     CtxCall &operator=(const CtxCall &) = delete;
 };
 
+// one line per N-sized call when PMC_HIP_LOG is set (samples-per-second logging)
+struct CallLog {
+    const pmc_ctx *c;
+    const char *what;
+    int64_t N;
+    int K, D;
+    std::chrono::steady_clock::time_point t0;
+    CallLog(const pmc_ctx *c_, const char *w, int64_t N_, int K_, int D_) : c(c_), what(w), N(N_), K(K_), D(D_)
+    {
+        if (c->log) t0 = std::chrono::steady_clock::now();
+    }
+    ~CallLog()
+    {
+        if (!c->log) return;
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "[pmc_hip] %s: N=%lld K=%d D=%d on %d device%s: %.3f ms, %.3e samples/s\n", what, (long long)N, K, D,
+                     c->nparts(), c->nparts() == 1 ? "" : "s", 1e3 * s, s > 0 ? (double)N / s : 0.0);
+    }
+};
+
 int use(const pmc_ctx *ctx)
 {
     if (!ctx) return failf(PMC_EINVAL, "NULL context");
-    HK(hipSetDevice(ctx->device), "hipSetDevice");
+    HK(hipSetDevice(ctx->parts[0]->device), "hipSetDevice");
     return PMC_OK;
 }
-int h2d(pmc_ctx *ctx, void *dst, const void *src, size_t bytes)
+
+// fn(part) for every part of the context: inline for a one-device context, on the parts' own threads otherwise (the
+// caller waits for all of them; the first failing part's status and message are the call's)
+int for_parts(pmc_ctx *ctx, const std::function<int(Part &)> &fn)
+{
+    const int n = ctx->nparts();
+    if (n == 1) return fn(*ctx->parts[0]);
+    for (Part *p : ctx->parts) {
+        std::lock_guard<std::mutex> lk(p->m);
+        p->job = &fn;
+        p->tuning = ctx->tuning;
+        p->rc = PMC_OK;
+        p->pending = true;
+        p->cv.notify_all();
+    }
+    int rc = PMC_OK;
+    for (Part *p : ctx->parts) {
+        std::unique_lock<std::mutex> lk(p->m);
+        p->cv.wait(lk, [p] { return !p->pending; });
+        if (p->rc < 0 && rc == PMC_OK) rc = failf(p->rc, "device %d (part %d): %s", p->device, p->index, p->err.c_str());
+    }
+    return rc;
+}
+
+int h2d(Part &pt, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return PMC_OK;
-    HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync (host to device)");
-    HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");   // the source may be pageable and short-lived
+    HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pt.stream), "hipMemcpyAsync (host to device)");
+    HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");     // the source may be pageable and short-lived
     return PMC_OK;
 }
-int d2h(pmc_ctx *ctx, void *dst, const void *src, size_t bytes)
+int d2h(Part &pt, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return PMC_OK;
-    HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync (device to host)");
-    HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pt.stream), "hipMemcpyAsync (device to host)");
+    HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
     return PMC_OK;
 }
-int workspace(pmc_ctx *ctx, int64_t N, int K, int D)
+int workspace(Part &pt, int64_t N, int K, int D)
 {
     const int64_t need = pmc_workspace_bytes(N > 0 ? N : 1, K, D);
     if (need < 0) return (int)need;
-    return ctx->ws.ensure((size_t)need);
+    return pt.ws.ensure((size_t)need);
+}
+
+// Before the parts run a call whose K-sized result is summed: room for one vector of n doubles per part on parts[0]'s
+// device (a one-part context needs none: its vector is the sum)
+int prepare_slots(pmc_ctx *ctx, size_t n)
+{
+    if (ctx->nparts() == 1) return PMC_OK;
+    return ctx->slots.ensure(sizeof(double) * n * (size_t)ctx->nparts());
+}
+// End of a part's job: its vector (pt.flat, n doubles) into its slot on parts[0]'s device, and the part's stream drained
+int publish(pmc_ctx *ctx, Part &pt, const double *d_vec, size_t n)
+{
+    if (ctx->nparts() == 1) return PMC_OK;
+    Part &p0 = *ctx->parts[0];
+    double *dst = ctx->slots.d() + (size_t)pt.index * n;
+    if (pt.device == p0.device)
+        HK(hipMemcpyAsync(dst, d_vec, sizeof(double) * n, hipMemcpyDeviceToDevice, pt.stream), "hipMemcpyAsync (slot)");
+    else
+        HK(hipMemcpyPeerAsync(dst, p0.device, d_vec, pt.device, sizeof(double) * n, pt.stream), "hipMemcpyPeerAsync (slot)");
+    HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
+    return PMC_OK;
+}
+// After all parts have published: parts[0].flat[0 .. n) = the slots added in part order (on parts[0]'s stream), then the
+// sum over the ranks of a sharded run.  The calling thread's device is parts[0]'s.
+int reduce(pmc_ctx *ctx, double *d_out, size_t n)
+{
+    Part &p0 = *ctx->parts[0];
+    if (ctx->nparts() > 1) CK(pmc_internal_ordered_sum(ctx->slots.d(), ctx->nparts(), (int64_t)n, (int64_t)n, d_out, p0.stream));
+    if (ctx->p2p) return pmc_p2p_allreduce_sum(ctx->p2p, d_out, (int64_t)n, p0.stream);
+    if (ctx->comm) return pmc_comm_allreduce_sum(ctx->comm, d_out, (int64_t)n, p0.stream);
+    return PMC_OK;
+}
+
+// contiguous blocks of N rows over n parts (sizes differ by at most one; pypmc_amd.parallel.shard_bounds)
+void split_rows(int64_t N, int n, std::vector<int64_t> &begin)
+{
+    begin.assign((size_t)n + 1, 0);
+    const int64_t base = N / n, extra = N % n;
+    for (int p = 0; p < n; ++p) begin[p + 1] = begin[p] + base + (p < extra ? 1 : 0);
 }
 
 // psi(x) for x > 0: recurrence up to x >= 10, then the asymptotic series (|error| < 1e-15 there)
@@ -248,9 +382,12 @@ int load_mix(pmc_mix *m, const double *h_w, const double *h_mu, const double *h_
     std::vector<int> all(K);
     for (int k = 0; k < K; ++k) all[k] = k;
     std::vector<double> host;
-    CK(build_mix_pack(m, all, host));
-    CK(m->pack.ensure(host.size() * sizeof(double)));
-    return h2d(m->ctx, m->pack.p, host.data(), host.size() * sizeof(double));
+    CK(build_mix_pack(m, all, host));                               // once; every part gets a copy
+    return for_parts(m->ctx, [&](Part &pt) -> int {
+        DevBuf &pk = m->pack[pt.index];
+        CK(pk.ensure(host.size() * sizeof(double)));
+        return h2d(pt, pk.p, host.data(), host.size() * sizeof(double));
+    });
 }
 
 // K x (1 + D + D(D+1)/2) statistics (pmc_sufficient_stats' layout) -> S0, M1, full symmetric M2
@@ -322,21 +459,60 @@ void new_shifts(const std::vector<double> &S0, const std::vector<double> &M1, in
     }
 }
 
-int means_pack(pmc_ctx *ctx, const std::vector<double> &shift, int K, int D)
+// the K x D shifts of a statistics pass as a pack of means, built once per pass on the host
+int means_pack_host(const std::vector<double> &shift, int K, int D, std::vector<double> &host)
 {
     const int64_t stride = pmc_pack_stride(D);
     if (stride < 0) return (int)stride;
-    std::vector<double> host((size_t)K * stride);
-    CK(pmc_pack_means(K, D, shift.data(), host.data()));
-    CK(ctx->spack.ensure(host.size() * sizeof(double)));
-    return h2d(ctx, ctx->spack.p, host.data(), host.size() * sizeof(double));
+    host.resize((size_t)K * stride);
+    return pmc_pack_means(K, D, shift.data(), host.data());
+}
+int upload_spack(Part &pt, const std::vector<double> &host)
+{
+    CK(pt.spack.ensure(host.size() * sizeof(double)));
+    return h2d(pt, pt.spack.p, host.data(), host.size() * sizeof(double));
 }
 
-int allreduce(pmc_ctx *ctx, double *d_buf, int64_t n)
+int parse_devices(const char *text, std::vector<int> &ids)
 {
-    if (ctx->p2p) return pmc_p2p_allreduce_sum(ctx->p2p, d_buf, n, ctx->stream);
-    if (!ctx->comm) return PMC_OK;
-    return pmc_comm_allreduce_sum(ctx->comm, d_buf, n, ctx->stream);
+    ids.clear();
+    const char *c = text;
+    while (*c) {
+        while (*c == ' ' || *c == ',') ++c;
+        if (!*c) break;
+        char *end = nullptr;
+        const long v = std::strtol(c, &end, 10);
+        if (end == c || v < 0) return failf(PMC_EINVAL, "PMC_HIP_DEVICES: cannot read \"%s\" (a comma separated list of device ordinals)", text);
+        ids.push_back((int)v);
+        c = end;
+    }
+    return PMC_OK;
+}
+
+void destroy_ctx(pmc_ctx *ctx)
+{
+    for (Part *p : ctx->parts) {
+        if (p->th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(p->m);
+                p->quit = true;
+                p->cv.notify_all();
+            }
+            p->th.join();
+        }
+        (void)hipSetDevice(p->device);
+        p->release_buffers();
+        if (p->stream) {
+            (void)hipStreamSynchronize(p->stream);
+            (void)pmc_internal_timing_stream(p->stream, 0);
+            (void)pmc_stream_release(p->stream);                    // the library's per-stream scratch slot
+            (void)hipStreamDestroy(p->stream);
+        }
+        delete p;
+    }
+    ctx->parts.clear();
+    if (ctx->tuning) pmc_internal_tuning_free(ctx->tuning);
+    delete ctx;
 }
 
 }  // namespace
@@ -344,27 +520,70 @@ int allreduce(pmc_ctx *ctx, double *d_buf, int64_t n)
 extern "C" {
 
 // ---- context ----------------------------------------------------------------------------------------------
+int pmc_init_devices(int n_devices, const int *device_ids, pmc_ctx **out)
+{
+    if (!out || n_devices < 0 || (n_devices > 0 && !device_ids)) return failf(PMC_EINVAL, "pmc_init_devices: bad argument");
+    const int have = pmc_device_count();
+    if (have < 0) return have;
+    std::vector<int> ids;
+    if (n_devices > 0) {
+        ids.assign(device_ids, device_ids + n_devices);
+    } else if (const char *e = std::getenv("PMC_HIP_DEVICES")) {
+        CK(parse_devices(e, ids));
+    }
+    if (ids.empty())
+        for (int d = 0; d < have; ++d) ids.push_back(d);            // every visible device
+    if (ids.empty()) return failf(PMC_ENODEVICE, "pmc_init_devices: no HIP device");
+    if ((int)ids.size() > MAX_PARTS) return failf(PMC_EINVAL, "pmc_init_devices: at most %d parts", MAX_PARTS);
+    for (int d : ids)
+        if (d < 0 || d >= have) return failf(PMC_ENODEVICE, "pmc_init_devices: device %d of %d", d, have);
+    pmc_ctx *ctx = new pmc_ctx();
+    ctx->tuning = pmc_internal_tuning_new();
+    if (const char *e = std::getenv("PMC_HIP_LOG")) ctx->log = std::atoi(e);
+    for (size_t i = 0; i < ids.size(); ++i) {
+        Part *p = new Part();
+        p->index = (int)i;
+        p->device = ids[i];
+        ctx->parts.push_back(p);
+        hipError_t e = hipSetDevice(p->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            destroy_ctx(ctx);
+            return hipf(e, "pmc_init_devices: hipStreamCreateWithFlags");
+        }
+        // the part's vector goes to parts[0]'s device by a peer copy: directly over xGMI where the devices allow it
+        // (staged through the host by the runtime where they do not)
+        if (i > 0 && p->device != ids[0]) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, p->device, ids[0]) == hipSuccess && can) {
+                e = hipDeviceEnablePeerAccess(ids[0], 0);
+                if (e != hipSuccess) (void)hipGetLastError();       // (enabled already: fine)
+            }
+        }
+    }
+    if (ids.size() > 1)
+        for (Part *p : ctx->parts) p->th = std::thread(worker_main, p);
+    (void)hipSetDevice(ids[0]);
+    *out = ctx;
+    return PMC_OK;
+}
+
 int pmc_init(int device, pmc_ctx **out)
 {
     if (!out) return failf(PMC_EINVAL, "pmc_init: NULL output");
     const int n = pmc_device_count();
     if (n < 0) return n;
     if (device < 0 || device >= n) return failf(PMC_ENODEVICE, "pmc_init: device %d of %d", device, n);
-    HK(hipSetDevice(device), "hipSetDevice");
-    pmc_ctx *ctx = new pmc_ctx();
-    ctx->device = device;
-    ctx->comm = nullptr;
-    ctx->p2p = nullptr;
-    ctx->stream = nullptr;
-    ctx->tuning = pmc_internal_tuning_new();
-    const hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        pmc_internal_tuning_free(ctx->tuning);
-        delete ctx;
-        return hipf(e, "hipStreamCreateWithFlags");
-    }
-    *out = ctx;
-    return PMC_OK;
+    return pmc_init_devices(1, &device, out);
+}
+
+int pmc_ctx_device_count(const pmc_ctx *ctx) { return ctx ? ctx->nparts() : failf(PMC_EINVAL, "NULL context"); }
+
+int pmc_ctx_devices(const pmc_ctx *ctx, int *h_device_ids, int max_ids)
+{
+    if (!ctx || !h_device_ids) return failf(PMC_EINVAL, "pmc_ctx_devices: bad argument");
+    for (int p = 0; p < ctx->nparts() && p < max_ids; ++p) h_device_ids[p] = ctx->parts[p]->device;
+    return ctx->nparts();
 }
 
 int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id)
@@ -372,7 +591,7 @@ int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id)
     CK(use(ctx));
     CtxCall call_(ctx);
     if (ctx->comm) return failf(PMC_EINVAL, "pmc_ctx_join: the context has a communicator already");
-    return pmc_comm_init(rank, world, h_id, ctx->device, &ctx->comm);
+    return pmc_comm_init(rank, world, h_id, ctx->parts[0]->device, &ctx->comm);
 }
 
 int pmc_ctx_p2p_open(pmc_ctx *ctx, int rank, int world, int64_t max_doubles, void *h_handle)
@@ -380,7 +599,7 @@ int pmc_ctx_p2p_open(pmc_ctx *ctx, int rank, int world, int64_t max_doubles, voi
     CK(use(ctx));
     CtxCall call_(ctx);
     if (ctx->comm || ctx->p2p) return failf(PMC_EINVAL, "pmc_ctx_p2p_open: the context has an exchange already");
-    CK(pmc_p2p_create(rank, world, max_doubles, ctx->device, &ctx->p2p));
+    CK(pmc_p2p_create(rank, world, max_doubles, ctx->parts[0]->device, &ctx->p2p));
     return pmc_p2p_handle(ctx->p2p, h_handle);
 }
 
@@ -389,29 +608,25 @@ int pmc_ctx_p2p_connect(pmc_ctx *ctx, const void *h_handles)
     CK(use(ctx));
     CtxCall call_(ctx);
     if (!ctx->p2p) return failf(PMC_EINVAL, "pmc_ctx_p2p_connect: call pmc_ctx_p2p_open first");
-    return pmc_p2p_connect(ctx->p2p, h_handles);
+    const int rc = pmc_p2p_connect(ctx->p2p, h_handles);
+    if (rc < 0) {                                                   // (mapping, peer access or the self-test failed: no exchange
+        (void)pmc_p2p_destroy(ctx->p2p);                            //  is left half-open; the caller joins an RCCL communicator
+        ctx->p2p = nullptr;                                         //  instead, on ALL ranks)
+    }
+    return rc;
 }
 
 int pmc_shutdown(pmc_ctx *ctx)
 {
     if (!ctx) return PMC_OK;
-    (void)hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->parts[0]->device);
     int rc = PMC_OK;
     ctx->mu.lock();                                                 // (a call still running in another thread finishes first)
     if (ctx->comm) rc = pmc_comm_destroy(ctx->comm);
     if (ctx->p2p) (void)pmc_p2p_destroy(ctx->p2p);
-    for (DevBuf *b : {&ctx->ws, &ctx->u, &ctx->scratch, &ctx->flat, &ctx->pack, &ctx->spack, &ctx->aux, &ctx->nk1,
-                      &ctx->nk2, &ctx->lat})
-        b->release();
-    if (ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)pmc_internal_timing_stream(ctx->stream, 0);
-        (void)pmc_stream_release(ctx->stream);                     // the library's per-stream scratch slot
-        (void)hipStreamDestroy(ctx->stream);
-    }
-    pmc_internal_tuning_free(ctx->tuning);
+    ctx->slots.release();
     ctx->mu.unlock();
-    delete ctx;
+    destroy_ctx(ctx);
     return rc;
 }
 
@@ -430,10 +645,10 @@ int pmc_mixture_create(pmc_ctx *ctx, int family, int K, int D, const double *h_w
     m->family = family;
     m->K = K;
     m->D = D;
+    m->pack.resize((size_t)ctx->nparts());
     const int rc = load_mix(m, h_w, h_mu, h_inv_sigma, h_log_norm, h_dof);
     if (rc < 0) {
-        m->pack.release();
-        delete m;
+        (void)pmc_mixture_destroy(m);
         return rc;
     }
     *out = m;
@@ -452,30 +667,46 @@ int pmc_mixture_update(pmc_mix *mix, const double *h_w, const double *h_mu, cons
 int pmc_mixture_destroy(pmc_mix *mix)
 {
     if (!mix) return PMC_OK;
-    (void)hipSetDevice(mix->ctx->device);
     CtxCall call_(mix->ctx);
-    mix->pack.release();
+    for (int p = 0; p < mix->ctx->nparts(); ++p) {
+        (void)hipSetDevice(mix->ctx->parts[p]->device);
+        mix->pack[p].release();
+    }
+    (void)hipSetDevice(mix->ctx->parts[0]->device);
     delete mix;
     return PMC_OK;
 }
 
 // ---- samples ----------------------------------------------------------------------------------------------
+static pmc_samples *new_samples(pmc_ctx *ctx, int64_t N, int D)
+{
+    pmc_samples *s = new pmc_samples();
+    s->ctx = ctx;
+    s->N = N;
+    s->D = D;
+    s->has_w = s->has_origin = false;
+    const size_t n = (size_t)ctx->nparts();
+    split_rows(N, (int)n, s->begin);
+    s->x.resize(n);
+    s->w.resize(n);
+    s->origin.resize(n);
+    return s;
+}
+
 int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_samples **out)
 {
     CK(use(ctx));
     CtxCall call_(ctx);
     if (!out || N < 0 || D < 1 || (N > 0 && !h_x)) return failf(PMC_EINVAL, "pmc_samples_upload: bad argument");
     if (pmc_padded_dim(D) < 0) return PMC_EINVAL;
-    pmc_samples *s = new pmc_samples();
-    s->ctx = ctx;
-    s->N = N;
-    s->D = D;
-    s->has_w = s->has_origin = false;
-    int rc = s->x.ensure(sizeof(double) * (size_t)(N > 0 ? N : 1) * D);
-    if (rc == PMC_OK) rc = h2d(ctx, s->x.p, h_x, sizeof(double) * (size_t)N * D);
+    pmc_samples *s = new_samples(ctx, N, D);
+    const int rc = for_parts(ctx, [&](Part &pt) -> int {
+        const int64_t n = s->n(pt.index);
+        CK(s->x[pt.index].ensure(sizeof(double) * (size_t)(n > 0 ? n : 1) * D));
+        return h2d(pt, s->x[pt.index].p, h_x + (size_t)s->begin[pt.index] * D, sizeof(double) * (size_t)n * D);
+    });
     if (rc < 0) {
-        s->x.release();
-        delete s;
+        (void)pmc_samples_free(s);
         return rc;
     }
     *out = s;
@@ -503,31 +734,35 @@ int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol,
             if (!chol_of_inverse(&mix->inv_sigma[(size_t)k * D * D], D, &chol[(size_t)k * D * D]))
                 return failf(PMC_ENOTPOSDEF, "pmc_samples_generate: inv_sigma of component %d is not positive definite", k);
     }
-    // parameters: [mu K*D | chol K*D*D | dof K] doubles, then the K+1 offsets
-    const size_t nd = (size_t)K * D + (size_t)K * D * D + K;
-    CK(ctx->aux.ensure(nd * sizeof(double) + (K + 1) * sizeof(int64_t)));
-    double *d_mu = ctx->aux.d(), *d_chol = d_mu + (size_t)K * D, *d_dof = d_chol + (size_t)K * D * D;
-    int64_t *d_off = (int64_t *)(d_dof + K);
-    CK(h2d(ctx, d_mu, mix->mu.data(), sizeof(double) * (size_t)K * D));
-    CK(h2d(ctx, d_chol, chol.data(), sizeof(double) * chol.size()));
-    if (mix->family == PMC_KIND_STUDENT_T) CK(h2d(ctx, d_dof, mix->dof.data(), sizeof(double) * K));
-    CK(h2d(ctx, d_off, off.data(), sizeof(int64_t) * (K + 1)));
-    pmc_samples *s = new pmc_samples();
-    s->ctx = ctx;
-    s->N = N;
-    s->D = D;
-    s->has_w = false;
+    pmc_samples *s = new_samples(ctx, N, D);
     s->has_origin = true;
-    int rc = s->x.ensure(sizeof(double) * (size_t)(N > 0 ? N : 1) * D);
-    if (rc == PMC_OK) rc = s->origin.ensure(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
-    if (rc == PMC_OK && N > 0)
-        rc = pmc_propose(d_mu, d_chol, mix->family == PMC_KIND_STUDENT_T ? d_dof : nullptr, d_off, K, D, N, first_sample, seed,
-                         s->x.d(), (int64_t *)s->origin.p, ctx->stream);
-    if (rc == PMC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = failf(PMC_EHIP, "pmc_samples_generate: stream error");
+    CallLog log_(ctx, "pmc_samples_generate", N, K, D);
+    // The samples are ordered by component and numbered 0 ... N-1 (mixture.pyx:192-206); part p generates the rows
+    // [begin_p, begin_p+1): the counts clipped to that range, the random stream counted from first_sample + begin_p --
+    // the very numbers one device would have produced for those rows.
+    const int rc = for_parts(ctx, [&](Part &pt) -> int {
+        const int64_t b = s->begin[pt.index], e = s->begin[pt.index + 1], n = e - b;
+        std::vector<int64_t> loc(K + 1);
+        for (int k = 0; k <= K; ++k) loc[k] = (off[k] < b ? b : (off[k] > e ? e : off[k])) - b;
+        // parameters: [mu K*D | chol K*D*D | dof K] doubles, then the K+1 offsets
+        const size_t nd = (size_t)K * D + (size_t)K * D * D + K;
+        CK(pt.aux.ensure(nd * sizeof(double) + (K + 1) * sizeof(int64_t)));
+        double *d_mu = pt.aux.d(), *d_chol = d_mu + (size_t)K * D, *d_dof = d_chol + (size_t)K * D * D;
+        int64_t *d_off = (int64_t *)(d_dof + K);
+        CK(h2d(pt, d_mu, mix->mu.data(), sizeof(double) * (size_t)K * D));
+        CK(h2d(pt, d_chol, chol.data(), sizeof(double) * chol.size()));
+        if (mix->family == PMC_KIND_STUDENT_T) CK(h2d(pt, d_dof, mix->dof.data(), sizeof(double) * K));
+        CK(h2d(pt, d_off, loc.data(), sizeof(int64_t) * (K + 1)));
+        CK(s->x[pt.index].ensure(sizeof(double) * (size_t)(n > 0 ? n : 1) * D));
+        CK(s->origin[pt.index].ensure(sizeof(int64_t) * (size_t)(n > 0 ? n : 1)));
+        if (n > 0)
+            CK(pmc_propose(d_mu, d_chol, mix->family == PMC_KIND_STUDENT_T ? d_dof : nullptr, d_off, K, D, n, first_sample + b,
+                           seed, s->x[pt.index].d(), (int64_t *)s->origin[pt.index].p, pt.stream));
+        HK(hipStreamSynchronize(pt.stream), "pmc_samples_generate: stream");
+        return PMC_OK;
+    });
     if (rc < 0) {
-        s->x.release();
-        s->origin.release();
-        delete s;
+        (void)pmc_samples_free(s);
         return rc;
     }
     *out = s;
@@ -536,31 +771,46 @@ int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol,
 
 int64_t pmc_samples_count(const pmc_samples *s) { return s ? s->N : (int64_t)failf(PMC_EINVAL, "NULL samples"); }
 
+int pmc_samples_shard(const pmc_samples *s, int part, int64_t *begin, int64_t *count)
+{
+    if (!s || part < 0 || part >= s->ctx->nparts()) return failf(PMC_EINVAL, "pmc_samples_shard: bad argument");
+    if (begin) *begin = s->begin[part];
+    if (count) *count = s->n(part);
+    return s->ctx->parts[part]->device;
+}
+
 int pmc_samples_download(const pmc_samples *s, double *h_x)
 {
-    if (!s || !h_x) return failf(PMC_EINVAL, "pmc_samples_download: bad argument");
+    if (!s || (!h_x && s->N > 0)) return failf(PMC_EINVAL, "pmc_samples_download: bad argument");
     CK(use(s->ctx));
     CtxCall call_(s->ctx);
-    return d2h(s->ctx, h_x, s->x.p, sizeof(double) * (size_t)s->N * s->D);
+    return for_parts(s->ctx, [&](Part &pt) -> int {
+        return d2h(pt, h_x + (size_t)s->begin[pt.index] * s->D, s->x[pt.index].p, sizeof(double) * (size_t)s->n(pt.index) * s->D);
+    });
 }
 
 int pmc_samples_origin(const pmc_samples *s, int64_t *h_origin)
 {
-    if (!s || !h_origin) return failf(PMC_EINVAL, "pmc_samples_origin: bad argument");
+    if (!s || (!h_origin && s->N > 0)) return failf(PMC_EINVAL, "pmc_samples_origin: bad argument");
     if (!s->has_origin) return failf(PMC_EINVAL, "pmc_samples_origin: these samples were uploaded, not generated");
     CK(use(s->ctx));
     CtxCall call_(s->ctx);
-    return d2h(s->ctx, h_origin, s->origin.p, sizeof(int64_t) * (size_t)s->N);
+    return for_parts(s->ctx, [&](Part &pt) -> int {
+        return d2h(pt, h_origin + s->begin[pt.index], s->origin[pt.index].p, sizeof(int64_t) * (size_t)s->n(pt.index));
+    });
 }
 
 int pmc_samples_free(pmc_samples *s)
 {
     if (!s) return PMC_OK;
-    (void)hipSetDevice(s->ctx->device);
     CtxCall call_(s->ctx);
-    s->x.release();
-    s->w.release();
-    s->origin.release();
+    for (int p = 0; p < s->ctx->nparts(); ++p) {
+        (void)hipSetDevice(s->ctx->parts[p]->device);
+        s->x[p].release();
+        s->w[p].release();
+        s->origin[p].release();
+    }
+    (void)hipSetDevice(s->ctx->parts[0]->device);
     delete s;
     return PMC_OK;
 }
@@ -572,17 +822,21 @@ int pmc_mix_logpdf(const pmc_mix *mix, const pmc_samples *s, double *h_out, doub
     pmc_ctx *ctx = mix->ctx;
     CK(use(ctx));
     CtxCall call_(ctx);
-    const int64_t N = s->N;
     const int K = mix->K, D = mix->D;
-    if (N == 0) return PMC_OK;
-    CK(workspace(ctx, N, K, D));
-    CK(ctx->nk1.ensure(sizeof(double) * (size_t)N * (h_individual ? K + 1 : 1)));
-    double *d_out = ctx->nk1.d(), *d_ind = h_individual ? d_out + N : nullptr;
-    CK(pmc_mixture_logpdf(s->x.d(), N, D, mix->pack.d(), K, mix->family, 0, d_out, d_ind, K, nullptr, nullptr, nullptr,
-                          nullptr, ctx->ws.p, ctx->stream));
-    if (h_out) CK(d2h(ctx, h_out, d_out, sizeof(double) * (size_t)N));
-    if (h_individual) CK(d2h(ctx, h_individual, d_ind, sizeof(double) * (size_t)N * K));
-    return PMC_OK;
+    if (s->N == 0) return PMC_OK;
+    CallLog log_(ctx, "pmc_mix_logpdf", s->N, K, D);
+    return for_parts(ctx, [&](Part &pt) -> int {
+        const int64_t N = s->n(pt.index), b = s->begin[pt.index];
+        if (N == 0) return PMC_OK;
+        CK(workspace(pt, N, K, D));
+        CK(pt.nk1.ensure(sizeof(double) * (size_t)N * (h_individual ? K + 1 : 1)));
+        double *d_out = pt.nk1.d(), *d_ind = h_individual ? d_out + N : nullptr;
+        CK(pmc_mixture_logpdf(s->x[pt.index].d(), N, D, mix->pack[pt.index].d(), K, mix->family, 0, d_out, d_ind, K, nullptr, nullptr,
+                              nullptr, nullptr, pt.ws.p, pt.stream));
+        if (h_out) CK(d2h(pt, h_out + b, d_out, sizeof(double) * (size_t)N));
+        if (h_individual) CK(d2h(pt, h_individual + (size_t)b * K, d_ind, sizeof(double) * (size_t)N * K));
+        return PMC_OK;
+    });
 }
 
 int pmc_mix_logpdf_components(const pmc_mix *mix, const pmc_samples *s, const int32_t *h_components, int ncomponents,
@@ -593,14 +847,13 @@ int pmc_mix_logpdf_components(const pmc_mix *mix, const pmc_samples *s, const in
     pmc_ctx *ctx = mix->ctx;
     CK(use(ctx));
     CtxCall call_(ctx);
-    const int64_t N = s->N;
     const int K = mix->K, D = mix->D, n = ncomponents;
     std::vector<int> sel(n);
     for (int i = 0; i < n; ++i) {
         if (h_components[i] < 0 || h_components[i] >= K) return failf(PMC_EINVAL, "pmc_mix_logpdf_components: component %d of %d", (int)h_components[i], K);
         sel[i] = h_components[i];
     }
-    if (N == 0) return PMC_OK;
+    if (s->N == 0) return PMC_OK;
     // the listed components as a pack of their own whose output columns are 0 ... n-1: an N x n matrix comes back and
     // is scattered into the listed columns of the caller's N x K array (every other column stays as it is)
     pmc_mix view;
@@ -619,17 +872,21 @@ int pmc_mix_logpdf_components(const pmc_mix *mix, const pmc_samples *s, const in
     }
     std::vector<double> host;
     CK(build_mix_pack(&view, all, host));
-    CK(ctx->pack.ensure(host.size() * sizeof(double)));
-    CK(h2d(ctx, ctx->pack.p, host.data(), host.size() * sizeof(double)));
-    CK(workspace(ctx, N, n, D));
-    CK(ctx->nk1.ensure(sizeof(double) * (size_t)N * n));
-    CK(pmc_mixture_logpdf(s->x.d(), N, D, ctx->pack.d(), n, mix->family, 0, nullptr, ctx->nk1.d(), n, nullptr, nullptr, nullptr,
-                          nullptr, ctx->ws.p, ctx->stream));
-    std::vector<double> cols((size_t)N * n);
-    CK(d2h(ctx, cols.data(), ctx->nk1.p, sizeof(double) * cols.size()));
-    for (int64_t r = 0; r < N; ++r)
-        for (int i = 0; i < n; ++i) h_individual[(size_t)r * K + sel[i]] = cols[(size_t)r * n + i];
-    return PMC_OK;
+    return for_parts(ctx, [&](Part &pt) -> int {
+        const int64_t N = s->n(pt.index), b = s->begin[pt.index];
+        if (N == 0) return PMC_OK;
+        CK(pt.pack.ensure(host.size() * sizeof(double)));
+        CK(h2d(pt, pt.pack.p, host.data(), host.size() * sizeof(double)));
+        CK(workspace(pt, N, n, D));
+        CK(pt.nk1.ensure(sizeof(double) * (size_t)N * n));
+        CK(pmc_mixture_logpdf(s->x[pt.index].d(), N, D, pt.pack.d(), n, mix->family, 0, nullptr, pt.nk1.d(), n, nullptr, nullptr,
+                              nullptr, nullptr, pt.ws.p, pt.stream));
+        std::vector<double> cols((size_t)N * n);
+        CK(d2h(pt, cols.data(), pt.nk1.p, sizeof(double) * cols.size()));
+        for (int64_t r = 0; r < N; ++r)
+            for (int i = 0; i < n; ++i) h_individual[(size_t)(b + r) * K + sel[i]] = cols[(size_t)r * n + i];
+        return PMC_OK;
+    });
 }
 
 int pmc_ctx_configure(pmc_ctx *ctx, const char *key, double value)
@@ -643,14 +900,43 @@ int pmc_ctx_timing_enable(pmc_ctx *ctx, int on)
 {
     CK(use(ctx));
     CtxCall call_(ctx);
-    return pmc_internal_timing_stream(ctx->stream, on);
+    for (Part *p : ctx->parts) {
+        HK(hipSetDevice(p->device), "hipSetDevice");
+        CK(pmc_internal_timing_stream(p->stream, on));
+    }
+    return use(ctx);
 }
 
 int pmc_ctx_get_timings(pmc_ctx *ctx, pmc_timing *h_out, int max_entries, int *n_entries)
 {
     CK(use(ctx));
     CtxCall call_(ctx);
-    return pmc_internal_get_timings(ctx->stream, h_out, max_entries, n_entries);
+    if (ctx->nparts() == 1) return pmc_internal_get_timings(ctx->parts[0]->stream, h_out, max_entries, n_entries);
+    // several devices: the entries of all parts merged by kernel name -- calls, flops and bytes added, ms = the LONGEST
+    // part's (the parts run side by side: that is the time the call saw)
+    if (!h_out || !n_entries || max_entries < 1) return failf(PMC_EINVAL, "pmc_ctx_get_timings: bad argument");
+    std::vector<pmc_timing> all;
+    for (Part *p : ctx->parts) {
+        HK(hipSetDevice(p->device), "hipSetDevice");
+        std::vector<pmc_timing> one(32);
+        int n = 0;
+        CK(pmc_internal_get_timings(p->stream, one.data(), 32, &n));
+        for (int i = 0; i < n && i < 32; ++i) {
+            size_t j = 0;
+            while (j < all.size() && std::strcmp(all[j].name, one[i].name) != 0) ++j;
+            if (j == all.size()) {
+                all.push_back(one[i]);
+            } else {
+                all[j].calls += one[i].calls;
+                all[j].flops += one[i].flops;
+                all[j].bytes += one[i].bytes;
+                if (one[i].ms > all[j].ms) all[j].ms = one[i].ms;
+            }
+        }
+    }
+    *n_entries = (int)all.size();
+    for (size_t i = 0; i < all.size() && (int)i < max_entries; ++i) h_out[i] = all[i];
+    return use(ctx);
 }
 
 int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target, const pmc_mix *target, double *h_w,
@@ -662,31 +948,39 @@ int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target,
     pmc_ctx *ctx = q->ctx;
     CK(use(ctx));
     CtxCall call_(ctx);
-    const int64_t N = s->N;
     const int D = q->D, Kmax = target && target->K > q->K ? target->K : q->K;
-    CK(ctx->flat.ensure(sizeof(double) * NSC));
-    double *d_sc = ctx->flat.d();
-    HK(hipMemsetAsync(d_sc, 0, sizeof(double) * NSC, ctx->stream), "hipMemsetAsync");
-    if (N > 0) {
-        CK(workspace(ctx, N, Kmax, D));
-        CK(s->w.ensure(sizeof(double) * (size_t)N));
-        CK(ctx->nk1.ensure(sizeof(double) * (size_t)N));
-        if (target) {
-            CK(pmc_importance_weights(s->x.d(), N, D, q->pack.d(), q->K, q->family, target->pack.d(), target->K, target->family,
-                                      nullptr, h_log_target_out ? ctx->nk1.d() : nullptr, s->w.d(), nullptr, d_sc, ctx->ws.p,
-                                      ctx->stream));
-            if (h_log_target_out) CK(d2h(ctx, h_log_target_out, ctx->nk1.p, sizeof(double) * (size_t)N));
-        } else {
-            CK(h2d(ctx, ctx->nk1.p, h_log_target, sizeof(double) * (size_t)N));
-            CK(pmc_mixture_logpdf(s->x.d(), N, D, q->pack.d(), q->K, q->family, 0, nullptr, nullptr, q->K, ctx->nk1.d(), s->w.d(),
-                                  nullptr, d_sc, ctx->ws.p, ctx->stream));
+    CallLog log_(ctx, "pmc_is_weights", s->N, q->K, D);
+    CK(prepare_slots(ctx, NSC));
+    CK(for_parts(ctx, [&](Part &pt) -> int {
+        const int i = pt.index;
+        const int64_t N = s->n(i), b = s->begin[i];
+        CK(pt.flat.ensure(sizeof(double) * NSC));
+        double *d_sc = pt.flat.d();
+        HK(hipMemsetAsync(d_sc, 0, sizeof(double) * NSC, pt.stream), "hipMemsetAsync");
+        if (N > 0) {
+            CK(workspace(pt, N, Kmax, D));
+            CK(s->w[i].ensure(sizeof(double) * (size_t)N));
+            CK(pt.nk1.ensure(sizeof(double) * (size_t)N));
+            if (target) {
+                CK(pmc_importance_weights(s->x[i].d(), N, D, q->pack[i].d(), q->K, q->family, target->pack[i].d(), target->K,
+                                          target->family, nullptr, h_log_target_out ? pt.nk1.d() : nullptr, s->w[i].d(), nullptr,
+                                          d_sc, pt.ws.p, pt.stream));
+                if (h_log_target_out) CK(d2h(pt, h_log_target_out + b, pt.nk1.p, sizeof(double) * (size_t)N));
+            } else {
+                CK(h2d(pt, pt.nk1.p, h_log_target + b, sizeof(double) * (size_t)N));
+                CK(pmc_mixture_logpdf(s->x[i].d(), N, D, q->pack[i].d(), q->K, q->family, 0, nullptr, nullptr, q->K, pt.nk1.d(),
+                                      s->w[i].d(), nullptr, d_sc, pt.ws.p, pt.stream));
+            }
+            if (h_w) CK(d2h(pt, h_w + b, s->w[i].p, sizeof(double) * (size_t)N));
         }
-        s->has_w = true;
-        if (h_w) CK(d2h(ctx, h_w, s->w.p, sizeof(double) * (size_t)N));
-    }
-    CK(allreduce(ctx, d_sc, NSC));
+        return publish(ctx, pt, d_sc, NSC);
+    }));
+    if (s->N > 0) s->has_w = true;
+    Part &p0 = *ctx->parts[0];
+    CK(reduce(ctx, p0.flat.d(), NSC));
     double sc[NSC];
-    CK(d2h(ctx, sc, d_sc, sizeof(sc)));
+    CK(d2h(p0, sc, p0.flat.d(), sizeof(sc)));
+    if (ctx->p2p) CK(pmc_p2p_status(ctx->p2p, p0.stream));
     if (sc[4] != 0.0) return failf(PMC_EINVAL, "pmc_is_weights: %g importance weights overflowed (math range error, importance_sampling.py:207)", sc[4]);
     if (h_sums) {
         h_sums[0] = sc[0];
@@ -706,52 +1000,64 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
     CtxCall call_(ctx);
     if (!s || s->ctx != ctx || K < 1 || !h_m || !h_W || !h_nu || !h_beta || !h_ln_pi || !h_ln_lambda || !h_N_k || !h_xbar || !h_S)
         return failf(PMC_EINVAL, "pmc_vb_estep: bad argument");
-    const int64_t N = s->N;
     const int D = s->D;
     const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
     if (stride < 0) return (int)stride;
+    CallLog log_(ctx, "pmc_vb_estep", s->N, K, D);
     // the posterior's pack (enum pmc_kind, PMC_KIND_VB): c0 = D / beta, c1 = nu, c2 = E[ln pi], c3 = E[ln|Lambda|] - D ln 2 pi
-    std::vector<double> c0(K), c3(K), host((size_t)K * stride);
+    std::vector<double> c0(K), c3(K), host((size_t)K * stride), shost;
     const double dl2pi = D * std::log(2. * 3.14159265358979323846);
     for (int k = 0; k < K; ++k) {
         c0[k] = D / h_beta[k];
         c3[k] = h_ln_lambda[k] - dl2pi;
     }
     CK(pmc_pack_components(K, D, h_m, h_W, c0.data(), h_nu, h_ln_pi, c3.data(), nullptr, nullptr, host.data()));
-    CK(ctx->pack.ensure(host.size() * sizeof(double)));
-    CK(h2d(ctx, ctx->pack.p, host.data(), host.size() * sizeof(double)));
     const size_t nflat = NSC + (size_t)K * PS;
-    CK(ctx->flat.ensure(sizeof(double) * nflat));
-    double *d_flat = ctx->flat.d();
-    CK(workspace(ctx, N, K, D));
-    CK(ctx->u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, K)));
-    const double *d_sw = nullptr;
-    if (h_sample_w && N > 0) {
-        CK(ctx->aux.ensure(sizeof(double) * (size_t)N));
-        CK(h2d(ctx, ctx->aux.p, h_sample_w, sizeof(double) * (size_t)N));
-        d_sw = ctx->aux.d();
-    }
+    CK(prepare_slots(ctx, nflat));
     std::vector<double> shift(h_shift ? h_shift : h_m, (h_shift ? h_shift : h_m) + (size_t)K * D);
     std::vector<double> flat(nflat), S0, M1, M2;
-    const bool want_nk = (h_r || h_log_rho) && N > 0;
+    const bool want_nk = (h_r || h_log_rho) && s->N > 0;
+    Part &p0 = *ctx->parts[0];
     for (int pass = 0; pass < 2; ++pass) {
         const bool shifted = pass == 1 || h_shift != nullptr;
-        if (shifted) CK(means_pack(ctx, shift, K, D));
-        const double *d_spack = shifted ? ctx->spack.d() : nullptr;
-        if (want_nk && pass == 0) {
-            CK(ctx->nk1.ensure(sizeof(double) * (size_t)N * K));
-            CK(ctx->nk2.ensure(sizeof(double) * (size_t)N * K));
-            CK(pmc_responsibilities(s->x.d(), N, D, ctx->pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, ctx->u.d(),
-                                    nullptr, nullptr, h_r ? ctx->nk1.d() : nullptr, h_log_rho ? ctx->nk2.d() : nullptr, nullptr,
-                                    K, d_flat, ctx->ws.p, ctx->stream));
-            CK(pmc_sufficient_stats(s->x.d(), N, D, d_spack ? d_spack : ctx->pack.d(), K, ctx->u.d(), d_flat + NSC, ctx->ws.p,
-                                    ctx->stream));
-        } else {
-            CK(pmc_estep_about(s->x.d(), N, D, ctx->pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, ctx->u.d(), nullptr,
-                               nullptr, d_flat + NSC, d_flat, ctx->ws.p, d_spack, ctx->stream));
-        }
-        CK(allreduce(ctx, d_flat, (int64_t)nflat));
-        CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * nflat));
+        if (shifted) CK(means_pack_host(shift, K, D, shost));
+        CK(for_parts(ctx, [&](Part &pt) -> int {
+            const int i = pt.index;
+            const int64_t N = s->n(i), b = s->begin[i];
+            if (pass == 0) {
+                CK(pt.pack.ensure(host.size() * sizeof(double)));
+                CK(h2d(pt, pt.pack.p, host.data(), host.size() * sizeof(double)));
+                CK(pt.flat.ensure(sizeof(double) * nflat));
+                CK(workspace(pt, N, K, D));
+                CK(pt.u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, K)));
+                if (h_sample_w && N > 0) {
+                    CK(pt.aux.ensure(sizeof(double) * (size_t)N));
+                    CK(h2d(pt, pt.aux.p, h_sample_w + b, sizeof(double) * (size_t)N));
+                }
+            }
+            const double *d_sw = h_sample_w && N > 0 ? pt.aux.d() : nullptr;
+            double *d_flat = pt.flat.d();
+            if (shifted) CK(upload_spack(pt, shost));
+            const double *d_spack = shifted ? pt.spack.d() : nullptr;
+            if (want_nk && pass == 0 && N > 0) {
+                CK(pt.nk1.ensure(sizeof(double) * (size_t)N * K));
+                CK(pt.nk2.ensure(sizeof(double) * (size_t)N * K));
+                CK(pmc_responsibilities(s->x[i].d(), N, D, pt.pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, pt.u.d(),
+                                        nullptr, nullptr, h_r ? pt.nk1.d() : nullptr, h_log_rho ? pt.nk2.d() : nullptr, nullptr,
+                                        K, d_flat, pt.ws.p, pt.stream));
+                CK(pmc_sufficient_stats(s->x[i].d(), N, D, d_spack ? d_spack : pt.pack.d(), K, pt.u.d(), d_flat + NSC, pt.ws.p,
+                                        pt.stream));
+                if (h_r) CK(d2h(pt, h_r + (size_t)b * K, pt.nk1.p, sizeof(double) * (size_t)N * K));
+                if (h_log_rho) CK(d2h(pt, h_log_rho + (size_t)b * K, pt.nk2.p, sizeof(double) * (size_t)N * K));
+            } else {
+                CK(pmc_estep_about(s->x[i].d(), N, D, pt.pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, pt.u.d(), nullptr,
+                                   nullptr, d_flat + NSC, d_flat, pt.ws.p, d_spack, pt.stream));
+            }
+            return publish(ctx, pt, d_flat, nflat);
+        }));
+        CK(reduce(ctx, p0.flat.d(), nflat));
+        CK(d2h(p0, flat.data(), p0.flat.d(), sizeof(double) * nflat));
+        if (ctx->p2p) CK(pmc_p2p_status(ctx->p2p, p0.stream));
         split_stats(flat.data() + NSC, K, D, S0, M1, M2);
         if (pass == 1 || !shift_is_far(S0, M1, M2, K, D)) break;
         new_shifts(S0, M1, K, D, shift);                              // second pass about the mean just found
@@ -759,10 +1065,6 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
     for (int k = 0; k < K; ++k) h_N_k[k] = S0[k] == 0.0 ? TINY : S0[k];   // variational.pyx:699-709
     centred_moments(h_N_k, h_N_k, M1, M2, shift.data(), K, D, h_xbar, h_S);
     if (h_elogqz) *h_elogqz = flat[0];
-    if (want_nk) {
-        if (h_r) CK(d2h(ctx, h_r, ctx->nk1.p, sizeof(double) * (size_t)N * K));
-        if (h_log_rho) CK(d2h(ctx, h_log_rho, ctx->nk2.p, sizeof(double) * (size_t)N * K));
-    }
     return PMC_OK;
 }
 
@@ -776,81 +1078,87 @@ int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s,
     if (!mix || !s || mix->ctx != ctx || s->ctx != ctx || mix->D != s->D || !h_alpha || !h_mu || !h_sigma)
         return failf(PMC_EINVAL, "pmc_pmc_update_stats: bad argument");
     if (h_w && weights_on_device) return failf(PMC_EINVAL, "pmc_pmc_update_stats: h_w or weights_on_device, not both");
-    if (weights_on_device && !s->has_w) return failf(PMC_EINVAL, "pmc_pmc_update_stats: no importance weights on the device (pmc_is_weights first)");
+    if (weights_on_device && !s->has_w && s->N > 0) return failf(PMC_EINVAL, "pmc_pmc_update_stats: no importance weights on the device (pmc_is_weights first)");
     if (!rb && !h_latent && !s->has_origin) return failf(PMC_EINVAL, "`rb` must be True if `latent` is not provided!");   // pmc.pyx:81-83
     const bool student = mix->family == PMC_KIND_STUDENT_T;
     if (student && !h_dof_const) return failf(PMC_EINVAL, "pmc_pmc_update_stats: StudentT components need h_dof_const");
-    const int64_t N = s->N;
     const int K = mix->K, D = mix->D;
-    const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
+    const int64_t PS = pmc_stats_stride(D);
+    CallLog log_(ctx, "pmc_pmc_update_stats", s->N, K, D);
     std::vector<int> live;
     for (int k = 0; k < K; ++k)
         if (mix->w[k] != 0.0) live.push_back(k);                       // pmc.pyx:66
     const int L = (int)live.size();
-    // weights and their local sum
-    const double *d_w = nullptr;
-    double local_norm = (double)N;
-    CK(ctx->flat.ensure(sizeof(double) * (NSC + (size_t)(L > 0 ? L : 1) * (PS + 2) + 1)));
-    double *d_flat = ctx->flat.d();
-    const size_t nstat = NSC + (size_t)L * PS + 2 * (size_t)L, nflat = nstat + 1;
-    CK(workspace(ctx, N, L > 0 ? L : 1, D));
-    if (h_w && N > 0) {
-        CK(ctx->aux.ensure(sizeof(double) * (size_t)N));
-        CK(h2d(ctx, ctx->aux.p, h_w, sizeof(double) * (size_t)N));
-        d_w = ctx->aux.d();
-        long double acc = 0.0L;
-        for (int64_t n = 0; n < N; ++n) acc += h_w[n];
-        local_norm = (double)acc;
-    } else if (weights_on_device && N > 0) {
-        d_w = s->w.d();
-        CK(pmc_weight_sums(d_w, N, d_flat, ctx->ws.p, ctx->stream));
-        double sc3[3];
-        CK(d2h(ctx, sc3, d_flat, sizeof(sc3)));
-        local_norm = sc3[0];
-    } else if (h_w || weights_on_device) {
-        local_norm = 0.0;
-    }
-    HK(hipMemsetAsync(d_flat, 0, sizeof(double) * nflat, ctx->stream), "hipMemsetAsync");
+    const size_t nstat = NSC + (size_t)L * PS + 2 * (size_t)L, nflat = nstat + 1;   // ... | this part's sum of weights
+    CK(prepare_slots(ctx, nflat));
     std::vector<double> shift((size_t)(L > 0 ? L : 1) * D, 0.0);
     for (int i = 0; i < L; ++i) std::memcpy(&shift[(size_t)i * D], &mix->mu[(size_t)live[i] * D], sizeof(double) * D);
-    const int64_t *d_lat = nullptr;
-    if (!rb && N > 0) {
-        if (h_latent) {
-            CK(ctx->lat.ensure(sizeof(int64_t) * (size_t)N));
-            CK(h2d(ctx, ctx->lat.p, h_latent, sizeof(int64_t) * (size_t)N));
-            d_lat = (const int64_t *)ctx->lat.p;
-        } else {
-            d_lat = (const int64_t *)s->origin.p;
-        }
-    }
+    std::vector<double> host, shost;
+    if (L > 0) CK(build_mix_pack(mix, live, host));
     std::vector<double> flat(nflat, 0.0), S0, M1, M2;
-    if (L > 0) {
-        std::vector<double> host;
-        CK(build_mix_pack(mix, live, host));
-        CK(ctx->pack.ensure(host.size() * sizeof(double)));
-        CK(h2d(ctx, ctx->pack.p, host.data(), host.size() * sizeof(double)));
-        CK(ctx->u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, L)));
-        if (student) CK(ctx->scratch.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, L)));
-        const int mode = rb ? PMC_RESP_PMC_RB : PMC_RESP_PMC_LATENT;
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) CK(means_pack(ctx, shift, L, D));
-            // dead components' all-zero columns take part in the row maximum (pmc.pyx:24-34)
-            CK(pmc_estep_about(s->x.d(), N, D, ctx->pack.d(), L, mix->family, mode, L < K ? 1 : 0, d_w, d_lat, ctx->u.d(),
-                               student ? ctx->scratch.d() : nullptr, student ? d_flat + NSC + (size_t)L * PS : nullptr,
-                               d_flat + NSC, d_flat, ctx->ws.p, pass == 1 ? ctx->spack.d() : nullptr, ctx->stream));
-            HK(hipMemcpyAsync(d_flat + nstat, &local_norm, sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
-            HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-            CK(allreduce(ctx, d_flat, (int64_t)nflat));
-            CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * nflat));
-            split_stats(flat.data() + NSC, L, D, S0, M1, M2);
-            if (pass == 1 || !shift_is_far(S0, M1, M2, L, D)) break;
-            new_shifts(S0, M1, L, D, shift);
-        }
-    } else {
-        HK(hipMemcpyAsync(d_flat + nstat, &local_norm, sizeof(double), hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync");
-        HK(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-        CK(allreduce(ctx, d_flat, (int64_t)nflat));
-        CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * nflat));
+    std::vector<double> norms((size_t)ctx->nparts(), 0.0);            // (kept across the passes)
+    const int mode = rb ? PMC_RESP_PMC_RB : PMC_RESP_PMC_LATENT;
+    Part &p0 = *ctx->parts[0];
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) CK(means_pack_host(shift, L, D, shost));
+        CK(for_parts(ctx, [&](Part &pt) -> int {
+            const int i = pt.index;
+            const int64_t N = s->n(i), b = s->begin[i];
+            CK(pt.flat.ensure(sizeof(double) * (NSC + (size_t)(L > 0 ? L : 1) * (PS + 2) + 1)));
+            double *d_flat = pt.flat.d();
+            const double *d_w = nullptr;
+            if (pass == 0) {
+                CK(workspace(pt, N, L > 0 ? L : 1, D));
+                // weights and their local sum
+                double local_norm = (double)N;
+                if (h_w && N > 0) {
+                    CK(pt.aux.ensure(sizeof(double) * (size_t)N));
+                    CK(h2d(pt, pt.aux.p, h_w + b, sizeof(double) * (size_t)N));
+                    long double acc = 0.0L;
+                    for (int64_t n = 0; n < N; ++n) acc += h_w[b + n];
+                    local_norm = (double)acc;
+                } else if (weights_on_device && N > 0) {
+                    CK(pmc_weight_sums(s->w[i].d(), N, d_flat, pt.ws.p, pt.stream));
+                    double sc3[3];
+                    CK(d2h(pt, sc3, d_flat, sizeof(sc3)));
+                    local_norm = sc3[0];
+                } else if (h_w || weights_on_device) {
+                    local_norm = 0.0;
+                }
+                norms[(size_t)i] = local_norm;
+                if (!rb && N > 0 && h_latent) {
+                    CK(pt.lat.ensure(sizeof(int64_t) * (size_t)N));
+                    CK(h2d(pt, pt.lat.p, h_latent + b, sizeof(int64_t) * (size_t)N));
+                }
+                if (L > 0) {
+                    CK(pt.pack.ensure(host.size() * sizeof(double)));
+                    CK(h2d(pt, pt.pack.p, host.data(), host.size() * sizeof(double)));
+                    CK(pt.u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, L)));
+                    if (student) CK(pt.scratch.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, L)));
+                }
+            }
+            if (N > 0) d_w = h_w ? pt.aux.d() : (weights_on_device ? s->w[i].d() : nullptr);
+            const int64_t *d_lat = nullptr;
+            if (!rb && N > 0) d_lat = h_latent ? (const int64_t *)pt.lat.p : (const int64_t *)s->origin[i].p;
+            HK(hipMemsetAsync(d_flat, 0, sizeof(double) * nflat, pt.stream), "hipMemsetAsync");
+            if (L > 0) {
+                if (pass == 1) CK(upload_spack(pt, shost));
+                // dead components' all-zero columns take part in the row maximum (pmc.pyx:24-34)
+                CK(pmc_estep_about(s->x[i].d(), N, D, pt.pack.d(), L, mix->family, mode, L < K ? 1 : 0, d_w, d_lat, pt.u.d(),
+                                   student ? pt.scratch.d() : nullptr, student ? d_flat + NSC + (size_t)L * PS : nullptr,
+                                   d_flat + NSC, d_flat, pt.ws.p, pass == 1 ? pt.spack.d() : nullptr, pt.stream));
+            }
+            HK(hipMemcpyAsync(d_flat + nstat, &norms[(size_t)i], sizeof(double), hipMemcpyHostToDevice, pt.stream), "hipMemcpyAsync");
+            HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
+            return publish(ctx, pt, d_flat, nflat);
+        }));
+        CK(reduce(ctx, p0.flat.d(), nflat));
+        CK(d2h(p0, flat.data(), p0.flat.d(), sizeof(double) * nflat));
+        if (ctx->p2p) CK(pmc_p2p_status(ctx->p2p, p0.stream));
+        if (L == 0) break;
+        split_stats(flat.data() + NSC, L, D, S0, M1, M2);
+        if (pass == 1 || !shift_is_far(S0, M1, M2, L, D)) break;
+        new_shifts(S0, M1, L, D, shift);
     }
     const double norm = flat[nstat];
     if (h_norm) *h_norm = norm;
@@ -891,42 +1199,63 @@ int pmc_weighted_moments(pmc_ctx *ctx, const pmc_samples *s, const double *h_w, 
     if (!s || s->ctx != ctx || !h_mean) return failf(PMC_EINVAL, "pmc_weighted_moments: bad argument");
     if (h_w && weights_on_device) return failf(PMC_EINVAL, "pmc_weighted_moments: h_w or weights_on_device, not both");
     if (weights_on_device && !s->has_w) return failf(PMC_EINVAL, "pmc_weighted_moments: no importance weights on the device (pmc_is_weights first)");
-    const int64_t N = s->N;
     const int D = s->D;
     const int64_t PS = pmc_stats_stride(D), stride = pmc_pack_stride(D);
     if (stride < 0) return (int)stride;
-    // the shift: the first sample of rank 0 (every rank must take its moments about the same point)
+    CallLog log_(ctx, "pmc_weighted_moments", s->N, 1, D);
+    // the shift: the first sample of rank 0 (every rank and every part must take its moments about the same point)
     std::vector<double> shift(D, 0.0);
     int rank = 0;
     if (ctx->comm) CK(pmc_comm_rank(ctx->comm, &rank, nullptr));
-    CK(ctx->flat.ensure(sizeof(double) * (size_t)(PS + NSC + D)));
-    double *d_flat = ctx->flat.d();                                    // [stats PS | sum w, sum w log w, sum w^2 ... (NSC) | shift D]
-    HK(hipMemsetAsync(d_flat, 0, sizeof(double) * (size_t)(PS + NSC + D), ctx->stream), "hipMemsetAsync");
-    if (rank == 0 && N > 0) HK(hipMemcpyAsync(d_flat + PS + NSC, s->x.p, sizeof(double) * D, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
-    CK(allreduce(ctx, d_flat + PS + NSC, D));
-    CK(d2h(ctx, shift.data(), d_flat + PS + NSC, sizeof(double) * D));
+    Part &p0 = *ctx->parts[0];
+    const size_t nflat = (size_t)(PS + NSC);
+    CK(p0.flat.ensure(sizeof(double) * (nflat + D)));
+    {
+        double *d_shift = p0.flat.d() + nflat;
+        HK(hipMemsetAsync(d_shift, 0, sizeof(double) * D, p0.stream), "hipMemsetAsync");
+        if (rank == 0 && s->N > 0) {
+            int first = 0;                                            // (the first part that holds a row)
+            while (s->n(first) == 0) ++first;
+            if (ctx->parts[first]->device == p0.device)
+                HK(hipMemcpyAsync(d_shift, s->x[first].p, sizeof(double) * D, hipMemcpyDeviceToDevice, p0.stream), "hipMemcpyAsync");
+            else
+                HK(hipMemcpyPeerAsync(d_shift, p0.device, s->x[first].p, ctx->parts[first]->device, sizeof(double) * D, p0.stream), "hipMemcpyPeerAsync");
+        }
+        if (ctx->p2p) CK(pmc_p2p_allreduce_sum(ctx->p2p, d_shift, D, p0.stream));
+        else if (ctx->comm) CK(pmc_comm_allreduce_sum(ctx->comm, d_shift, D, p0.stream));
+        CK(d2h(p0, shift.data(), d_shift, sizeof(double) * D));
+    }
     std::vector<double> hp((size_t)stride);
     CK(pmc_pack_means(1, D, shift.data(), hp.data()));
-    CK(ctx->spack.ensure(hp.size() * sizeof(double)));
-    CK(h2d(ctx, ctx->spack.p, hp.data(), hp.size() * sizeof(double)));
-    CK(workspace(ctx, N, 1, D));
-    // u = the weights in the library's tile-major layout with K = 1: the weight vector itself, zero behind the samples
-    const size_t ulen = (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, 1);
-    CK(ctx->u.ensure(sizeof(double) * ulen));
-    HK(hipMemsetAsync(ctx->u.p, 0, sizeof(double) * ulen, ctx->stream), "hipMemsetAsync");
-    if (N > 0) {
-        if (h_w) CK(h2d(ctx, ctx->u.p, h_w, sizeof(double) * (size_t)N));
-        else if (weights_on_device) HK(hipMemcpyAsync(ctx->u.p, s->w.p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync");
-        else {
-            std::vector<double> ones((size_t)N, 1.0);
-            CK(h2d(ctx, ctx->u.p, ones.data(), sizeof(double) * (size_t)N));
+    CK(prepare_slots(ctx, nflat));
+    CK(for_parts(ctx, [&](Part &pt) -> int {
+        const int i = pt.index;
+        const int64_t N = s->n(i), b = s->begin[i];
+        CK(pt.flat.ensure(sizeof(double) * (nflat + D)));
+        double *d_flat = pt.flat.d();                                     // [stats PS | sum w, sum w log w, sum w^2 ... (NSC)]
+        HK(hipMemsetAsync(d_flat, 0, sizeof(double) * nflat, pt.stream), "hipMemsetAsync");
+        CK(upload_spack(pt, hp));
+        CK(workspace(pt, N, 1, D));
+        // u = the weights in the library's tile-major layout with K = 1: the weight vector itself, zero behind the samples
+        const size_t ulen = (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, 1);
+        CK(pt.u.ensure(sizeof(double) * ulen));
+        HK(hipMemsetAsync(pt.u.p, 0, sizeof(double) * ulen, pt.stream), "hipMemsetAsync");
+        if (N > 0) {
+            if (h_w) CK(h2d(pt, pt.u.p, h_w + b, sizeof(double) * (size_t)N));
+            else if (weights_on_device) HK(hipMemcpyAsync(pt.u.p, s->w[i].p, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, pt.stream), "hipMemcpyAsync");
+            else {
+                std::vector<double> ones((size_t)N, 1.0);
+                CK(h2d(pt, pt.u.p, ones.data(), sizeof(double) * (size_t)N));
+            }
+            CK(pmc_sufficient_stats(s->x[i].d(), N, D, pt.spack.d(), 1, pt.u.d(), d_flat, pt.ws.p, pt.stream));
+            CK(pmc_weight_sums(pt.u.d(), N, d_flat + PS, pt.ws.p, pt.stream));
         }
-        CK(pmc_sufficient_stats(s->x.d(), N, D, ctx->spack.d(), 1, ctx->u.d(), d_flat, ctx->ws.p, ctx->stream));
-        CK(pmc_weight_sums(ctx->u.d(), N, d_flat + PS, ctx->ws.p, ctx->stream));
-    }
-    CK(allreduce(ctx, d_flat, PS + NSC));
-    std::vector<double> flat((size_t)(PS + NSC));
-    CK(d2h(ctx, flat.data(), d_flat, sizeof(double) * flat.size()));
+        return publish(ctx, pt, d_flat, nflat);
+    }));
+    CK(reduce(ctx, p0.flat.d(), nflat));
+    std::vector<double> flat(nflat);
+    CK(d2h(p0, flat.data(), p0.flat.d(), sizeof(double) * nflat));
+    if (ctx->p2p) CK(pmc_p2p_status(ctx->p2p, p0.stream));
     std::vector<double> S0, M1, M2;
     split_stats(flat.data(), 1, D, S0, M1, M2);
     const double sw = S0[0], q = flat[(size_t)PS + 2];

@@ -294,6 +294,20 @@ __device__ __forceinline__ double log_any(double t)
     return log(t);
 }
 
+// Rows whose result must be NaN: a component value that is NaN or +inf (the reference's exp(a - max) of such a row is NaN,
+// _regularize.pyx:72-81, variational.pyx:728-755).  -inf -- a Mahalanobis form beyond 1e308 -- is NOT one: exp(-inf) = 0,
+// the component drops out and the others carry the row, as in the reference (student_t.pyx:159-164, gauss.pyx:151).
+// exp_clamped turns a NaN argument into e = 0, so the NaN has to travel separately: one v_cmp_class per pair (in the place
+// of the multiply-add 0 * v + poison of rounds 1-4, which also poisoned -inf), its lane mask OR-ed on the scalar unit.
+struct RowPoison {
+    unsigned long long bad = 0;
+    __device__ __forceinline__ void see(double v) { bad |= __ballot(__builtin_amdgcn_class(v, 0x203)); }   // sNaN | qNaN | +inf
+    __device__ __forceinline__ double value() const
+    {
+        return ((bad >> (threadIdx.x & 63)) & 1ull) ? __longlong_as_double(0x7ff8000000000000LL) : 0.0;
+    }
+};
+
 // a_nk from maha_nk, in the reference's operation order (see enum pmc_kind).
 template <int D, int KIND>
 __device__ __forceinline__ double component_value(double maha, cdouble *c, double &expo)

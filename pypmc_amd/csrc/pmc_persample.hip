@@ -432,7 +432,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
     // the mixture itself (kind KIND), then -- pmc_importance_weights only -- the TARGET mixture of the
     // importance weights (kind KIND2), evaluated on the same registers: the samples are read once
     const ExpConst EC;
-    double poison = 0.0;                                 // NaN if the row has a NaN / infinite coordinate (lse_step)
+    RowPoison rowp;                                      // a NaN / +inf component value makes the row NaN (lse_step drops it)
     // kept Mahalanobis forms (pmc_*_keep: a.atile), or -- pmc_importance_weights_emit: a.u -- the place where the
     // responsibilities of the PMC update will stand: the forms are parked there and replaced below
     double *const mkeep = a.u != nullptr ? a.u : a.atile;
@@ -454,10 +454,10 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
             if (first && keep_tile)                      // wave-uniform: keep maha_nk for the PMC update of these samples
                 mkeep[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = maha;
             lse_step(v, pk[dm.DT + 4], m, s, EC);
-            poison = fma(0.0, v, poison);
+            rowp.see(v);
         }
         if (first) m_first = m;
-        return (log_any(s) + m) + poison;                    // _regularize.pyx:81
+        return (log_any(s) + m) + rowp.value();              // _regularize.pyx:81
     };
     const double lse = mixture(ic<KIND>{}, a.pack, a.K, true);
     double lse_target = 0.0;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         // already: every parked form is read ONCE (k_resp_tiles: three times, in a launch of its own).
         static_assert(KIND == PMC_KIND_GAUSS || KIND == PMC_KIND_STUDENT_T, "emit: density kinds only");
         const double wn = (a.log_target != nullptr || a.pack2 != nullptr) ? sc[0] : 1.0;
-        const double swv = valid ? wn + poison : 0.0;
+        const double swv = valid ? wn + rowp.value() : 0.0;
         const double denom = exp(lse) + TINY;                               // pmc.pyx:41
         const double em = exp(m_first), inv_denom = 1. / denom;
         double *ut = a.u + (size_t)(n >> 6) * a.K * 64 + (threadIdx.x & 63);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
         double M = a.max_init_zero ? 0.0 : -DBL_MAX;
         // exp_le0 below turns a NaN a_nk into e = 0.  The VB normalisation makes that NaN again (0 / 0); the PMC
         // kinds would get rho = 0 where the reference has NaN, so there the sample's weight carries it
-        double poison = 0.0;
+        RowPoison rowp;
         const ExpConst EC;
         cdouble *pk = (cdouble *)a.pack;
         engine.begin(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);
@@ -618,12 +618,12 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 }
             }
             M = max_f64(v, M);                            // (a NaN value leaves M alone, like `if v > M`)
-            if constexpr (KIND != PMC_KIND_VB) poison = fma(0.0, v, poison);
+            if constexpr (KIND != PMC_KIND_VB) rowp.see(v);
             if (k < klds) pl[k * 64] = v;                 // wave-uniform branch
             else ut[(size_t)k * 64] = v;
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
-        const double swv = valid ? sw + poison : 0.0;    // (one select per sample instead of one per pair)
+        const double swv = valid ? sw + rowp.value() : 0.0;    // (one select per sample instead of one per pair)
         auto parked_global = [&](int k) { return ut[(size_t)k * 64]; };
         auto parked_lds = [&](int k) { return pl[k * 64]; };
 
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
 #endif
         double *pl = dyn_lds + Engine::LDS_DOUBLES + (size_t)(threadIdx.x >> 6) * GS * 64 + lane;
         const ExpConst EC;
-        double poison = 0.0;                              // NaN if a component value of the row is NaN
+        RowPoison rowp;                                   // NaN if a component value of the row is NaN / +inf
         double Mrun = -DBL_MAX, srun = 0.0, tbrun = 0.0;
         cdouble *pk = (cdouble *)a.pack;
         engine.begin(a.pack, K, PMC_RESIDENT_MAX_DIM_RESP);
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                 double expo = 0.0;
                 const double v = component_value<D, KIND>(maha, pk + dm.DT, expo);
                 Mg = max_f64(v, Mg);
-                poison = fma(0.0, v, poison);
+                rowp.see(v);
                 pl[j * 64] = v;
             }
             // pass 2 of the group: u' = exp(a - M_g) [* w_k], written once
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             gs[(size_t)g * 64] = Mg;
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
-        const double swv = valid ? sw + poison : 0.0;
+        const double swv = valid ? sw + rowp.value() : 0.0;
         if constexpr (KIND == PMC_KIND_VB) {
             // variational.pyx:748-755, :1003-1013
             const double norm_inv = 1. / srun;

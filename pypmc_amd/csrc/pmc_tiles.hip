@@ -37,14 +37,15 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64) void k_resp_tiles(const PmcArgsT 
             return component_value<1, KIND>(mt[(size_t)((cint64 *)c)[5] * 64], c, expo);
         };
         const ExpConst EC;
-        double M = a.max_init_zero ? 0.0 : -DBL_MAX, poison = 0.0;
+        double M = a.max_init_zero ? 0.0 : -DBL_MAX;
+        RowPoison rowp;
         for (int k = 0; k < K; ++k) {
             const double v = value(k);
             M = max_f64(v, M);
-            poison = fma(0.0, v, poison);
+            rowp.see(v);
         }
         const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
-        const double swv = valid ? sw + poison : 0.0;
+        const double swv = valid ? sw + rowp.value() : 0.0;
         // e_nk = exp(a_nk - M) is formed twice -- for the row sum and again for rho -- rather than parked between the
         // passes: the kernel is bound by its HBM traffic (three reads of the kept forms and one write of u instead
         // of two reads, a write and a read of e, and the write of u: 12.3 -> 9.4 ms at K = 128, N = 1.25e7)

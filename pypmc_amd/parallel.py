@@ -180,40 +180,104 @@ def _native_all_reduce(t):
 
 # ---- the one-shot exchange among the ranks of a node (include/pmc_hip.h: pmc_p2p_*), optional --------------------
 _p2p = None               # (ctypes handle of the pmc_p2p, the library, capacity in doubles)
+_p2p_reason = None        # why the exchange was asked for and is NOT in use (the RCCL / gloo collective runs instead)
+_P2P_HANDLE_BYTES = 128   # PMC_P2P_HANDLE_BYTES
+
+
+def _agree(d, ok, where):
+    """True only if ``ok`` on EVERY rank (one sum all-reduce of the failure flags): the ranks must all use the exchange or
+    all stay with the default collective"""
+    import torch
+    t = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=where)
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    return float(t.cpu()[0]) == 0.0
 
 
 def enable_p2p_collective(max_doubles=1 << 18, device=None):
     """Run the path's all-reduce of DEVICE buffers of up to ``max_doubles`` doubles as the library's one-shot exchange
     (``pmc_p2p_allreduce_sum``: every rank writes its vector into a mailbox of every peer through HIP IPC and adds the
     G vectors in rank order -- one hop instead of a ring's 2 (G - 1), bit-identical on all ranks and from run to run).
-    The ranks of ONE node; the existing process group only carries the 64-byte mailbox handles at set-up.  Opt-in
-    (``PMC_P2P_COLLECTIVE=1`` makes ``init_from_env`` call this): tested with several processes on one GPU; RCCL stays
-    the default for multi-GPU runs until a box with more than one GPU has timed both."""
-    global _p2p
+    The ranks of ONE node; the existing process group only carries the mailbox handles at set-up.  Opt-in
+    (``PMC_P2P_COLLECTIVE=1`` makes ``init_from_env`` call this).
+
+    Returns True if the exchange is in use.  It is NOT when the ranks are not on one host, are more than 16, a peer's
+    device is not reachable, the mapping fails or the connect-time self-test round (a known pattern, compared bit for
+    bit on every rank) does not come back right on ANY rank: the reason is logged and kept (``p2p_status()``), nothing
+    stays half-open, and the default collective (RCCL / gloo) keeps running -- on all ranks alike."""
+    global _p2p, _p2p_reason
     d = _dist()
     if d is None:
         raise RuntimeError("enable_p2p_collective needs an initialised torch.distributed process group")
     if _p2p is not None:
-        return
+        return True
     import ctypes as C
+    import logging
+    import socket
+    import zlib
     import torch
     from . import _lib
+    log = logging.getLogger(__name__)
     lib = _lib.load()
     dev = torch.cuda.current_device() if device is None else int(device)
     world, me = d.get_world_size(), d.get_rank()
-    h = C.c_void_p()
-    _lib.check(lib.pmc_p2p_create(me, world, int(max_doubles), dev, C.byref(h)), "pmc_p2p_create")
-    mine = (C.c_char * 64)()
-    _lib.check(lib.pmc_p2p_handle(h, C.cast(mine, C.c_void_p)), "pmc_p2p_handle")
     where = torch.device("cuda", dev) if d.get_backend() == "nccl" else torch.device("cpu")
-    allh = torch.zeros(world * 64, dtype=torch.float64, device=where)      # (a sum all-reduce: every backend has one)
-    allh[me * 64:(me + 1) * 64] = torch.tensor(list(bytes(mine)), dtype=torch.float64, device=where)
+
+    def give_up(reason):
+        global _p2p_reason
+        _p2p_reason = reason
+        log.warning("one-shot exchange not used (%s): the %s collective stays", reason, d.get_backend())
+        return False
+
+    # one node, at most 16 ranks: known before anything is allocated (advice r4)
+    hosts = torch.zeros(world, dtype=torch.float64, device=where)
+    hosts[me] = float(zlib.crc32(socket.gethostname().encode()) + 1)
+    d.all_reduce(hosts, op=d.ReduceOp.SUM)
+    hosts = hosts.cpu().tolist()
+    if world > 16:
+        return give_up("%d ranks: the mailboxes serve at most 16" % world)
+    if len(set(hosts)) != 1:
+        return give_up("the ranks run on %d different hosts" % len(set(hosts)))
+    h = C.c_void_p()
+    err = None
+    if lib.pmc_p2p_create(me, world, int(max_doubles), dev, C.byref(h)) < 0:
+        err = "rank %d: %s" % (me, _lib.last_error())
+        h = None
+    mine = (C.c_char * _P2P_HANDLE_BYTES)()
+    if h is not None and lib.pmc_p2p_handle(h, C.cast(mine, C.c_void_p)) < 0:
+        err = "rank %d: %s" % (me, _lib.last_error())
+    n = _P2P_HANDLE_BYTES
+    allh = torch.zeros(world * n, dtype=torch.float64, device=where)      # (a sum all-reduce: every backend has one)
+    allh[me * n:(me + 1) * n] = torch.tensor(list(bytes(mine)), dtype=torch.float64, device=where)
     d.all_reduce(allh, op=d.ReduceOp.SUM)
+    if not _agree(d, err is None, where):
+        if h is not None:
+            lib.pmc_p2p_destroy(h)
+        return give_up(err or "a peer could not create its mailbox")
     raw = bytes(int(v) for v in allh.cpu().tolist())
     buf = (C.c_char * len(raw)).from_buffer_copy(raw)
-    _lib.check(lib.pmc_p2p_connect(h, C.cast(buf, C.c_void_p)), "pmc_p2p_connect")
-    d.barrier()                                          # every mailbox is mapped everywhere before the first round
+    # (collective: mapping + the self-test round; a rank that fails makes its peers' self-test time out)
+    if lib.pmc_p2p_connect(h, C.cast(buf, C.c_void_p)) < 0:
+        err = "rank %d: %s" % (me, _lib.last_error())
+    ok = _agree(d, err is None, where)
+    d.barrier()                                          # every mailbox is mapped everywhere before the first round / nobody
+    if not ok:                                           # unmaps one a peer's self-test may still write to
+        lib.pmc_p2p_destroy(h)
+        return give_up(err or "a peer's connect / self-test failed")
     _p2p = (h, lib, int(max_doubles))
+    _p2p_reason = None
+    return True
+
+
+def p2p_status():
+    """dict(enabled, info, reason): whether the one-shot exchange is in use, pmc_p2p_info's line
+    ("memory=finegrained world=4 ... selftest=passed"), or why it is not"""
+    if _p2p is None:
+        return dict(enabled=False, info=None, reason=_p2p_reason)
+    import ctypes as C
+    h, lib, _ = _p2p
+    buf = C.create_string_buffer(256)
+    lib.pmc_p2p_info(h, buf, 256)
+    return dict(enabled=True, info=buf.value.decode(), reason=None)
 
 
 def disable_p2p_collective():
@@ -234,6 +298,10 @@ def _p2p_all_reduce(t):
     h, lib, _ = _p2p
     stream = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     _lib.check(lib.pmc_p2p_allreduce_sum(h, C.c_void_p(t.data_ptr()), t.numel(), stream), "pmc_p2p_allreduce_sum")
+    # The caller reads the sum on the host next (it synchronises anyway): a round in which a peer did not arrive within
+    # PMC_P2P_TIMEOUT_S -- the buffer is NaN then, never this rank's own numbers -- is an error here, not a silent
+    # divergence of the ranks' mixtures (advice r4)
+    _lib.check(lib.pmc_p2p_status(h, stream), "pmc_p2p_allreduce_sum")
 
 
 def _collective_device(d):

@@ -34,11 +34,34 @@ hipError_t hipGetLastError(void) { return hipSuccess; }
 
 hipError_t hipMalloc(void **p, size_t bytes) { *p = std::calloc(bytes ? bytes : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+hipError_t hipExtMallocWithFlags(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+hipError_t hipHostFree(void *p) { return hipFree(p); }
+hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipMallocAsync(void **p, size_t bytes, hipStream_t) { return hipMalloc(p, bytes); }
 hipError_t hipFreeAsync(void *p, hipStream_t) { return hipFree(p); }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind, hipStream_t)
 {
     std::memmove(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemcpyPeerAsync(void *dst, int, const void *src, int, size_t bytes, hipStream_t)
+{
+    std::memmove(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipDeviceCanAccessPeer(int *can, int a, int b) { *can = (a == 0 && b == 0); return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+hipError_t hipDeviceGetPCIBusId(char *buf, int len, int d)
+{
+    if (d != 0 || len < 13) return hipErrorInvalidDevice;
+    std::strcpy(buf, "0000:00:00.0");
+    return hipSuccess;
+}
+hipError_t hipDeviceGetByPCIBusId(int *d, const char *id)
+{
+    if (std::strcmp(id, "0000:00:00.0") != 0) return hipErrorInvalidDevice;
+    *d = 0;
     return hipSuccess;
 }
 hipError_t hipMemset(void *dst, int v, size_t bytes) { std::memset(dst, v, bytes); return hipSuccess; }

@@ -126,12 +126,22 @@ static void kernel_level(int K, int D, int64_t N, uint64_t seed)
     EXPECT(pmc_estep(x.d(), N, D, dpack.d(), K, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stats.d(), nullptr, ws.p, nullptr) == PMC_EINVAL);
 }
 
-static void handle_layer(int device_calls, int K, int D, int64_t N, uint64_t seed)
+// nparts = 0: pmc_init(0); nparts > 0: a context of that many parts, all on device 0 (virtual shards: own streams, own
+// scratch, own host threads, the K-sized vectors added in part order)
+static void handle_layer(int nparts, int K, int D, int64_t N, uint64_t seed)
 {
-    (void)device_calls;
     const Mixture m = make_mixture(K, D, seed), t = make_mixture(3, D, seed + 1);
     pmc_ctx *ctx = nullptr;
-    EXPECT(pmc_init(0, &ctx) == PMC_OK && ctx);
+    if (nparts == 0) {
+        EXPECT(pmc_init(0, &ctx) == PMC_OK && ctx);
+        nparts = 1;
+    } else {
+        const std::vector<int> ids((size_t)nparts, 0);
+        EXPECT(pmc_init_devices(nparts, ids.data(), &ctx) == PMC_OK && ctx);
+    }
+    EXPECT(pmc_ctx_device_count(ctx) == nparts);
+    int devs[64];
+    EXPECT(pmc_ctx_devices(ctx, devs, 64) == nparts && devs[0] == 0);
     pmc_mix *q = nullptr, *tq = nullptr, *st = nullptr;
     EXPECT(pmc_mixture_create(ctx, PMC_KIND_GAUSS, K, D, m.w.data(), m.mu.data(), m.prec.data(), m.ln.data(), nullptr, &q) == PMC_OK);
     EXPECT(pmc_mixture_create(ctx, PMC_KIND_GAUSS, 3, D, t.w.data(), t.mu.data(), t.prec.data(), t.ln.data(), nullptr, &tq) == PMC_OK);
@@ -148,6 +158,14 @@ static void handle_layer(int device_calls, int K, int D, int64_t N, uint64_t see
     pmc_samples *s = nullptr, *gen = nullptr;
     EXPECT(pmc_samples_upload(ctx, x.data(), N, D, &s) == PMC_OK);
     EXPECT(pmc_samples_count(s) == N);
+    {
+        int64_t b = -1, c = -1, total = 0;
+        for (int p = 0; p < nparts; ++p) {
+            EXPECT(pmc_samples_shard(s, p, &b, &c) == 0 && b == total);
+            total += c;
+        }
+        EXPECT(total == N && pmc_samples_shard(s, nparts, &b, &c) == PMC_EINVAL);
+    }
     EXPECT(pmc_samples_download(s, x.data()) == PMC_OK);
     std::vector<int64_t> counts(K, N / K), origin((size_t)(N / K) * K);
     EXPECT(pmc_samples_generate(ctx, q, nullptr, counts.data(), 1234u, 0, &gen) == PMC_OK);
@@ -187,7 +205,7 @@ static void handle_layer(int device_calls, int K, int D, int64_t N, uint64_t see
     EXPECT(pmc_mix_logpdf(q, s, out.data(), nullptr) == PMC_OK);
     pmc_timing tm[16];
     int nt = 0;
-    EXPECT(pmc_ctx_get_timings(ctx, tm, 16, &nt) == PMC_OK && nt == 1 && tm[0].calls == 1);
+    EXPECT(pmc_ctx_get_timings(ctx, tm, 16, &nt) == PMC_OK && nt == 1 && tm[0].calls == (N >= nparts ? nparts : (int)N));
     EXPECT(pmc_ctx_get_timings(ctx, tm, 16, &nt) == PMC_OK && nt == 0);
     // mismatched handles
     pmc_ctx *other = nullptr;
@@ -273,8 +291,28 @@ int main()
     handle_layer(0, 4, 3, 1000, 11);
     handle_layer(0, 8, 20, 20011, 12);
     handle_layer(0, 5, 70, 300, 13);
+    // contexts of several parts (virtual shards on the one device of the stand-in): worker threads, slots, ordered sum
+    handle_layer(2, 4, 3, 1000, 31);
+    handle_layer(3, 8, 20, 20011, 32);
+    handle_layer(6, 5, 70, 4, 33);                        // fewer samples than parts: empty shards
+    handle_layer(8, 3, 2, 17, 34);
     pmc_ctx *none = nullptr;
     EXPECT(pmc_init(1, &none) == PMC_ENODEVICE && !none);
+    {
+        const int bad_ids[2] = {0, 1};
+        EXPECT(pmc_init_devices(2, bad_ids, &none) == PMC_ENODEVICE && !none);
+        EXPECT(pmc_init_devices(-1, nullptr, &none) == PMC_EINVAL && pmc_init_devices(2, nullptr, &none) == PMC_EINVAL);
+        setenv("PMC_HIP_DEVICES", "0, 0,0", 1);
+        EXPECT(pmc_init_devices(0, nullptr, &none) == PMC_OK && none && pmc_ctx_device_count(none) == 3);
+        EXPECT(pmc_shutdown(none) == PMC_OK);
+        none = nullptr;
+        setenv("PMC_HIP_DEVICES", "0,x", 1);
+        EXPECT(pmc_init_devices(0, nullptr, &none) == PMC_EINVAL && !none);
+        unsetenv("PMC_HIP_DEVICES");
+        EXPECT(pmc_init_devices(0, nullptr, &none) == PMC_OK && none && pmc_ctx_device_count(none) == 1);   // every visible device
+        EXPECT(pmc_shutdown(none) == PMC_OK);
+        none = nullptr;
+    }
     EXPECT(pmc_shutdown(nullptr) == PMC_OK && pmc_mixture_destroy(nullptr) == PMC_OK && pmc_samples_free(nullptr) == PMC_OK);
     // many contexts in sequence: a destroyed stream's scratch slot goes to the next new stream (256 slots in all)
     for (int i = 0; i < 600; ++i) {
@@ -302,6 +340,37 @@ int main()
     // the one-shot exchange: two "ranks" in this process (the stand-in's IPC handle carries the pointer), through the
     // kernel-level entry points and through two contexts
     {
+        // (kernels do not run here: the connect-time self-test cannot pass -- first that it fails CLOSED, then the rest
+        //  of the bookkeeping with the self-test switched off)
+        {
+            pmc_p2p *a = nullptr, *b = nullptr;
+            unsigned char h[2 * PMC_P2P_HANDLE_BYTES];
+            EXPECT(pmc_p2p_create(0, 2, 1000, 0, &a) == PMC_OK && pmc_p2p_create(1, 2, 1000, 0, &b) == PMC_OK);
+            EXPECT(pmc_p2p_handle(a, h) == PMC_OK && pmc_p2p_handle(b, h + PMC_P2P_HANDLE_BYTES) == PMC_OK);
+            EXPECT(pmc_p2p_connect(a, h) == PMC_EHIP && std::strstr(pmc_last_error(), "self-test") != nullptr);
+            Dev v(8 * 1000);
+            EXPECT(pmc_p2p_allreduce_sum(a, v.d(), 10, nullptr) == PMC_EINVAL);   // not connected: nothing half-open
+            char info[200];
+            EXPECT(pmc_p2p_info(a, info, sizeof(info)) == PMC_OK && std::strstr(info, "selftest=failed") && std::strstr(info, "memory=finegrained"));
+            unsigned char junk[2 * PMC_P2P_HANDLE_BYTES];
+            std::memset(junk, 7, sizeof(junk));
+            EXPECT(pmc_p2p_connect(b, junk) == PMC_EHIP && std::strstr(pmc_last_error(), "not a handle") != nullptr);
+            EXPECT(pmc_p2p_destroy(a) == PMC_OK && pmc_p2p_destroy(b) == PMC_OK);
+            pmc_ctx *c0 = nullptr;
+            EXPECT(pmc_init(0, &c0) == PMC_OK);
+            EXPECT(pmc_ctx_p2p_open(c0, 0, 2, 5000, h) == PMC_OK);
+            std::memcpy(h + PMC_P2P_HANDLE_BYTES, h, PMC_P2P_HANDLE_BYTES);
+            EXPECT(pmc_ctx_p2p_connect(c0, h) == PMC_EHIP);                       // self-test fails: the context has no exchange left
+            EXPECT(pmc_ctx_p2p_open(c0, 0, 2, 5000, h) == PMC_OK);                // ... and can open a new one
+            EXPECT(pmc_shutdown(c0) == PMC_OK);
+            setenv("PMC_P2P_MEMORY", "nonsense", 1);
+            EXPECT(pmc_p2p_create(0, 2, 1000, 0, &a) == PMC_EINVAL);
+            setenv("PMC_P2P_MEMORY", "coarse", 1);
+            EXPECT(pmc_p2p_create(0, 1, 1000, 0, &a) == PMC_OK && pmc_p2p_info(a, info, sizeof(info)) == PMC_OK && std::strstr(info, "memory=coarse"));
+            EXPECT(pmc_p2p_destroy(a) == PMC_OK);
+            unsetenv("PMC_P2P_MEMORY");
+        }
+        setenv("PMC_P2P_SELFTEST", "0", 1);
         pmc_p2p *a = nullptr, *b = nullptr;
         unsigned char h[2 * PMC_P2P_HANDLE_BYTES];
         EXPECT(pmc_p2p_create(0, 2, 1000, 0, &a) == PMC_OK && pmc_p2p_create(1, 2, 1000, 0, &b) == PMC_OK);

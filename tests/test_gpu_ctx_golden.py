@@ -22,10 +22,14 @@ def lib():
     return _lib.load()
 
 
-@pytest.fixture()
-def ctx(lib):
+# every golden vector twice: through a one-device context, and through ONE context of three parts (pmc_init_devices with
+# the box's GPU named three times: virtual shards with their own streams, scratch and host threads, the K-sized vectors
+# added in part order -- SURVEY 8(b) row 1, verdict r4 #1)
+@pytest.fixture(params=[(0,), (0, 0, 0)], ids=["one_device", "three_parts"])
+def ctx(lib, request):
     h = C.c_void_p()
-    assert lib.pmc_init(0, C.byref(h)) == 0, lib.pmc_last_error()
+    ids = (C.c_int * len(request.param))(*request.param)
+    assert lib.pmc_init_devices(len(request.param), ids, C.byref(h)) == 0, lib.pmc_last_error()
     yield h
     assert lib.pmc_shutdown(h) == 0
 

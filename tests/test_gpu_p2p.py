@@ -41,6 +41,36 @@ def test_ordered_sum_bit_for_bit(world):
         np.testing.assert_array_equal(got["big"], np.full(3, world * (world + 1) / 2.0))
 
 
+def test_a_failed_self_test_leaves_the_default_collective_on_every_rank():
+    """verdict r4 #2: the self-test of ONE rank is forced to fail; nobody uses the exchange, everybody knows why, and the
+    sums still come out (through the process group's own collective)"""
+    import torch.multiprocessing as mp
+    world = 3
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(p2p_worker.run_selftest_failure, args=(world, tmp), nprocs=world, join=True)
+        ranks = [dict(np.load(os.path.join(tmp, "fail_rank%d.npz" % r))) for r in range(world)]
+    ref = p2p_worker.vector(0, 777, 5)
+    for r in range(1, world):
+        ref = ref + p2p_worker.vector(r, 777, 5)
+    for i, got in enumerate(ranks):
+        assert not bool(got["used"]) and not bool(got["enabled"]) and str(got["collective"]) == "gloo", (i, got)
+        assert "self-test" in str(got["reason"]) or "peer" in str(got["reason"]), str(got["reason"])
+        np.testing.assert_allclose(got["sum"], ref, rtol=1e-15)
+    assert "self-test" in str(ranks[1]["reason"])               # the rank that was made to fail names its own finding
+
+
+def test_a_round_that_times_out_is_nan_and_an_error_never_a_local_sum():
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(p2p_worker.run_timeout, args=(2, tmp), nprocs=2, join=True)
+        r0, r1 = [dict(np.load(os.path.join(tmp, "timeout_rank%d.npz" % r))) for r in range(2)]
+    ref = p2p_worker.vector(0, 100, 1) + p2p_worker.vector(1, 100, 1)
+    np.testing.assert_array_equal(r0["good"], ref)
+    np.testing.assert_array_equal(r1["good"], ref)
+    assert bool(r0["raised"]) and bool(r0["again"])
+    assert np.isnan(r0["after"]).all(), "a timed-out round must not leave the rank's own numbers behind"
+
+
 def test_sharded_front_end_over_the_one_shot_exchange():
     """the two-rank HIP run of tests/test_gpu_distributed.py with PMC_P2P_COLLECTIVE=1: same results as one process"""
     import torch.multiprocessing as mp
