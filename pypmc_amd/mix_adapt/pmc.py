@@ -160,6 +160,48 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
     return density, live_components, stat_components, stats, weight_normalization, need_renormalize, shift
 
 
+def _sharded_update(samples, density, weights, latent, rb, mincount, copy, student):
+    """``samples`` is a ``pypmc_amd.devices.ShardedSamples``: the N-sized part of the update runs on all devices of its
+    group (pmc_pmc_update_stats: every device its block, the statistics added in device order, the far-shift second
+    pass and the reference's normalisations inside); what is left here is the K-sized bookkeeping of pmc.pyx:53-118.
+    ``latent``: None, a host array, or 'origin' (the generating components kept with generated samples).
+    Returns density, live components, dict k -> (alpha, mu, sigma, dof constant), renormalise?"""
+    need_renormalize = False
+    if copy:
+        density = deepcopy(density)
+    K = len(density)
+    use_origin = isinstance(latent, str) and latent == 'origin'
+    if latent is None:
+        if mincount > 0:
+            raise ValueError('`mincount` must be 0 if `latent` is not provided!')
+        if not rb:
+            raise ValueError('`rb` must be True if `latent` is not provided!')
+        count = None
+    elif use_origin:
+        if samples.counts is None:
+            raise ValueError("latent='origin' needs samples a DeviceGroup generated")
+        count = samples.counts.astype(np.float64)
+    else:
+        latent = np.asarray(latent)
+        count = np.histogram(latent, bins=K, range=(0, K))[0].astype(np.float64)
+    if weights is not None and not hasattr(weights, 'samples'):
+        weights = np.asarray(weights)
+        assert len(weights.shape) == 1, 'Weights must be one-dimensional.'
+        assert len(weights) == len(samples), \
+            "Number of weights (%s) does not match the number of samples (%s)." % (len(weights), len(samples))
+    live_components = [k for k in range(K) if density.weights[k] != 0]
+    stat_components = list(live_components)
+    res = samples.group.pmc_update_stats(density, samples, weights, latent, rb)
+    if count is not None:
+        for k in live_components:                                  # (edited while iterated, as pmc.pyx:110-116)
+            if count[k] < mincount:
+                live_components.remove(k)
+                density.weights[k] = 0.
+                need_renormalize = True
+                logger.warning("Component %i died because of too few (%i) samples." % (k, count[k]))
+    return density, live_components, stat_components, res, need_renormalize
+
+
 def _is_sorted(a):
     """non-decreasing?  (numpy array or device tensor)"""
     if len(a) < 2:
@@ -243,6 +285,10 @@ def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=
     behind by the weighting pass itself; the update is then the statistics kernel alone.  Both refuse any other
     density, sample set or weights than the ones they were formed with (``ValueError``)."""
     assert samples is not None
+    if hasattr(samples, 'group') and hasattr(samples, 'shards'):      # ShardedSamples of a DeviceGroup (several GPUs)
+        density, live, _, res, renorm = _sharded_update(samples, density, weights, latent, rb, mincount, copy, False)
+        new = {k: (res["alpha"][k], (res["mu"][k], res["sigma"][k])) for k in live}
+        return _apply_updates(density, live, new, renorm)
     if isinstance(samples, np.ndarray):          # device-resident tensors pass through untouched
         samples = np.ascontiguousarray(samples, dtype=np.float64)
     density, live, stat_comps, stats, norm, renorm, shift = \
@@ -272,20 +318,31 @@ def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solv
     (reference: pmc.pyx:499-739, same signature and semantics; ``mahalanobis``, ``responsibilities``: see
     ``gaussian_pmc``)."""
     assert samples is not None
-    if isinstance(samples, np.ndarray):
-        samples = np.ascontiguousarray(samples, dtype=np.float64)
-    density, live, stat_comps, stats, norm, renorm, shift = \
-        _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis,
-                            responsibilities, student=True)
+    sharded = hasattr(samples, 'group') and hasattr(samples, 'shards')
+    if sharded:
+        density, live, stat_comps, res, renorm = _sharded_update(samples, density, weights, latent, rb, mincount, copy, True)
+        stats = None
+    else:
+        if isinstance(samples, np.ndarray):
+            samples = np.ascontiguousarray(samples, dtype=np.float64)
+        density, live, stat_comps, stats, norm, renorm, shift = \
+            _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, backend, mahalanobis,
+                                responsibilities, student=True)
     D = density.dim
     new = {}
+    if sharded and stat_comps:
+        # the devices' sums were turned into alpha, mu, sigma and the dof constant by the library (pmc_pmc_update_stats)
+        alpha = res["alpha"][stat_comps]
+        mu, cov = res["mu"][stat_comps], res["sigma"][stat_comps]
+        const = res["dof_const"][stat_comps]
     if stat_comps:
         # S0g = sum w rho gamma, V1 = sum w rho; mean: normalised by sum w rho gamma; covariance: by sum w rho
         # (pmc.pyx:620-630; _stats.centred_moments with S0_cov = V1)
-        _, S0g, _, mu, cov, _, V1, V2 = stats
+        if not sharded:
+            _, S0g, _, mu, cov, _, V1, V2 = stats
+            alpha = V1 / norm
         old_dof = np.array([density.components[k].dof for k in stat_comps])
-        alpha = V1 / norm
-        if dof_solver_steps:
+        if dof_solver_steps and not sharded:
             # sum_n w_n (xi + delta)_nk of pmc.pyx:659-679 assembled from the device sums:
             #   rho (log(.5(b+nu)) - psi(.5(D+nu)))      -> V2 - psi(.5(D+nu)) V1
             #   (1-rho)(log(.5 nu) - psi(.5 nu))          -> (W - V1)(log(.5 nu) - psi(.5 nu))

@@ -9,7 +9,9 @@ Division of labour
   host   (K-sized, replicated on every rank): digamma expectations (10.65-66), M-step (10.58-62),
       the other six bound terms (10.71-77), pruning, convergence control.
 With torch.distributed initialised each rank holds a shard of the data; the statistics vector is
-all-reduced once per E-step (pypmc_amd.parallel).
+all-reduced once per E-step (pypmc_amd.parallel).  ``GaussianInference(data, ..., devices=[0, 1, 2, 3])`` instead shards
+the data over the GPUs of this node from ONE process (pypmc_amd.devices.DeviceGroup: the library owns the shards and adds
+the statistics in device order).
 """
 import logging
 
@@ -35,8 +37,16 @@ class GaussianInference(object):
     (variational.pyx:27-114): ``GaussianInference(data, components=0, weights=None,
     initial_guess="first", **variational_parameters)``."""
 
-    def __init__(self, data, components=0, weights=None, initial_guess="first", backend=None, **kwargs):
+    def __init__(self, data, components=0, weights=None, initial_guess="first", backend=None, devices=None, **kwargs):
         self._backend = backend
+        self._group = None
+        if devices is not None:
+            # (extension) the GPUs of this node behind this one process: a list of device ordinals or a DeviceGroup
+            if parallel.active():
+                raise ValueError('``devices`` shards the data inside this process; do not combine it with a '
+                                 'torch.distributed process group (one rank per GPU)')
+            from ..devices import DeviceGroup
+            self._group = DeviceGroup.of(devices)
         on_device = hasattr(data, 'device') and not isinstance(data, np.ndarray)    # torch tensor: stays put
         if not on_device:
             data = np.asarray(data, dtype=np.float64)
@@ -67,9 +77,16 @@ class GaussianInference(object):
             self._parse_initial_guess(initial_guess)
         self._initialize_intermediate()
 
-        be = get_backend(self._backend)
-        self._data_dev = be.asdevice(self.data if on_device else np.ascontiguousarray(self.data))
-        self._weights_dev = be.asdevice(self.weights) if self.weights is not None else None
+        if self._group is not None:
+            host = self.data.detach().cpu().numpy() if on_device else self.data
+            self._samples = self._group.upload(host)              # contiguous shards, device order = row order
+            self._weights_host = None if self.weights is None else \
+                np.ascontiguousarray(self.weights.detach().cpu().numpy() if hasattr(self.weights, 'detach') else self.weights)
+            self._data_dev = self._weights_dev = None
+        else:
+            be = get_backend(self._backend)
+            self._data_dev = be.asdevice(self.data if on_device else np.ascontiguousarray(self.data))
+            self._weights_dev = be.asdevice(self.weights) if self.weights is not None else None
         self.E_step()
 
     # ------------------------------------------------------------------------- E / M steps
@@ -81,6 +98,8 @@ class GaussianInference(object):
         cs = ComponentSet(PMC_KIND_VB, self.m, self.W, c0=D / self.beta, c1=self.nu,
                           c2=self.expectation_ln_pi,
                           c3=self.expectation_det_ln_lambda - D * np.log(2. * np.pi))
+        if self._group is not None:
+            return self._E_step_group(cs)
         be = get_backend(self._backend)
         # The moments are taken about the previous E-step's x_mean_comp once there is one (else about m): x_mean_comp is
         # then bit-stable as soon as the responsibilities are -- the property of the reference's two passes
@@ -113,6 +132,25 @@ class GaussianInference(object):
             raise np.linalg.LinAlgError('Encountered inf or nan in update of sample covariance\n' + str(self.S))
         self._expectation_log_q_Z = float(scalars[0])
         self._estep_set = cs            # parameters the current r / log_rho belong to
+        self._nk_cache = {}
+
+    def _E_step_group(self, cs):
+        """the E-step over the devices of ``self._group``: one call of the handle layer (pmc_vb_estep) -- every device its
+        shard, the statistics added in device order, the far-shift second pass and the reference's normalisation inside"""
+        prev = getattr(self, '_shift_prev', None)
+        shift = prev if (prev is not None and prev.shape == self.m.shape and np.isfinite(prev).all()) else None
+        res = self._group.vb_estep(self._samples, self._weights_host, self.m, self.W, self.nu, self.beta,
+                                   self.expectation_ln_pi, self.expectation_det_ln_lambda, shift=shift)
+        if not np.isfinite(res["N_comp"]).any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(res["N_comp"]))
+        self.N_comp = res["N_comp"]
+        self.inv_N_comp = 1. / self.N_comp
+        self.x_mean_comp, self.S = res["x_mean_comp"], res["S"]
+        self._shift_prev = self.x_mean_comp.copy()
+        if not np.isfinite(self.S).any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of sample covariance\n' + str(self.S))
+        self._expectation_log_q_Z = res["log_q_Z"]
+        self._estep_set = cs
         self._nk_cache = {}
 
     def M_step(self):
@@ -153,6 +191,10 @@ class GaussianInference(object):
         this rank's shard (the reference keeps all three resident: variational.pyx:636-638)."""
         if name not in self._nk_cache:
             be = get_backend(self._backend)
+            if self._group is not None and self._data_dev is None:
+                # (read rarely: the three N x K matrices come from ONE device, the default backend's)
+                self._data_dev = be.asdevice(self.data if not isinstance(self.data, np.ndarray) else np.ascontiguousarray(self.data))
+                self._weights_dev = be.asdevice(self._weights_host) if self._weights_host is not None else None
             res = be.estep(self._data_dev, self._estep_set, PMC_RESP_VB, sample_w=self._weights_dev,
                            want_r=True, want_log_rho=True, want_exponent=True)
             self._nk_cache = dict(r=be.tohost(res["r"]), log_rho=be.tohost(res["log_rho"]),

@@ -27,6 +27,11 @@ def _on_device(a):
     return hasattr(a, 'device') and not isinstance(a, np.ndarray)
 
 
+def _sharded(samples):
+    from ..devices import ShardedSamples
+    return isinstance(samples, ShardedSamples)
+
+
 def _moments(samples, weights, backend):
     assert len(samples) == len(weights), \
         "The number of samples (got %i) must equal the number of weights (got %i)." % (len(samples), len(weights))
@@ -38,6 +43,8 @@ def _moments(samples, weights, backend):
 def calculate_mean(samples, weights, backend=None):
     """Weighted sample mean (reference: importance_sampling.py:46-61), reduced on the GPU by the
     statistics kernel."""
+    if _sharded(samples):                     # a DeviceGroup's sample set: every device its block, one ordered sum
+        return samples.group.weighted_moments(samples, weights, want_cov=False)[0]
     S0, M1, _, shift, _ = _moments(samples, weights, backend)
     return shift + M1 / S0
 
@@ -45,6 +52,8 @@ def calculate_mean(samples, weights, backend=None):
 def calculate_covariance(samples, weights, backend=None):
     """Weighted sample covariance with the (sum w)^2 / ((sum w)^2 - sum w^2) correction
     (reference: importance_sampling.py:63-83), reduced on the GPU by the statistics kernel."""
+    if _sharded(samples):
+        return samples.group.weighted_moments(samples, weights)[1]
     S0, M1, M2, _, Q = _moments(samples, weights, backend)
     dbar = M1 / S0
     return S0 * S0 / (S0 * S0 - Q) * (M2 / S0 - np.outer(dbar, dbar))
@@ -62,12 +71,29 @@ class ImportanceSampler(object):
     ``device=True`` (extension): ``samples`` / ``weights`` / ``target_values`` are
     :class:`DeviceHistory` objects — ``run`` proposes on the GPU straight into the store, weights
     there, and only a target that is a host callable sees host copies of the samples.  Indexing
-    the histories still yields (lazy) host arrays, ``.device(i)`` the device views."""
+    the histories still yields (lazy) host arrays, ``.device(i)`` the device views.
+
+    ``devices=[0, 1, 2, 3]`` (extension; a list of ordinals or a ``pypmc_amd.devices.DeviceGroup``): the GPUs of this
+    node behind this ONE process.  ``run`` draws the component counts from ``rng`` on the host (bit-exact counts and
+    origins), generates contiguous blocks of the samples on the devices, weights them there -- in one pass with a
+    Gauss / Student-t mixture target, through a host copy of the samples with any other callable -- and records
+    samples, weights and target values in the (host) histories as the reference does.  ``last_run`` is the sharded
+    sample set with its weights still on the devices: ``gaussian_pmc(sampler.last_run, proposal,
+    weights=sampler.last_run.weights)`` adapts the proposal without moving anything N-sized again.  The samples of a
+    run arrive ordered by generating component (the weights do not depend on the order; the reference shuffles)."""
 
     def __init__(self, target, proposal, indicator=None, prealloc=0, save_target_values=False,
-                 rng=np.random.mtrand, backend=None, device=False):
+                 rng=np.random.mtrand, backend=None, device=False, devices=None):
         self._backend = backend
         self.device = bool(device)
+        self._group = None
+        self.last_run = None
+        if devices is not None:
+            if self.device:
+                raise ValueError('``device=True`` (one GPU, device-resident histories) and ``devices=[...]`` (several GPUs '
+                                 'behind this process) are two modes: choose one')
+            from ..devices import DeviceGroup
+            self._group = DeviceGroup.of(devices)
         self.proposal = deepcopy(proposal)
         self.rng = rng
         self._batch_target = None
@@ -102,6 +128,8 @@ class ImportanceSampler(object):
         are ordered by generating component and that component index is returned per sample."""
         if N == 0:
             return 0
+        if self._group is not None:
+            return self._run_group(N, trace_sort)
         if self.device:
             res = self.run_device(N, trace_sort=trace_sort, store=True)
             return get_backend(self._backend).tohost(res["origin"]) if trace_sort else None
@@ -111,6 +139,37 @@ class ImportanceSampler(object):
             return origin
         this_samples = self._get_samples(N, trace_sort=False)
         self._calculate_weights(this_samples, N)
+
+    def _run_group(self, N, trace_sort, store=True):
+        """one run over the devices of ``self._group`` (see the class docstring)"""
+        from ..density.mixture import MixtureDensity
+        g, prop = self._group, self.proposal
+        if not isinstance(prop, MixtureDensity):
+            raise TypeError('``devices=[...]`` needs a MixtureDensity proposal (Gauss or StudentT components)')
+        counts = self.rng.multinomial(N, prop.weights)                     # mixture.pyx:192
+        seed = int(self.rng.randint(0, 2 ** 31 - 1)) | (int(self.rng.randint(0, 2 ** 31 - 1)) << 32)
+        run = g.generate(prop, counts, seed)
+        tgt = getattr(self._batch_target, '__self__', None)
+        mixture_target = isinstance(tgt, MixtureDensity)
+        if mixture_target:
+            try:
+                g.mixture(tgt)
+            except TypeError:
+                mixture_target = False                                      # foreign component types: the host path
+        host_x = run.host() if (store or not mixture_target) else None
+        if mixture_target:
+            res = g.importance_weights(prop, run, target=tgt, want_weights=store,
+                                       want_log_target=store and self.target_values is not None)
+        else:
+            res = g.importance_weights(prop, run, log_target=self._target_values(host_x, N), want_weights=store)
+        self.last_weight_sums = res["sums"]
+        self.last_run = run
+        if store:
+            self.samples.append(N)[:] = host_x
+            self.weights.append(N)[:, 0] = res["weights"]
+            if self.target_values is not None:
+                self.target_values.append(N)[:, 0] = res["log_target"]
+        return np.repeat(np.arange(len(prop.components)), counts) if trace_sort else None
 
     def run_device(self, N, trace_sort=False, target_density=None, store=False, keep_mahalanobis=False,
                    prepare_update=False):

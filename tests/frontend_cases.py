@@ -338,15 +338,21 @@ def case_history(be):
 
 
 # ------------------------------------------------------------------------------------------------
+# tests/test_gpu_devices_frontend.py sets this to a list of device ordinals: the VB cases then run through
+# GaussianInference(..., devices=DEVICES) -- one process, the data sharded over those devices by the library
+DEVICES = None
+
+
 def _vb_from_golden(g, be, weighted):
     from pypmc_amd.density.mixture import create_gaussian_mixture
     from pypmc_amd.mix_adapt.variational import GaussianInference
     sw = g["sample_weights"] if weighted else None
+    extra = dict(devices=DEVICES) if DEVICES is not None else {}
     if str(g["init_kind"]) == "mixture":
         guess = create_gaussian_mixture(g["init_mu"], g["init_sigma"], g["init_weights"])
-        return GaussianInference(g["data"], initial_guess=guess, weights=sw, backend=be)
+        return GaussianInference(g["data"], initial_guess=guess, weights=sw, backend=be, **extra)
     return GaussianInference(g["data"], components=len(g["init_weights"]), initial_guess="first",
-                             weights=sw, backend=be)
+                             weights=sw, backend=be, **extra)
 
 
 def _check_vb_stage(vb, g, stage):

@@ -1,0 +1,206 @@
+"""verdict r4 #1, the front-end half: pypmc's own classes over several GPUs from ONE Python process --
+``GaussianInference(data, devices=[...])``, ``ImportanceSampler(..., devices=[...])``, ``gaussian_pmc / student_t_pmc`` on the
+sharded run it leaves -- through pypmc_amd.devices.DeviceGroup (the handle layer's pmc_init_devices).  The one GPU of the
+test box is named several times (virtual shards).  Parity: the golden vectors generated from the reference itself."""
+import numpy as np
+import pytest
+
+import frontend_cases
+from conftest import load_golden
+from frontend_cases import _mix_from, _check_mix
+
+pytestmark = pytest.mark.gpu
+DEVS = [0, 0, 0]
+
+
+@pytest.fixture(scope="module")
+def be():
+    from pypmc_amd.backend import HipBackend
+    return HipBackend()
+
+
+@pytest.fixture(scope="module")
+def group():
+    from pypmc_amd.devices import DeviceGroup
+    g = DeviceGroup(DEVS)
+    assert g.devices == DEVS
+    yield g
+    g.close()
+
+
+def test_gaussian_inference_golden_over_three_shards(be):
+    """every golden VB case of the one-device front-end (first E-step, an update, run() to convergence, the posterior,
+    r / log_rho / the exponent) with the data sharded over three parts by the library"""
+    frontend_cases.DEVICES = DEVS
+    try:
+        frontend_cases.case_vb_golden(be)
+    finally:
+        frontend_cases.DEVICES = None
+
+
+def test_gaussian_inference_matches_the_one_device_object(be):
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    rs = np.random.RandomState(5)
+    D, K, N = 6, 5, 30011
+    centres = rs.normal(0, 4, (K, D))
+    data = centres[rs.randint(0, K, N)] + rs.normal(size=(N, D))
+    w = rs.uniform(0.5, 1.5, N)
+    one = GaussianInference(data, components=K + 2, weights=w, backend=be)
+    many = GaussianInference(data, components=K + 2, weights=w, backend=be, devices=[0, 0, 0, 0])
+    for _ in range(6):
+        one.update()
+        many.update()
+    for name in ("N_comp", "x_mean_comp", "S", "m", "W", "alpha", "beta", "nu"):
+        np.testing.assert_allclose(getattr(many, name), getattr(one, name), rtol=1e-9, atol=1e-11, err_msg=name)
+    assert abs(many.likelihood_bound() - one.likelihood_bound()) <= 1e-10 * abs(one.likelihood_bound())
+    np.testing.assert_allclose(many.r, one.r, rtol=1e-8, atol=1e-300)
+    assert many.run(50) == one.run(50)
+    assert many.K == one.K
+    with pytest.raises(ValueError, match="remove all components"):
+        many.prune(1e9)
+
+
+@pytest.mark.parametrize("tag", ["d2k3", "d5k4"])
+def test_gaussian_pmc_golden_on_sharded_samples(be, group, tag):
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+    g = load_golden("pmc_gauss_" + tag)
+    x, iw, latent = g["samples"], g["weights"], g["latent"]
+    N = len(x)
+    xs = group.upload(x)
+    assert len(xs) == N and sum(c for _, _, c in xs.shards()) == N
+    prop = _mix_from(g, "in_", False, be)
+    cases = dict(rb_w=dict(weights=iw), rb_u=dict(),
+                 rb_w_latent_min=dict(weights=iw, latent=latent, rb=True, mincount=int(0.25 * N)),
+                 nrb_w=dict(weights=iw, latent=latent, rb=False),
+                 nrb_u=dict(latent=latent, rb=False))
+    for cname, kw in cases.items():
+        before = prop.weights.copy()
+        res = gaussian_pmc(xs, prop, **kw)
+        np.testing.assert_array_equal(prop.weights, before)
+        _check_mix(res, g, cname + "_", False, tag + " " + cname)
+    dead = _mix_from(g, "in_", False, be)
+    dead.weights[1] = 0.
+    dead.normalize()
+    res = gaussian_pmc(xs, dead, weights=iw)
+    _check_mix(res, g, "dead_rb_w_", False, tag + " dead", live=[k for k in range(len(res)) if k != 1])
+    assert res.weights[1] == 0.
+    with pytest.raises(ValueError, match="mincount"):
+        gaussian_pmc(xs, prop, mincount=10)
+    with pytest.raises(ValueError, match="rb"):
+        gaussian_pmc(xs, prop, rb=False)
+
+
+@pytest.mark.parametrize("tag", ["d2k3", "d4k3"])
+def test_student_t_pmc_golden_on_sharded_samples(be, group, tag):
+    from pypmc_amd.mix_adapt.pmc import student_t_pmc
+    g = load_golden("pmc_student_" + tag)
+    x, iw, latent = g["samples"], g["weights"], g["latent"]
+    xs = group.upload(x)
+    prop = _mix_from(g, "in_", True, be)
+    cases = dict(rb_w_dof=dict(weights=iw, dof_solver_steps=100),
+                 rb_w_nodof=dict(weights=iw, dof_solver_steps=0),
+                 rb_u_dof=dict(dof_solver_steps=100),
+                 nrb_w_dof=dict(weights=iw, latent=latent, rb=False, dof_solver_steps=100),
+                 nrb_u_nodof=dict(latent=latent, rb=False, dof_solver_steps=0),
+                 rb_w_clamp=dict(weights=iw, dof_solver_steps=100, mindof=5., maxdof=5.5))
+    for cname, kw in cases.items():
+        res = student_t_pmc(xs, prop, **kw)
+        _check_mix(res, g, cname + "_", True, tag + " " + cname)
+
+
+@pytest.mark.parametrize("student", [False, True])
+def test_importance_sampler_over_devices_draws_what_one_device_draws(be, student):
+    """same generator state -> same counts, same Philox seed -> the very samples ``device=True`` generates on one GPU,
+    the same weights, perplexity sums and target values; the histories are host arrays as in the reference"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture, create_t_mixture
+    from pypmc_amd.sampler.importance_sampling import ImportanceSampler, calculate_mean, calculate_covariance
+    from pypmc_amd.tools.convergence import perp, ess
+    from test_gpu_ctx import mk
+    D, K, N = 5, 4, 20001
+    mu, cov, w = mk(K, D, 8, spread=2.0)
+    prop = create_t_mixture(mu, cov, np.full(K, 5.), w) if student else create_gaussian_mixture(mu, cov, w)
+    target = create_gaussian_mixture(*mk(3, D, 9, spread=1.5))
+    np.random.seed(77)
+    a = ImportanceSampler(target.evaluate, prop, save_target_values=True, devices=[0, 0, 0])
+    oa = a.run(N, trace_sort=True)
+    np.random.seed(77)
+    b = ImportanceSampler(target.evaluate, prop, save_target_values=True, device=True, backend=be)
+    ob = b.run(N, trace_sort=True)
+    np.testing.assert_array_equal(oa, ob)
+    np.testing.assert_array_equal(a.samples[-1], b.samples[-1])
+    np.testing.assert_array_equal(a.weights[-1], b.weights[-1])
+    np.testing.assert_array_equal(a.target_values[-1], b.target_values[-1])
+    np.testing.assert_allclose(a.last_weight_sums, b.last_weight_sums, rtol=1e-13)
+    wts = a.weights[-1][:, 0]
+    sw, swl, sw2 = a.last_weight_sums
+    assert abs(np.exp(-(swl / sw - np.log(sw))) / N - perp(wts)) < 1e-10 and abs(sw ** 2 / sw2 / N - ess(wts)) < 1e-10
+    # a second run appends; a host callable as target sees a host copy of the samples
+    a.run(1000)
+    assert len(a.samples[:]) == N + 1000 and len(a.weights[-1]) == 1000
+    np.random.seed(78)
+    c = ImportanceSampler(lambda x: -0.5 * float(np.dot(x, x)), prop, devices=[0, 0])
+    c.run(3000)
+    xs, ws = c.samples[-1], c.weights[-1][:, 0]
+    np.testing.assert_allclose(ws, np.exp(-0.5 * (xs ** 2).sum(axis=1) - prop.multi_evaluate(xs)), rtol=1e-10)
+    # weighted moments of the sharded run, weights still on the devices
+    run = a.last_run
+    m = calculate_mean(run, run.weights)
+    x1, w1 = a.samples[-1], a.weights[-1][:, 0]
+    np.testing.assert_allclose(m, (w1[:, None] * x1).sum(axis=0) / w1.sum(), rtol=1e-11, atol=1e-12)
+    cv = calculate_covariance(run, run.weights)
+    d = x1 - m
+    ref = np.einsum('n,ni,nj->ij', w1, d, d) / w1.sum() * (w1.sum() ** 2 / (w1.sum() ** 2 - (w1 ** 2).sum()))
+    np.testing.assert_allclose(cv, ref, rtol=1e-9, atol=1e-11)
+
+
+def test_pmc_loop_over_devices_finds_both_modes(be):
+    """the reference's examples/pmc.py scenario (:15-73) with the sampler and the update on a DeviceGroup: nothing N-sized
+    returns to the host between the weighting pass and the update (``last_run.weights``)"""
+    from pypmc_amd.density.gauss import Gauss
+    from pypmc_amd.density.mixture import MixtureDensity, create_gaussian_mixture
+    from pypmc_amd.devices import DeviceGroup
+    from pypmc_amd.sampler.importance_sampling import ImportanceSampler
+    from pypmc_amd.mix_adapt.pmc import gaussian_pmc
+    g = load_golden("example_pmc")
+    target = create_gaussian_mixture(g["target_means"], g["target_covs"], g["target_weights"])
+    initial = MixtureDensity([Gauss(m, np.eye(2)) for m in g["prop_means"]])
+    np.random.seed(int(g["seed"]))
+    with DeviceGroup([0, 0, 0, 0]) as grp:
+        sampler = ImportanceSampler(target.evaluate, initial, devices=grp)
+        for i in range(int(g["steps"])):
+            origin = sampler.run(int(g["n_per_step"]), trace_sort=True)
+            np.testing.assert_array_equal(origin, g["origin_%d" % i])           # counts from the host generator: bit-exact
+            run = sampler.last_run
+            one = gaussian_pmc(sampler.samples[-1], sampler.proposal, sampler.weights[-1][:, 0], origin, mincount=20, rb=True,
+                               backend=be)
+            gaussian_pmc(run, sampler.proposal, run.weights, 'origin', mincount=20, rb=True, copy=False)
+            np.testing.assert_allclose(sampler.proposal.weights, one.weights, rtol=1e-10, atol=1e-14)
+            np.testing.assert_allclose([c.mu for c in sampler.proposal.components], [c.mu for c in one.components], rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose([c.sigma for c in sampler.proposal.components], [c.sigma for c in one.components], rtol=1e-9, atol=1e-11)
+        w = sampler.proposal.weights
+        assert abs(w[0] - 0.3) < 0.05 and abs(w[1] - 0.7) < 0.05 and w[2] < 0.05
+
+
+def test_argument_errors(be):
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.devices import DeviceGroup
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    from pypmc_amd.sampler.importance_sampling import ImportanceSampler
+    from pypmc_amd._lib import HipLibraryError
+    with pytest.raises(HipLibraryError, match="device 7"):
+        DeviceGroup([0, 7])
+    prop = create_gaussian_mixture([np.zeros(2)], [np.eye(2)])
+    with pytest.raises(ValueError, match="two modes"):
+        ImportanceSampler(prop.evaluate, prop, device=True, devices=[0, 0])
+    g = DeviceGroup([0, 0])
+    a, b = g.upload(np.zeros((10, 2))), g.upload(np.ones((10, 2)))
+    g.importance_weights(prop, a, log_target=np.zeros(10))
+    with pytest.raises(ValueError, match="another sample set"):
+        g.pmc_update_stats(prop, b, weights=a.weights)
+    with pytest.raises(ValueError, match="no importance weights"):
+        b.weights
+    with pytest.raises(OverflowError):
+        g.importance_weights(prop, a, log_target=np.full(10, 1e4))
+    vb = GaussianInference(np.random.RandomState(0).normal(size=(50, 2)), components=2, devices=g)
+    assert vb._group is g and vb.N == 50
+    g.close()
