@@ -111,23 +111,24 @@ def measured_traffic(kernel, N):
     return None, None
 
 
-def live_traffic(kernel, N, timeout=150):
-    """HBM bytes per launch of `kernel`, measured NOW: this script again under rocprofv3 (kernel trace + ONE PMC
-    counter per pass: FETCH_SIZE, then WRITE_SIZE -- separate passes and nothing but the kernel trace beside them,
-    as MI355X_MICROARCH.md prescribes), two steps at the same N.  FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE,
-    KiB -> bytes.  (None, reason) if rocprofv3 is missing or a pass fails."""
+def live_counters(kernel, N, timeout=150):
+    """HBM bytes per launch of `kernel` and the shader clock it ran at, measured NOW: this script again under rocprofv3
+    (kernel trace + ONE PMC counter per pass: FETCH_SIZE, WRITE_SIZE, SQ_BUSY_CYCLES -- separate passes and nothing but
+    the kernel trace beside them, as MI355X_MICROARCH.md prescribes), two steps at the same N.  Traffic = FETCH_SIZE x 2
+    (gfx950 correction) + WRITE_SIZE, KiB -> bytes; clock = SQ_BUSY_CYCLES / 32 shader engines / the launch's duration.
+    Returns (traffic or None, source or reason, clock in GHz or None)."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", None
     want = {"k_stats": "k_stats_gemm"}.get(kernel, kernel)      # the statistics kernel pmc_estep runs at K = 32
-    kib = {}
+    val, dur = {}, {}
     work = tempfile.mkdtemp(prefix="pmc_traffic_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_BUSY_CYCLES"):
             out = os.path.join(work, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--n", str(N),
@@ -136,21 +137,28 @@ def live_traffic(kernel, N, timeout=150):
                                stderr=subprocess.PIPE, text=True, timeout=timeout)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
-            per = {}
+                if counter == "SQ_BUSY_CYCLES":
+                    break                                        # (the traffic stands without the clock)
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode), None
+            per, ns = {}, {}
             for row in csv.DictReader(open(files[0])):
                 if want in row["Kernel_Name"] and row["Counter_Name"] == counter:
                     per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                    ns[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
             if not per:
-                return None, "no launch of %s in the %s pass" % (want, counter)
-            kib[counter] = sum(per.values()) / len(per)
+                if counter == "SQ_BUSY_CYCLES":
+                    break
+                return None, "no launch of %s in the %s pass" % (want, counter), None
+            val[counter] = sum(per.values()) / len(per)
+            dur[counter] = sum(ns.values()) / len(ns)
     except (OSError, subprocess.SubprocessError, KeyError, ValueError) as exc:
-        return None, "traffic measurement failed: %r" % (exc,)
+        return None, "traffic measurement failed: %r" % (exc,), None
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    return (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0, \
+    clock = val["SQ_BUSY_CYCLES"] / 32.0 / dur["SQ_BUSY_CYCLES"] if "SQ_BUSY_CYCLES" in val else None
+    return (2.0 * val["FETCH_SIZE"] + val["WRITE_SIZE"]) * 1024.0, \
         "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one counter per pass) on " \
-        "`bench.py --steps 2 --warmup 1` at the same N; FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KiB -> bytes"
+        "`bench.py --steps 2 --warmup 1` at the same N; FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KiB -> bytes", clock
 
 
 def reference_ratio():
@@ -212,7 +220,7 @@ def cpu_baseline(seconds_target, mu, cov, w, tmu, tcov, tw, vbp):
     return out
 
 
-def baseline_configs(be, reps=3, select=None):
+def baseline_configs(be, reps=5, select=None):
     """BASELINE.json's configurations 2-5 on this GPU (one GPU's share where a configuration is quoted on 8),
     through the public front-end with the samples resident on the device: median wall time of ``reps`` calls
     (device synchronised on both sides), the library's own per-kernel times (pmc_get_timings) of those calls, and
@@ -237,14 +245,25 @@ def baseline_configs(be, reps=3, select=None):
             fn()
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
+        # ... then wall AND kernels in the SAME calls (verdict r4 #4): host_ms = wall - sum of the kernels' own times, per
+        # call, is everything that is not a hot kernel -- Python, ctypes, pack building, K-sized LAPACK, copies, launch gaps
+        tw, host = [], []
         be.kernel_timings()
-        be.kernel_timing(True)                           # ... the kernels' own times in a loop of their own
+        be.kernel_timing(True)
         for _ in range(reps):
+            t0 = time.perf_counter()
             fn()
             torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            one = be.kernel_timings()                    # (synchronises; clears the record)
+            tw.append(dt)
+            host.append(dt * 1e3 - sum(v["ms"] for v in one.values()))
+            kern_last = one
         be.kernel_timing(False)
-        kern = {k_: v["ms"] / reps for k_, v in be.kernel_timings().items()}
-        return float(np.median(ts)), kern
+        kern = {k_: v["ms"] for k_, v in kern_last.items()}
+        extra = {"ms_with_event_records": float(np.median(tw)) * 1e3, "host_ms": float(np.median(host)),
+                 "host_ms_all": [round(h, 4) for h in host], "ms_all": [round(t_ * 1e3, 4) for t_ in ts]}
+        return float(np.median(ts)), kern, extra
 
     def entry(workload, N, flops_per_sample, t, kern, **extra):
         tf = flops_per_sample * N / t * 1e-12
@@ -264,8 +283,8 @@ def baseline_configs(be, reps=3, select=None):
         np.random.seed(7)
         x2 = mix.propose(N2, device=True)
         cs = component_set(mix.components, mix.weights)
-        t, kern = timed(lambda: be.logpdf(x2, cs))
-        out["cfg2"] = entry("MixtureDensity.multi_evaluate D=20 K=16 Gauss", N2, flops_logpdf(K2, D2), t, kern)
+        t, kern, ex = timed(lambda: be.logpdf(x2, cs))
+        out["cfg2"] = entry("MixtureDensity.multi_evaluate D=20 K=16 Gauss", N2, flops_logpdf(K2, D2), t, kern, **ex)
         del x2
 
     if want("cfg3"):
@@ -278,10 +297,10 @@ def baseline_configs(be, reps=3, select=None):
         np.random.seed(8)
         x3 = prop.propose(N3, device=True)
         pcs, tcs = component_set(prop.components, prop.weights), component_set(tgt.components, tgt.weights)
-        t, kern = timed(lambda: be.importance_weights(x3, pcs, tcs))
+        t, kern, ex = timed(lambda: be.importance_weights(x3, pcs, tcs))
         f3 = (K3 + 4) * (D3 * D3 + 4 * D3) + K3 * 80 + 4 * 40      # c_tr = 40, +40 for Student-t's log
         out["cfg3"] = entry("Student-t nu=8 D=30 K=32 proposal vs K_t=4 Gauss target: weights + perplexity sums",
-                            N3, f3, t, kern)
+                            N3, f3, t, kern, **ex)
         del x3
 
     # -- config 4: GaussianInference.E_step, D=20, K=64: N=1e7 on one GPU and one GPU's share of 8
@@ -294,9 +313,9 @@ def baseline_configs(be, reps=3, select=None):
         np.random.seed(9)
         x4 = mix4.propose(N4, device=True)
         vb = GaussianInference(x4, initial_guess=mix4)
-        t, kern = timed(vb.E_step)
+        t, kern, ex = timed(vb.E_step)
         out[label] = entry("GaussianInference.E_step D=20 K=64 (host conversion of the K-sized sums included)",
-                           N4, f4, t, kern)
+                           N4, f4, t, kern, **ex)
         del vb, x4
 
     if not want("cfg5"):
@@ -318,13 +337,85 @@ def baseline_configs(be, reps=3, select=None):
         run = sampler.run_device(N5, trace_sort=True, prepare_update=True)
         gaussian_pmc(run["samples"], sampler.proposal, run["weights"], run["origin"], mincount=0, rb=True,
                      copy=False, mahalanobis=run["mahalanobis"], responsibilities=run["responsibilities"])
-    t, kern = timed(iteration)
+    t, kern, ex = timed(iteration)
     f5 = flops_logpdf(K5 + KT5, D5) + flops_stats(K5, D5) + D5 * (D5 + 1)
     out["cfg5"] = entry("PMC iteration D=40 K=128: propose -> weights (proposal evaluated once, responsibilities "
                         "of the update emitted by the same pass) -> statistics -> host update, one GPU's share of "
-                        "N=1e8 over 8", N5, f5, t, kern)
+                        "N=1e8 over 8", N5, f5, t, kern, **ex)
     out["seconds"] = time.perf_counter() - t_all
     return out
+
+
+def main_single_process(args):
+    """The headline step over several devices from ONE process: the handle layer's multi-device
+    context behind pypmc_amd.devices.DeviceGroup.  Samples are generated on the devices (resident before the clock
+    starts), weak scaling as in the multi-rank mode: --n samples per device."""
+    from pypmc_amd.devices import DeviceGroup
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    ids = [int(v) for v in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    assert len(ids) == args.gpus, "--gpus %d but --devices names %d" % (args.gpus, len(ids))
+    g = DeviceGroup(ids)
+    n_total = args.n * len(ids) if args.scaling == "weak" else args.n
+    mu, cov, w = mk(K, D, 1)
+    tmu, tcov, tw = mk(K_T, D, 11)
+    proposal, target = create_gaussian_mixture(mu, cov, w), create_gaussian_mixture(tmu, tcov, tw)
+    W, beta, nu, ln_pi, ln_lambda = vb_params(mu, cov, w, n_total)
+    counts = np.random.RandomState(1234).multinomial(n_total, w)
+    samples = g.generate(proposal, counts, seed=99)
+
+    def step():
+        r = g.importance_weights(proposal, samples, target=target, want_weights=False)
+        e = g.vb_estep(samples, None, mu, W, nu, beta, ln_pi, ln_lambda)
+        return r, e
+
+    for _ in range(args.prewarm + args.warmup):
+        step()
+    g.kernel_timings()
+    g.kernel_timing(True)
+    marks = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r, e = step()                                    # (synchronous: the K-sized results are on the host)
+        marks.append(time.perf_counter())
+    elapsed = marks[-1] - t0
+    g.kernel_timing(False)
+    timings = g.kernel_timings()
+    per_step = np.diff(np.array([t0] + marks)) * 1e3
+    ms_per_step = elapsed / args.steps * 1e3
+    assert abs(e["N_comp"].sum() / n_total - 1) < 1e-9, "sum_k N_k != N (a device's share is missing)"
+    sw, swl, _ = r["sums"]
+    hot = {k_: v for k_, v in timings.items() if k_ in ("k_logpdf", "k_resp", "k_stats", "k_estep_fused")}
+    dominant = max(hot, key=lambda k_: hot[k_]["ms"])
+    # per launch and DEVICE: a kernel's entry adds flops over the devices and keeps the slowest device's time
+    nd = len(ids)
+    per_launch = {k_: dict(ms=v["ms"] / (v["calls"] / nd), flops=v["flops"] / v["calls"], bytes=v["bytes"] / v["calls"])
+                  for k_, v in hot.items()}
+    dom = per_launch[dominant]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) * 1e-12
+    line = {
+        "metric": "IS samples/sec + VB E-step samples/sec at N=1e7, K=32, D=20",
+        "value": n_total / (ms_per_step * 1e-3),
+        "unit": "samples/s through one IS weighting pass plus one VB E-step",
+        "n_gpus": len(ids), "steps": args.steps, "warmup": args.warmup, "prewarm_steps": args.prewarm, "ms_per_step": ms_per_step,
+        "step_ms": {"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max())},
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "IS weights (K=32 Gauss proposal, K_t=4 Gauss target, perplexity/ESS sums) "
+                               "+ VB E-step (r_nk, N_k, x_k, S_k, E[log q(Z)], sum over the devices)",
+                   "N_per_gpu": n_total // len(ids), "N_total": n_total, "K": K, "D": D, "K_target": K_T,
+                   "parallelism": "ONE process, samples sharded x%d by the library (pmc_init_devices)" % len(ids),
+                   "devices": ids, "virtual_shards": len(set(ids)) < len(ids)},
+        "dist": {"backend": "single process: peer copies + ordered sum on the first device (no RCCL, no IPC)",
+                 "world_size": 1, "devices": len(ids), "sum_doubles": 8 + K * (1 + D + D * (D + 1) // 2)},
+        "kernel_ms": {k_: v["ms"] for k_, v in per_launch.items()},
+        "perplexity": float(np.exp(-(swl / sw - np.log(sw))) / n_total),
+        "roofline": {"bound": PIPE_OF.get(dominant, "valu"), "kernel": dominant, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                     "note": "per device: the slowest device's launch time (pmc_ctx_get_timings), the flops of one device's "
+                             "share; with virtual shards the launches of the parts share ONE GPU and stretch each other"},
+    }
+    print(json.dumps(line))
+    samples.free()
+    g.close()
 
 
 def main():
@@ -351,7 +442,16 @@ def main():
                     help="run the step's two independent halves (IS pass, VB E-step) side by side on two HIP streams: "
                          "about 4 %% more samples/s, but overlapping kernels stretch each other, so the per-kernel "
                          "roofline of such a run is not comparable -- off by default")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N devices behind THIS one process (pypmc_amd.devices.DeviceGroup: pmc_init_devices, lib-owned "
+                         "shards, a host thread per device, the statistics added in device order) instead of one rank per GPU "
+                         "under torch.distributed.run; the same step, the same metric")
+    ap.add_argument("--devices", default=None, metavar="0,1,2,3",
+                    help="with --single-process: the device ordinals (default 0 ... gpus-1); an ordinal may repeat -- virtual "
+                         "shards on one GPU (the projection a one-GPU box can make)")
     args = ap.parse_args()
+    if args.single_process:
+        return main_single_process(args)
 
     import torch
     import torch.distributed as dist
@@ -453,12 +553,13 @@ def main():
     torch.cuda.synchronize()
     be.kernel_timings()                              # clear the library's record
     be.kernel_timing(True)                           # HIP events on the launch stream around every hot kernel
-    phase = []
+    phase, marks = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         evs = tuple(ev() for _ in range(5))
-        r, host = step(evs)
+        r, host = step(evs)                          # (ends with the K-sized result on the host: the step is complete)
         phase.append(evs)
+        marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
@@ -475,6 +576,7 @@ def main():
         n_sum = float(t.item())
     assert n_sum == float(n_total), (n_sum, n_total)
     ms_per_step = elapsed / args.steps * 1e3
+    per_step = np.diff(np.array([t0] + marks)) * 1e3 # this rank's steps, one by one (box variance vs code changes)
 
     is_ms = float(np.mean([p[0].elapsed_time(p[1]) for p in phase]))
     vb_ms = float(np.mean([p[1].elapsed_time(p[4]) for p in phase]))
@@ -495,7 +597,7 @@ def main():
                       for k_, v in hot.items()}
         dom = per_launch[dominant]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) * 1e-12
-        traffic, traffic_src = (None, "switched off") if (args.no_traffic or world > 1) else live_traffic(dominant, N)
+        traffic, traffic_src, sq_clock = (None, "switched off", None) if (args.no_traffic or world > 1) else live_counters(dominant, N)
         traffic_live = traffic is not None
         if traffic is None:
             why = traffic_src
@@ -508,6 +610,7 @@ def main():
             "value": n_total / (ms_per_step * 1e-3),
             "unit": "samples/s through one IS weighting pass plus one VB E-step",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": args.prewarm, "ms_per_step": ms_per_step,
+            "step_ms": {"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max())},
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "IS weights (K=32 Gauss proposal, K_t=4 Gauss target, perplexity/ESS sums) "
@@ -536,6 +639,9 @@ def main():
                          "frac_of_attainable": achieved / ATTAINABLE_TFLOPS[PIPE_OF.get(dominant, "valu")],
                          "per_kernel_bound": {k_: PIPE_OF.get(k_, "valu") for k_ in per_launch},
                          "traffic": traffic,
+                         # shader clock of the dominant kernel in the counter pass of THIS run (SQ_BUSY_CYCLES / 32 shader
+                         # engines / duration): what separates a slow box (power, thermals) from a slow kernel
+                         "sq_clock_ghz": sq_clock,
                          "traffic_measured_live": bool(traffic is not None and traffic_live),
                          "traffic_source": traffic_src,
                          "timing_source": "pmc_get_timings: HIP events on the launch stream around each kernel, "
@@ -588,15 +694,19 @@ def main():
                 torch.cuda.synchronize()
                 share_ms = (time.perf_counter() - t_s) / 20 * 1e3
                 be.kernel_timings()
-                be.kernel_timing(True)                   # ... the kernels' own times in a loop of their own
+                be.kernel_timing(True)                   # ... then wall and the kernels' own times in the SAME calls
+                torch.cuda.synchronize()
+                t_s = time.perf_counter()
                 for _ in range(10):
                     share_step()
                 torch.cuda.synchronize()
+                share_ev_ms = (time.perf_counter() - t_s) / 10 * 1e3
                 be.kernel_timing(False)
                 kt8 = {k_: v["ms"] / v["calls"] for k_, v in be.kernel_timings().items()}
                 e8_ms = kt8.get("k_resp", 0.0) + kt8.get("k_stats", 0.0) + kt8.get("k_estep_fused", 0.0)
                 ef_ms = kern.get("k_resp", 0.0) + kern.get("k_stats", 0.0) + kern.get("k_estep_fused", 0.0)
                 line["share_of_8"] = {"N": n8, "ms_per_step": share_ms, "kernel_ms": kt8,
+                                      "ms_with_event_records": share_ev_ms, "host_ms": share_ev_ms - sum(kt8.values()),
                                       "step_speedup_vs_full_batch": ms_per_step / share_ms,
                                       "estep_kernels_speedup_vs_full_batch": ef_ms / e8_ms if e8_ms > 0 else None,
                                       "note": "one GPU, N / 8 samples: a projection of strong scaling, not a measurement of it"}

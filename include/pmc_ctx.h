@@ -121,6 +121,21 @@ int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_sa
  */
 int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol, const int64_t *h_counts,
                          uint64_t seed, int64_t first_sample, pmc_samples **out);
+/*
+ * A sample array that is ALREADY on the context's device (a torch tensor of the front-end, the output of another
+ * library): N x D row-major fp64 at d_x, borrowed -- not copied, not freed by pmc_samples_free, and the caller keeps it
+ * alive and unchanged while the handle is in use.  One-device contexts only.  Work that produced the array on another
+ * stream must have completed (the context launches on its own stream).
+ */
+int pmc_samples_wrap(pmc_ctx *ctx, const double *d_x, int64_t N, int D, pmc_samples **out);
+/*
+ * Sample weights of the VB E-step that stay with the handle (GaussianInference normalises its weights once, in the
+ * constructor, variational.pyx:86-100, and uses them in every E-step): copied to the shards from the host (h_w: N
+ * doubles; NULL removes them), or a borrowed device array next to a wrapped sample array.  pmc_vb_estep uses them when it
+ * is called with h_sample_w == NULL; an h_sample_w given there is uploaded for that call and wins.
+ */
+int pmc_samples_set_sample_weights(pmc_samples *s, const double *h_w);
+int pmc_samples_wrap_sample_weights(pmc_samples *s, const double *d_w);
 int64_t pmc_samples_count(const pmc_samples *s);
 /* rows [*begin, *begin + *count) live on part `part` of the context; returns that part's device ordinal */
 int pmc_samples_shard(const pmc_samples *s, int part, int64_t *begin, int64_t *count);
@@ -160,7 +175,8 @@ int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target,
  * GaussianInference.E_step (pypmc/mix_adapt/variational.pyx:116-127) for K components from the variational
  * parameters the object holds --  h_m K x D, h_W K x D x D, h_nu, h_beta K, h_ln_pi = expectation_ln_pi K,
  * h_ln_lambda = expectation_det_ln_lambda K (:759-772, :800-804) -- and optional sample weights h_sample_w (N, as
- * the constructor normalised them, :86-100; NULL = unweighted).  Results in the reference's conventions, over ALL
+ * the constructor normalised them, :86-100; NULL = the weights that stay with the handle,
+ * pmc_samples_set_sample_weights, or unweighted).  Results in the reference's conventions, over ALL
  * ranks' samples:
  *   h_N_k   K          N_comp, zeros regularised to tiny (:699-709)
  *   h_xbar  K x D      x_mean_comp (:806-853)
@@ -171,7 +187,10 @@ int pmc_is_weights(const pmc_mix *q, pmc_samples *s, const double *h_log_target,
  * makes x_mean_comp and S bit-stable as soon as r is) and repeated about the mean just found when that turns out
  * more than 10 of the component's own standard deviations away (the reference takes the mean first, then the
  * covariance about it).  Non-finite inputs come back as non-finite sums; the reference's checks of N_comp and S
- * (variational.pyx:122-126) stay with the caller.
+ * (variational.pyx:122-126) stay with the caller.  PMC_ENOTPOSDEF names the component whose W_k does not factorise.
+ * For compiled dimensions (D <= 64) nothing K-sized runs on the host: the parameters go up in one copy, the pack
+ * (pmc_pack_components_device), the shift pack and the conversion (pmc_convert_stats_device) are kernels, one copy
+ * brings N_comp / x_mean_comp / S / E[log q(Z)] back -- bit for bit what the host functions give.
  */
 int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, int K, const double *h_m,
                  const double *h_W, const double *h_nu, const double *h_beta, const double *h_ln_pi,

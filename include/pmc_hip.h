@@ -339,6 +339,35 @@ int pmc_estep(const double *d_x, int64_t N, int D, const double *d_pack, int K, 
               double *d_scratch, double *d_vsums, double *d_stats, double *d_scalars, void *d_workspace,
               void *stream);
 
+/* ---- device-side packs and conversion (round 5) --------------------------------------------------------- */
+/*
+ * The K-sized steps around an E-step that ran on the host -- the Cholesky factorisations of pmc_pack_components
+ * (variational.pyx:116-136 hands W_k over after every M-step), pmc_pack_means for a shifted statistics pass, and the
+ * conversion of the statistics into the reference's conventions (pmc_host_convert_stats in pmc_ctx.h;
+ * variational.pyx:699-932, pmc.pyx:188-222) -- as small kernels on the caller's stream: at one GPU's share of an 8-way
+ * sharded E-step they were 15 % of the call.  Same operations in the same order as the host functions: identical bits.
+ *
+ * pmc_pack_components_device: the arguments of pmc_pack_components as DEVICE arrays (d_c0 ... d_column may be NULL with
+ *   the same defaults); compiled dimensions (D <= pmc_max_compiled_dim()) only.  d_status: 2 K doubles on the device
+ *   ([1 + failing pivot or 0, K | its value, K], every slot written); after the stream is synchronised copy them to the host and ask
+ *   pmc_pack_status(K, h_status): PMC_OK, or PMC_ENOTPOSDEF naming the lowest component whose matrix does not factorise
+ *   (its pack is then unusable; kernels that read it return NaN, they do not hang).  d_shift / d_shift_pack (both or
+ *   neither): the K x D shifts of a statistics pass and the pack that receives them (pmc_pack_means) in the same launch.
+ * pmc_pack_means_device: pmc_pack_means alone.
+ * pmc_convert_stats_device: d_stats = the K x pmc_stats_stride(D) statistics (pmc_sufficient_stats' layout), d_shift
+ *   K x D, d_n_cov K or NULL, d_scalars the call's 8 scalar sums or NULL;  d_out (pmc_convert_stats_len(K, D) doubles) =
+ *   [S0 K | M1 K D | mean K D | cov K D D | far K | scalars 8]: far_k = 1.0 if component k's mean lies more than 10 of its
+ *   standard deviations from its shift -- everything a caller reads after an E-step, in one block for one copy.
+ */
+int pmc_pack_components_device(int K, int D, const double *d_mu, const double *d_prec, const double *d_c0, const double *d_c1,
+                               const double *d_c2, const double *d_c3, const double *d_weight, const int32_t *d_column,
+                               double *d_pack, double *d_status, const double *d_shift, double *d_shift_pack, void *stream);
+int pmc_pack_status(int K, const double *h_status);
+int pmc_pack_means_device(int K, int D, const double *d_mu, double *d_pack, void *stream);
+int64_t pmc_convert_stats_len(int K, int D);
+int pmc_convert_stats_device(int K, int D, const double *d_stats, const double *d_shift, const double *d_n_cov,
+                             const double *d_scalars, double *d_out, void *stream);
+
 /* ---- a PMC iteration without evaluating the proposal twice --------------------------------------- */
 /*
  * The reference evaluates the proposal's component densities on the same samples twice per PMC iteration:

@@ -54,6 +54,11 @@ SIGNATURES = {
     "pmc_tile": (_int, []),
     "pmc_pack_components": (_int, [_int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i32, _dp]),
     "pmc_pack_means": (_int, [_int, _int, _dp, _dp]),
+    "pmc_pack_components_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_pack_status": (_int, [_int, _dp]),
+    "pmc_pack_means_device": (_int, [_int, _int, _vp, _vp, _vp]),
+    "pmc_convert_stats_len": (_i64, [_int, _int]),
+    "pmc_convert_stats_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmc_stream_release": (_int, [_vp]),
     "pmc_workspace_bytes": (_i64, [_i64, _int, _int]),
     "pmc_tile_buffer_len": (_i64, [_i64, _int]),
@@ -126,6 +131,9 @@ CTX_SIGNATURES = {
     "pmc_mixture_destroy": (_int, [_vp]),
     "pmc_samples_upload": (_int, [_vp, _dp, _i64, _int, _pp]),
     "pmc_samples_generate": (_int, [_vp, _vp, _dp, _ip, C.c_uint64, _i64, _pp]),
+    "pmc_samples_wrap": (_int, [_vp, _vp, _i64, _int, _pp]),
+    "pmc_samples_set_sample_weights": (_int, [_vp, _dp]),
+    "pmc_samples_wrap_sample_weights": (_int, [_vp, _vp]),
     "pmc_samples_count": (_i64, [_vp]),
     "pmc_samples_download": (_int, [_vp, _dp]),
     "pmc_samples_origin": (_int, [_vp, _ip]),

@@ -140,6 +140,7 @@ class HipBackend(object):
         self._ws = {}            # launch stream -> scratch (calls on different streams may overlap)
         self._bufs = {}
         self.profile = None      # set to a list to collect (entry point, start, end) event triples
+        self._ctx = None         # a handle-layer context on this device (include/pmc_ctx.h), made on first use
 
     # Densities keep a reference to their backend and are deep-copied / pickled by the front-end
     # (MixtureDensity copies its components, ImportanceSampler its proposal): a backend is a
@@ -567,12 +568,68 @@ class HipBackend(object):
         M2[jl, il] = h[1 + D:]
         return float(h[0]), h[1:1 + D].copy(), M2, shift[0], float(sums[2])
 
+    # ------------------------------------------------------------------ the E-step as ONE call of the handle layer
+    def ctx(self):
+        """this backend's handle-layer context (pmc_init on its device): host arrays in, the reference's conventions out,
+        everything K-sized in between on the device"""
+        if self._ctx is None:
+            h = C.c_void_p()
+            _lib.check(self.lib.pmc_init(self.device.index or 0, C.byref(h)), "pmc_init")
+            self._ctx = h
+        return self._ctx
+
+    def wrap_samples(self, x, sample_w=None):
+        """``x`` (N x D device tensor, kept alive by the returned object) as a sample handle of ``ctx()`` -- borrowed, not
+        copied; optional sample weights (N, device tensor) likewise.  For ``vb_estep``."""
+        x = self.asdevice(x)
+        w = self.asdevice(sample_w).reshape(x.shape[0]) if sample_w is not None else None
+        self.torch.cuda.current_stream(self.device).synchronize()      # (the context launches on a stream of its own)
+        return _WrappedSamples(self, x, w)
+
+    def vb_estep(self, samples, m, W, nu, beta, ln_pi, ln_lambda, shift=None):
+        """GaussianInference.E_step (variational.pyx:116-127) as ONE call of the library (pmc_vb_estep): the parameters
+        go up in one copy, the pack, the shift pack and the conversion to N_comp / x_mean_comp / S are kernels, one copy
+        brings the results back; the far-shift second pass happens inside.  dict(N_comp, x_mean_comp, S, log_q_Z)."""
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        K, D = m.shape
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        Nk, xbar, S, elq = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(1)
+        sh = c(shift).reshape(K, D) if shift is not None else None
+        _lib.check(self._timed("pmc_vb_estep", self.lib.pmc_vb_estep, self.ctx(), samples._h, None, K, _dptr(m), _dptr(c(W)), _dptr(c(nu)),
+                               _dptr(c(beta)), _dptr(c(ln_pi)), _dptr(c(ln_lambda)), _dptr(sh) if sh is not None else None, _dptr(Nk),
+                               _dptr(xbar), _dptr(S), _dptr(elq), None, None), "pmc_vb_estep")
+        return dict(N_comp=Nk, x_mean_comp=xbar, S=S, log_q_Z=float(elq[0]))
+
     def stats_len(self, K, D):
         """length of the flat statistics buffer of estep()"""
         return NSCALARS + K * int(self.lib.pmc_stats_stride(D)) + 2 * K
 
     def stats_stride(self, D):
         return int(self.lib.pmc_stats_stride(D))
+
+
+class _WrappedSamples(object):
+    """a device tensor (and optional sample weights) lent to the backend's handle-layer context"""
+
+    def __init__(self, be, x, w):
+        self.be, self.x, self.w, self._h = be, x, w, None
+        h = C.c_void_p()
+        _lib.check(be.lib.pmc_samples_wrap(be.ctx(), C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], C.byref(h)),
+                   "pmc_samples_wrap")
+        self._h = h
+        if w is not None:
+            _lib.check(be.lib.pmc_samples_wrap_sample_weights(h, C.c_void_p(w.data_ptr())), "pmc_samples_wrap_sample_weights")
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                self.be.lib.pmc_samples_free(self._h)
+                self._h = None
+        except Exception:  # pragma: no cover
+            pass
+
+    def __deepcopy__(self, memo):
+        return _WrappedSamples(self.be, self.x, self.w)
 
 
 _default = None

@@ -569,6 +569,140 @@ __global__ __launch_bounds__(256) void k_combine_weights(const double *__restric
     if (flag && !(fabs(w) <= 1.7976931348623157e308)) atomicAdd(flag, 1.0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K-sized work on the device (round 5): the parameter pack, the shift pack and the conversion of the statistics into
+// the reference's conventions -- what the host did between the M-step and the E-step's first launch and behind its last
+// (verdict r4 #3: 15 % of an E-step at one GPU's share of eight).  Same operations in the same order as the host
+// functions they stand in for (pmc_pack_components, pmc_pack_means, pmc_host_convert_stats; -ffp-contract=off here as
+// there, sqrt and division correctly rounded on both sides): the SAME BITS, which the tests hold them to.
+// ---------------------------------------------------------------------------------------------
+// One wavefront per component, lane j = column j of the upper factor (D <= 64); the matrix and its factor in LDS (the
+// matrix is read from global memory ONCE, coalesced: a load per row of the factorisation would put a memory latency in
+// front of each of its D dependent steps).  status = [1 + failing pivot, or 0 (K) | its value (K)]: nothing to initialise,
+// every component writes its two slots.
+// blocks K ... 2K-1 (when means != NULL): the pack of the shifts of a statistics pass (pmc_pack_means) in the same launch.
+__global__ __launch_bounds__(64) void k_pack_build(const double *mu, const double *prec, const double *c0, const double *c1,
+                                                  const double *c2, const double *c3, const double *weight, const int *column,
+                                                  int K, int D, int Dp, int stride, double *pack, double *status,
+                                                  const double *means, double *mpack)
+{
+    extern __shared__ double lds[];
+    const int j = threadIdx.x;
+    if ((int)blockIdx.x >= K) {
+        const int k = blockIdx.x - K;
+        double *pk = mpack + (size_t)k * stride;
+        for (int idx = j; idx < stride; idx += 64) pk[idx] = 0.0;
+        __syncthreads();
+        if (j < D) pk[j] = means[(size_t)k * D + j];
+        if (j == 0) {
+            double *c = pk + Dp + Dp * (Dp + 1) / 2;
+            c[4] = 1.0;
+            ((long long *)c)[5] = (long long)k;
+        }
+        return;
+    }
+    const int k = blockIdx.x;
+    double *Rl = lds, *Al = lds + D * D;
+    double *pk = pack + (size_t)k * stride;
+    const double *A = prec + (size_t)k * D * D;
+    for (int idx = j; idx < D * D; idx += 64) Al[idx] = A[idx];
+    for (int idx = j; idx < stride; idx += 64) pk[idx] = 0.0;
+    __syncthreads();
+    if (j < D) pk[j] = mu[(size_t)k * D + j];
+    int bad_i = -1;
+    double bad_s = 0.0;
+    for (int i = 0; i < D; ++i) {
+        double s = 0.0;
+        if (j >= i && j < D) {
+            s = Al[i * D + j];
+            for (int l = 0; l < i; ++l) s -= Rl[l * D + i] * Rl[l * D + j];
+        }
+        const double sii = __shfl(s, i, 64);                          // the pivot, to every lane
+        if (!(sii > 0.0) || !isfinite(sii)) {
+            bad_i = i;
+            bad_s = sii;
+            break;                                                    // (wave-uniform)
+        }
+        const double rii = sqrt(sii);
+        if (j == i) Rl[i * D + i] = rii;
+        else if (j > i && j < D) Rl[i * D + j] = s / rii;
+        __syncthreads();
+    }
+    if (j == 0) {
+        status[k] = (double)(bad_i + 1);                              // 0 = factorised, else 1 + the failing pivot
+        status[K + k] = bad_s;
+    }
+    if (bad_i >= 0) return;
+    // packed row-major (i, j >= i) for the compiled dimension; padding rows / columns stay zero
+    for (int i = 0; i < D; ++i)
+        if (j >= i && j < D) pk[Dp + i * Dp - i * (i - 1) / 2 + (j - i)] = Rl[i * D + j];
+    if (j == 0) {
+        double *c = pk + Dp + Dp * (Dp + 1) / 2;
+        c[0] = c0 ? c0[k] : 0.0;
+        c[1] = c1 ? c1[k] : 0.0;
+        c[2] = c2 ? c2[k] : 0.0;
+        c[3] = c3 ? c3[k] : 0.0;
+        c[4] = weight ? weight[k] : 1.0;
+        ((long long *)c)[5] = column ? (long long)column[k] : (long long)k;
+    }
+}
+
+// pmc_host_convert_stats on the device.  out = [S0 K | M1 K D | mean K D | cov K D D | far K (0 / 1 per component) |
+// scalars PMC_NSCALARS (a copy of `scalars`, or zeros)]: everything a caller reads after an E-step in ONE block of memory
+__global__ __launch_bounds__(256) void k_convert_stats(const double *stats, const double *shift, const double *ncov, int K, int D,
+                                                      const double *scalars, double *out)
+{
+    __shared__ double s0s[1024];
+    __shared__ double total_s;
+    const int k = blockIdx.x, PS = 1 + D + D * (D + 1) / 2;
+    const double *b = stats + (size_t)k * PS;
+    double *S0 = out, *M1 = S0 + K, *mean = M1 + (size_t)K * D, *cov = mean + (size_t)K * D, *far = cov + (size_t)K * D * D;
+    const double tiny = 2.2250738585072014e-308;
+    // the total over the components, added in their order (shift_is_far's threshold): loads side by side, one lane adds
+    double total = 0.0;
+    for (int q0 = 0; q0 < K; q0 += 1024) {
+        const int nq = K - q0 < 1024 ? K - q0 : 1024;
+        __syncthreads();
+        for (int q = threadIdx.x; q < nq; q += 256) s0s[q] = stats[(size_t)(q0 + q) * PS];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int q = 0; q < nq; ++q)
+                if (isfinite(s0s[q])) total += s0s[q];
+    }
+    if (threadIdx.x == 0) total_s = total;
+    const double s0 = b[0];
+    const double nm = s0 == 0.0 ? tiny : s0;
+    const double ncr = ncov ? ncov[k] : s0;
+    const double nc = ncr == 0.0 ? tiny : ncr;
+    if (threadIdx.x == 0) S0[k] = s0;
+    if (k == 0 && threadIdx.x < PMC_NSCALARS) (far + K)[threadIdx.x] = scalars ? scalars[threadIdx.x] : 0.0;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        M1[(size_t)k * D + i] = b[1 + i];
+        mean[(size_t)k * D + i] = shift[(size_t)k * D + i] + b[1 + i] / nm;
+    }
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int i = e / D, jj = e % D;
+        const int hi = i > jj ? i : jj, lo = i > jj ? jj : i;
+        const double m2 = b[1 + D + hi * (hi + 1) / 2 + lo];
+        const double prod = (b[1 + i] / nm) * (b[1 + jj] / nm);
+        cov[((size_t)k * D + i) * D + jj] = (m2 - nm * prod) / nc;
+    }
+    __syncthreads();
+    // _stats.py::shift_is_far (limit 100) for this component: the D coordinates side by side, any hit counts
+    int hit = 0;
+    if (isfinite(s0) && s0 > 1e-200 && s0 > 1e-6 * total_s) {
+        for (int i = threadIdx.x; i < D; i += 256) {
+            const double db = b[1 + i] / s0, dbar2 = db * db;
+            const double raw = b[1 + D + i * (i + 1) / 2 + i] / s0;
+            const double v = raw - dbar2, t = 1e-14 * raw;
+            const double var = (v != v || t != t) ? v + t : (v > t ? v : t);
+            if (dbar2 > 100. * var) hit = 1;
+        }
+    }
+    hit = __syncthreads_or(hit);
+    if (threadIdx.x == 0) far[k] = hit ? 1.0 : 0.0;
+}
+
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 
 // statistics launch geometry
@@ -1096,6 +1230,68 @@ int pmc_pack_components(int K, int D, const double *mu, const double *prec, cons
     for (const Bad &b : bad_of)                                 // (workers hold ascending ranges: the first hit is the lowest index)
         if (b.k >= 0)
             return fail(PMC_ENOTPOSDEF, "precision matrix of component %d is not positive definite (pivot %d = %g)", b.k, b.i, b.s);
+    return PMC_OK;
+}
+
+// ---- the K-sized host steps on the device (include/pmc_hip.h: "device-side packs and conversion") ---------------------
+int pmc_pack_components_device(int K, int D, const double *d_mu, const double *d_prec, const double *d_c0, const double *d_c1,
+                               const double *d_c2, const double *d_c3, const double *d_weight, const int32_t *d_column,
+                               double *d_pack, double *d_status, const double *d_shift, double *d_shift_pack, void *stream)
+{
+    if (K < 1 || !d_mu || !d_prec || !d_pack || !d_status || ((d_shift != nullptr) != (d_shift_pack != nullptr)))
+        return fail(PMC_EINVAL, "pmc_pack_components_device: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
+    if (D > PMC_MAX_DIM || pmc_engine(ks->dim) == PMC_ENG_DPP)
+        return fail(PMC_EINVAL, "pmc_pack_components_device: compiled dimensions up to %d in the row-major layout only (D = %d): "
+                    "build the pack on the host (pmc_pack_components)", PMC_MAX_DIM, D);
+    hipLaunchKernelGGL(k_pack_build, dim3((unsigned)(d_shift ? 2 * K : K)), dim3(64), sizeof(double) * 2 * (size_t)D * D,
+                       (hipStream_t)stream, d_mu, d_prec, d_c0, d_c1, d_c2, d_c3, d_weight, (const int *)d_column, K, D, ks->dim,
+                       pmc_pack_stride_c(ks->dim), d_pack, d_status, d_shift, d_shift_pack);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_pack_build launch");
+    return PMC_OK;
+}
+
+int pmc_pack_status(int K, const double *h_status)
+{
+    if (K < 1 || !h_status) return fail(PMC_EINVAL, "pmc_pack_status: bad argument");
+    for (int k = 0; k < K; ++k)
+        if (h_status[k] != 0.0)
+            return fail(PMC_ENOTPOSDEF, "precision matrix of component %d is not positive definite (pivot %d = %g)", k,
+                        (int)h_status[k] - 1, h_status[K + k]);
+    return PMC_OK;
+}
+
+int pmc_pack_means_device(int K, int D, const double *d_mu, double *d_pack, void *stream)
+{
+    if (K < 1 || !d_mu || !d_pack) return fail(PMC_EINVAL, "pmc_pack_means_device: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks || D > PMC_MAX_DIM) return fail(PMC_EINVAL, "pmc_pack_means_device: compiled dimensions only (D = %d)", D);
+    // (the means half of k_pack_build alone: its first K blocks are skipped by an offset of -K in the block index)
+    hipLaunchKernelGGL(k_pack_build, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, (const int *)nullptr, 0, D, ks->dim,
+                       pmc_pack_stride_c(ks->dim), (double *)nullptr, (double *)nullptr, d_mu, d_pack);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_pack_build (means) launch");
+    return PMC_OK;
+}
+
+int64_t pmc_convert_stats_len(int K, int D)
+{
+    if (K < 1 || D < 1) return fail(PMC_EINVAL, "pmc_convert_stats_len: bad K / D");
+    return (int64_t)K * (2 + 2 * (int64_t)D + (int64_t)D * D) + PMC_NSCALARS;
+}
+
+int pmc_convert_stats_device(int K, int D, const double *d_stats, const double *d_shift, const double *d_n_cov,
+                             const double *d_scalars, double *d_out, void *stream)
+{
+    if (K < 1 || D < 1 || !d_stats || !d_shift || !d_out) return fail(PMC_EINVAL, "pmc_convert_stats_device: bad argument");
+    hipLaunchKernelGGL(k_convert_stats, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, d_stats, d_shift, d_n_cov, K, D,
+                       d_scalars, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_convert_stats launch");
     return PMC_OK;
 }
 

@@ -93,7 +93,7 @@ struct DevBuf {
 struct Part {
     int index = 0, device = 0;
     hipStream_t stream = nullptr;
-    DevBuf ws, u, scratch, flat, pack, spack, aux, nk1, nk2, lat;
+    DevBuf ws, u, scratch, flat, pack, spack, aux, nk1, nk2, lat, params, result;
     // the worker (multi-part contexts only)
     std::thread th;
     std::mutex m;
@@ -105,7 +105,7 @@ struct Part {
     const void *tuning = nullptr;
     void release_buffers()
     {
-        for (DevBuf *b : {&ws, &u, &scratch, &flat, &pack, &spack, &aux, &nk1, &nk2, &lat}) b->release();
+        for (DevBuf *b : {&ws, &u, &scratch, &flat, &pack, &spack, &aux, &nk1, &nk2, &lat, &params, &result}) b->release();
     }
 };
 
@@ -151,6 +151,9 @@ struct pmc_samples {
     std::vector<int64_t> begin;                                     // nparts + 1: part p holds rows [begin[p], begin[p + 1])
     std::vector<DevBuf> x, w, origin;                               // per part
     bool has_w, has_origin;
+    bool borrowed = false;                                          // pmc_samples_wrap: x[0] is the caller's memory
+    std::vector<DevBuf> sw;                                         // per part: resident sample weights of the VB E-step
+    bool has_sw = false, sw_borrowed = false;
     int64_t n(int p) const { return begin[p + 1] - begin[p]; }
 };
 
@@ -690,6 +693,7 @@ static pmc_samples *new_samples(pmc_ctx *ctx, int64_t N, int D)
     s->x.resize(n);
     s->w.resize(n);
     s->origin.resize(n);
+    s->sw.resize(n);
     return s;
 }
 
@@ -709,6 +713,21 @@ int pmc_samples_upload(pmc_ctx *ctx, const double *h_x, int64_t N, int D, pmc_sa
         (void)pmc_samples_free(s);
         return rc;
     }
+    *out = s;
+    return PMC_OK;
+}
+
+int pmc_samples_wrap(pmc_ctx *ctx, const double *d_x, int64_t N, int D, pmc_samples **out)
+{
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    if (!out || N < 0 || D < 1 || (N > 0 && !d_x)) return failf(PMC_EINVAL, "pmc_samples_wrap: bad argument");
+    if (ctx->nparts() != 1) return failf(PMC_EINVAL, "pmc_samples_wrap: a context of one device only (the array lives on one)");
+    if (pmc_padded_dim(D) < 0) return PMC_EINVAL;
+    pmc_samples *s = new_samples(ctx, N, D);
+    s->borrowed = true;
+    s->x[0].p = const_cast<double *>(d_x);
+    s->x[0].cap = sizeof(double) * (size_t)N * D;
     *out = s;
     return PMC_OK;
 }
@@ -769,6 +788,38 @@ int pmc_samples_generate(pmc_ctx *ctx, const pmc_mix *mix, const double *h_chol,
     return PMC_OK;
 }
 
+int pmc_samples_set_sample_weights(pmc_samples *s, const double *h_w)
+{
+    if (!s) return failf(PMC_EINVAL, "pmc_samples_set_sample_weights: NULL samples");
+    pmc_ctx *ctx = s->ctx;
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    if (s->sw_borrowed)
+        for (DevBuf &b : s->sw) b.p = nullptr, b.cap = 0;
+    s->sw_borrowed = false;
+    s->has_sw = false;
+    if (!h_w) return PMC_OK;
+    CK(for_parts(ctx, [&](Part &pt) -> int {
+        const int64_t n = s->n(pt.index);
+        CK(s->sw[pt.index].ensure(sizeof(double) * (size_t)(n > 0 ? n : 1)));
+        return h2d(pt, s->sw[pt.index].p, h_w + s->begin[pt.index], sizeof(double) * (size_t)n);
+    }));
+    s->has_sw = true;
+    return PMC_OK;
+}
+
+int pmc_samples_wrap_sample_weights(pmc_samples *s, const double *d_w)
+{
+    if (!s || !d_w) return failf(PMC_EINVAL, "pmc_samples_wrap_sample_weights: bad argument");
+    if (s->ctx->nparts() != 1) return failf(PMC_EINVAL, "pmc_samples_wrap_sample_weights: a context of one device only");
+    CtxCall call_(s->ctx);
+    if (!s->sw_borrowed) s->sw[0].release();
+    s->sw[0].p = const_cast<double *>(d_w);
+    s->sw[0].cap = sizeof(double) * (size_t)s->N;
+    s->sw_borrowed = s->has_sw = true;
+    return PMC_OK;
+}
+
 int64_t pmc_samples_count(const pmc_samples *s) { return s ? s->N : (int64_t)failf(PMC_EINVAL, "NULL samples"); }
 
 int pmc_samples_shard(const pmc_samples *s, int part, int64_t *begin, int64_t *count)
@@ -806,6 +857,9 @@ int pmc_samples_free(pmc_samples *s)
     CtxCall call_(s->ctx);
     for (int p = 0; p < s->ctx->nparts(); ++p) {
         (void)hipSetDevice(s->ctx->parts[p]->device);
+        if (s->borrowed) s->x[p].p = nullptr, s->x[p].cap = 0;      // (not ours to free)
+        if (s->sw_borrowed) s->sw[p].p = nullptr, s->sw[p].cap = 0;
+        s->sw[p].release();
         s->x[p].release();
         s->w[p].release();
         s->origin[p].release();
@@ -1004,30 +1058,64 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
     const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
     if (stride < 0) return (int)stride;
     CallLog log_(ctx, "pmc_vb_estep", s->N, K, D);
+    // Compiled dimensions: NOTHING K-sized is computed on the host between the caller's arrays and the results (round 5,
+    // verdict r4 #3) -- the raw parameters go up in one copy, the pack (K Cholesky factorisations), the shift pack and the
+    // conversion to N_comp / x_mean_comp / S are kernels on the parts' streams (pmc_hip.h: same operations in the same
+    // order as the host functions, same bits), and one copy brings the results back.  Beyond (D > 64): the host builds
+    // the pack and converts, as before.
+    const bool on_device = D <= pmc_max_compiled_dim() && std::getenv("PMC_CTX_HOST_PACKS") == nullptr;
+    const size_t KD = (size_t)K * D, KDD = KD * D;
     // the posterior's pack (enum pmc_kind, PMC_KIND_VB): c0 = D / beta, c1 = nu, c2 = E[ln pi], c3 = E[ln|Lambda|] - D ln 2 pi
-    std::vector<double> c0(K), c3(K), host((size_t)K * stride), shost;
+    // staging: [m | W | c0 | nu | ln_pi | c3 | shift]
+    std::vector<double> stage(KD + KDD + 4 * (size_t)K + KD), host, shost;
+    double *g_m = stage.data(), *g_W = g_m + KD, *g_c0 = g_W + KDD, *g_nu = g_c0 + K, *g_lp = g_nu + K, *g_c3 = g_lp + K,
+           *g_shift = g_c3 + K;
+    std::memcpy(g_m, h_m, sizeof(double) * KD);
+    std::memcpy(g_W, h_W, sizeof(double) * KDD);
+    std::memcpy(g_nu, h_nu, sizeof(double) * K);
+    std::memcpy(g_lp, h_ln_pi, sizeof(double) * K);
     const double dl2pi = D * std::log(2. * 3.14159265358979323846);
     for (int k = 0; k < K; ++k) {
-        c0[k] = D / h_beta[k];
-        c3[k] = h_ln_lambda[k] - dl2pi;
+        g_c0[k] = D / h_beta[k];
+        g_c3[k] = h_ln_lambda[k] - dl2pi;
     }
-    CK(pmc_pack_components(K, D, h_m, h_W, c0.data(), h_nu, h_ln_pi, c3.data(), nullptr, nullptr, host.data()));
-    const size_t nflat = NSC + (size_t)K * PS;
+    std::memcpy(g_shift, h_shift ? h_shift : h_m, sizeof(double) * KD);
+    if (!on_device) {
+        host.resize((size_t)K * stride);
+        CK(pmc_pack_components(K, D, h_m, h_W, g_c0, h_nu, h_ln_pi, g_c3, nullptr, nullptr, host.data()));
+    }
+    // results of the device path: [S0 K | M1 K D | mean K D | cov K D D | far K | scalars NSC] (pmc_convert_stats_device) and,
+    // behind them, the pack builder's status [pivot K | value K]: one copy to the host
+    const size_t nflat = NSC + (size_t)K * PS, nconv = (size_t)pmc_convert_stats_len(K, D), nres = nconv + 2 * (size_t)K;
     CK(prepare_slots(ctx, nflat));
-    std::vector<double> shift(h_shift ? h_shift : h_m, (h_shift ? h_shift : h_m) + (size_t)K * D);
-    std::vector<double> flat(nflat), S0, M1, M2;
+    std::vector<double> shift(g_shift, g_shift + KD), flat(nflat), res(nres), S0, M1, M2;
     const bool want_nk = (h_r || h_log_rho) && s->N > 0;
     Part &p0 = *ctx->parts[0];
+    if (on_device) CK(p0.result.ensure(sizeof(double) * nres));
+    bool far = false;
     for (int pass = 0; pass < 2; ++pass) {
         const bool shifted = pass == 1 || h_shift != nullptr;
-        if (shifted) CK(means_pack_host(shift, K, D, shost));
+        if (shifted && !on_device) CK(means_pack_host(shift, K, D, shost));
         CK(for_parts(ctx, [&](Part &pt) -> int {
             const int i = pt.index;
             const int64_t N = s->n(i), b = s->begin[i];
             if (pass == 0) {
-                CK(pt.pack.ensure(host.size() * sizeof(double)));
-                CK(h2d(pt, pt.pack.p, host.data(), host.size() * sizeof(double)));
+                CK(pt.pack.ensure((size_t)K * stride * sizeof(double)));
                 CK(pt.flat.ensure(sizeof(double) * nflat));
+                if (on_device) {
+                    CK(pt.params.ensure(sizeof(double) * (stage.size() + 2 * (size_t)K)));
+                    CK(h2d(pt, pt.params.p, stage.data(), sizeof(double) * stage.size()));
+                    double *d = pt.params.d();
+                    double *d_status = (&pt == &p0) ? p0.result.d() + nconv : d + stage.size();
+                    if (shifted) CK(pt.spack.ensure((size_t)K * stride * sizeof(double)));
+                    // the pack -- and, in the same launch, the pack of the caller's shifts
+                    CK(pmc_pack_components_device(K, D, d, d + KD, d + KD + KDD, d + KD + KDD + K, d + KD + KDD + 2 * (size_t)K,
+                                                  d + KD + KDD + 3 * (size_t)K, nullptr, nullptr, pt.pack.d(), d_status,
+                                                  shifted ? d + KD + KDD + 4 * (size_t)K : nullptr, shifted ? pt.spack.d() : nullptr,
+                                                  pt.stream));
+                } else {
+                    CK(h2d(pt, pt.pack.p, host.data(), host.size() * sizeof(double)));
+                }
                 CK(workspace(pt, N, K, D));
                 CK(pt.u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, K)));
                 if (h_sample_w && N > 0) {
@@ -1035,9 +1123,20 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
                     CK(h2d(pt, pt.aux.p, h_sample_w + b, sizeof(double) * (size_t)N));
                 }
             }
-            const double *d_sw = h_sample_w && N > 0 ? pt.aux.d() : nullptr;
+            const double *d_sw = N > 0 ? (h_sample_w ? pt.aux.d() : (s->has_sw ? s->sw[i].d() : nullptr)) : nullptr;
             double *d_flat = pt.flat.d();
-            if (shifted) CK(upload_spack(pt, shost));
+            if (shifted) {
+                if (on_device) {
+                    if (pass == 1) {                                   // (pass 0: built with the pack, above)
+                        double *d_shift = pt.params.d() + KD + KDD + 4 * (size_t)K;
+                        CK(h2d(pt, d_shift, shift.data(), sizeof(double) * KD));
+                        CK(pt.spack.ensure((size_t)K * stride * sizeof(double)));
+                        CK(pmc_pack_means_device(K, D, d_shift, pt.spack.d(), pt.stream));
+                    }
+                } else {
+                    CK(upload_spack(pt, shost));
+                }
+            }
             const double *d_spack = shifted ? pt.spack.d() : nullptr;
             if (want_nk && pass == 0 && N > 0) {
                 CK(pt.nk1.ensure(sizeof(double) * (size_t)N * K));
@@ -1056,11 +1155,34 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
             return publish(ctx, pt, d_flat, nflat);
         }));
         CK(reduce(ctx, p0.flat.d(), nflat));
-        CK(d2h(p0, flat.data(), p0.flat.d(), sizeof(double) * nflat));
-        if (ctx->p2p) CK(pmc_p2p_status(ctx->p2p, p0.stream));
-        split_stats(flat.data() + NSC, K, D, S0, M1, M2);
-        if (pass == 1 || !shift_is_far(S0, M1, M2, K, D)) break;
+        if (on_device) {
+            // conversion on the first device; [converted | scalars | pack status] come back in ONE copy
+            double *d_res = p0.result.d();
+            CK(pmc_convert_stats_device(K, D, p0.flat.d() + NSC, p0.params.d() + KD + KDD + 4 * (size_t)K, nullptr, p0.flat.d(),
+                                        d_res, p0.stream));
+            CK(d2h(p0, res.data(), d_res, sizeof(double) * nres));
+            if (ctx->p2p) CK(pmc_p2p_status(ctx->p2p, p0.stream));
+            if (pass == 0) CK(pmc_pack_status(K, res.data() + nconv));
+            far = false;
+            for (int k = 0; k < K; ++k) far = far || res[nconv - NSC - (size_t)K + k] != 0.0;
+            if (pass == 1 || !far) break;
+            S0.assign(res.data(), res.data() + K);
+            M1.assign(res.data() + K, res.data() + K + KD);
+        } else {
+            CK(d2h(p0, flat.data(), p0.flat.d(), sizeof(double) * nflat));
+            if (ctx->p2p) CK(pmc_p2p_status(ctx->p2p, p0.stream));
+            split_stats(flat.data() + NSC, K, D, S0, M1, M2);
+            if (pass == 1 || !shift_is_far(S0, M1, M2, K, D)) break;
+        }
         new_shifts(S0, M1, K, D, shift);                              // second pass about the mean just found
+    }
+    if (on_device) {
+        const double *r_S0 = res.data(), *r_mean = r_S0 + K + KD, *r_cov = r_mean + KD;
+        for (int k = 0; k < K; ++k) h_N_k[k] = r_S0[k] == 0.0 ? TINY : r_S0[k];   // variational.pyx:699-709
+        std::memcpy(h_xbar, r_mean, sizeof(double) * KD);
+        std::memcpy(h_S, r_cov, sizeof(double) * KDD);
+        if (h_elogqz) *h_elogqz = res[nconv - NSC];
+        return PMC_OK;
     }
     for (int k = 0; k < K; ++k) h_N_k[k] = S0[k] == 0.0 ? TINY : S0[k];   // variational.pyx:699-709
     centred_moments(h_N_k, h_N_k, M1, M2, shift.data(), K, D, h_xbar, h_S);

@@ -52,6 +52,7 @@ class ShardedSamples(object):
         self.group, self._h, self.N, self.dim = group, handle, int(N), int(D)
         self.counts = None if counts is None else np.asarray(counts, dtype=np.int64)   # generated: per component
         self.has_weights = False
+        self.has_sample_weights = False
         self._host_w = None
 
     def __len__(self):
@@ -87,6 +88,13 @@ class ShardedSamples(object):
         o = np.empty(self.N, dtype=np.int64)
         _lib.check(self.group.lib.pmc_samples_origin(self._h, _ip(o)), "pmc_samples_origin")
         return o
+
+    def set_sample_weights(self, w):
+        """sample weights of the VB E-step that stay on the devices next to the samples (``None`` removes them):
+        ``DeviceGroup.vb_estep(samples, None, ...)`` then uses them without another upload"""
+        w = None if w is None else _c64(w).reshape(self.N)
+        _lib.check(self.group.lib.pmc_samples_set_sample_weights(self._h, _dp(w)), "pmc_samples_set_sample_weights")
+        self.has_sample_weights = w is not None
 
     def host_weights(self):
         if self._host_w is None:

@@ -82,11 +82,18 @@ class GaussianInference(object):
             self._samples = self._group.upload(host)              # contiguous shards, device order = row order
             self._weights_host = None if self.weights is None else \
                 np.ascontiguousarray(self.weights.detach().cpu().numpy() if hasattr(self.weights, 'detach') else self.weights)
+            self._samples.set_sample_weights(self._weights_host)  # resident: every E-step uses them
             self._data_dev = self._weights_dev = None
         else:
             be = get_backend(self._backend)
             self._data_dev = be.asdevice(self.data if on_device else np.ascontiguousarray(self.data))
             self._weights_dev = be.asdevice(self.weights) if self.weights is not None else None
+            # One process, one device: the E-step is ONE call of the library's handle layer on the resident data (the
+            # pack, the shift pack and the conversion of the sums run on the device: backend.vb_estep).  Sharded over
+            # ranks the sums pass through torch.distributed between the kernels and the conversion: the two-call form.
+            self._vb_samples = None
+            if not parallel.active() and hasattr(be, "wrap_samples") and type(self).E_step is GaussianInference.E_step:
+                self._vb_samples = be.wrap_samples(self._data_dev, self._weights_dev)
         self.E_step()
 
     # ------------------------------------------------------------------------- E / M steps
@@ -95,11 +102,11 @@ class GaussianInference(object):
         self._update_expectation_det_ln_lambda()        # first: catches an invalid W early
         self._update_expectation_ln_pi()
         D = self.dim
+        if self._group is not None or getattr(self, '_vb_samples', None) is not None:
+            return self._E_step_group()
         cs = ComponentSet(PMC_KIND_VB, self.m, self.W, c0=D / self.beta, c1=self.nu,
                           c2=self.expectation_ln_pi,
                           c3=self.expectation_det_ln_lambda - D * np.log(2. * np.pi))
-        if self._group is not None:
-            return self._E_step_group(cs)
         be = get_backend(self._backend)
         # The moments are taken about the previous E-step's x_mean_comp once there is one (else about m): x_mean_comp is
         # then bit-stable as soon as the responsibilities are -- the property of the reference's two passes
@@ -134,13 +141,18 @@ class GaussianInference(object):
         self._estep_set = cs            # parameters the current r / log_rho belong to
         self._nk_cache = {}
 
-    def _E_step_group(self, cs):
-        """the E-step over the devices of ``self._group``: one call of the handle layer (pmc_vb_estep) -- every device its
-        shard, the statistics added in device order, the far-shift second pass and the reference's normalisation inside"""
+    def _E_step_group(self):
+        """the E-step as one call of the handle layer (pmc_vb_estep) -- over the devices of ``self._group`` (every device
+        its shard, the statistics added in device order) or on the backend's one device; the far-shift second pass and the
+        reference's normalisation happen inside"""
         prev = getattr(self, '_shift_prev', None)
         shift = prev if (prev is not None and prev.shape == self.m.shape and np.isfinite(prev).all()) else None
-        res = self._group.vb_estep(self._samples, self._weights_host, self.m, self.W, self.nu, self.beta,
-                                   self.expectation_ln_pi, self.expectation_det_ln_lambda, shift=shift)
+        if self._group is not None:
+            res = self._group.vb_estep(self._samples, None, self.m, self.W, self.nu, self.beta,
+                                       self.expectation_ln_pi, self.expectation_det_ln_lambda, shift=shift)
+        else:
+            res = get_backend(self._backend).vb_estep(self._vb_samples, self.m, self.W, self.nu, self.beta,
+                                                      self.expectation_ln_pi, self.expectation_det_ln_lambda, shift=shift)
         if not np.isfinite(res["N_comp"]).any():
             raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(res["N_comp"]))
         self.N_comp = res["N_comp"]
@@ -150,7 +162,8 @@ class GaussianInference(object):
         if not np.isfinite(self.S).any():
             raise np.linalg.LinAlgError('Encountered inf or nan in update of sample covariance\n' + str(self.S))
         self._expectation_log_q_Z = res["log_q_Z"]
-        self._estep_set = cs
+        # (the parameters the current r / log_rho belong to; the arrays are replaced, never edited in place, by M_step / prune)
+        self._estep_set = (self.m, self.W, self.beta, self.nu, self.expectation_ln_pi, self.expectation_det_ln_lambda)
         self._nk_cache = {}
 
     def M_step(self):
@@ -191,6 +204,10 @@ class GaussianInference(object):
         this rank's shard (the reference keeps all three resident: variational.pyx:636-638)."""
         if name not in self._nk_cache:
             be = get_backend(self._backend)
+            if isinstance(self._estep_set, tuple):
+                m, W, beta, nu, ln_pi, ln_lam = self._estep_set
+                self._estep_set = ComponentSet(PMC_KIND_VB, m, W, c0=self.dim / beta, c1=nu, c2=ln_pi,
+                                               c3=ln_lam - self.dim * np.log(2. * np.pi))
             if self._group is not None and self._data_dev is None:
                 # (read rarely: the three N x K matrices come from ONE device, the default backend's)
                 self._data_dev = be.asdevice(self.data if not isinstance(self.data, np.ndarray) else np.ascontiguousarray(self.data))
