@@ -79,9 +79,13 @@ class Responsibilities(object):
 
     @staticmethod
     def _key(t):
-        # (storage and shape, not the modification counter: a run of a DeviceHistory is a view whose counter moves with
-        #  every later append to the history)
-        return (t.data_ptr(), tuple(t.shape)) if hasattr(t, "data_ptr") else None
+        # storage and shape -- and, for a tensor that owns its storage, its modification counter (in-place edits, a
+        # recycled allocation).  A run of a DeviceHistory is a VIEW whose counter moves with every later append to the
+        # history: there the address and the shape are all there is.
+        if not hasattr(t, "data_ptr"):
+            return None
+        own = getattr(t, "_base", None) is None
+        return (t.data_ptr(), tuple(t.shape), getattr(t, "_version", None) if own else None)
 
     def host_matrix(self, be):
         """u as an N x K host array (the tile-major values times their groups' factors)"""
@@ -94,19 +98,29 @@ class Responsibilities(object):
             t = t * np.repeat(f, 16, axis=1)[:, :self.K, :]
         return np.concatenate([t[i].T for i in range(nt)])[:self.N] if nt else np.zeros((0, self.K))
 
-    def matches(self, comps_full, weights, samples=None):
-        """True for the very mixture (means, precisions, component weights, normalisations), the very sample weights
+    def mismatch(self, comps_full, weights, samples=None):
+        """None for the very mixture (means, precisions, component weights, normalisations), the very sample weights
         (the importance weights of that pass: the same tensor, not modified in place since) and -- when ``samples`` is
-        a device tensor -- the very sample array (same storage and shape) these values were formed with"""
+        a device tensor -- the very sample array these values were formed with; else which of them differs:
+        'density', 'weights' or 'samples'"""
         c = self.comps
         same = comps_full is c or (comps_full.K == c.K and comps_full.kind == c.kind and
                                    np.array_equal(comps_full.mu, c.mu) and np.array_equal(comps_full.precision, c.precision)
                                    and np.array_equal(comps_full.weight, c.weight) and np.array_equal(comps_full.c0, c.c0)
                                    and np.array_equal(comps_full.c3, c.c3))
-        if not same or weights is not self.weights or getattr(weights, "_version", None) != self._weights_version:
-            return False
+        if not same:
+            return 'density'
+        if weights is not self.weights or getattr(weights, "_version", None) != self._weights_version:
+            return 'weights'
         key = self._key(samples)
-        return key is None or self._samples_key is None or key == self._samples_key
+        if key is None or self._samples_key is None:
+            return None
+        if key[:2] != self._samples_key[:2]:
+            return 'samples'
+        return None if (key[2] is None or self._samples_key[2] is None or key[2] == self._samples_key[2]) else 'samples'
+
+    def matches(self, comps_full, weights, samples=None):
+        return self.mismatch(comps_full, weights, samples) is None
 
 
 def _dptr(a):

@@ -942,12 +942,18 @@ size_t gscale_offset(long long N, int K, const PmcKernelSet *ks)
 // the Mahalanobis forms as one matrix product (pmc_mgemm.hip): selection, workspace region, launches
 // ---------------------------------------------------------------------------------------------
 // Tolerance of the guard in units of a_nk (0 switches the form off): a sample whose priced rounding error
-// eps_g (Theta_1 |d|^2 + Theta_2 |d| + Theta_3) exceeds it sends its workgroup to the exact kernel.  eps_g = 1e-15 is
-// three times the largest (difference to the exact kernel) / (Theta-sum) seen -- 3.4e-16, i.e. 1.5 ulp of the sum of the
-// terms' magnitudes (scripts/mgemm_check.py; tests/test_gpu_mgemm.py holds every case to it) -- and the tolerance
-// leaves a factor 2 to the contract's 1e-10 on responsibilities, i.e. on differences of a_nk.
+// eps_g (Theta_1 |d|^2 + Theta_2 |d| + Theta_3) exceeds it sends its workgroup to the exact kernel (eps_g: mgemm_eps below,
+// ~1e-15); the tolerance leaves a factor 2 to the contract's 1e-10 on responsibilities, i.e. on differences of a_nk.
 #define g_mgemm_tol (tun().mgemm_tol)                     // default 5e-11
-constexpr double PMC_MGEMM_EPS = 1e-15;
+// The guard's error constant, per compiled dimension (advice r4): the expanded form is a dot product of n = (D + 1)(D + 2) / 2
+// monomial terms accumulated in fp64 -- a hard bound would be n u sum|theta z| (u = 1.1e-16: 9.5e-14 at D = 40), which refuses
+// healthy data; what is used is the PROBABILISTIC sqrt(n) u growth of a sum of rounding errors with a safety factor:
+// eps_g = 0.32 sqrt(n) u = 3.5e-17 sqrt(n): 8.3e-16 at D = 32, 1.03e-15 at D = 40 (the constant of round 4), 1.22e-15 at
+// D = 48.  The largest (difference to the exact kernel) / (Theta-sum) seen over all tests and the fuzz is 5.1e-16 at D = 40
+// (scripts/mgemm_check.py); tests/test_gpu_mgemm.py holds every case -- ill-conditioned covariances and dimensions below the
+// padded one included -- to 0.75 eps_g.  It is not a proof: a caller who needs the exact kernels' bits sets
+// "maha_gemm_tolerance" to 0.
+inline double mgemm_eps(int Dc) { return 3.5e-17 * std::sqrt(0.5 * (Dc + 1.0) * (Dc + 2.0)); }
 #define g_mgemm_min_n (tun().mgemm_min_n)                 // default 32768: samples from which the form is tried at all
 // component tiles per pass (0: the exact kernels).  K is padded to a multiple of 16 NCT and a padded component costs
 // what a real one does; two tiles per pass cost 4.5 % more per pair than four (profiles/r03_maha_gemm_prototype.txt),
@@ -1006,7 +1012,7 @@ hipError_t mgemm_run(const PmcKernelSet *ks, int nct, int kind, const PmcArgsA &
     q.ctab = (const double *)(base + r.ctab);
     q.center = (const double *)(base + r.center);
     q.guard = (const double *)(base + r.head);
-    q.eps_tol = g_mgemm_tol / PMC_MGEMM_EPS;
+    q.eps_tol = g_mgemm_tol / mgemm_eps(ks->dim);
     q.blockflag = (int *)(base + r.flags);
     q.redo = (int *)(base + r.head + 32);
     e = ks->theta(a.pack, a.K, kpad, kind, (double *)(base + r.img), (double *)(base + r.ctab), (double *)(base + r.center),

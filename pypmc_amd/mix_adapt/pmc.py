@@ -105,9 +105,18 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
         if responsibilities is not None and rb:
             # the weighting pass left u = w rho of these very samples, weights and parameters: statistics only
             full = component_set(density.components, density.weights)
-            if len(live_components) < K or responsibilities.N != N_local or not responsibilities.matches(full, weights, samples):
+            why = 'density' if (len(live_components) < K or responsibilities.N != N_local) else \
+                responsibilities.mismatch(full, weights, samples)
+            if why == 'samples':
+                # the same density and weights but another storage behind ``samples`` (a copy of the run, a history that
+                # was reallocated by a later append -- advice r4): nothing proves the values are stale, nothing proves
+                # they are not; the update forms its responsibilities itself
+                logger.info("``responsibilities`` belong to another sample array: recomputed")
+                res = be.estep(samples, cs, mode, max_init_zero=len(live_components) < K, sample_w=weights)
+            elif why is not None:
                 raise ValueError('``responsibilities`` were not formed with this density, these samples and weights')
-            res = be.estep_from_u(samples, cs, responsibilities)
+            else:
+                res = be.estep_from_u(samples, cs, responsibilities)
         elif mahalanobis is not None and rb:
             # the weighting pass kept maha_nk of these very samples: rho without a second evaluation
             full = component_set(density.components, density.weights)

@@ -140,6 +140,15 @@ def test_front_end_iteration_without_a_responsibility_kernel(be):
             with pytest.raises(ValueError):                            # other weights than the pass formed
                 pypmc.mix_adapt.pmc.gaussian_pmc(run["samples"], sampler.proposal, run["weights"].clone(), run["origin"],
                                                  responsibilities=run["responsibilities"])
+            # advice r4: an equal COPY of the samples (a history reallocated by a later append looks like this) is not an
+            # error -- nothing proves the values stale -- the update just forms its responsibilities itself
+            be.kernel_timings()
+            be.kernel_timing(True)
+            again = pypmc.mix_adapt.pmc.gaussian_pmc(run["samples"].clone(), sampler.proposal, run["weights"], run["origin"],
+                                                     responsibilities=run["responsibilities"])
+            be.kernel_timing(False)
+            assert "k_resp" in be.kernel_timings()
+            np.testing.assert_allclose(again.weights, new.weights, rtol=1e-11)
     a, b = results
     np.testing.assert_allclose(b.weights, a.weights, rtol=1e-11)
     for ca, cb in zip(a.components, b.components):

@@ -11,7 +11,10 @@ from test_gpu_kernels import mk, draw, gauss_set, student_set, assert_rel
 
 pytestmark = pytest.mark.gpu
 TOL = 5e-11          # the library's default "maha_gemm_tolerance"
-EPS_G = 1e-15        # the guard's error constant (csrc/pmc_api.hip)
+def EPS_G(D):
+    """the guard's error constant (csrc/pmc_api.hip::mgemm_eps): 3.5e-17 sqrt(number of monomials) of the compiled dimension"""
+    Dc = 32 if D <= 32 else 40 if D <= 40 else 48
+    return 3.5e-17 * np.sqrt(0.5 * (Dc + 1.) * (Dc + 2.))
 
 
 @pytest.fixture(scope="module")
@@ -56,7 +59,7 @@ def report(be, N, K, D):
 def guard_bound(rep, mu, x):
     cen = 0.5 * (mu.min(axis=0) + mu.max(axis=0))
     dn = np.linalg.norm(x - cen, axis=1)
-    return EPS_G * (rep["norms"][0] * dn ** 2 + rep["norms"][1] * dn + rep["norms"][2])
+    return EPS_G(x.shape[1]) * (rep["norms"][0] * dn ** 2 + rep["norms"][1] * dn + rep["norms"][2])
 
 
 CASES = [(32, 32, 3000), (32, 64, 2049), (31, 32, 1500), (40, 128, 2500), (40, 32, 1111), (40, 96, 1300), (37, 64, 1290),
@@ -451,3 +454,33 @@ def test_target_with_more_components_than_the_proposal_on_a_fresh_workspace(orc,
     assert_rel(b.tohost(res["out"])[sub], logq, what="log q")
     assert_rel(b.tohost(res["log_target"])[sub], logp, what="log P")
     assert_rel(b.tohost(res["weights"])[sub], orc.is_weights(logp, logq), what="weights")
+
+
+@pytest.mark.parametrize("D", [31, 32, 33, 37, 40, 41, 45, 48])
+@pytest.mark.parametrize("cond", [1e2, 1e4, 1e6])
+def test_guard_price_covers_ill_conditioned_covariances_in_every_compiled_dimension(be, orc, small, D, cond):
+    """advice r4: eps_g is a probabilistic constant (sqrt(n) u growth), so it is held against the cases that stress it --
+    covariances of condition number up to 1e6 with random orientations, means off the centre, every compiled dimension and
+    real dimensions below the padded one -- with the tolerance opened wide so that the FORM runs on all of them: its
+    difference to the exact kernel must stay below 0.75 of the price eps_g (Theta-sum) it quotes for each sample."""
+    K, N = 32, 1200
+    mu, cov, w = mk(K, D, 700 + D)
+    rs = np.random.RandomState(int(D + np.log10(cond)))
+    for k in range(K):
+        q, _ = np.linalg.qr(rs.normal(size=(D, D)))
+        cov[k] = (q * np.logspace(-np.log10(cond) / 2, np.log10(cond) / 2, D)).dot(q.T)
+        cov[k] = 0.5 * (cov[k] + cov[k].T)
+    x, _ = draw(mu, cov, w, N, 8)
+    cs, inv, ln = gauss_set(mu, cov, w)
+    be.configure("maha_gemm_tolerance", 1.0)               # price everything in: the form runs on every workgroup
+    try:
+        got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+        rep = report(be, N, K, D)
+    finally:
+        be.configure("maha_gemm_tolerance", TOL)
+    assert rep["refused"] == 0
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    ratio = (np.abs(got - ex) / guard_bound(rep, mu, x)).max()
+    assert ratio < 0.75, "D = %d, cond = %g: difference / price = %.3f" % (D, cond, ratio)
+    ref, _ = orc.mixture_multi_evaluate(0, x[:300], w, mu, inv, ln)
+    assert_rel(ex[:300], ref, rtol=1e-9 * max(1.0, cond / 1e4), what="exact kernel vs oracle")
