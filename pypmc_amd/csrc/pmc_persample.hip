@@ -803,6 +803,35 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             const int kb = g * GS, kn = (K - kb < GS) ? K - kb : GS;
             // pass 1 of the group: a_nk -> LDS, the group's maximum
             double Mg = -DBL_MAX;
+#ifdef PMC_AB_ONLINE
+            // A/B switch, TIMING ONLY (wrong numbers): the instruction stream of an "online" form that never parks a group --
+            // u' = exp(a - M_ref) against a reference known BEFORE the group (here: the running maximum), written as soon as
+            // a_nk exists, no second pass over LDS.  What such a form could gain at best (verdict r4 #6); a real one would add
+            // the rescue of rows whose maximum jumps by more than the exponent range within a group -- which, for samples
+            // drawn from the mixture itself, is every row in the group that holds its own component.
+            double sg = 0.0, tbg = 0.0;
+            const double Mref = Mrun;
+            for (int j = 0; j < kn; ++j, pk += dm.STRIDE) {
+                const double maha = engine.eval(pk, kb + j);
+                double expo = 0.0;
+                const double v = component_value<D, KIND>(maha, pk + dm.DT, expo);
+                Mg = max_f64(v, Mg);
+                rowp.see(v);
+                const double lr = max_f64(v - Mref, -1075.0);
+                const double e = exp_clamped(lr, EC);
+                if constexpr (KIND == PMC_KIND_VB) {
+                    tbg = fma(e, lr, tbg);
+                    sg += e;
+                    store_u(ut + (size_t)(kb + j) * 64, zero_to_tiny(e));
+                } else {
+                    const double we = (pk + dm.DT)[4] * e;
+                    sg += we;
+                    store_u(ut + (size_t)(kb + j) * 64, we);
+                }
+            }
+            auto expstep = [&](int, double) {};
+            if (false)
+#else
             for (int j = 0; j < kn; ++j, pk += dm.STRIDE) {
                 const double maha = engine.eval(pk, kb + j);
                 double expo = 0.0;
@@ -813,6 +842,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
             }
             // pass 2 of the group: u' = exp(a - M_g) [* w_k], written once
             double sg = 0.0, tbg = 0.0;
+#endif
+#ifndef PMC_AB_ONLINE
             auto expstep = [&](int j, double v) {
                 const double lr = max_f64(v - Mg, -1075.0);
                 const double e = exp_clamped(lr, EC);
@@ -826,6 +857,7 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
                     store_u(ut + (size_t)(kb + j) * 64, we);
                 }
             };
+#endif
             descend(kn, 0, [&](int j) { return pl[j * 64]; }, expstep);
             // the group joins the row's running maximum / sum / bound term; its maximum waits in the factor's place
             const double Mn = max_f64(Mg, Mrun);
