@@ -304,8 +304,8 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *                                groups of 16 components -- every u_nk written once, nothing parked in HBM, no
  *                                normalisation pass; the per-(sample, group) factors w_n exp(M_g - M) / s are left to the
  *                                statistics kernel, which multiplies its weight operand with them (VB and Gaussian
- *                                Rao-Blackwell PMC).  0 never, 1 where it is faster (compiled D <= 16, 20, 32, 40;
- *                                D = 24 from K = 128 on), 2 always.  The workspace holds the factors (8 ceil(K/16) bytes per sample).
+ *                                Rao-Blackwell PMC).  0 never, 1 where it is faster (compiled D <= 16, 20, 24, 32, 40;
+ *                                D = 30 from K = 64 on), 2 always.  The workspace holds the factors (8 ceil(K/16) bytes per sample).
  * pmc_sufficient_stats itself always takes its moments about the pack's own shifts.
  *
  * Two things a caller should know about these large-batch forms (verdict r4):

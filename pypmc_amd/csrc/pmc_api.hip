@@ -332,14 +332,17 @@ struct TuneScope {
 // pmc_estep's responsibilities in groups of 16 with their factors left to k_stats_gemm (k_resp_groups): 0 never,
 // 1 where it pays, 2 wherever the common-shift statistics run.  Where it pays (scripts/resp_groups_ab.py matrix,
 // profiles/r03_resp_groups.txt; responsibilities + statistics, per 2e6 samples): compiled D <= 16 at any K (-2 ... -19 %),
-// D = 20, 32, 40 from K = 64 on (-2 ... -6 %: the parked traffic of k_resp costs clock there); it loses at D = 24, 30, 48,
-// 64 (+2 ... +14 %: 25-40 more registers than k_resp) and is neutral at D = 20, K = 32.
+// D = 20, 32, 40 from K = 64 on (-2 ... -6 %: the parked traffic of k_resp costs clock there); round 3 saw it lose at D = 24,
+// 30, 48, 64 (+2 ... +14 %: 25-40 more registers than k_resp) and neutral at D = 20, K = 32 (round 5: see below).
 #define g_resp_groups (tun().resp_groups)
 bool resp_groups_pays(int dim, int K)
 {
     if (g_resp_groups != 1) return g_resp_groups == 2;
-    // measured per (D, K) with scripts/resp_groups_ab.py matrix (profiles/r03_resp_groups.txt)
-    return dim <= 16 || dim == 20 || dim == 32 || dim == 40 || (dim == 24 && K >= 128);
+    // measured per (D, K) with scripts/resp_groups_ab.py matrix (profiles/r03_resp_groups.txt; re-measured in round 5,
+    // profiles/r05_resp_groups_matrix.txt: since the hand-scheduled scalar loads of round 4 the grouped form also wins at
+    // D = 24 from K = 32 on (-2 / -5 / -9 % of the pair at K = 32 / 64 / 128) and at D = 30 from K = 64 on (-3 / -6.5 %);
+    // it still loses at D = 64 (+8 %); D = 32 ... 48 run k_mgemm at these batch sizes either way)
+    return dim <= 16 || dim == 20 || dim == 24 || (dim == 30 && K >= 64) || dim == 32 || dim == 40;
 }
 
 

@@ -404,9 +404,11 @@ template <int D> struct GemmCfg {
 #ifdef PMC_GEMM_C                                          // tuning overrides (scripts/tune_unit.sh)
     static constexpr int C = PMC_GEMM_C, CGW = PMC_GEMM_CGW, SL = PMC_GEMM_SL, NS = PMC_GEMM_NS;
 #else
-    static constexpr int C = D <= 8 ? 3 : (D <= 10 ? 5 : (D <= 12 ? 3 : (D <= 20 ? 5 : (D <= 24 ? 6 : (D <= 30 ? 4 :
+    // (D = 24: 325 monomials = 21 column tiles = 3 x 7 -- the 6 x 4 = 24 of rounds 3-4 left an eighth of the matrix slots
+    //  idle: 3.19 -> 3.04 ms per 4e6 x 64, profiles/r05_d24_sweep.txt; 7 x 3 needs 112 accumulator registers and is slower)
+    static constexpr int C = D <= 8 ? 3 : (D <= 10 ? 5 : (D <= 12 ? 3 : (D <= 20 ? 5 : (D <= 24 ? 3 : (D <= 30 ? 4 :
                              (D <= 32 ? 3 : (D <= 40 ? 7 : (D <= 48 ? 5 : 6))))))));
-    static constexpr int CGW = D <= 10 ? 1 : (D <= 16 ? 2 : (D <= 20 ? 3 : (D <= 24 ? 4 : (D <= 30 ? 8 : (D <= 32 ? 12 : 8)))));
+    static constexpr int CGW = D <= 10 ? 1 : (D <= 16 ? 2 : (D <= 20 ? 3 : (D <= 24 ? 7 : (D <= 30 ? 8 : (D <= 32 ? 12 : 8)))));
     static constexpr int SL = D <= 10 ? 8 : (D <= 20 ? 4 : (D <= 24 ? 2 : 1));
     static constexpr int NS = D <= 32 ? 2 : 1;
 #endif
