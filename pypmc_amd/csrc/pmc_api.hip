@@ -1412,7 +1412,8 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
                 8.0 * N * (D + 1 + (d_individual ? K : 0) + (d_maha_tiles ? K : 0)));
         // D >= 32: the forms of all components as one matrix product where its guard allows (pmc_mgemm.hip), the exact
         // kernel behind it for the workgroups it refused
-        const int nct = (d_workspace && !d_individual && !d_maha_tiles && !max_init_zero && ks->padded != 2)
+        // (with `individual` too since round 5: the N x K matrix is written from the accumulator layout)
+        const int nct = (d_workspace && !d_maha_tiles && !max_init_zero && ks->padded != 2 && (d_out || !d_individual))
                             ? mgemm_pick(ks, N, K) : 0;
         hipError_t e = hipSuccess;
         if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st);

@@ -207,10 +207,11 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
         ik[(size_t)s * 64 + 16 * g] = v;
     }
     if (tid == 0) {
-        double *o = ctab + (size_t)k * 4;                  // (read by the Student-t epilogue only)
+        double *o = ctab + (size_t)k * 4;                  // (o[0], o[1]: the Student-t epilogue; o[2], o[3]: `individual`)
         o[0] = c[0] + logw;
         o[1] = c[1];
-        o[2] = o[3] = 0.0;
+        o[2] = logw;                                       // the product returns a_nk + log w_k: `individual` takes it off again
+        o[3] = (double)((const long long *)c)[5];          // the component's output column (mixture.pyx:138: individual[:, k])
         // |d a / d maha|
         const double sk = kind == PMC_KIND_GAUSS ? 0.5 : (kind == PMC_KIND_STUDENT_T ? fabs(c[1] * c[2]) : 0.5 * fabs(c[1]));
         double th[3] = {sk * sqrt(sums[0]), 2.0 * sk * sqrt(sums[1]), sk * fabs(sums[2])};
@@ -349,6 +350,26 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                         tt *= c01[1];
                         tt += c01[0];
                         acc[c][t][r] = tt;
+                    }
+                }
+        }
+        // `individual` (mixture.pyx:138-151: the N x K component log-densities, the reference's own intermediate): straight
+        // from the accumulator layout -- lane (g, s) holds components g + 4 r of tile c for the samples 16 t + s, the four
+        // lane groups write four neighbouring columns of a row
+        if (a.individual != nullptr && kind != PMC_KIND_VB) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = (pass * NTP + half * NCT + c) * 16 + g + 4 * r;
+                    if (kk < K) {
+                        const md2 lc = *(const md2 *)(ct + (c * 16 + 4 * r) * 4 + 2);
+                        const long long col = (long long)lc[1];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const long long nt = tile * 64 + 16 * t + s16;
+                            if (nt < a.N) a.individual[nt * a.ld + col] = acc[c][t][r] - lc[0];
+                        }
                     }
                 }
         }
