@@ -88,6 +88,7 @@ const char *const g_timing_names[T_COUNT] = {"k_logpdf", "k_resp", "k_stats", "k
                                              "finishing reductions"};
 struct TimingRec {
     hipStream_t st;       // the stream the launch went to (the handle layer reads its own context's records)
+    int dev;              // ... and its device: an event belongs to the device it was created on
     int id;
     int calls;            // 1, or 0 for a bracket that continues the previous launch of the same kernel
     hipEvent_t a, b;
@@ -103,14 +104,18 @@ bool timing_stream_on(hipStream_t st)                      // (g_timing_mutex he
         if (q == st) return true;
     return false;
 }
-std::vector<hipEvent_t> g_timing_pool;
+// events wait for their next use per DEVICE (an event can only be recorded on a stream of the device it was created on,
+// and one process may drive several devices: pmc_init_devices)
+constexpr int PMC_TIMING_MAX_DEVICES = 64;
+std::vector<hipEvent_t> g_timing_pool[PMC_TIMING_MAX_DEVICES];
 constexpr size_t PMC_TIMING_MAX_RECORDS = 1 << 16;
 
-hipEvent_t timing_event()
+hipEvent_t timing_event(int dev)                            // (g_timing_mutex held; the calling thread's device is `dev`)
 {
-    if (!g_timing_pool.empty()) {
-        hipEvent_t e = g_timing_pool.back();
-        g_timing_pool.pop_back();
+    std::vector<hipEvent_t> &pool = g_timing_pool[dev];
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
         return e;
     }
     hipEvent_t e = nullptr;
@@ -127,10 +132,13 @@ struct Timed {
     {
         std::lock_guard<std::mutex> lock(g_timing_mutex);
         if (!(g_timing_on || timing_stream_on(st)) || g_timing_recs.size() >= PMC_TIMING_MAX_RECORDS) return;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PMC_TIMING_MAX_DEVICES) return;
         rec.st = st;
+        rec.dev = dev;
         rec.id = id; rec.calls = calls; rec.flops = flops; rec.bytes = bytes;
-        rec.a = timing_event();
-        rec.b = timing_event();
+        rec.a = timing_event(dev);
+        rec.b = timing_event(dev);
         if (!rec.a || !rec.b) return;
         on = hipEventRecord(rec.a, st) == hipSuccess;
     }
@@ -2089,8 +2097,8 @@ static int collect_timings(hipStream_t stream, pmc_timing *h_out, int max_entrie
     {
         std::lock_guard<std::mutex> lock(g_timing_mutex);
         for (const TimingRec &r : recs) {
-            g_timing_pool.push_back(r.a);
-            g_timing_pool.push_back(r.b);
+            g_timing_pool[r.dev].push_back(r.a);
+            g_timing_pool[r.dev].push_back(r.b);
         }
     }
     int n = 0;

@@ -387,8 +387,7 @@ template <int NT, int NW> static hipError_t launch_maha(const PmcArgsM &a, hipSt
     const int D16 = (a.D + 15) & ~15;
     const size_t lds = sizeof(double) * ((size_t)D16 * (16 * NT + 1) + 2 * NW * 16 * NT);
     if (lds > 65536) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_big_maha<NT, NW>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t once = PMC_SET_LDS_PER_DEVICE((&k_big_maha<NT, NW>), 160 * 1024);
         if (once != hipSuccess) return once;
     }
     const long long nsub = ((a.N + 63) >> 6) * 4;

@@ -573,12 +573,19 @@ template <int KIND, int NCH> hipError_t launch_fused_kq(const PmcArgsF &a, unsig
 {
     const size_t lds = sizeof(double) * fused_lds_doubles(D_, a.qs, a.K);
     if (lds > 65536) {
-        static size_t configured = 0;                              // grows with K
-        if (lds > configured) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_estep_fused<D_, P_, KIND, NCH>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // grows with K; per DEVICE (the attribute is a device's, and one process may drive several: pmc_init_devices) and
+        // safe against two host threads arriving at once (a second identical call is harmless)
+        static std::atomic<size_t> configured[256];
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::atomic<size_t> &have = configured[dev & 255];
+        if (lds > have.load(std::memory_order_acquire)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_estep_fused<D_, P_, KIND, NCH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            configured = lds;
+            size_t cur = have.load(std::memory_order_relaxed);
+            while (cur < lds && !have.compare_exchange_weak(cur, lds, std::memory_order_release)) {}
         }
     }
     hipLaunchKernelGGL((k_estep_fused<D_, P_, KIND, NCH>), dim3(grid), dim3(FW * 64), lds, st, a);

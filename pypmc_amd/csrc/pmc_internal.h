@@ -76,6 +76,29 @@ __host__ __device__ constexpr int pmc_resp_klds(int D)
     return (pmc_engine(D) == PMC_ENG_MFMA || D < 12) ? 16 : 19;
 }
 
+// hipFuncSetAttribute is a per-DEVICE setting.  One process may drive several devices (pmc_init_devices: a host thread per
+// device): a function-local `static const hipError_t once = hipFuncSetAttribute(...)` -- the form of rounds 1-4, when a
+// process had one device -- would raise a kernel's dynamic LDS limit on the FIRST device only and let the launches on the
+// others fail.  Here: one bit per device ordinal and call site, set once the call succeeded on that device.
+#include <atomic>
+inline hipError_t pmc_lds_attr_dev(std::atomic<unsigned long long> *done, const void *fn, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<unsigned long long> &word = done[(dev >> 6) & 3];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (word.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) word.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+#define PMC_SET_LDS_PER_DEVICE(fnptr, bytes)                                                          \
+    ([&]() -> hipError_t {                                                                            \
+        static std::atomic<unsigned long long> done_[4];                                              \
+        return pmc_lds_attr_dev(done_, reinterpret_cast<const void *>(fnptr), (int)(bytes));          \
+    }())
+
 __host__ __device__ constexpr int pmc_tri(int D) { return D * (D + 1) / 2; }
 __host__ __device__ constexpr int pmc_pack_stride_c(int D) { return (D + pmc_tri(D) + 6 + 7) & ~7; }
 __host__ __device__ constexpr int pmc_stats_stride_c(int D) { return 1 + D + pmc_tri(D); }

@@ -705,8 +705,7 @@ template <int NCT, int HW> static hipError_t mgemm_launch(const PmcArgsQ &q, uns
     using C = MgCfg<D_>;
     constexpr size_t lds = C::lds_bytes(NCT * HW);
     static_assert(lds + 1024 <= 160 * 1024, "k_mgemm: the sample image and the theta buffers exceed the LDS");
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mgemm<D_, NCT, HW>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t once = PMC_SET_LDS_PER_DEVICE((&k_mgemm<D_, NCT, HW>), lds);
     if (once != hipSuccess) return once;
     hipLaunchKernelGGL((k_mgemm<D_, NCT, HW>), dim3(grid), dim3(256 * HW), lds, st, q);
     return hipGetLastError();

@@ -900,10 +900,9 @@ template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, h
     const size_t lds = sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
                                          (size_t)PMC_A_WAVES * a.klds * 64);
     if (lds > 65536) {
-        static const hipError_t once = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&k_resp<D_, P_, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            (int)(sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
-                                    (size_t)PMC_A_WAVES * pmc_resp_klds(D_) * 64)));
+        const hipError_t once = PMC_SET_LDS_PER_DEVICE(
+            (&k_resp<D_, P_, KIND>), sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
+                                                       (size_t)PMC_A_WAVES * pmc_resp_klds(D_) * 64));
         if (once != hipSuccess) return once;
     }
     hipLaunchKernelGGL((k_resp<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
@@ -915,8 +914,7 @@ template <int KIND> hipError_t launch_resp_groups_k(const PmcArgsA &a, unsigned 
     constexpr size_t lds = sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
                                              (size_t)PMC_A_WAVES * PMC_RESP_GROUP * 64);
     if constexpr (lds > 65536) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resp_groups<D_, P_, KIND>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t once = PMC_SET_LDS_PER_DEVICE((&k_resp_groups<D_, P_, KIND>), lds);
         if (once != hipSuccess) return once;
     }
     hipLaunchKernelGGL((k_resp_groups<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);

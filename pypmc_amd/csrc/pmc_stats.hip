@@ -885,8 +885,7 @@ extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_stats_gemm_d, PMC_D, PMC_PADDED
     else {
         static_assert(CF::LDS_BYTES <= 160 * 1024, "k_stats_gemm tile buffers exceed the LDS");
         static_assert(16 % CF::SL == 0 && CF::W <= 16, "k_stats_gemm slicing");
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stats_gemm<D_, P_>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::LDS_BYTES);
+        const hipError_t once = PMC_SET_LDS_PER_DEVICE((&k_stats_gemm<D_, P_>), CF::LDS_BYTES);
         if (once != hipSuccess) return once;
         hipLaunchKernelGGL((k_stats_gemm<D_, P_>), dim3(grid), dim3(64 * CF::W), CF::LDS_BYTES, st, b);
         return hipGetLastError();
@@ -901,9 +900,7 @@ extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_stats_d, PMC_D, PMC_PADDED)(con
                            (64 * Blocking<D_>::PITCH * 2 + ((ucomp * 64 * 8 + 1023) / 1024) * 128);
     static_assert(lds <= 160 * 1024, "statistics tile buffers exceed the LDS");
     if constexpr (lds > 65536) {
-        static const hipError_t once = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&k_stats<D_, P_, SW_>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t once = PMC_SET_LDS_PER_DEVICE((&k_stats<D_, P_, SW_>), lds);
         if (once != hipSuccess) return once;
     }
     hipLaunchKernelGGL((k_stats<D_, P_, SW_>), dim3(grid), dim3(SW_ * 64), lds, st, b);

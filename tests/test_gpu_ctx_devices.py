@@ -224,7 +224,7 @@ def test_logpdf_and_importance_weights(lib, mctx, one, student, D, K, N):
     # documents: 1e-11, not bit for bit
     threshold_case = D == 40 and N // n < 32768 <= N
     for i in (0, 1, 2, 3, 4, 6):
-        if threshold_case and i in (0, 3, 6):
+        if threshold_case and i in (0, 1, 3, 6):             # (log q, the individual matrix, the weights twice)
             np.testing.assert_allclose(got[i], ref[i], rtol=1e-10)
         else:
             np.testing.assert_array_equal(got[i], ref[i])
