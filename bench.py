@@ -711,6 +711,29 @@ def main():
                                       "estep_kernels_speedup_vs_full_batch": ef_ms / e8_ms if e8_ms > 0 else None,
                                       "note": "one GPU, N / 8 samples: a projection of strong scaling, not a measurement of it"}
                 del xs
+                # the same share through the ONE-PROCESS multi-GPU path (pmc_init_devices: what each of 8 devices would run,
+                # host arrays in and out, the pack built and the sums converted on the device), before the cross-device sum
+                try:
+                    from pypmc_amd.devices import DeviceGroup
+                    from pypmc_amd.density.mixture import create_gaussian_mixture
+                    grp = DeviceGroup([local_rank])
+                    q_mix, t_mix = create_gaussian_mixture(mu, cov, w), create_gaussian_mixture(tmu, tcov, tw)
+                    gs = grp.generate(q_mix, np.random.RandomState(5).multinomial(n8, w), seed=7)
+
+                    def group_step():
+                        grp.importance_weights(q_mix, gs, target=t_mix, want_weights=False)
+                        return grp.vb_estep(gs, None, mu, W, nu, beta, ln_pi, ln_lambda)
+                    t_w = time.perf_counter()
+                    while time.perf_counter() - t_w < 0.1:
+                        group_step()
+                    t_s = time.perf_counter()
+                    for _ in range(20):
+                        group_step()
+                    line["share_of_8"]["single_process_ms_per_step"] = (time.perf_counter() - t_s) / 20 * 1e3
+                    gs.free()
+                    grp.close()
+                except Exception as exc:                 # (reported, never fatal for the headline)
+                    line["share_of_8"]["single_process_error"] = repr(exc)
             del x, r
             torch.cuda.empty_cache()
             line["configs"] = baseline_configs(be)

@@ -182,6 +182,23 @@ template <int D, int G> __device__ __forceinline__ double mahalanobis_sp(const d
         asm volatile(".set pmc_touch_i, 0\n .rept %2\n s_load_dword %0, %1, pmc_touch_i*64\n .set pmc_touch_i, pmc_touch_i+1\n .endr"
                      : "+s"(landing) : "s"(pk), "n"(LINES) : "memory");
     }
+#ifdef PMC_AB_BIAS
+    // A/B switch, TIMING ONLY (wrong numbers): the instruction stream of the "bias" form |R x' - b|^2 with b = R (mu - c)
+    // in the place of mu and x' = x - c formed once per sample -- no subtraction per pair, no d[] registers.  What that
+    // form could gain at best.
+    // (the stream read in order: row i = its bias, then its D - i coefficients -- the layout a bias pack would have)
+    double maha = 0.0;
+    static_for<0, D>([&](auto I) {
+        constexpr int i = decltype(I)::value, row = i * (D + 1) - i * (i - 1) / 2;
+        double y = -coef(std::integral_constant<int, row>{});
+        static_for<i, D>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            y = fma(coef(std::integral_constant<int, row + 1 + j - i>{}), xv[j], y);
+        });
+        maha = fma(y, y, maha);
+    });
+    return maha;
+#else
     double d[D];
     static_for<0, D>([&](auto J) { constexpr int j = decltype(J)::value; d[j] = xv[j] - coef(J); });
     double maha = 0.0;
@@ -195,6 +212,7 @@ template <int D, int G> __device__ __forceinline__ double mahalanobis_sp(const d
         maha = fma(y, y, maha);
     });
     return maha;
+#endif
 }
 
 // acc += coef[lane N of this lane's 16-lane row] * d  -- v_fmac_f64 with a DPP row broadcast on its first
