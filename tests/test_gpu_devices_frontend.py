@@ -206,3 +206,23 @@ def test_argument_errors(be):
     vb = GaussianInference(np.random.RandomState(0).normal(size=(50, 2)), components=2, devices=g)
     assert vb._group is g and vb.N == 50
     g.close()
+
+
+def test_example_script_runs_both_scenarios():
+    """examples/pmc_devices.py: the reference's example scenario and config 5's loop on virtual shards, as a script"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "pmc_devices.py")
+    r = subprocess.run([sys.executable, script, "0,0,0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [l for l in r.stdout.splitlines() if l.startswith("step")][-1]
+    w = [float(v) for v in last.split("[")[1].split("]")[0].split()]
+    w = sorted(w)
+    assert w[0] < 0.05 and abs(w[1] - 0.3) < 0.06 and abs(w[2] - 0.7) < 0.06, last     # both modes found, the third component starved
+    r = subprocess.run([sys.executable, script, "0,0", "200000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    perps = [float(l.split("perplexity")[1]) for l in r.stdout.splitlines() if l.startswith("iteration")]
+    assert len(perps) == 5 and perps[-1] > perps[0] and perps[-1] > 0.5, perps
