@@ -107,32 +107,45 @@ __device__ __forceinline__ double chi_square(const Philox &g, unsigned long long
     return 2.0 * result * boost;
 }
 
+constexpr int PROPOSE_OFFS_LDS = 1025;   // prefix offsets of up to 1024 components sit in LDS (8 KB)
 #if PMC_D > 0
 constexpr int PCH = 16;          // coordinates staged per pass
 constexpr int PPITCH = PCH + 1;  // row pitch of the staging buffer in doubles (odd: conflict-free column writes)
 
 // x_i = mu_i + scale * sum_{j <= i} L_ij z_j, coordinates in passes of PCH through the wavefront's LDS stage so
 // that they leave in 128-byte row segments (4 rows per store instruction) instead of 64 scattered 8-byte
-// stores per coordinate.  The factor is read through pointer type P: the scalar cache when the whole wavefront
-// draws from one component (samples arrive ordered by component, so all but K - 1 wavefronts do: the
-// coefficient becomes an SGPR operand of the multiply-add instead of a 64-lane vector load of one address),
-// ordinary loads otherwise.
-template <int D, bool PADDED, class P>
-__device__ __forceinline__ void affine_out(P L, P mu, int dreal, const double (&z)[D], double scale, double *st,
-                                           int lane, double *__restrict__ out, int rows)
+// stores per coordinate.  The factor is ALWAYS read through the scalar cache (the coefficient is an SGPR operand of the
+// multiply-add instead of a 64-lane vector load of one address): samples arrive ordered by component, so all but K - 1
+// wavefronts draw from one component; a wavefront that straddles a boundary walks its distinct components one after the
+// other, the lanes of the others idle (rounds 2-4 gave such wavefronts a second copy of the loop with per-lane vector
+// loads).  At D >= 40 the kernel spills (256 registers at two wavefronts per SIMD, 65-71 more wanted: the D / 2 Box-Muller
+// pairs and the D (D + 1) / 2 hoisted scalar loads); serialising the pairs or the rows' loads by artificial dependencies
+// changes neither the spills nor the time, and one wavefront per SIMD without spills is slower (round 3) -- left as it is.
+template <int D, bool PADDED>
+__device__ __forceinline__ void affine_out(const double *chol, const double *mus, int k, int dreal, const double (&z)[D],
+                                           double scale, double *st, int lane, double *__restrict__ out, int rows)
 {
 #pragma unroll
     for (int c0 = 0; c0 < D; c0 += PCH) {
         if (PADDED && c0 >= dreal) break;
+        unsigned long long todo = __ballot(1);
+        while (todo) {                                               // (one round for all but K - 1 wavefronts)
+            const int first = __ffsll((long long)todo) - 1;
+            const int kf = __builtin_amdgcn_readlane(k, first);
+            const bool mine = k == kf;
+            todo &= ~__ballot(mine);
+            cdouble *L = (cdouble *)(chol + (size_t)kf * dreal * dreal);
+            cdouble *mu = (cdouble *)(mus + (size_t)kf * dreal);
 #pragma unroll
-        for (int i = c0; i < c0 + PCH && i < D; ++i) {
-            double acc = 0.0;
-            if (!PADDED || i < dreal) {
+            for (int i = c0; i < c0 + PCH && i < D; ++i) {
+                double acc = 0.0;
+                if (!PADDED || i < dreal) {
 #pragma unroll
-                for (int j = 0; j <= i; ++j) acc = fma(L[i * dreal + j], z[j], acc);
-                acc = mu[i] + acc * scale;
+                    for (int j = 0; j <= i; ++j) acc = fma(L[i * dreal + j], z[j], acc);
+                    acc = mu[i] + acc * scale;
+                }
+                if (mine) st[lane * PPITCH + (i - c0)] = acc;
             }
-            st[lane * PPITCH + (i - c0)] = acc;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): this wavefront's LDS writes have landed
         const int ncol = (dreal - c0 < PCH) ? dreal - c0 : PCH;  // columns of this pass
@@ -159,6 +172,15 @@ template <int D, bool PADDED>
 __global__ __launch_bounds__(256, 2) void k_propose(const PmcArgsP a)
 {
     __shared__ double stage[4][64 * PPITCH];
+    __shared__ long long offs[PROPOSE_OFFS_LDS];
+    // the K + 1 prefix offsets -> LDS, one coalesced load per workgroup: the binary search below is log2 K DEPENDENT loads,
+    // a memory latency each when they go to global memory (7 of them at K = 128: ~10 % of a wavefront's life with two
+    // wavefronts per SIMD to hide it; K = 4 ran 30 % faster per sample than K = 128 at D = 40)
+    const bool in_lds = a.K + 1 <= PROPOSE_OFFS_LDS;
+    if (in_lds) {
+        for (int t = threadIdx.x; t <= a.K; t += 256) offs[t] = a.offsets[t];
+        __syncthreads();
+    }
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n0 = n - lane;                               // first sample of this wavefront
@@ -168,9 +190,16 @@ __global__ __launch_bounds__(256, 2) void k_propose(const PmcArgsP a)
     // component of sample n: offsets[k] <= n < offsets[k+1]  (binary search, K+1 entries)
     const long long nn = valid ? n : a.N - 1;
     int lo = 0, hi = a.K;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.offsets[mid] <= nn) lo = mid; else hi = mid;
+    if (in_lds) {
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offs[mid] <= nn) lo = mid; else hi = mid;
+        }
+    } else {
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.offsets[mid] <= nn) lo = mid; else hi = mid;
+        }
     }
     const int k = lo;
     const Philox g = {(unsigned)a.seed, (unsigned)(a.seed >> 32)};
@@ -191,14 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_propose(const PmcArgsP a)
     }
     const int rows = (int)((a.N - n0 < 64) ? a.N - n0 : 64);     // samples of this wavefront
     double *__restrict__ out = a.x + n0 * (long long)dreal;
-    const int kfirst = __builtin_amdgcn_readfirstlane(k);
-    if (__all(k == kfirst)) {                                    // wave-uniform branch
-        affine_out<D, PADDED>((cdouble *)(a.chol + (size_t)kfirst * dreal * dreal),
-                              (cdouble *)(a.mu + (size_t)kfirst * dreal), dreal, z, scale, stage[wave], lane, out, rows);
-    } else {
-        affine_out<D, PADDED>(a.chol + (size_t)k * dreal * dreal, a.mu + (size_t)k * dreal, dreal, z, scale,
-                              stage[wave], lane, out, rows);
-    }
+    affine_out<D, PADDED>(a.chol, a.mu, k, dreal, z, scale, stage[wave], lane, out, rows);
     if (a.origin != nullptr && valid) a.origin[n] = k;
 }
 
