@@ -168,8 +168,11 @@ __device__ __forceinline__ void affine_out(const double *chol, const double *mus
 
 // (two wavefronts per SIMD: the unrolled Box-Muller pairs take every register they are given -- 316 at D = 40
 //  without a bound, one wavefront per SIMD; bounded to 256: 5.3 -> 4.2 ms per 1.25e7 samples; to 128 it spills: 6.2)
+#ifndef PMC_PROPOSE_WAVES
+#define PMC_PROPOSE_WAVES 2
+#endif
 template <int D, bool PADDED>
-__global__ __launch_bounds__(256, 2) void k_propose(const PmcArgsP a)
+__global__ __launch_bounds__(256, PMC_PROPOSE_WAVES) void k_propose(const PmcArgsP a)
 {
     __shared__ double stage[4][64 * PPITCH];
     __shared__ long long offs[PROPOSE_OFFS_LDS];
