@@ -421,10 +421,12 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  *   component means), theta_k from P_k = R_k^T R_k and mu_k - c -- a dense product on v_mfma_f64_16x16x4_f64 with the
  *   per-sample epilogue fused behind it.  Its rounding error grows with |P| |x - c|^2 instead of maha, so every sample is
  *   priced first: eps_g (Theta_1 |x - c|^2 + Theta_2 |x - c| + Theta_3) with the maxima over the components of
- *   s_k |P_k|_F, 2 s_k |P_k (mu_k - c)|, s_k (mu_k - c)^T P_k (mu_k - c)  (s_k = |d a / d maha|), eps_g = 1e-15; a workgroup
- *   (256 samples) that holds a sample beyond the tolerance, or a non-finite coordinate, is done by the exact kernel,
- *   launched behind in the same call.  pmc_mixture_logpdf / pmc_importance_weights[_emit_grouped] / pmc_estep take the
- *   form when they are given a workspace, no N x K output is asked for, and
+ *   s_k |P_k|_F, 2 s_k |P_k (mu_k - c)|, s_k (mu_k - c)^T P_k (mu_k - c)  (s_k = |d a / d maha|), eps_g = 3.5e-17 sqrt(number of
+ *   monomials) ~ 1e-15 -- a probabilistic constant, see csrc/pmc_api.hip --; a workgroup (256 samples) that holds a sample
+ *   beyond the tolerance, or a non-finite coordinate, is done by the exact kernel, launched behind in the same call.
+ *   Compiled sample dimensions 32, 40, 48 and (round 5) 64, i.e. D = 31 ... 64.  pmc_mixture_logpdf (with or without
+ *   d_individual) / pmc_importance_weights[_emit_grouped] / pmc_estep take the form when they are given a workspace, every
+ *   component has a positive weight, K >= 24 pads to a multiple of 32 / 64 within 20 %, and
  *   pmc_configure("maha_gemm_tolerance", t) (default 5e-11, in units of a_nk; 0 = never) / ("maha_gemm_min_n", default
  *   32768) allow it.
  */

@@ -349,7 +349,7 @@ bool resp_groups_pays(int dim, int K)
     // measured per (D, K) with scripts/resp_groups_ab.py matrix (profiles/r03_resp_groups.txt; re-measured in round 5,
     // profiles/r05_resp_groups_matrix.txt: since the hand-scheduled scalar loads of round 4 the grouped form also wins at
     // D = 24 from K = 32 on (-2 / -5 / -9 % of the pair at K = 32 / 64 / 128) and at D = 30 from K = 64 on (-3 / -6.5 %);
-    // it still loses at D = 64 (+8 %); D = 32 ... 48 run k_mgemm at these batch sizes either way)
+    // it still loses at D = 64 (+8 %); D = 32 ... 64 run k_mgemm at these batch sizes either way)
     return dim <= 16 || dim == 20 || dim == 24 || (dim == 30 && K >= 64) || dim == 32 || dim == 40;
 }
 

@@ -5,6 +5,7 @@
 
 #include <cfloat>
 #include <type_traits>
+#include <utility>
 
 #ifndef PMC_D
 #error "compile with -DPMC_D=<dimension>"
@@ -21,12 +22,17 @@ typedef __attribute__((address_space(4))) const double cdouble;        // scalar
 typedef __attribute__((address_space(4))) const long long cint64;
 
 template <int I> using ic = std::integral_constant<int, I>;
+// f(ic<B>{}), ..., f(ic<E - 1>{}) in this order, as ONE flat sequence of calls (a fold over the index pack).  Not the
+// recursive form f(ic<B>{}); static_for<B + 1, E>(f): the inliner works bottom-up and copies the tail of the recursion once
+// per level -- quadratic in E - B, ten minutes of compile time for the 545 steps of k_mgemm<64> (forty seconds this way;
+// the code that comes out is the same).
+template <int B, class F, int... I> __device__ __forceinline__ void static_for_pack(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(ic<B + I>{}), ...);
+}
 template <int B, int E, class F> __device__ __forceinline__ void static_for(F &&f)
 {
-    if constexpr (B < E) {
-        f(ic<B>{});
-        static_for<B + 1, E>(f);
-    }
+    if constexpr (B < E) static_for_pack<B>(f, std::make_integer_sequence<int, E - B>{});
 }
 
 // ---------------------------------------------------------------------------------------------

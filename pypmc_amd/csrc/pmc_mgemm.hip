@@ -1,5 +1,5 @@
 // pmc_mgemm.hip -- the Mahalanobis forms of ALL components of a mixture as one matrix product on the fp64 matrix pipe,
-// with the per-sample epilogues of k_logpdf / k_resp_groups fused behind it (compiled dimensions 32, 40, 48):
+// with the per-sample epilogues of k_logpdf / k_resp_groups fused behind it (compiled dimensions 32, 40, 48, 64):
 //
 //     maha_nk = (x_n - mu_k)^T P_k (x_n - mu_k) = sum_m theta_km z_nm,      P_k = R_k^T R_k,
 //     z_n = the (D + 1)(D + 2) / 2 monomials of d = x_n - c up to degree 2 about ONE centre c common to all components,
@@ -41,17 +41,20 @@ typedef __attribute__((address_space(1))) const void mg_gvoid_t;
 typedef __attribute__((address_space(3))) void mg_lvoid_t;
 
 template <int D> struct MgCfg {
-    static constexpr bool ENABLED = D == 32 || D == 40 || D == 48;
+    static constexpr bool ENABLED = D == 32 || D == 40 || D == 48 || D == 64;
     static constexpr int Q = D / 4;
     static constexpr int ND = 2 * Q + 1;                   // deltas per a
     static constexpr int NQ = Q * ND;                      // quadratic steps
     static constexpr int NSTEP = NQ + Q + 1;
-    static constexpr int CH = 16;                          // steps per staged chunk of theta
-    static constexpr int NCH = (NSTEP + CH - 1) / CH;
+    // steps per staged chunk of theta: 16; 8 at D = 64, where the image of 256 samples (133 KB) leaves 27 KB for the
+    // two theta buffers.  The chunk count is rounded up to an even number (the buffer a step reads is a compile-time
+    // constant of the step: passes must start on buffer 0), padding steps carry zero coefficients.
+    static constexpr int CH = D == 64 ? 8 : 16;
+    static constexpr int NCH = ((NSTEP + CH - 1) / CH + 1) / 2 * 2;
     static constexpr int NSTEPP = NCH * CH;
     // row stride of the LDS image of d (doubles): >= 64 and Q RS = 16 mod 32, so that the two lane groups of a
     // half-wavefront read 32 banks apart
-    static constexpr int RS = D == 32 ? 66 : (D == 40 ? 72 : (D == 48 ? 68 : 64));
+    static constexpr int RS = D == 32 ? 66 : (D == 40 ? 72 : (D == 48 ? 68 : 65));
     // component tiles that share a monomial product: what the LDS holds next to the image of 256 samples
     static constexpr int NCT_MAX = D <= 40 ? 4 : 2;
     static constexpr size_t lds_bytes(int nct)
@@ -579,6 +582,10 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });
+        // chunks of padding steps behind the last real one (D = 64: the chunk count is rounded up to an even number): no
+        // step reads them, but the boundary in front of each is what stages the chunk behind it -- the last one the NEXT
+        // pass's first chunk
+        static_for<(NSTEP + CH - 1) / CH, NCH>([&](auto C_) { boundary(ic<decltype(C_)::value * CH>{}); });
     }
 
     // ---- HW = 2: the two halves of a sample row meet -- half 1 hands its running maximum / sum / bound term to half 0

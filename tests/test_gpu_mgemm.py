@@ -1,4 +1,4 @@
-"""The matrix-product form of the Mahalanobis forms (csrc/pmc_mgemm.hip; compiled D = 32, 40, 48): against the oracle
+"""The matrix-product form of the Mahalanobis forms (csrc/pmc_mgemm.hip; compiled D = 32, 40, 48, 64): against the oracle
 (bilinear_sym -> multi_evaluate -> logsumexp2D, pypmc/tools/_linalg.pyx:10-39, density/gauss.pyx:146-151,
 student_t.pyx:154-164, tools/_regularize.pyx:57-84; rho, pmc.pyx:23-43; the VB E-step, variational.pyx:675-1013),
 against the exact kernels it stands in for, and on the cases its guard exists for -- means 30 sigma from the centre,
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 5e-11          # the library's default "maha_gemm_tolerance"
 def EPS_G(D):
     """the guard's error constant (csrc/pmc_api.hip::mgemm_eps): 3.5e-17 sqrt(number of monomials) of the compiled dimension"""
-    Dc = 32 if D <= 32 else 40 if D <= 40 else 48
+    Dc = 32 if D <= 32 else 40 if D <= 40 else 48 if D <= 48 else 64
     return 3.5e-17 * np.sqrt(0.5 * (Dc + 1.) * (Dc + 2.))
 
 
@@ -63,7 +63,8 @@ def guard_bound(rep, mu, x):
 
 
 CASES = [(32, 32, 3000), (32, 64, 2049), (31, 32, 1500), (40, 128, 2500), (40, 32, 1111), (40, 96, 1300), (37, 64, 1290),
-         (48, 32, 1500), (48, 64, 1027), (44, 96, 1100), (40, 28, 1200), (40, 120, 1100)]
+         (48, 32, 1500), (48, 64, 1027), (44, 96, 1100), (40, 28, 1200), (40, 120, 1100),
+         (64, 64, 1300), (64, 32, 1029), (56, 64, 1100), (49, 32, 1200), (64, 128, 1100), (61, 96, 1050)]   # round 5: Dc = 64
 
 
 @pytest.mark.parametrize("D,K,N", CASES)
@@ -84,7 +85,7 @@ def test_gauss_logpdf_vs_oracle(be, orc, small, D, K, N):
 
 
 @pytest.mark.parametrize("D,K,N,dof", [(32, 32, 2000, 8.), (40, 64, 1500, 3.), (40, 128, 1100, 50.), (48, 32, 1200, 5.),
-                                       (36, 32, 1300, 1.5)])
+                                       (36, 32, 1300, 1.5), (64, 64, 1200, 6.), (56, 32, 1100, 4.)])
 def test_student_logpdf_vs_oracle(be, orc, small, D, K, N, dof):
     mu, cov, w = mk(K, D, 400 + D + K)
     x, _ = draw(mu, cov * 1.3, w, N, 18)
@@ -101,7 +102,8 @@ def test_student_logpdf_vs_oracle(be, orc, small, D, K, N, dof):
     assert (np.abs(got - ex) / guard_bound(rep, mu, x)).max() < 0.75
 
 
-@pytest.mark.parametrize("D,K,N", [(32, 32, 2500), (40, 128, 1500), (40, 64, 1100), (48, 64, 1300), (35, 32, 1200)])
+@pytest.mark.parametrize("D,K,N", [(32, 32, 2500), (40, 128, 1500), (40, 64, 1100), (48, 64, 1300), (35, 32, 1200), (64, 64, 1200),
+                                   (56, 32, 1100)])
 def test_importance_weights_and_emitted_responsibilities(be, orc, small, D, K, N):
     """configuration 5's pair of calls: weights + u = w rho (grouped: values x factors) + the statistics"""
     mu, cov, w = mk(K, D, 500 + D + K)
@@ -154,7 +156,7 @@ def vb_set(mu, cov, D, K, seed):
 
 
 @pytest.mark.parametrize("D,K,N,weighted", [(32, 32, 20000, False), (40, 64, 17000, True), (40, 128, 16500, False),
-                                            (48, 32, 18000, True)])
+                                            (48, 32, 18000, True), (64, 64, 17000, False), (57, 32, 16500, True)])
 def test_estep_vs_oracle(be, orc, small, D, K, N, weighted):
     """pmc_estep (VB and Gaussian Rao-Blackwell PMC): k_mgemm's grouped responsibilities + the common-shift statistics.
     Overlapping components (responsibilities that are not one-hot), so that the soft-max itself is tested."""
@@ -331,13 +333,13 @@ def test_bitwise_determinism_and_selection(be, small):
             first = cur
         for a, b in zip(first, cur):
             np.testing.assert_array_equal(a, b)
-    # which shapes take the form: compiled D = 32, 40, 48 (padded 31 ... 48), K within ~20 % of a multiple of 32 / 64,
+    # which shapes take the form: compiled D = 32, 40, 48, 64 (padded 31 ... 64), K within ~20 % of a multiple of 32 / 64,
     # N from the threshold on
     lib = be.lib
     assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 40) == 2
     assert lib.pmc_maha_gemm_tiles(N, 96, 33) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 48) == 2
     assert lib.pmc_maha_gemm_tiles(N, 100, 40) == 0 and lib.pmc_maha_gemm_tiles(N, 16, 40) == 0
-    assert lib.pmc_maha_gemm_tiles(N, 128, 30) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 64) == 0
+    assert lib.pmc_maha_gemm_tiles(N, 128, 30) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 64) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 57) == 2
     assert lib.pmc_maha_gemm_tiles(N, 128, 72) == 0 and lib.pmc_maha_gemm_tiles(999, 128, 40) == 0
     be.configure("maha_gemm_min_n", 32768)
     assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(32768, 128, 40) == 4
@@ -456,7 +458,7 @@ def test_target_with_more_components_than_the_proposal_on_a_fresh_workspace(orc,
     assert_rel(b.tohost(res["weights"])[sub], orc.is_weights(logp, logq), what="weights")
 
 
-@pytest.mark.parametrize("D", [31, 32, 33, 37, 40, 41, 45, 48])
+@pytest.mark.parametrize("D", [31, 32, 33, 37, 40, 41, 45, 48, 49, 57, 64])
 @pytest.mark.parametrize("cond", [1e2, 1e4, 1e6])
 def test_guard_price_covers_ill_conditioned_covariances_in_every_compiled_dimension(be, orc, small, D, cond):
     """advice r4: eps_g is a probabilistic constant (sqrt(n) u growth), so it is held against the cases that stress it --
@@ -487,7 +489,7 @@ def test_guard_price_covers_ill_conditioned_covariances_in_every_compiled_dimens
 
 
 @pytest.mark.parametrize("D,K,N,student", [(32, 32, 2500, False), (40, 128, 1500, False), (40, 64, 1111, True), (48, 64, 1300, False),
-                                           (37, 96, 1290, False), (44, 32, 1100, True)])
+                                           (37, 96, 1290, False), (44, 32, 1100, True), (64, 64, 1200, False), (56, 32, 1100, True)])
 def test_individual_through_the_matrix_product(be, orc, small, D, K, N, student):
     """verdict r4 #5: multi_evaluate(x, individual=...) -- the N x K component log-densities, the reference's own
     intermediate (mixture.pyx:138-151) -- no longer sends the call to the exact engine: the matrix is written from the
