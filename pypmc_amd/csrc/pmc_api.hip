@@ -71,6 +71,11 @@ int fail(int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    // A failed runtime call (a hipMalloc beyond the device's memory, ...) leaves its code behind as the thread's "last
+    // error", and the hipGetLastError behind the NEXT kernel launch would report it as that launch's: the error has been
+    // handed to the caller here, so it is taken off the runtime's slate (every failure of the library, the handle layer
+    // and the exchange passes through this function).
+    if (code == PMC_EHIP) (void)hipGetLastError();
     return code;
 }
 

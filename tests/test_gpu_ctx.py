@@ -381,6 +381,34 @@ def test_argument_errors(lib, ctx):
     lib.pmc_samples_free(s)
 
 
+def test_out_of_memory_is_an_error_and_leaves_the_context_usable(lib, ctx):
+    """a request beyond the device's memory: an error code and a message, no handle, no abort -- and no stale HIP error
+    for the next launch to trip over (hipGetLastError behind a launch would report the failed hipMalloc)"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    D, K = 3, 2
+    mu, cov, w = mk(K, D, 77)
+    mixture = create_gaussian_mixture(mu, cov, w)
+    q = make_mix(lib, ctx, mixture)
+    huge = np.array([2 ** 35, 2 ** 35], dtype=np.int64)             # 2^36 samples x 3 x 8 bytes = 1.6 TB
+    h = C.c_void_p()
+    assert lib.pmc_samples_generate(ctx, q, None, ip(huge), 1, 0, C.byref(h)) < 0 and not h.value
+    assert b"hipMalloc" in lib.pmc_last_error() or b"memory" in lib.pmc_last_error().lower(), lib.pmc_last_error()
+    x = np.random.RandomState(5).normal(size=(1000, D))
+    s = upload(lib, ctx, x)
+    out = np.empty(1000)
+    assert lib.pmc_mix_logpdf(q, s, dp(out), None) == 0, lib.pmc_last_error()
+    from oracle import oracle as orc
+    comps = mixture.components
+    ref, _ = orc.mixture_multi_evaluate(0, x, mixture.weights, mu, np.array([c.inv_sigma for c in comps]),
+                                        np.array([c.log_normalization for c in comps]))
+    np.testing.assert_allclose(out, ref, rtol=1e-10)
+    counts = np.array([500, 500], dtype=np.int64)
+    assert lib.pmc_samples_generate(ctx, q, None, ip(counts), 1, 0, C.byref(h)) == 0, lib.pmc_last_error()
+    lib.pmc_samples_free(h)
+    lib.pmc_samples_free(s)
+    lib.pmc_mixture_destroy(q)
+
+
 def test_many_contexts_in_sequence(lib):
     """300 contexts, each with a stream of its own (non-blocking), each running a finishing reduction as its very first
     launch: the library's per-stream scratch (at most 256 slots) is released with the context and re-used, and its
