@@ -378,3 +378,64 @@ def test_errors_timings_options_and_threads(lib):
         for o in results[tag][1:]:
             for a, b in zip(first, o):
                 np.testing.assert_array_equal(a, b)                # bit-reproducible from call to call
+
+
+@pytest.mark.parametrize("ids", [[0], [0, 0, 0]], ids=["one_device", "three_parts"])
+def test_more_than_2_to_31_samples_through_the_handle_layer(lib, ids):
+    """2^31 + 5 one-dimensional samples generated on the device(s): sample counts, shard boundaries and origins are 64-bit
+    all the way through the handle layer -- closed forms of the K-sized results, nothing N-sized on the host"""
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    h = open_ctx(lib, ids)
+    K, D = 2, 1
+    N = 2 ** 31 + 5
+    mu = np.array([[-2.0], [1.0]])
+    var = np.array([0.25, 2.25])
+    w = np.array([0.25, 0.75])                                     # = counts / N: E[rho_k] = w_k below
+    mixture = create_gaussian_mixture(mu, var.reshape(K, 1, 1), w)
+    q = make_mix(lib, h, mixture)
+    counts = np.array([N // 4, N - N // 4], dtype=np.int64)
+    s = C.c_void_p()
+    assert lib.pmc_samples_generate(h, q, None, ip(counts), 11, 0, C.byref(s)) == 0, lib.pmc_last_error()
+    assert lib.pmc_samples_count(s) == N
+    total = 0
+    for part in range(len(ids)):
+        b, c = C.c_int64(), C.c_int64()
+        assert lib.pmc_samples_shard(s, part, C.byref(b), C.byref(c)) == 0
+        assert b.value == total
+        total += c.value
+    assert total == N
+    # latent form with the origin the handle kept: alpha = counts / N, mu and sigma the blocks' moments
+    alpha, nmu, nsig, norm = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D)), np.zeros(1)
+    assert lib.pmc_pmc_update_stats(h, q, s, None, 0, None, 0, dp(alpha), dp(nmu), dp(nsig), None, None, dp(norm)) == 0, \
+        lib.pmc_last_error()
+    assert norm[0] == N
+    np.testing.assert_allclose(alpha, counts / N, rtol=1e-13)
+    for k in range(K):
+        assert abs(nmu[k, 0] - mu[k, 0]) < 6 * np.sqrt(var[k] / counts[k])
+        assert abs(nsig[k, 0, 0] / var[k] - 1) < 6 * np.sqrt(2.0 / counts[k])
+    # Rao-Blackwellised form: alpha sums to one, and E_q[log q] = -entropy to Monte-Carlo accuracy
+    ll = np.zeros(1)
+    assert lib.pmc_pmc_update_stats(h, q, s, None, 0, None, 1, dp(alpha), dp(nmu), dp(nsig), None, dp(ll), dp(norm)) == 0
+    assert abs(alpha.sum() - 1) < 1e-12 and np.abs(alpha - counts / N).max() < 2e-4
+    assert np.isfinite(ll[0]) and -2.5 < ll[0] / N < -1.0
+    # VB E-step with the front-end's start values for this mixture (its constructor wants samples: a small host batch)
+    np.random.seed(3)
+    vb = GaussianInference(mixture.propose(4000), initial_guess=mixture)
+    m, W, nu, beta, ln_pi, ln_lam = [np.ascontiguousarray(a, dtype=np.float64) for a in
+                                     (vb.m, vb.W, vb.nu, vb.beta, vb.expectation_ln_pi, vb.expectation_det_ln_lambda)]
+    Nk, xbar, S, elq = np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(1)
+    assert lib.pmc_vb_estep(h, s, None, K, dp(m), dp(W), dp(nu), dp(beta), dp(ln_pi), dp(ln_lam), None,
+                            dp(Nk), dp(xbar), dp(S), dp(elq), None, None) == 0, lib.pmc_last_error()
+    assert abs(Nk.sum() / N - 1) < 1e-11 and np.abs(Nk / N - counts / N).max() < 2e-2
+    assert np.isfinite(elq[0]) and elq[0] <= 0
+    # weighted moments (w = 1): the mixture's mean and variance
+    mean, cov = np.empty(D), np.empty((D, D))
+    assert lib.pmc_weighted_moments(h, s, None, 0, dp(mean), dp(cov)) == 0
+    f = counts / N
+    mix_mean = float((f * mu[:, 0]).sum())
+    mix_var = float((f * (var + mu[:, 0] ** 2)).sum() - mix_mean ** 2)
+    assert abs(mean[0] - mix_mean) < 6 * np.sqrt(mix_var / N) and abs(cov[0, 0] / mix_var - 1) < 1e-3
+    lib.pmc_samples_free(s)
+    lib.pmc_mixture_destroy(q)
+    assert lib.pmc_shutdown(h) == 0

@@ -450,3 +450,86 @@ def test_fused_estep_many_rounds(be, D, K):
         del two
     be.release()
     torch.cuda.empty_cache()
+
+
+def test_more_than_2_to_31_samples(be):
+    """The sample COUNT beyond 2^31 (the tests above take byte offsets there, not the row index): 2^31 + 70 001
+    one-dimensional samples through propose, log-pdf, importance weights, the one-kernel E-step and the two-kernel
+    E-step.  Closed forms at both ends and in the middle, the global sums against torch, and additivity of the statistics
+    over two blocks that are each on tested ground."""
+    import torch
+    from pypmc_amd.backend import ComponentSet
+    dev = be.device
+    D, K = 1, 2
+    N = 2 ** 31 + 70_001
+    mu = np.array([[-1.5], [2.0]])
+    sig = np.array([0.7, 1.3])
+    w = np.array([0.3, 0.7])
+    counts = np.array([N // 3, N - N // 3], dtype=np.int64)
+    x, origin = be.propose(mu, sig.reshape(K, 1, 1), None, counts, seed=5)
+    assert x.shape == (N, 1) and origin.shape == (N,)
+    edge = int(counts[0])
+    assert int(origin[0]) == 0 and int(origin[edge - 1]) == 0 and int(origin[edge]) == 1 and int(origin[N - 1]) == 1
+    assert int(origin.sum()) == int(counts[1])                                     # bit-exact origins, all 2^31 of them
+    del origin
+    for k, sl in ((0, slice(0, edge)), (1, slice(edge, N))):
+        seg = x[sl, 0]
+        assert abs(float(seg.mean()) - mu[k, 0]) < 6 * sig[k] / np.sqrt(counts[k])
+        assert abs(float(seg.var()) / sig[k] ** 2 - 1) < 6 * np.sqrt(2.0 / counts[k])
+    assert bool(torch.isfinite(x).all())
+    ln = -0.5 * np.log(2 * np.pi) - np.log(sig)
+    inv = (1.0 / sig ** 2).reshape(K, 1, 1)
+    cs = ComponentSet(0, mu, inv, c0=ln, weight=w)
+
+    def closed_form(xs):
+        a = torch.tensor(np.log(w) + ln, device=dev) - 0.5 * (xs - torch.tensor(mu[:, 0], device=dev)) ** 2 * torch.tensor(inv[:, 0, 0], device=dev)
+        return torch.logsumexp(a, dim=1)
+
+    res = be.logpdf(x, cs, want_scalars=True)
+    out = res["out"]
+    worst = 0.0
+    step = 2 ** 28
+    for b in range(0, N, step):                                  # every row, block by block (the N x 2 temporaries)
+        ref = closed_form(x[b:b + step])
+        worst = max(worst, float(((out[b:b + step] - ref).abs() / ref.abs().clamp_min(1e-300)).max()))
+        del ref
+    assert worst < 1e-10, worst
+    # importance weights against a one-component target: log w = log p - log q, the fused sums against torch
+    tm, ts = 0.5, 2.0
+    target = ComponentSet(0, np.array([[tm]]), np.array([[[1 / ts ** 2]]]), c0=np.array([-0.5 * np.log(2 * np.pi) - np.log(ts)]),
+                          weight=np.ones(1))
+    iw = be.importance_weights(x, cs, target, want_out=True)
+    assert float((iw["out"] - out).abs().max()) == 0.0           # the proposal's log-density: the same kernel body
+    logp = -0.5 * np.log(2 * np.pi) - np.log(ts) - 0.5 * ((x[:, 0] - tm) / ts) ** 2
+    logp -= out
+    lw = logp.exp_()
+    wts = iw["weights"]
+    assert float(((wts - lw).abs() / lw).max()) < 1e-10
+    sc = iw["scalars"].cpu().numpy()
+    assert abs(sc[0] / float(wts.sum()) - 1) < 1e-11             # sum w: the fused reduction over 2^31 rows
+    assert abs(sc[2] / float((wts * wts).sum()) - 1) < 1e-11     # sum w^2
+    del wts
+    del logp, iw, lw, out, res
+    torch.cuda.empty_cache()
+    # E-step, Gaussian PMC Rao-Blackwell mode: one kernel at D = 1; additivity over [0, 2^30) and [2^30, N)
+    assert be.lib.pmc_estep_is_fused(K, D, cs.kind, 1) == 1
+    h = 2 ** 30
+    whole = be.estep(x, cs, 1)["stats"].cpu().numpy().copy()
+    parts = be.estep(x[:h], cs, 1)["stats"].cpu().numpy() + be.estep(x[h:], cs, 1)["stats"].cpu().numpy()
+    from pypmc_amd.mix_adapt._stats import split_stats
+    a, b = split_stats(whole, K, D), split_stats(parts, K, D)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-11)
+    assert abs(a[1].sum() / N - 1) < 1e-11                       # sum_k sum_n rho_nk = N
+    np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-11 * N)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-10)
+    # ... and the two kernels with the N x K matrix written out (34 GB): rows sum to one at both ends, same statistics
+    two = be.estep(x, cs, 1, want_r=True)
+    r = two["r"]
+    for sl in (slice(0, 1000), slice(N - 1000, N)):
+        assert float((r[sl].sum(dim=1) - 1).abs().max()) < 1e-12
+    c = split_stats(two["stats"].cpu().numpy(), K, D)
+    np.testing.assert_allclose(c[1], a[1], rtol=1e-11)
+    np.testing.assert_allclose(c[3], a[3], rtol=1e-10)
+    del r, two, x
+    be.release()
+    torch.cuda.empty_cache()
