@@ -103,9 +103,16 @@ struct Part {
     int rc = PMC_OK;
     std::string err;
     const void *tuning = nullptr;
+    // pinned staging for the small copies of a call (h2d / d2h below)
+    char *stage = nullptr;
+    size_t stage_off = 0;
+    bool stage_tried = false;
     void release_buffers()
     {
         for (DevBuf *b : {&ws, &u, &scratch, &flat, &pack, &spack, &aux, &nk1, &nk2, &lat, &params, &result}) b->release();
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr;
+        stage_off = 0;
     }
 };
 
@@ -227,18 +234,63 @@ int for_parts(pmc_ctx *ctx, const std::function<int(Part &)> &fn)
     return rc;
 }
 
+// Host <-> device copies of a part.  The K-sized parameters and results of a call (up to STAGE_SMALL bytes) go through a
+// pinned buffer of the part: a copy out of pageable memory has to be waited for before the caller's array may go away --
+// a stream synchronisation with the GPU idle behind it, in front of the kernels of EVERY call -- while a copy out of the
+// staging buffer is just queued (the caller's array has been read by the memcpy), and the runtime does not stage it a
+// second time.  The buffer is filled from the front; it starts over whenever the stream is known to be drained (behind
+// the wait of a d2h, or the wait it takes itself when it is full).  Everything that consumes such a copy runs on the same
+// stream; whoever hands results to another stream or device (publish) drains the stream itself.
+constexpr size_t STAGE_BYTES = (size_t)4 << 20, STAGE_SMALL = (size_t)1 << 20;
+bool stage_ready(Part &pt)
+{
+    if (!pt.stage && !pt.stage_tried) {
+        pt.stage_tried = true;
+        void *p = nullptr;
+        if (hipHostMalloc(&p, STAGE_BYTES, hipHostMallocPortable) == hipSuccess) pt.stage = (char *)p;
+        else (void)hipGetLastError();                               // (no pinned memory to be had: the plain copies below)
+    }
+    return pt.stage != nullptr;
+}
+int stage_room(Part &pt, size_t bytes)
+{
+    if (pt.stage_off + bytes > STAGE_BYTES) {
+        HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
+        pt.stage_off = 0;
+    }
+    return PMC_OK;
+}
 int h2d(Part &pt, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return PMC_OK;
+    if (bytes <= STAGE_SMALL && stage_ready(pt)) {
+        CK(stage_room(pt, bytes));
+        char *b = pt.stage + pt.stage_off;
+        std::memcpy(b, src, bytes);
+        HK(hipMemcpyAsync(dst, b, bytes, hipMemcpyHostToDevice, pt.stream), "hipMemcpyAsync (host to device)");
+        pt.stage_off += (bytes + 255) & ~(size_t)255;
+        return PMC_OK;
+    }
     HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pt.stream), "hipMemcpyAsync (host to device)");
     HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");     // the source may be pageable and short-lived
+    pt.stage_off = 0;
     return PMC_OK;
 }
 int d2h(Part &pt, void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return PMC_OK;
+    if (bytes <= STAGE_SMALL && stage_ready(pt)) {
+        CK(stage_room(pt, bytes));
+        char *b = pt.stage + pt.stage_off;
+        HK(hipMemcpyAsync(b, src, bytes, hipMemcpyDeviceToHost, pt.stream), "hipMemcpyAsync (device to host)");
+        HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
+        std::memcpy(dst, b, bytes);
+        pt.stage_off = 0;
+        return PMC_OK;
+    }
     HK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pt.stream), "hipMemcpyAsync (device to host)");
     HK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
+    pt.stage_off = 0;
     return PMC_OK;
 }
 int workspace(Part &pt, int64_t N, int K, int D)
@@ -504,9 +556,9 @@ void destroy_ctx(pmc_ctx *ctx)
             p->th.join();
         }
         (void)hipSetDevice(p->device);
+        if (p->stream) (void)hipStreamSynchronize(p->stream);
         p->release_buffers();
         if (p->stream) {
-            (void)hipStreamSynchronize(p->stream);
             (void)pmc_internal_timing_stream(p->stream, 0);
             (void)pmc_stream_release(p->stream);                    // the library's per-stream scratch slot
             (void)hipStreamDestroy(p->stream);
