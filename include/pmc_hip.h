@@ -428,7 +428,11 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  *   d_individual) / pmc_importance_weights[_emit_grouped] / pmc_estep take the form when they are given a workspace, every
  *   component has a positive weight, K >= 24 pads to a multiple of 32 / 64 within 20 %, and
  *   pmc_configure("maha_gemm_tolerance", t) (default 5e-11, in units of a_nk; 0 = never) / ("maha_gemm_min_n", default
- *   32768) allow it.
+ *   32768) allow it.  Compiled dimensions 20 and 24 (D = 17 ... 24, round 5) have it for the passes that emit no u only --
+ *   pmc_mixture_logpdf, pmc_importance_weights -- and only with four full component tiles per pass (K pads to a multiple of
+ *   64 within 20 %, K >= 96 at D <= 20, K >= 48 at D = 21 ... 24): below that, and for the emitting passes and pmc_estep, the
+ *   vector kernels are the faster ones.  The log q of an emitting and of a non-emitting pass over the same samples
+ *   therefore agree within the tolerance there, not bit for bit (at D >= 31 both take the same form).
  */
 int64_t pmc_gscale_len(int64_t N, int K);
 /* component tiles (of 16) per pass the matrix-product form would run this shape with; 0: the exact kernels */

@@ -974,12 +974,19 @@ inline double mgemm_eps(int Dc) { return 3.5e-17 * std::sqrt(0.5 * (Dc + 1.0) * 
 // component tiles per pass (0: the exact kernels).  K is padded to a multiple of 16 NCT and a padded component costs
 // what a real one does; two tiles per pass cost 4.5 % more per pair than four (profiles/r03_maha_gemm_prototype.txt),
 // and the form as a whole is ~20 % ahead of the exact kernels, so more padding than that is not worth it.
-int mgemm_pick(const PmcKernelSet *ks, long long N, int K)
+// Compiled dimensions 20 and 24 (round 5): 61 / 85 steps per pass instead of 216 at D = 40, so a pass's prologue and epilogue
+// weigh three times as much and the vector kernels are closer -- the form pays for the NON-emitting passes (log-pdf,
+// importance weights) of mixtures with four full tiles per pass only: D = 24: -10 % at K = 64, -16 % at K = 128; D = 20: -2 % at
+// K = 64 (not taken), -11 % at K = 128; with two tiles per pass it loses (D = 20, K = 32: +14 %), and its emitting epilogue
+// loses against k_resp_groups at every K (profiles/r05_mgemm_small.txt).
+int mgemm_pick(const PmcKernelSet *ks, long long N, int K, bool emit)
 {
     if (!ks->mgemm || ks->mg_nstepp <= 0 || !(g_mgemm_tol > 0.0) || N < g_mgemm_min_n || K < 24) return 0;
+    const bool small_dim = ks->dim < 32;
+    if (small_dim && (emit || K < (ks->dim <= 20 ? 96 : 48))) return 0;
     int best = 0;
     double bestc = 1.2 * K;
-    for (int nct = ks->mg_nct_max; nct >= 2; nct /= 2) {
+    for (int nct = ks->mg_nct_max; nct >= (small_dim ? 4 : 2); nct /= 2) {
         const double c = (double)(ceil_div(K, 16 * nct) * 16 * nct) * (nct >= 4 ? 1.0 : 1.045);
         if (c <= bestc) { bestc = c; best = nct; }
     }
@@ -1427,7 +1434,7 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         // kernel behind it for the workgroups it refused
         // (with `individual` too since round 5: the N x K matrix is written from the accumulator layout)
         const int nct = (d_workspace && !d_maha_tiles && !max_init_zero && ks->padded != 2 && (d_out || !d_individual))
-                            ? mgemm_pick(ks, N, K) : 0;
+                            ? mgemm_pick(ks, N, K, false) : 0;
         hipError_t e = hipSuccess;
         if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st);
         if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
@@ -1480,7 +1487,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         // components, which would pad a pass of 32 / 64 -- goes first, through the exact kernel, into log P; the matrix
         // kernel reads it as given target values; the two-mixture exact kernel behind does the workgroups the guard refused.
         const int nct = (d_workspace && !d_maha_tiles && ks->padded != 2 && (!d_u || (kind == PMC_KIND_GAUSS && d_gscale)))
-                            ? mgemm_pick(ks, N, K) : 0;
+                            ? mgemm_pick(ks, N, K, d_u != nullptr) : 0;
         hipError_t e = hipSuccess;
         if (nct) {
             double *lt = d_log_target_out ? d_log_target_out
@@ -1564,7 +1571,7 @@ int pmc_maha_gemm_tiles(int64_t N, int K, int D)
     if (N < 0 || K < 1) return fail(PMC_EINVAL, "pmc_maha_gemm_tiles: bad N/K");
     const PmcKernelSet *ks = kernels_for(D);
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
-    return ks->padded == 2 ? 0 : mgemm_pick(ks, N, K);
+    return ks->padded == 2 ? 0 : mgemm_pick(ks, N, K, false);
 }
 
 int pmc_maha_gemm_report(const void *d_workspace, int64_t N, int K, int D, void *stream, double *h_norms,
@@ -1573,7 +1580,7 @@ int pmc_maha_gemm_report(const void *d_workspace, int64_t N, int K, int D, void 
     if (!d_workspace || !h_norms || !h_refused || !h_workgroups || N < 1 || K < 1)
         return fail(PMC_EINVAL, "pmc_maha_gemm_report: bad argument");
     const PmcKernelSet *ks = kernels_for(D);
-    if (!ks || ks->padded == 2 || !mgemm_pick(ks, N, K))
+    if (!ks || ks->padded == 2 || !mgemm_pick(ks, N, K, false))
         return fail(PMC_EINVAL, "pmc_maha_gemm_report: the matrix-product form is not taken for this shape");
     long long refused = 0, nb = 0;
     const int rc = mgemm_report(ks, d_workspace, N, K, (hipStream_t)stream, h_norms, &refused, &nb);
@@ -2177,7 +2184,7 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
                                ((kind == PMC_KIND_VB && mode == PMC_RESP_VB) || (kind == PMC_KIND_GAUSS && mode == PMC_RESP_PMC_RB));
         // D >= 32: the forms of all components as one matrix product with the grouped epilogue fused behind it
         // (pmc_mgemm.hip); k_resp_groups then only does the workgroups its guard refused
-        const int nct = groupable ? mgemm_pick(ks, N, K) : 0;
+        const int nct = groupable ? mgemm_pick(ks, N, K, true) : 0;
         if (groupable && (nct || resp_groups_pays(ks->dim, K))) {
             // the statistics will run as the component x monomial product: responsibilities in groups of one row
             // block, written once, their per-(sample, group) factors left to that kernel (k_resp_groups)

@@ -1,5 +1,5 @@
 // pmc_mgemm.hip -- the Mahalanobis forms of ALL components of a mixture as one matrix product on the fp64 matrix pipe,
-// with the per-sample epilogues of k_logpdf / k_resp_groups fused behind it (compiled dimensions 32, 40, 48, 64):
+// with the per-sample epilogues of k_logpdf / k_resp_groups fused behind it (compiled dimensions 20, 24, 32, 40, 48, 64):
 //
 //     maha_nk = (x_n - mu_k)^T P_k (x_n - mu_k) = sum_m theta_km z_nm,      P_k = R_k^T R_k,
 //     z_n = the (D + 1)(D + 2) / 2 monomials of d = x_n - c up to degree 2 about ONE centre c common to all components,
@@ -41,7 +41,10 @@ typedef __attribute__((address_space(1))) const void mg_gvoid_t;
 typedef __attribute__((address_space(3))) void mg_lvoid_t;
 
 template <int D> struct MgCfg {
-    static constexpr bool ENABLED = D == 32 || D == 40 || D == 48 || D == 64;
+    // 32 ... 64: every call that qualifies.  20 and 24 (round 5): the log-pdf / importance-weight pass of mixtures with many
+    // components only (pmc_api.hip::mgemm_pick) -- with 61 / 85 steps per pass the epilogue weighs three times what it does
+    // at D = 40, and the emitting epilogue (the E-step) loses against k_resp_groups there (profiles/r05_mgemm_small.txt)
+    static constexpr bool ENABLED = D == 20 || D == 24 || D == 32 || D == 40 || D == 48 || D == 64;
     static constexpr int Q = D / 4;
     static constexpr int ND = 2 * Q + 1;                   // deltas per a
     static constexpr int NQ = Q * ND;                      // quadratic steps
@@ -54,7 +57,7 @@ template <int D> struct MgCfg {
     static constexpr int NSTEPP = NCH * CH;
     // row stride of the LDS image of d (doubles): >= 64 and Q RS = 16 mod 32, so that the two lane groups of a
     // half-wavefront read 32 banks apart
-    static constexpr int RS = D == 32 ? 66 : (D == 40 ? 72 : (D == 48 ? 68 : 65));
+    static constexpr int RS = D == 20 ? 80 : (D == 24 ? 72 : (D == 32 ? 66 : (D == 40 ? 72 : (D == 48 ? 68 : 65))));
     // component tiles that share a monomial product: what the LDS holds next to the image of 256 samples
     static constexpr int NCT_MAX = D <= 40 ? 4 : 2;
     static constexpr size_t lds_bytes(int nct)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 5e-11          # the library's default "maha_gemm_tolerance"
 def EPS_G(D):
     """the guard's error constant (csrc/pmc_api.hip::mgemm_eps): 3.5e-17 sqrt(number of monomials) of the compiled dimension"""
-    Dc = 32 if D <= 32 else 40 if D <= 40 else 48 if D <= 48 else 64
+    Dc = 20 if D <= 20 else 24 if D <= 24 else 32 if D <= 32 else 40 if D <= 40 else 48 if D <= 48 else 64
     return 3.5e-17 * np.sqrt(0.5 * (Dc + 1.) * (Dc + 2.))
 
 
@@ -64,7 +64,9 @@ def guard_bound(rep, mu, x):
 
 CASES = [(32, 32, 3000), (32, 64, 2049), (31, 32, 1500), (40, 128, 2500), (40, 32, 1111), (40, 96, 1300), (37, 64, 1290),
          (48, 32, 1500), (48, 64, 1027), (44, 96, 1100), (40, 28, 1200), (40, 120, 1100),
-         (64, 64, 1300), (64, 32, 1029), (56, 64, 1100), (49, 32, 1200), (64, 128, 1100), (61, 96, 1050)]   # round 5: Dc = 64
+         (64, 64, 1300), (64, 32, 1029), (56, 64, 1100), (49, 32, 1200), (64, 128, 1100), (61, 96, 1050),   # round 5: Dc = 64
+         # round 5: Dc = 20 / 24, the non-emitting passes of mixtures with four full tiles per pass
+         (20, 128, 3000), (19, 112, 1500), (17, 192, 1100), (24, 64, 2000), (24, 128, 1100), (22, 56, 1300), (21, 120, 1050)]
 
 
 @pytest.mark.parametrize("D,K,N", CASES)
@@ -85,7 +87,8 @@ def test_gauss_logpdf_vs_oracle(be, orc, small, D, K, N):
 
 
 @pytest.mark.parametrize("D,K,N,dof", [(32, 32, 2000, 8.), (40, 64, 1500, 3.), (40, 128, 1100, 50.), (48, 32, 1200, 5.),
-                                       (36, 32, 1300, 1.5), (64, 64, 1200, 6.), (56, 32, 1100, 4.)])
+                                       (36, 32, 1300, 1.5), (64, 64, 1200, 6.), (56, 32, 1100, 4.), (24, 64, 1500, 5.),
+                                       (20, 128, 1200, 9.)])
 def test_student_logpdf_vs_oracle(be, orc, small, D, K, N, dof):
     mu, cov, w = mk(K, D, 400 + D + K)
     x, _ = draw(mu, cov * 1.3, w, N, 18)
@@ -140,6 +143,41 @@ def test_importance_weights_and_emitted_responsibilities(be, orc, small, D, K, N
     a2 = be.tohost(be.estep_from_u(x, prop, resp)["stats"])[8:8 + K * ps].reshape(K, ps)
     assert (np.abs(a2 - a) / (np.abs(a).max(axis=1, keepdims=True) + 1e-300)).max() < 1e-12
     np.testing.assert_allclose(resp.host_matrix(be), u, rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("D,K,N", [(24, 64, 2100), (20, 128, 1500), (23, 120, 1100)])
+def test_small_dimensions_take_the_form_for_the_weighting_pass_and_not_for_emitting_passes(be, orc, small, D, K, N):
+    """round 5: compiled dimensions 20 / 24 -- importance weights (no u asked for) run through the matrix product and agree
+    with the oracle and, within the guard's price, with the exact kernels; the emitting pass and the E-step stay with the
+    vector kernels (k_resp_groups is the faster one there): bit for bit the exact path's numbers"""
+    mu, cov, w = mk(K, D, 900 + D + K)
+    x, _ = draw(mu, cov, w, N, 23)
+    tmu, tcov, tw = mk(4, D, 79)
+    prop, inv, ln = gauss_set(mu, cov, w)
+    target, tinv, tln = gauss_set(0.5 * tmu, tcov, tw)
+    logq, _ = orc.mixture_multi_evaluate(0, x, w, mu, inv, ln)
+    logp, _ = orc.mixture_multi_evaluate(0, x, tw, 0.5 * tmu, tinv, tln)
+    res = be.importance_weights(x, prop, target, want_out=True, want_log_target=True)
+    rep = report(be, N, K, D)
+    assert rep["refused"] == 0 and rep["workgroups"] == -(-N // 256)
+    got = be.tohost(res["out"])
+    assert_rel(got, logq, what="log q")
+    assert_rel(be.tohost(res["log_target"]), logp, what="log P")
+    wts = be.tohost(res["weights"])
+    assert_rel(wts, orc.is_weights(logp, logq), what="importance weights")
+    assert_rel(be.tohost(res["scalars"])[:3], [wts.sum(), (wts * np.log(wts)).sum(), (wts ** 2).sum()], rtol=1e-11, what="weight sums")
+    ex = exact(be, lambda: be.tohost(be.importance_weights(x, prop, target, want_out=True)["out"]))
+    diff = np.abs(got - ex)
+    assert diff.max() > 0, "the form did not run"
+    assert (diff / guard_bound(rep, mu, x)).max() < 0.75
+    # emitting pass and E-step: the exact path, whatever the tolerance
+    em = be.importance_weights(x, prop, target, want_out=True, emit=True)
+    em_out, em_u = be.tohost(em["out"]).copy(), em["responsibilities"].host_matrix(be)
+    st = be.tohost(be.estep(x, prop, 1)["stats"]).copy()
+    ex_em = exact(be, lambda: be.importance_weights(x, prop, target, want_out=True, emit=True))
+    np.testing.assert_array_equal(em_out, be.tohost(ex_em["out"]))
+    np.testing.assert_array_equal(em_u, ex_em["responsibilities"].host_matrix(be))
+    np.testing.assert_array_equal(st, exact(be, lambda: be.tohost(be.estep(x, prop, 1)["stats"])))
 
 
 def vb_set(mu, cov, D, K, seed):
@@ -341,6 +379,10 @@ def test_bitwise_determinism_and_selection(be, small):
     assert lib.pmc_maha_gemm_tiles(N, 100, 40) == 0 and lib.pmc_maha_gemm_tiles(N, 16, 40) == 0
     assert lib.pmc_maha_gemm_tiles(N, 128, 30) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 64) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 57) == 2
     assert lib.pmc_maha_gemm_tiles(N, 128, 72) == 0 and lib.pmc_maha_gemm_tiles(999, 128, 40) == 0
+    # D <= 24: four full tiles per pass or nothing (and never for an emitting pass: test_small_dimensions_... below)
+    assert lib.pmc_maha_gemm_tiles(N, 128, 20) == 4 and lib.pmc_maha_gemm_tiles(N, 64, 20) == 0 and lib.pmc_maha_gemm_tiles(N, 32, 20) == 0
+    assert lib.pmc_maha_gemm_tiles(N, 64, 24) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 24) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 16) == 0
+    assert lib.pmc_maha_gemm_tiles(N, 120, 18) == 4 and lib.pmc_maha_gemm_tiles(N, 100, 18) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 28) == 0
     be.configure("maha_gemm_min_n", 32768)
     assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(32768, 128, 40) == 4
 
@@ -458,14 +500,14 @@ def test_target_with_more_components_than_the_proposal_on_a_fresh_workspace(orc,
     assert_rel(b.tohost(res["weights"])[sub], orc.is_weights(logp, logq), what="weights")
 
 
-@pytest.mark.parametrize("D", [31, 32, 33, 37, 40, 41, 45, 48, 49, 57, 64])
+@pytest.mark.parametrize("D", [17, 20, 21, 24, 31, 32, 33, 37, 40, 41, 45, 48, 49, 57, 64])
 @pytest.mark.parametrize("cond", [1e2, 1e4, 1e6])
 def test_guard_price_covers_ill_conditioned_covariances_in_every_compiled_dimension(be, orc, small, D, cond):
     """advice r4: eps_g is a probabilistic constant (sqrt(n) u growth), so it is held against the cases that stress it --
     covariances of condition number up to 1e6 with random orientations, means off the centre, every compiled dimension and
     real dimensions below the padded one -- with the tolerance opened wide so that the FORM runs on all of them: its
     difference to the exact kernel must stay below 0.75 of the price eps_g (Theta-sum) it quotes for each sample."""
-    K, N = 32, 1200
+    K, N = (128 if D <= 20 else 64 if D <= 24 else 32), 1200          # (D <= 24: the form wants four full tiles per pass)
     mu, cov, w = mk(K, D, 700 + D)
     rs = np.random.RandomState(int(D + np.log10(cond)))
     for k in range(K):
@@ -489,7 +531,8 @@ def test_guard_price_covers_ill_conditioned_covariances_in_every_compiled_dimens
 
 
 @pytest.mark.parametrize("D,K,N,student", [(32, 32, 2500, False), (40, 128, 1500, False), (40, 64, 1111, True), (48, 64, 1300, False),
-                                           (37, 96, 1290, False), (44, 32, 1100, True), (64, 64, 1200, False), (56, 32, 1100, True)])
+                                           (37, 96, 1290, False), (44, 32, 1100, True), (64, 64, 1200, False), (56, 32, 1100, True),
+                                           (24, 64, 1300, False), (20, 128, 1100, True)])
 def test_individual_through_the_matrix_product(be, orc, small, D, K, N, student):
     """verdict r4 #5: multi_evaluate(x, individual=...) -- the N x K component log-densities, the reference's own
     intermediate (mixture.pyx:138-151) -- no longer sends the call to the exact engine: the matrix is written from the
