@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): IS samples/s + VB E-step samples/s at N=1e7, K=32, D=20.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -397,7 +397,7 @@ def main_single_process(args):
         "value": n_total / (ms_per_step * 1e-3),
         "unit": "samples/s through one IS weighting pass plus one VB E-step",
         "n_gpus": len(ids), "steps": args.steps, "warmup": args.warmup, "prewarm_steps": args.prewarm, "ms_per_step": ms_per_step,
-        "step_ms": {"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max())},
+        "step_ms": {"all": [round(float(v), 3) for v in per_step], "min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max())},
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "IS weights (K=32 Gauss proposal, K_t=4 Gauss target, perplexity/ESS sums) "
                                "+ VB E-step (r_nk, N_k, x_k, S_k, E[log q(Z)], sum over the devices)",
@@ -421,7 +421,7 @@ def main_single_process(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--samples-per-gpu", dest="n", type=int, default=10_000_000, help="samples per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per variant")
@@ -506,6 +506,9 @@ def main():
 
     s_is, s_vb = (torch.cuda.Stream(), torch.cuda.Stream()) if args.two_streams else (None, None)
 
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
     def step(events=None):
         """one pass of the hot path over the resident batch; K-sized results reach the host every step"""
         if events:
@@ -537,22 +540,19 @@ def main():
             events[4].record()
         return r, host
 
-    def ev():
-        return torch.cuda.Event(enable_timing=True)
-
     # Clocks first: the chip needs ~50 ms of this load before its clock settles (under rocprofv3 the first calls of
     # k_logpdf take 3.75, 3.57, 3.43, 3.39, 3.33 ms, from the sixth on 3.23-3.30: profiles/r04_bench_n1_kernel_stats.csv),
     # so a short warm-up would put the ramp into the timed steps.  Untimed, the same step, reported as `prewarm_steps`.
     # (a COUNT, not a duration: every rank must enter the step's collective the same number of times)
     for _ in range(args.prewarm):
         step()
-    for _ in range(args.warmup):
-        step()
+    be.kernel_timing(True)                           # HIP events on the launch stream around every hot kernel -- on for the
+    for _ in range(args.warmup):                     # warm-up too: the timed steps run exactly what the warm-up ran (the
+        step([ev() for _ in range(5)])               # library's event pool exists, torch's event cache is filled)
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     be.kernel_timings()                              # clear the library's record
-    be.kernel_timing(True)                           # HIP events on the launch stream around every hot kernel
     phase, marks = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -610,7 +610,7 @@ def main():
             "value": n_total / (ms_per_step * 1e-3),
             "unit": "samples/s through one IS weighting pass plus one VB E-step",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": args.prewarm, "ms_per_step": ms_per_step,
-            "step_ms": {"min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max())},
+            "step_ms": {"all": [round(float(v), 3) for v in per_step], "min": float(per_step.min()), "median": float(np.median(per_step)), "max": float(per_step.max())},
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "IS weights (K=32 Gauss proposal, K_t=4 Gauss target, perplexity/ESS sums) "
