@@ -425,8 +425,12 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  *   monomials) ~ 1e-15 -- a probabilistic constant, see csrc/pmc_api.hip --; a workgroup (256 samples) that holds a sample
  *   beyond the tolerance, or a non-finite coordinate, is done by the exact kernel, launched behind in the same call.
  *   Compiled sample dimensions 32, 40, 48 and (round 5) 64, i.e. D = 31 ... 64.  pmc_mixture_logpdf (with or without
- *   d_individual) / pmc_importance_weights[_emit_grouped] / pmc_estep take the form when they are given a workspace, every
- *   component has a positive weight, K >= 24 pads to a multiple of 32 / 64 within 20 %, and
+ *   d_individual) / pmc_importance_weights[_emit_grouped] / pmc_estep take the form when they are given a workspace, no
+ *   weight is negative or non-finite -- and, for the emitting passes and pmc_estep, none is zero: the passes that emit no u
+ *   take components WITHOUT weight (pruned components of a PMC run) along: they stay out of the sum, and a workgroup in which
+ *   such a component's value lies more than 700 above every weighted live one -- the only case in which the reference's
+ *   maximum over ALL unweighted values (_regularize.pyx:73-77) changes the result: its terms underflow -- is done by the exact
+ *   kernel behind --, K >= 24 pads to a multiple of 32 / 64 within 20 %, and
  *   pmc_configure("maha_gemm_tolerance", t) (default 5e-11, in units of a_nk; 0 = never) / ("maha_gemm_min_n", default
  *   32768) allow it.  Compiled dimensions 20 and 24 (D = 17 ... 24, round 5) have it for the passes that emit no u only --
  *   pmc_mixture_logpdf, pmc_importance_weights -- and only with four full component tiles per pass (K pads to a multiple of

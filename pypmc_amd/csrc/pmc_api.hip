@@ -1019,8 +1019,10 @@ size_t mgemm_offset(long long N, int K, const PmcKernelSet *ks)
     return (gscale_offset(N, K, ks) + gscale_bytes(N, K, ks) + 255) & ~(size_t)255;
 }
 // k_theta_build + k_mgemm on `a` (a.blockflag / a.redo are set here for the exact kernel the caller launches behind)
+// allow_dead: components with weight 0 are handled by the matrix kernel (the passes that emit no u); otherwise such a
+// mixture is refused as a whole and the exact kernel behind does it
 hipError_t mgemm_run(const PmcKernelSet *ks, int nct, int kind, const PmcArgsA &a, PmcArgsA &fallback, void *d_workspace,
-                     hipStream_t st)
+                     hipStream_t st, bool allow_dead)
 {
     const MgRegion r = mgemm_region(a.N, a.K, ks);
     char *base = (char *)d_workspace + mgemm_offset(a.N, a.K, ks);
@@ -1038,7 +1040,7 @@ hipError_t mgemm_run(const PmcKernelSet *ks, int nct, int kind, const PmcArgsA &
     q.eps_tol = g_mgemm_tol / mgemm_eps(ks->dim);
     q.blockflag = (int *)(base + r.flags);
     q.redo = (int *)(base + r.head + 32);
-    e = ks->theta(a.pack, a.K, kpad, kind, (double *)(base + r.img), (double *)(base + r.ctab), (double *)(base + r.center),
+    e = ks->theta(a.pack, a.K, kpad, kind | (allow_dead ? 0x100 : 0), (double *)(base + r.img), (double *)(base + r.ctab), (double *)(base + r.center),
                   (unsigned long long *)(base + r.head), st);
     if (e != hipSuccess) return e;
     q.a = a;
@@ -1436,7 +1438,7 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         const int nct = (d_workspace && !d_maha_tiles && !max_init_zero && ks->padded != 2 && (d_out || !d_individual))
                             ? mgemm_pick(ks, N, K, false) : 0;
         hipError_t e = hipSuccess;
-        if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st);
+        if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st, true);
         if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
         e = ks->padded == 2 ? big_logpdf(ks, kind, kind, a, D, st) : ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
@@ -1499,7 +1501,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
             if (e != hipSuccess) return hipfail(e, "k_logpdf (target) launch");
             PmcArgsA ga = a;
             ga.pack2 = nullptr; ga.K2 = 0; ga.log_target_out = nullptr; ga.log_target = lt; ga.vpartials = nullptr;
-            e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st);
+            e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st, d_u == nullptr);
             if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
         }
         e = ks->padded == 2 ? big_logpdf(ks, kind, target_kind, a, D, st)
@@ -2201,7 +2203,7 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
             {
                 Timed t(T_RESP, st, flops_pairs((double)N, K, D), 8.0 * N * (D + K + ceil_div(K, PMC_RESP_GROUP)));
                 hipError_t e = hipSuccess;
-                if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st);
+                if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st, false);
                 if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
                 e = ks->resp_groups(kind, a, (unsigned)nblocks, st);
                 if (e != hipSuccess) return hipfail(e, "k_resp_groups launch");

@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
     constexpr int STRIDE = pmc_pack_stride_c(D), T = pmc_tri(D), Q = C::Q, ND = C::ND, NQ = C::NQ;
     __shared__ double cen[D], dlt[D], Pd[D], Rm[D][D + 1], Pm[D][D + 1], red[256];
     const int k = blockIdx.x, tid = threadIdx.x;
+    // (bit 8 of `kind`: components without weight are allowed -- see `dead` below)
+    const bool allow_dead = (kind & 0x100) != 0;
+    kind &= 0xff;
     // the common centre: midrange of the component means per coordinate (every workgroup for itself, same bits: minimum
     // and maximum do not depend on the order).  Four groups of 64 threads take every fourth component, eight loads in
     // flight each: as one chain of K dependent L2 round trips per coordinate this was most of the kernel's 65 us.
@@ -193,7 +196,13 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
     // i.e. every coefficient times `scale`, the constant monomial plus `shift`.
     const double *c = pk + D + T;
     const bool vb = kind == PMC_KIND_VB;
-    const double logw = vb ? 0.0 : log(c[4]);
+    // A component WITHOUT weight (a pruned component of a PMC run: pmc.pyx:109-117 sets its weight to 0 and leaves it in the
+    // mixture) adds nothing to the sum but takes part in the reference's row maximum with its unweighted value
+    // (logsumexp2D, _regularize.pyx:73-77).  Where the caller allows it (the passes that emit no u), its value comes out of
+    // the product WITHOUT a log-weight, its column number is stored negated as the mark, and k_mgemm keeps its values out of
+    // sum and maximum but tracks their maximum per sample: see the a-posteriori test at the end of k_mgemm.
+    const bool dead = !vb && allow_dead && c[4] == 0.0;
+    const double logw = (vb || dead) ? 0.0 : log(c[4]);
     const double scale = kind == PMC_KIND_GAUSS ? -0.5 : (vb ? -0.5 * c[1] : c[2]);
     const double shift = kind == PMC_KIND_GAUSS ? c[0] + logw : (vb ? c[2] + 0.5 * (c[3] - c[0]) : 1.0);
     for (int idx = tid; idx < C::NSTEPP * 4; idx += 256) {
@@ -218,12 +227,16 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
         o[1] = c[1];
         o[2] = logw;                                       // the product returns a_nk + log w_k: `individual` takes it off again
         o[3] = (double)((const long long *)c)[5];          // the component's output column (mixture.pyx:138: individual[:, k])
+        if (dead) {
+            o[3] = -(o[3] + 1.0);
+            atomicAdd((int *)guard + 10, 1);               // (the head's count of dead components: k_mgemm's switch)
+        }
         // |d a / d maha|
         const double sk = kind == PMC_KIND_GAUSS ? 0.5 : (kind == PMC_KIND_STUDENT_T ? fabs(c[1] * c[2]) : 0.5 * fabs(c[1]));
         double th[3] = {sk * sqrt(sums[0]), 2.0 * sk * sqrt(sums[1]), sk * fabs(sums[2])};
-        // A component without weight takes part in the reference's row maximum (logsumexp2D, _regularize.pyx:73-77) but
-        // has no logarithm to fold in: such mixtures stay with the exact kernels (a NaN norm refuses every sample)
-        if (!vb && !(c[4] > 0.0 && c[4] <= DBL_MAX)) th[0] = __longlong_as_double(0x7ff8000000000000LL);
+        // A weight that is negative or not finite -- or zero where the caller's epilogue has no place for dead components
+        // (the emitting passes) -- keeps the mixture with the exact kernels: a NaN norm refuses every sample
+        if (!vb && !dead && !(c[4] > 0.0 && c[4] <= DBL_MAX)) th[0] = __longlong_as_double(0x7ff8000000000000LL);
         for (int q = 0; q < 3; ++q) {
             // non-negative doubles order like their bit patterns; a NaN's pattern lies above every number's, so it wins
             // and the guard refuses every sample
@@ -330,6 +343,9 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
 
     // per-sample running state of the row (lane l = sample l of the tile): maximum, sum, VB bound term
     double Mrun = -DBL_MAX, srun = 0.0, tbrun = 0.0;
+    // components without weight (k_theta_build): the running maximum of THEIR values per sample, for the test at the end
+    const int has_dead = __builtin_amdgcn_readfirstlane(((const int *)q.guard)[10]);
+    double Mdrun = -DBL_MAX;
     const ExpConst EC;
     const bool emit = a.u != nullptr;
     const int G = (K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                     const int kk = (pass * NTP + half * NCT + c) * 16 + g + 4 * r;
                     if (kk < K) {
                         const md2 lc = *(const md2 *)(ct + (c * 16 + 4 * r) * 4 + 2);
-                        const long long col = (long long)lc[1];
+                        const long long col = (long long)(lc[1] < 0.0 ? -lc[1] - 1.0 : lc[1]);   // (negated: no weight)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const long long nt = tile * 64 + 16 * t + s16;
@@ -378,6 +394,28 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                         }
                     }
                 }
+        }
+        if (has_dead) {
+            // values of components without weight: into their own maximum, out of the pass's (a value no maximum takes and
+            // whose exp is 0, as the padding components have)
+            double Md[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dd = ct[(c * 16 + 4 * r) * 4 + 3] < 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        Md[t] = max_f64(Md[t], dd ? acc[c][t][r] : -DBL_MAX);
+                        acc[c][t][r] = dd ? -DBL_MAX : acc[c][t][r];
+                    }
+                }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Md[t] = max_f64(Md[t], mg_xor16(Md[t]));
+                Md[t] = max_f64(Md[t], mg_xor32(Md[t]));
+            }
+            Mdrun = max_f64(Mdrun, g == 0 ? Md[0] : (g == 1 ? Md[1] : (g == 2 ? Md[2] : Md[3])));
         }
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
@@ -601,16 +639,33 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
             mine[0] = Mrun;
             mine[1] = srun;
             mine[2] = tbrun;
+            mine[3] = Mdrun;
         }
         __syncthreads();
         if (half == 0) {
             const double Mo = mine[0], so = mine[1], to = mine[2];
+            Mdrun = max_f64(Mdrun, mine[3]);
             const double Mn = max_f64(Mo, Mrun);
             const double ar = max_f64(Mrun - Mn, -1075.0), ag = max_f64(Mo - Mn, -1075.0);
             const double cr = exp_clamped(ar, EC), cg = exp_clamped(ag, EC);
             if (kind == PMC_KIND_VB) tbrun = cr * fma(ar, srun, tbrun) + cg * fma(ag, so, to);
             srun = cr * srun + cg * so;
             Mrun = Mn;
+        }
+    }
+
+    // ---- components without weight, a posteriori: the reference takes its row maximum over ALL components' unweighted values
+    // (logsumexp2D, _regularize.pyx:73-77), the sum here is relative to the maximum of the weighted values of those that
+    // have a weight -- the same number unless a dead component's value lies so far above every live one that the
+    // reference's terms exp(a_k - max) leave the normal range (it then returns a degraded sum, or log 0 = -inf).  The
+    // weighted live maximum is a lower bound of the unweighted one (log w <= 0): within 700 of the dead maximum every
+    // live term of the reference is a normal number and the two agree to rounding; a sample beyond that sends its
+    // workgroup to the exact kernel behind, which does the reference's arithmetic (its outputs overwrite these).
+    if (has_dead && half == 0) {
+        const bool far = valid && !(Mdrun - Mrun <= 700.0);
+        if (__any(far) && lane == 0) {
+            q.blockflag[blockIdx.x] = 1;
+            *q.redo = 1;
         }
     }
 

@@ -341,16 +341,83 @@ def test_non_finite_coordinates_and_zero_weights(be, orc, small):
     np.testing.assert_array_equal(got[768:1024], ex[768:1024])
     ref, _ = orc.mixture_multi_evaluate(0, x[:256], w, mu, inv, ln)
     assert_rel(got[:256], ref, what="the clean workgroups")
-    # a component without weight takes part in the reference's row maximum (_regularize.pyx:73-77): no logarithm to fold
-    # into the image -- the whole call stays with the exact kernel
+    # a negative weight has no logarithm and no meaning: the whole call stays with the exact kernel
     w0 = w.copy()
-    w0[5] = 0.0
+    w0[5] = -0.1
     cs0 = gauss_set(mu, cov, w0)[0]
     xc, _ = draw(mu, cov, w, N, 8)
     got0 = be.tohost(be.logpdf(xc, cs0, want_scalars=True)["out"])
     rep0 = report(be, N, K, D)
     assert rep0["refused"] == rep0["workgroups"]
     np.testing.assert_array_equal(got0, exact(be, lambda: be.tohost(be.logpdf(xc, cs0, want_scalars=True)["out"])))
+
+
+@pytest.mark.parametrize("D,K,N,student", [(40, 64, 2500, False), (32, 32, 1500, False), (48, 64, 1300, True), (64, 64, 1200, False),
+                                           (24, 64, 1500, False), (37, 128, 1100, True)])
+def test_components_without_weight(be, orc, small, D, K, N, student):
+    """round 5: a pruned component (weight 0, still in the mixture: pmc.pyx:109-117) no longer sends the whole call to the
+    exact engine.  It takes part in the reference's row maximum with its unweighted value (logsumexp2D,
+    _regularize.pyx:73-77) and adds nothing to the sum: the matrix kernel keeps it out of both and tests a posteriori that
+    no dead component's value lies more than 700 above the live maximum -- the only case in which the reference's number
+    differs (its terms exp(a - max) underflow); such workgroups go to the exact kernel.  Log-density, `individual` (the dead
+    columns too, as the reference fills them), importance weights; against the oracle's reference loops."""
+    mu, cov, w = mk(K, D, 950 + D + K)
+    dead = np.arange(K) % 5 == 2
+    w = np.where(dead, 0.0, w)
+    w /= w.sum()
+    x, _ = draw(mu, cov, np.full(K, 1.0 / K), N, 31)                # samples around the dead components too
+    if student:
+        dofs = np.full(K, 7.0) + 0.25 * (np.arange(K) % 5)
+        cs, inv, ln, pf, idf = student_set(mu, cov, w, dofs)
+        ev = lambda xs: orc.mixture_multi_evaluate(1, xs, w, mu, inv, ln, pf, idf)
+        be.configure("maha_gemm_tolerance", 1e-9)
+    else:
+        cs, inv, ln = gauss_set(mu, cov, w)
+        ev = lambda xs: orc.mixture_multi_evaluate(0, xs, w, mu, inv, ln)
+    try:
+        ref, ref_ind = ev(x)
+        res = be.logpdf(x, cs, want_individual=True, want_scalars=True)
+        rep = report(be, N, K, D)
+        assert rep["refused"] == 0, rep
+        got, ind = be.tohost(res["out"]), be.tohost(res["individual"])
+        assert_rel(got, ref, what="log q with dead components")
+        assert_rel(ind, ref_ind, what="individual with dead components")
+        ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+        assert np.abs(got - ex).max() > 0, "the form did not run"
+        assert (np.abs(got - ex) / guard_bound(rep, mu, x)).max() < 0.75 * (2.0 if student else 1.0)
+        # importance weights against a small target: the same pass with the weights behind it
+        tmu, tcov, tw = mk(4, D, 83)
+        target, tinv, tln = gauss_set(0.5 * tmu, tcov, tw)
+        logp, _ = orc.mixture_multi_evaluate(0, x, tw, 0.5 * tmu, tinv, tln)
+        iw = be.importance_weights(x, cs, target, want_out=True)
+        assert report(be, N, K, D)["refused"] == 0
+        assert_rel(be.tohost(iw["weights"]), orc.is_weights(logp, ref), what="importance weights with dead components")
+        # a dead component FAR above every live one at some samples: points 45 sigma from all live components, right on a
+        # dead one -- the reference's terms underflow there (log 0 = -inf or a degraded sum); those workgroups take the exact
+        # kernel and give its numbers bit for bit, the others stay with the form
+        far = mu[2] + 60.0 * np.sqrt(np.diag(cov[2]).max()) * np.ones(D) / np.sqrt(D) * np.sqrt(D)
+        mu2 = mu.copy()
+        mu2[2] = far                                                 # component 2 (dead) moved far away from everything
+        xs = x.copy()
+        xs[700:703] = far + 0.01
+        if student:
+            cs2 = student_set(mu2, cov, w, dofs)[0]
+            ref2, _ = orc.mixture_multi_evaluate(1, xs, w, mu2, inv, ln, pf, idf)
+        else:
+            cs2 = gauss_set(mu2, cov, w)[0]
+            ref2, _ = orc.mixture_multi_evaluate(0, xs, w, mu2, inv, ln)
+        be.configure("maha_gemm_tolerance", 1.0)                     # (the a-priori guard out of the way: the centre moved)
+        got2 = be.tohost(be.logpdf(xs, cs2, want_scalars=True)["out"])
+        rep2 = report(be, N, K, D)
+        ex2 = exact(be, lambda: be.tohost(be.logpdf(xs, cs2, want_scalars=True)["out"]))
+        if not student:                                              # (Student-t tails are too heavy for an underflow at 60 sigma)
+            assert rep2["refused"] == 1, rep2
+            np.testing.assert_array_equal(got2[512:768], ex2[512:768])
+        both = np.isfinite(ref2) & np.isfinite(got2)
+        assert np.array_equal(np.isfinite(ref2), np.isfinite(got2))
+        assert_rel(got2[both], ref2[both], rtol=1e-9, what="log q, dead component far away")
+    finally:
+        be.configure("maha_gemm_tolerance", TOL)
 
 
 def test_bitwise_determinism_and_selection(be, small):
