@@ -55,14 +55,21 @@ template <int D> struct MgCfg {
     static constexpr int CH = D == 64 ? 8 : 16;
     static constexpr int NCH = ((NSTEP + CH - 1) / CH + 1) / 2 * 2;
     static constexpr int NSTEPP = NCH * CH;
+    // (the kernel's own chunk: finer where the pass holds more tiles than the LDS has room for at CH steps -- D = 48 with
+    //  four tiles per pass: 8 steps; the image's layout does not depend on it, a tile's steps are contiguous)
+    static constexpr int ch_of(int ntp) { return (D == 48 && ntp == 4) ? 8 : CH; }
     // row stride of the LDS image of d (doubles): >= 64 and Q RS = 16 mod 32, so that the two lane groups of a
     // half-wavefront read 32 banks apart
     static constexpr int RS = D == 20 ? 80 : (D == 24 ? 72 : (D == 32 ? 66 : (D == 40 ? 72 : (D == 48 ? 68 : 65))));
     // component tiles that share a monomial product: what the LDS holds next to the image of 256 samples
+#ifdef PMC_MG_D48_TWO_TILES                               // (A/B: D = 48 as in round 4, two tiles per pass, one wavefront per SIMD)
     static constexpr int NCT_MAX = D <= 40 ? 4 : 2;
+#else
+    static constexpr int NCT_MAX = D <= 48 ? 4 : 2;
+#endif
     static constexpr size_t lds_bytes(int nct)
     {
-        return sizeof(double) * (size_t)(2 * nct * CH * 64 + 4 * D * RS + 2 * nct * 64);
+        return sizeof(double) * (size_t)(2 * nct * ch_of(nct) * 64 + 4 * D * RS + 2 * nct * 64);
     }
 };
 
@@ -259,7 +266,8 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
 {
     constexpr int NTP = NCT * HW;                          // component tiles per pass
     using C = MgCfg<D>;
-    constexpr int Q = C::Q, RS = C::RS, CH = C::CH, NCH = C::NCH, ND = C::ND, NQ = C::NQ, NSTEP = C::NSTEP;
+    constexpr int Q = C::Q, RS = C::RS, CH = C::ch_of(NTP), NCH = C::NSTEPP / CH, ND = C::ND, NQ = C::NQ, NSTEP = C::NSTEP;
+    static_assert(NCH * CH == C::NSTEPP, "the kernel's chunk divides the image's padded step count");
     static_assert(RS >= 64 && (Q * RS) % 32 == 16, "bank spread of the rotated views");
     static_assert(NCH % 2 == 0, "the chunk's buffer is a compile-time constant of the step");
     extern __shared__ double lds[];

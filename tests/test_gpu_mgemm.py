@@ -442,7 +442,7 @@ def test_bitwise_determinism_and_selection(be, small):
     # N from the threshold on
     lib = be.lib
     assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 40) == 2
-    assert lib.pmc_maha_gemm_tiles(N, 96, 33) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 48) == 2
+    assert lib.pmc_maha_gemm_tiles(N, 96, 33) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 48) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 48) == 2
     assert lib.pmc_maha_gemm_tiles(N, 100, 40) == 0 and lib.pmc_maha_gemm_tiles(N, 16, 40) == 0
     assert lib.pmc_maha_gemm_tiles(N, 128, 30) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 64) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 57) == 2
     assert lib.pmc_maha_gemm_tiles(N, 128, 72) == 0 and lib.pmc_maha_gemm_tiles(999, 128, 40) == 0
