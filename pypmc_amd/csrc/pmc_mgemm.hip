@@ -55,17 +55,22 @@ template <int D> struct MgCfg {
     static constexpr int CH = D == 64 ? 8 : 16;
     static constexpr int NCH = ((NSTEP + CH - 1) / CH + 1) / 2 * 2;
     static constexpr int NSTEPP = NCH * CH;
-    // (the kernel's own chunk: finer where the pass holds more tiles than the LDS has room for at CH steps -- D = 48 with
-    //  four tiles per pass: 8 steps; the image's layout does not depend on it, a tile's steps are contiguous)
-    static constexpr int ch_of(int ntp) { return (D == 48 && ntp == 4) ? 8 : CH; }
+    // (the kernel's own chunk: finer where the pass holds more tiles than the LDS has room for at CH steps -- four tiles per
+    //  pass: 8 steps at D = 48, 4 at D = 64 (154 KB in all); the image's layout does not depend on it, a tile's steps are
+    //  contiguous)
+    static constexpr int ch_of(int ntp) { return (D == 48 && ntp == 4) ? 8 : ((D == 64 && ntp == 4) ? 4 : CH); }
     // row stride of the LDS image of d (doubles): >= 64 and Q RS = 16 mod 32, so that the two lane groups of a
     // half-wavefront read 32 banks apart
     static constexpr int RS = D == 20 ? 80 : (D == 24 ? 72 : (D == 32 ? 66 : (D == 40 ? 72 : (D == 48 ? 68 : 65))));
     // component tiles that share a monomial product: what the LDS holds next to the image of 256 samples
-#ifdef PMC_MG_D48_TWO_TILES                               // (A/B: D = 48 as in round 4, two tiles per pass, one wavefront per SIMD)
+    // four everywhere since round 5 (two wavefronts per SIMD with two tiles each); the A/B switches rebuild round 4's two
+    // tiles on one wavefront at D = 48 / 64 (scripts/mgemm_d48_ab.py, scripts/mgemm_d64_four_ab.py)
+#if defined(PMC_MG_D48_TWO_TILES)
     static constexpr int NCT_MAX = D <= 40 ? 4 : 2;
-#else
+#elif defined(PMC_MG_D64_TWO_TILES)
     static constexpr int NCT_MAX = D <= 48 ? 4 : 2;
+#else
+    static constexpr int NCT_MAX = 4;
 #endif
     static constexpr size_t lds_bytes(int nct)
     {

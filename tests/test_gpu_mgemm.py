@@ -444,7 +444,7 @@ def test_bitwise_determinism_and_selection(be, small):
     assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 40) == 2
     assert lib.pmc_maha_gemm_tiles(N, 96, 33) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 48) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 48) == 2
     assert lib.pmc_maha_gemm_tiles(N, 100, 40) == 0 and lib.pmc_maha_gemm_tiles(N, 16, 40) == 0
-    assert lib.pmc_maha_gemm_tiles(N, 128, 30) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 64) == 2 and lib.pmc_maha_gemm_tiles(N, 64, 57) == 2
+    assert lib.pmc_maha_gemm_tiles(N, 128, 30) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 64) == 4 and lib.pmc_maha_gemm_tiles(N, 64, 57) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 64) == 2
     assert lib.pmc_maha_gemm_tiles(N, 128, 72) == 0 and lib.pmc_maha_gemm_tiles(999, 128, 40) == 0
     # D <= 24: four full tiles per pass or nothing (and never for an emitting pass: test_small_dimensions_... below)
     assert lib.pmc_maha_gemm_tiles(N, 128, 20) == 4 and lib.pmc_maha_gemm_tiles(N, 64, 20) == 0 and lib.pmc_maha_gemm_tiles(N, 32, 20) == 0
