@@ -150,9 +150,15 @@ struct Timed {
     ~Timed()
     {
         if (!on) return;
-        hipEventRecord(rec.b, st);
+        const bool ok = hipEventRecord(rec.b, st) == hipSuccess;
         std::lock_guard<std::mutex> lock(g_timing_mutex);
-        g_timing_recs.push_back(rec);
+        if (ok) {
+            g_timing_recs.push_back(rec);
+        } else {                                           // (no stop event, no record: the pair goes back to its pool)
+            (void)hipGetLastError();
+            g_timing_pool[rec.dev].push_back(rec.a);
+            g_timing_pool[rec.dev].push_back(rec.b);
+        }
     }
 };
 
