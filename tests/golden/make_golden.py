@@ -52,7 +52,12 @@ def mk(K, D, seed, dof=None):
     return mu, cov, w
 
 
+ONLY = None
+
+
 def save(name, **arrays):
+    if ONLY is not None and not name.startswith(ONLY):
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
     print("%-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.))
@@ -78,7 +83,10 @@ def comp_params(mix, student=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref-build", default="/tmp/pypmc_ref")
+    ap.add_argument("--only", default=None, help="write only the files whose name starts with this (the others are left as they are)")
     args = ap.parse_args()
+    global ONLY
+    ONLY = args.only
     warnings.simplefilter("ignore")
     ensure_reference(args.ref_build)
 
@@ -169,6 +177,39 @@ def main():
         out = mix.multi_evaluate(x, individual=individual)
         save("logpdf_student_" + tag, x=x, out=out, individual=individual,
              **comp_params(mix, student=True))
+
+    # ------------------------------------------------------------------ pruned (zero-weight) components at a dimension
+    # where the matrix-product form of the GPU path applies: the reference's row maximum runs over ALL components'
+    # unweighted values (logsumexp2D), so samples that sit on a dead component far from every live one come out degraded
+    # (the live terms exp(a - max) underflow) or as log 0 = -inf.  All components share ONE covariance (the file stays
+    # small: one inverse, as the reference computed it).  Rows 0 ... 383: samples of the live mixture; 384 ... 511: samples
+    # around the dead component 3, which sits 70 sigma away, approaching it from 20 sigma.
+    for tag, K, D, seed in (("d40k32", 32, 40, 51), ("d24k64", 64, 24, 52)):
+        mu, cov, w = mk(K, D, seed)
+        cov = np.repeat(cov[:1], K, axis=0)
+        w[np.arange(K) % 5 == 3] = 0.0
+        w /= w.sum()
+        live = w > 0
+        np.random.seed(9)
+        x_live = create_gaussian_mixture(mu[live], cov[live], w[live]).propose(384)
+        rs = np.random.RandomState(10)
+        L = np.linalg.cholesky(cov[0])
+        sig = np.sqrt(np.linalg.eigvalsh(cov[0]).max())
+        far_dir = np.ones(D) / np.sqrt(D)
+        dist = np.linspace(20., 70., 128)
+        x_far = mu[3] + dist[:, None] * sig * far_dir + rs.normal(size=(128, D)).dot(L.T)
+        mu_far = mu.copy()
+        mu_far[3] = mu[3] + dist[-1] * sig * far_dir
+        x = np.vstack([x_live, x_far])
+        mix_far = create_gaussian_mixture(mu_far, cov, np.full(K, 1. / K))
+        mix_far.weights[:] = w
+        individual = np.empty((len(x), K))
+        out = mix_far.multi_evaluate(x, individual=individual)
+        c0 = mix_far.components[0]
+        assert all(np.array_equal(c.inv_sigma, c0.inv_sigma) for c in mix_far.components)
+        save("logpdf_dead_" + tag, x=x, out=out, weights=np.array(mix_far.weights), mu=mu_far, sigma0=cov[0],
+             inv_sigma0=c0.inv_sigma, log_norm0=c0._local_gauss.log_normalization,
+             individual_live_max=individual[:, live].max(axis=1), individual_dead_max=individual[:, ~live].max(axis=1))
 
     # ------------------------------------------------------------------ importance weights
     for tag, K, D, N, seed, student in (("gauss_d2", 3, 2, 400, 41, False),

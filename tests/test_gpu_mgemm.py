@@ -180,6 +180,41 @@ def test_small_dimensions_take_the_form_for_the_weighting_pass_and_not_for_emitt
     np.testing.assert_array_equal(st, exact(be, lambda: be.tohost(be.estep(x, prop, 1)["stats"])))
 
 
+@pytest.mark.parametrize("tag", ["d40k32", "d24k64"])
+@pytest.mark.parametrize("tol", [TOL, 1.0])
+def test_dead_components_far_away_against_the_reference_golden(be, small, tag, tol):
+    """tests/golden/logpdf_dead_*.npz, generated from the reference: a mixture with pruned components, 384 samples of the
+    live mixture and 128 that approach a dead component 70 sigma away -- there the reference's terms exp(a - max over ALL
+    components) underflow and it returns log 0 = -inf (81 rows).  Through the matrix-product form: the first workgroup
+    stays with it, the second is sent to the exact kernel -- a priori at the default tolerance (the samples are far from the
+    centre), a posteriori (dead maximum - live maximum > 700) with the a-priori guard opened wide -- and every row agrees
+    with the reference: the same -inf rows, 1e-10 elsewhere."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "logpdf_dead_%s.npz" % tag))
+    from pypmc_amd.backend import ComponentSet
+    x, w, mu = g["x"], g["weights"], g["mu"]
+    K, D = mu.shape
+    inv = np.repeat(g["inv_sigma0"][None], K, axis=0)
+    cs = ComponentSet(0, mu, inv, c0=np.full(K, float(g["log_norm0"])), weight=w)
+    be.configure("maha_gemm_min_n", 256)
+    be.configure("maha_gemm_tolerance", tol)
+    try:
+        assert be.lib.pmc_maha_gemm_tiles(len(x), K, D) > 0
+        got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+        rep = report(be, len(x), K, D)
+    finally:
+        be.configure("maha_gemm_tolerance", TOL)
+        be.configure("maha_gemm_min_n", 32768)
+    assert rep["workgroups"] == 2 and rep["refused"] == 1, rep
+    ref = g["out"]
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and not np.isnan(got).any()
+    fin = np.isfinite(ref)
+    assert_rel(got[fin], ref[fin], what="log q against the reference's golden vector")
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    np.testing.assert_array_equal(got[256:], ex[256:])               # the redone workgroup: the exact kernel's numbers
+    assert np.abs(got[:256] - ex[:256]).max() > 0                     # the other one: the form's
+
+
 def vb_set(mu, cov, D, K, seed):
     from pypmc_amd.backend import ComponentSet
     rs = np.random.RandomState(seed)

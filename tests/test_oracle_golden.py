@@ -61,6 +61,21 @@ def test_gauss_mixture_logpdf_bitexact(tag):
     np.testing.assert_array_equal(indm, ind)
 
 
+@pytest.mark.parametrize("tag", ["d40k32", "d24k64"])
+def test_gauss_mixture_with_dead_components_far_away_bitexact(tag):
+    """pruned (zero-weight) components take part in the row maximum (logsumexp2D, _regularize.pyx:73-77): samples that sit on a
+    dead component 70 sigma from every live one come out of the reference as log 0 = -inf -- and of the oracle, bit for bit"""
+    g = load_golden("logpdf_dead_" + tag)
+    K = len(g["weights"])
+    inv = np.repeat(g["inv_sigma0"][None], K, axis=0)
+    out, ind = orc.mixture_multi_evaluate(0, g["x"], g["weights"], g["mu"], inv, np.full(K, float(g["log_norm0"])))
+    np.testing.assert_array_equal(out, g["out"])
+    live = g["weights"] > 0
+    np.testing.assert_array_equal(ind[:, live].max(axis=1), g["individual_live_max"])
+    np.testing.assert_array_equal(ind[:, ~live].max(axis=1), g["individual_dead_max"])
+    assert np.isneginf(out).sum() == 81 and np.isfinite(out[:384]).all()
+
+
 @pytest.mark.parametrize("tag", ["d3k2", "d30k8", "d2k3"])
 def test_student_mixture_logpdf_bitexact(tag):
     g = load_golden("logpdf_student_" + tag)
