@@ -75,6 +75,29 @@ def test_multi_evaluate(lib, ctx, name):
     lib.pmc_samples_free(s)
 
 
+@pytest.mark.parametrize("tag", ["d40k32", "d24k64"])
+@pytest.mark.parametrize("min_n", [32768, 128])
+def test_multi_evaluate_pruned_components_far_away(lib, ctx, tag, min_n):
+    """round 5: a mixture with pruned (zero-weight) components, some samples on a dead component 70 sigma from every live one --
+    the reference returns log 0 = -inf there (logsumexp2D's maximum runs over ALL components).  Through the handle layer with
+    the exact kernels (default threshold) and with the matrix-product form forced on from 128 samples per part."""
+    g = load_golden("logpdf_dead_" + tag)
+    K = len(g["weights"])
+    gg = dict(weights=g["weights"], mu=g["mu"], inv_sigma=np.repeat(g["inv_sigma0"][None], K, axis=0),
+              log_norm=np.full(K, float(g["log_norm0"])))
+    assert lib.pmc_ctx_configure(ctx, b"maha_gemm_min_n", float(min_n)) == 0, lib.pmc_last_error()
+    m, _ = mix_from(lib, ctx, gg, "")
+    s = upload(lib, ctx, g["x"])
+    N = len(g["x"])
+    out = np.empty(N)
+    assert lib.pmc_mix_logpdf(m, s, dp(out), None) == 0, lib.pmc_last_error()
+    assert np.array_equal(np.isneginf(out), np.isneginf(g["out"])) and not np.isnan(out).any()
+    fin = np.isfinite(g["out"])
+    assert rel(out[fin], g["out"][fin]) < 1e-10
+    lib.pmc_mixture_destroy(m)
+    lib.pmc_samples_free(s)
+
+
 @pytest.mark.parametrize("name", ["gauss_d2k3", "gauss_d5k4", "gauss_d20k16", "gauss_d1k2", "gauss_d7k1"])
 def test_multi_evaluate_components_subset(lib, ctx, name):
     """multi_evaluate(x, individual=..., components=subset) on the reference (mixture.pyx:153-156): only the listed
