@@ -211,6 +211,21 @@ def main():
              inv_sigma0=c0.inv_sigma, log_norm0=c0._local_gauss.log_normalization,
              individual_live_max=individual[:, live].max(axis=1), individual_dead_max=individual[:, ~live].max(axis=1))
 
+    # ------------------------------------------------------------------ Student-t mixtures at dimensions where the GPU path
+    # evaluates the Mahalanobis forms as a matrix product (shared scale matrix: the file stays small)
+    for tag, K, D, N, seed, dof in (("d40k32", 32, 40, 512, 61, 6.), ("d64k64", 64, 64, 512, 62, 11.)):
+        mu, cov, w = mk(K, D, seed)
+        cov = np.repeat(cov[:1], K, axis=0)
+        dofs = np.full(K, dof) + 0.5 * (np.arange(K) % 4)
+        mix = create_t_mixture(mu, cov, dofs, w)
+        np.random.seed(11)
+        x = mix.propose(N)
+        out = mix.multi_evaluate(x)
+        c0 = mix.components[0]
+        assert all(np.array_equal(c.inv_sigma, c0.inv_sigma) for c in mix.components)
+        save("logpdf_student_shared_" + tag, x=x, out=out, weights=np.array(mix.weights), mu=mu, dof=dofs,
+             inv_sigma0=c0.inv_sigma, log_norm=np.array([c._local_t.log_normalization for c in mix.components]))
+
     # ------------------------------------------------------------------ importance weights
     for tag, K, D, N, seed, student in (("gauss_d2", 3, 2, 400, 41, False),
                                         ("student_d5", 4, 5, 300, 42, True)):

@@ -215,6 +215,32 @@ def test_dead_components_far_away_against_the_reference_golden(be, small, tag, t
     assert np.abs(got[:256] - ex[:256]).max() > 0                     # the other one: the form's
 
 
+@pytest.mark.parametrize("tag", ["d40k32", "d64k64"])
+def test_student_t_against_the_reference_golden(be, small, tag):
+    """tests/golden/logpdf_student_shared_*.npz (StudentT.multi_evaluate + logsumexp2D of the reference, student_t.pyx:154-164)
+    through the matrix-product form: every workgroup stays with it, 1e-10 against the reference's numbers"""
+    import os
+    from pypmc_amd.backend import ComponentSet
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "logpdf_student_shared_%s.npz" % tag))
+    x, w, mu, dof = g["x"], g["weights"], g["mu"], g["dof"]
+    K, D = mu.shape
+    inv = np.repeat(g["inv_sigma0"][None], K, axis=0)
+    cs = ComponentSet(1, mu, inv, c0=g["log_norm"], c1=-.5 * (dof + D), c2=1. / dof, c3=dof, weight=w)
+    be.configure("maha_gemm_min_n", 256)
+    be.configure("maha_gemm_tolerance", 1e-9)             # (Student-t: the slope (nu + D) / 2 nu prices small dof out by default)
+    try:
+        got = be.tohost(be.logpdf(x, cs, want_scalars=True)["out"])
+        rep = report(be, len(x), K, D)
+    finally:
+        be.configure("maha_gemm_tolerance", TOL)
+        be.configure("maha_gemm_min_n", 32768)
+    assert rep["refused"] == 0 and rep["workgroups"] == 2, rep
+    assert_rel(got, g["out"], what="Student-t log q against the reference's golden vector")
+    ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
+    assert np.abs(got - ex).max() > 0, "the form did not run"
+    assert_rel(ex, g["out"], rtol=1e-12, what="exact kernel against the golden vector")
+
+
 def vb_set(mu, cov, D, K, seed):
     from pypmc_amd.backend import ComponentSet
     rs = np.random.RandomState(seed)

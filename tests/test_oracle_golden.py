@@ -76,6 +76,16 @@ def test_gauss_mixture_with_dead_components_far_away_bitexact(tag):
     assert np.isneginf(out).sum() == 81 and np.isfinite(out[:384]).all()
 
 
+@pytest.mark.parametrize("tag", ["d40k32", "d64k64"])
+def test_student_mixture_logpdf_large_dimensions_bitexact(tag):
+    g = load_golden("logpdf_student_shared_" + tag)
+    K, D = g["mu"].shape
+    pf, idf = student_consts(g["dof"], D)
+    inv = np.repeat(g["inv_sigma0"][None], K, axis=0)
+    out, _ = orc.mixture_multi_evaluate(1, g["x"], g["weights"], g["mu"], inv, g["log_norm"], pf, idf)
+    np.testing.assert_array_equal(out, g["out"])
+
+
 @pytest.mark.parametrize("tag", ["d3k2", "d30k8", "d2k3"])
 def test_student_mixture_logpdf_bitexact(tag):
     g = load_golden("logpdf_student_" + tag)
