@@ -310,7 +310,7 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *
  * Two things a caller should know about these large-batch forms (verdict r4):
  *   1. The selection depends on the BATCH SIZE (grouped responsibilities / common-shift statistics from
- *      N * ceil(K / 32) >= 524288, the matrix-product Mahalanobis forms from N >= 32768), and each form agrees with the
+ *      N * ceil(K / 32) >= 524288, the matrix-product Mahalanobis forms from N >= 256), and each form agrees with the
  *      exact kernels to ~1e-11 relative, not bit for bit.  Results are bit-reproducible from run to run for the SAME
  *      shard sizes; a rank or device count that moves a shard across a threshold changes low-order bits of the
  *      statistics (well inside the 1e-10 contract).  pmc_configure can pin either form on or off if bit-identity
@@ -410,7 +410,7 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  * of a value per pair and a factor per (sample, group of 16 components) -- d_gscale: pmc_gscale_len(N, K) doubles,
  * tile-major like d_u ((tile * ceil(K / 16) + group) * 64 + lane).  It lets the weighting pass write every d_u value
  * ONCE, relative to its group's maximum, before the row's log-sum-exp is known; the statistics kernel (common-shift
- * form) multiplies its weight operand with the factors.  From compiled D = 32 on (Gaussian proposal, N >= 32768,
+ * form) multiplies its weight operand with the factors.  From compiled D = 32 on (Gaussian proposal, N >= 256,
  * K a multiple of 32 up to ~20 % padding) the pass is then the matrix-product form of the Mahalanobis forms, see
  * "maha_gemm_tolerance" below; everywhere else d_u is complete and the factors are ones.  pmc_estep_from_u_grouped may
  * complete d_u IN PLACE (the factors become ones) when the statistics kernel that applies factors is not the one the
@@ -432,7 +432,7 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  *   maximum over ALL unweighted values (_regularize.pyx:73-77) changes the result: its terms underflow -- is done by the exact
  *   kernel behind --, K >= 24 pads to a multiple of 32 / 64 within 20 %, and
  *   pmc_configure("maha_gemm_tolerance", t) (default 5e-11, in units of a_nk; 0 = never) / ("maha_gemm_min_n", default
- *   32768) allow it.  Compiled dimensions 20 and 24 (D = 17 ... 24, round 5) have it for the passes that emit no u only --
+ *   256: one workgroup of samples; 32768 until round 5) allow it.  Compiled dimensions 20 and 24 (D = 17 ... 24, round 5) have it for the passes that emit no u only --
  *   pmc_mixture_logpdf, pmc_importance_weights -- and only with four full component tiles per pass (K pads to a multiple of
  *   64 within 20 %, K >= 96 at D <= 20, K >= 48 at D = 21 ... 24): below that, and for the emitting passes and pmc_estep, the
  *   vector kernels are the faster ones.  The log q of an emitting and of a non-emitting pass over the same samples

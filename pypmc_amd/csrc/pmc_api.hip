@@ -312,7 +312,7 @@ struct PmcTuning {
     int resp_groups = 1;
     size_t big_scratch_bytes = 256u << 20;
     double mgemm_tol = 5e-11;
-    long long mgemm_min_n = 32768;
+    long long mgemm_min_n = 256;
 };
 PmcTuning g_tuning;
 std::mutex g_tuning_mutex;
@@ -976,7 +976,11 @@ size_t gscale_offset(long long N, int K, const PmcKernelSet *ks)
 // padded one included -- to 0.75 eps_g.  It is not a proof: a caller who needs the exact kernels' bits sets
 // "maha_gemm_tolerance" to 0.
 inline double mgemm_eps(int Dc) { return 3.5e-17 * std::sqrt(0.5 * (Dc + 1.0) * (Dc + 2.0)); }
-#define g_mgemm_min_n (tun().mgemm_min_n)                 // default 32768: samples from which the form is tried at all
+// Samples from which the form is tried at all: 256, one workgroup (32768 until round 5).  Small batches are latency-bound in both
+// forms -- one wavefront walks ALL components, 2.7 us each in the exact engine at D = 40 -- and the matrix kernel's walk is the
+// shorter one at every size, k_theta_build included: D = 40, K = 128: 347 -> 248 us for 256 ... 65536 samples, D = 64, K = 128:
+// 1100 -> 563 us (profiles/r05_mgemm_crossover.txt).
+#define g_mgemm_min_n (tun().mgemm_min_n)
 // component tiles per pass (0: the exact kernels).  K is padded to a multiple of 16 NCT and a padded component costs
 // what a real one does; two tiles per pass cost 4.5 % more per pair than four (profiles/r03_maha_gemm_prototype.txt),
 // and the form as a whole is ~20 % ahead of the exact kernels, so more padding than that is not worth it.

@@ -31,10 +31,14 @@ def timeit(fn, reps=200):
 
 
 be.configure("maha_gemm_min_n", 0)
-for D, K in ((40, 128), (32, 32), (48, 64), (40, 32)):
+shapes = ((40, 128), (32, 32), (48, 64), (40, 32), (64, 64), (64, 128), (24, 64), (24, 128), (20, 128), (36, 64))
+sizes = (256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144)
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    sizes = (256, 512, 1024, 2048, 4096, 16384, 65536)
+for D, K in shapes:
     mu, cov, w = mk(K, D, 5)
     comps = gauss_set(mu, cov, w)[0]
-    for N in (4096, 8192, 16384, 32768, 65536, 131072, 262144):
+    for N in sizes:
         x = be.asdevice(np.random.RandomState(1).normal(size=(N, D)) * 3)
         be.configure("maha_gemm_tolerance", 0.0)
         t_ex = timeit(lambda: be.logpdf(x, comps, want_scalars=True))

@@ -64,7 +64,9 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, n
         be.configure("stats_common_shift_min_fill", 0)
         be.configure("stats_common_shift_min_k", 2)
         be.configure("estep_grouped_responsibilities", 2)
-        be.configure("maha_gemm_min_n", 16384)               # D = 32 ... 48: the matrix-product form of the Mahalanobis forms
+        be.configure("maha_gemm_min_n", 256)                 # the matrix-product form of the Mahalanobis forms (its default)
+    else:
+        be.configure("maha_gemm_min_n", 2 ** 40)             # this sweep holds the exact kernels to bitwise identities
     try:
         return _sweep(seed, rounds, be, dims, verbose, kmax, nmax, fast_paths, rs, worst, orc, ComponentSet, split_stats,
                       centred_moments)
@@ -74,7 +76,7 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, n
             be.configure("stats_common_shift_min_fill", 0.63)
             be.configure("stats_common_shift_min_k", 17)
             be.configure("estep_grouped_responsibilities", 1)
-            be.configure("maha_gemm_min_n", 32768)
+        be.configure("maha_gemm_min_n", 256)
 
 
 def _sweep(seed, rounds, be, dims, verbose, kmax, nmax, fast_paths, rs, worst, orc, ComponentSet, split_stats, centred_moments):

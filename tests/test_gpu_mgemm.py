@@ -23,7 +23,7 @@ def be():
     b = HipBackend()
     yield b
     b.configure("maha_gemm_tolerance", TOL)
-    b.configure("maha_gemm_min_n", 32768)
+    b.configure("maha_gemm_min_n", 256)
 
 
 @pytest.fixture(scope="module")
@@ -34,11 +34,11 @@ def orc():
 
 @pytest.fixture()
 def small(be):
-    """the form from 1000 samples on (its default threshold is 32768: below, its fixed cost does not pay)"""
+    """the form from 1000 samples on, whatever an earlier test left behind (the default is 256 since round 5)"""
     be.configure("maha_gemm_min_n", 1000)
     be.configure("maha_gemm_tolerance", TOL)
     yield
-    be.configure("maha_gemm_min_n", 32768)
+    be.configure("maha_gemm_min_n", 256)
     be.configure("maha_gemm_tolerance", TOL)
 
 
@@ -204,7 +204,7 @@ def test_dead_components_far_away_against_the_reference_golden(be, small, tag, t
         rep = report(be, len(x), K, D)
     finally:
         be.configure("maha_gemm_tolerance", TOL)
-        be.configure("maha_gemm_min_n", 32768)
+        be.configure("maha_gemm_min_n", 256)
     assert rep["workgroups"] == 2 and rep["refused"] == 1, rep
     ref = g["out"]
     assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and not np.isnan(got).any()
@@ -233,7 +233,7 @@ def test_student_t_against_the_reference_golden(be, small, tag):
         rep = report(be, len(x), K, D)
     finally:
         be.configure("maha_gemm_tolerance", TOL)
-        be.configure("maha_gemm_min_n", 32768)
+        be.configure("maha_gemm_min_n", 256)
     assert rep["refused"] == 0 and rep["workgroups"] == 2, rep
     assert_rel(got, g["out"], what="Student-t log q against the reference's golden vector")
     ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
@@ -511,8 +511,10 @@ def test_bitwise_determinism_and_selection(be, small):
     assert lib.pmc_maha_gemm_tiles(N, 128, 20) == 4 and lib.pmc_maha_gemm_tiles(N, 64, 20) == 0 and lib.pmc_maha_gemm_tiles(N, 32, 20) == 0
     assert lib.pmc_maha_gemm_tiles(N, 64, 24) == 4 and lib.pmc_maha_gemm_tiles(N, 32, 24) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 16) == 0
     assert lib.pmc_maha_gemm_tiles(N, 120, 18) == 4 and lib.pmc_maha_gemm_tiles(N, 100, 18) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 28) == 0
-    be.configure("maha_gemm_min_n", 32768)
+    be.configure("maha_gemm_min_n", 32768)                # (the option: round 4's default)
     assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(32768, 128, 40) == 4
+    be.configure("maha_gemm_min_n", 256)
+    assert lib.pmc_maha_gemm_tiles(255, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(256, 128, 40) == 4
 
 
 def test_front_end_iteration_takes_the_form(be):
