@@ -84,3 +84,19 @@ def test_bench_plain_python_has_no_group_unless_forced():
     assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1 and line["dist"]["allreduce_ms"] > 0.0
     line = _bench([sys.executable], ["--force-dist"], dict(os.environ, PMC_NATIVE_COLLECTIVE="1"))
     assert line["dist"]["backend"] == "rccl:libpmc_hip" and line["dist"]["allreduce_ms"] > 0.0
+
+
+def test_bench_single_process_over_virtual_shards():
+    """bench.py --gpus 2 --single-process --devices 0,0: the driver's contract line from ONE process that owns both shards
+    (pmc_init_devices; the same ordinal twice on a one-GPU box)"""
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0", "--steps", "3", "--warmup", "1",
+            "--samples-per-gpu", "300000", "--no-cpu-baseline", "--no-configs", "--no-traffic"]
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["unit"].startswith("samples/s")
+    assert line["config"]["N_total"] == 600000 and line["dtype"] == "f64"
+    assert 0 < line["roofline"]["frac"] < 1 and len(line["step_ms"]["all"]) == 3
