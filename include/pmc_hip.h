@@ -424,6 +424,11 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  *   s_k |P_k|_F, 2 s_k |P_k (mu_k - c)|, s_k (mu_k - c)^T P_k (mu_k - c)  (s_k = |d a / d maha|), eps_g = 3.5e-17 sqrt(number of
  *   monomials) ~ 1e-15 -- a probabilistic constant, see csrc/pmc_api.hip --; a workgroup (256 samples) that holds a sample
  *   beyond the tolerance, or a non-finite coordinate, is done by the exact kernel, launched behind in the same call.
+ *   Student-t (round 5): the slope s = (nu + D) / (2 (nu + maha)) depends on the pair -- (nu + D) / (2 nu) at maha = 0, a
+ *   fraction of it for all but the rare pair with maha << nu --, so the norms price maha itself (s_k = 1), and the pair's
+ *   bound, price x its own slope, is tested in the epilogue where maha is known; a workgroup with a pair beyond the
+ *   tolerance raises its flag there and is redone by the exact kernel like the others.  (Until round 5 the worst slope
+ *   priced every pair and Student-t mixtures of small nu hardly ever took the form.)
  *   Compiled sample dimensions 32, 40, 48 and (round 5) 64, i.e. D = 31 ... 64.  pmc_mixture_logpdf (with or without
  *   d_individual) / pmc_importance_weights[_emit_grouped] / pmc_estep take the form when they are given a workspace, no
  *   weight is negative or non-finite -- and, for the emitting passes and pmc_estep, none is zero: the passes that emit no u

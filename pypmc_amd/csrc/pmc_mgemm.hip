@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
             atomicAdd((int *)guard + 10, 1);               // (the head's count of dead components: k_mgemm's switch)
         }
         // |d a / d maha|
-        const double sk = kind == PMC_KIND_GAUSS ? 0.5 : (kind == PMC_KIND_STUDENT_T ? fabs(c[1] * c[2]) : 0.5 * fabs(c[1]));
+        // (Student-t: 1 -- the norms price the error of maha itself; the slope (nu + D) / (2 (nu + maha)) depends on the pair and
+        //  is applied where maha is known, in k_mgemm's epilogue: see `viol` there)
+        const double sk = kind == PMC_KIND_GAUSS ? 0.5 : (kind == PMC_KIND_STUDENT_T ? 1.0 : 0.5 * fabs(c[1]));
         double th[3] = {sk * sqrt(sums[0]), 2.0 * sk * sqrt(sums[1]), sk * fabs(sums[2])};
         // A weight that is negative or not finite -- or zero where the caller's epilogue has no place for dead components
         // (the emitting passes) -- keeps the mixture with the exact kernels: a NaN norm refuses every sample
@@ -277,6 +279,8 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
     static_assert(NCH % 2 == 0, "the chunk's buffer is a compile-time constant of the step");
     extern __shared__ double lds[];
     double *th = lds;                                      // [2][NTP][CH * 64]
+    double *s_price = th;                                  // [4][64] the guard's price per sample (Student-t epilogue): in the
+                                                           // first theta buffer, read before the barrier in front of stage(0)
     double *dl = lds + 2 * NTP * CH * 64;                  // [4][D][RS]
     double *cts = dl + 4 * D * RS;                         // [2][NTP * 16][4]
     __shared__ int s_flag;
@@ -311,7 +315,13 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
         }
         const double dn = sqrt(dsq);
         const double e = fma(fma(q.guard[0], dn, q.guard[1]), dn, q.guard[2]);
-        if (__any(!(e <= q.eps_tol)) && lane == 0) s_flag = 1;
+        s_price[wave * 64 + lane] = e;
+        // Gauss / VB: the price IS the error bound of a_nk (constant slope).  Student-t: it prices maha; the slope
+        // |da / dmaha| = (nu + D) / (2 (nu + maha)) is at most (nu + D) / (2 nu) but a fraction of that for all but the rare
+        // pair with maha << nu, so the pairs are tested one by one behind the product (epilogue) and only samples that are
+        // hopeless at any conceivable slope (or not finite) are refused here
+        const double lim = kind == PMC_KIND_STUDENT_T ? 4096.0 * q.eps_tol : q.eps_tol;
+        if (__any(!(e <= lim)) && lane == 0) s_flag = 1;
     }
     __syncthreads();
     const int flagged = s_flag;
@@ -321,6 +331,14 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
     }
     if (flagged) return;                                   // the exact kernel behind does this workgroup's samples
 
+    // Student-t: the prices of the four samples this lane holds pairs of (accumulator layout: samples 16 t + s16), and the
+    // verdict of the pair-by-pair test
+    double Et[4] = {0.0, 0.0, 0.0, 0.0};
+    bool viol = false;
+    if (kind == PMC_KIND_STUDENT_T) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Et[t] = s_price[wave * 64 + 16 * t + s16];
+    }
     const unsigned dwa = (unsigned)(uintptr_t)(mg_lvoid_t *)dw;
     const unsigned tha = (unsigned)(uintptr_t)(mg_lvoid_t *)th + 8u * lane + 8u * (unsigned)(half * NCT * CH * 64);
     unsigned base[4];
@@ -379,8 +397,13 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const md2 c01 = *(const md2 *)(ct + (c * 16 + 4 * r) * 4);
+                    // the pair's error bound: price of maha x slope, slope = |c1| / (nu t) with t = 1 + maha / nu just computed
+                    // and nu = -2 c1 - D (c1 = -(nu + D) / 2); tested as  |c1| / nu * price > tolerance * t  (1 % for the
+                    // approximate reciprocal; padding components have c1 = 0)
+                    const double cc = 1.01 * fabs(c01[1]) * __builtin_amdgcn_rcp(-2.0 * c01[1] - (double)a.dreal);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
+                        viol |= cc * Et[t] > q.eps_tol * acc[c][t][r];
                         double tt = log_pos(acc[c][t][r]);               // student_t.pyx:161-164
                         tt *= c01[1];
                         tt += c01[0];
@@ -680,6 +703,11 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
             q.blockflag[blockIdx.x] = 1;
             *q.redo = 1;
         }
+    }
+    // ---- Student-t, a posteriori: a pair whose error bound exceeds the tolerance (every wavefront for the pairs it held)
+    if (kind == PMC_KIND_STUDENT_T && __any(viol) && lane == 0) {
+        q.blockflag[blockIdx.x] = 1;
+        *q.redo = 1;
     }
 
     // ---- per sample (lane l = sample l, half 0): the row's log-sum-exp / normalisation, outputs, the factor's row part
