@@ -18,7 +18,8 @@
 // |P| |x - c|^2, not with maha.  A guard prices it per sample BEFORE any work is done,
 //     E_n = eps_g (Theta_1 |d_n|^2 + Theta_2 |d_n| + Theta_3),
 //     Theta_1 = max_k s_k |P_k|_F,  Theta_2 = max_k 2 s_k |P_k delta_k|,  Theta_3 = max_k s_k delta_k^T P_k delta_k
-// (s_k = |d a_nk / d maha_nk|: 1/2 Gauss, (nu + D) / (2 nu) Student-t, nu_k / 2 VB), and a workgroup with a sample
+// (s_k = |d a_nk / d maha_nk|: 1/2 Gauss, nu_k / 2 VB; Student-t: 1 -- its slope (nu + D) / (2 (nu + maha)) is the pair's and is
+// applied in the epilogue, where a pair beyond the tolerance raises the workgroup's flag a posteriori), and a workgroup with a sample
 // beyond the tolerance (or a non-finite coordinate) writes nothing but its flag: the exact kernel launched behind
 // (k_logpdf / k_resp_groups with PmcArgsA::blockflag) does exactly the flagged workgroups' samples.
 //
