@@ -376,7 +376,11 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
     // per-sample running state of the row (lane l = sample l of the tile): maximum, sum, VB bound term
     double Mrun = -DBL_MAX, srun = 0.0, tbrun = 0.0;
     // components without weight (k_theta_build): the running maximum of THEIR values per sample, for the test at the end
+#ifdef PMC_MG_AB_PLAIN                                     // (A/B, timing only: without the dead-component and Student-t pair tests)
+    constexpr int has_dead = 0;
+#else
     const int has_dead = __builtin_amdgcn_readfirstlane(((const int *)q.guard)[10]);
+#endif
     double Mdrun = -DBL_MAX;
     const ExpConst EC;
     const bool emit = a.u != nullptr;
@@ -404,7 +408,9 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                     const double cc = 1.01 * fabs(c01[1]) * __builtin_amdgcn_rcp(-2.0 * c01[1] - (double)a.dreal);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
+#ifndef PMC_MG_AB_PLAIN
                         viol |= cc * Et[t] > q.eps_tol * acc[c][t][r];
+#endif
                         double tt = log_pos(acc[c][t][r]);               // student_t.pyx:161-164
                         tt *= c01[1];
                         tt += c01[0];
