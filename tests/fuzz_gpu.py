@@ -36,7 +36,12 @@ def stats_err(one, two, K, D, split_stats):
     largest (an off-diagonal entry that nearly cancels carries the rounding of its terms)."""
     a, b = split_stats(one, K, D), split_stats(two, K, D)
     tiny = 1e-300
-    e = [np.max(np.abs(a[0] - b[0]) / (np.abs(b[0]) + 1e-9 * np.abs(b[0]).max() + tiny))]
+    floor0 = np.full(len(b[0]), 1e-9 * np.abs(b[0]).max())
+    # scalar 0 (VB: E[log q(Z)] = sum_n w_n sum_k r log r): every sample's term is formed to a few ulps of 1, so the sum carries an
+    # ABSOLUTE error of (sum of the sample weights) x eps however small it is -- nearly one-hot responsibilities make it tiny
+    # (the oracle check in _sweep uses the same floor)
+    floor0[0] = max(floor0[0], 1e-4 * np.abs(b[1]).sum())
+    e = [np.max(np.abs(a[0] - b[0]) / (np.abs(b[0]) + floor0 + tiny))]
     cnt = np.abs(b[1]) + 1e-12 * np.abs(b[1]).max() + tiny               # (components nobody belongs to: on the total's scale)
     e.append(np.max(np.abs(a[1] - b[1]) / cnt))
     m2 = np.abs(b[3]).reshape(K, -1).max(axis=1)
