@@ -33,24 +33,32 @@ def rel(a, b, floor=1e-300):
 def stats_err(one, two, K, D, split_stats):
     """Two forms of the same statistics vector against each other, every block on ITS scale: counts and scalars
     relative, first moments against sqrt(count * largest second moment), second moments against the component's
-    largest (an off-diagonal entry that nearly cancels carries the rounding of its terms)."""
+    largest (an off-diagonal entry that nearly cancels carries the rounding of its terms).  A value that is not finite in
+    one form only -- or a NaN that is not 0 / 0 of two all-zero vectors -- counts as an infinite error."""
     a, b = split_stats(one, K, D), split_stats(two, K, D)
     tiny = 1e-300
+
+    def worst(diff, scale):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            q = np.abs(diff) / scale
+        q = np.where((diff == 0) & ~np.isfinite(q), 0.0, q)          # 0 / 0: both forms hold an exact zero on a zero scale
+        return float("inf") if np.isnan(q).any() else float(np.max(q))
+
     floor0 = np.full(len(b[0]), 1e-9 * np.abs(b[0]).max())
     # scalar 0 (VB: E[log q(Z)] = sum_n w_n sum_k r log r): every sample's term is formed to a few ulps of 1, so the sum carries an
     # ABSOLUTE error of (sum of the sample weights) x eps however small it is -- nearly one-hot responsibilities make it tiny
     # (the oracle check in _sweep uses the same floor)
     floor0[0] = max(floor0[0], 1e-4 * np.abs(b[1]).sum())
-    e = [np.max(np.abs(a[0] - b[0]) / (np.abs(b[0]) + floor0 + tiny))]
+    e = [worst(a[0] - b[0], np.abs(b[0]) + floor0 + tiny)]
     cnt = np.abs(b[1]) + 1e-12 * np.abs(b[1]).max() + tiny               # (components nobody belongs to: on the total's scale)
-    e.append(np.max(np.abs(a[1] - b[1]) / cnt))
+    e.append(worst(a[1] - b[1], cnt))
     m2 = np.abs(b[3]).reshape(K, -1).max(axis=1)
     m2 = m2 + 1e-12 * m2.max() + tiny
-    e.append(np.max(np.abs(a[2] - b[2]) / np.sqrt(cnt * m2)[:, None]))
-    e.append(np.max(np.abs(a[3] - b[3]) / m2[:, None, None]))
+    e.append(worst(a[2] - b[2], np.sqrt(cnt * m2)[:, None]))
+    e.append(worst(a[3] - b[3], m2[:, None, None]))
     if np.any(b[4]):
-        e.append(np.max(np.abs(a[4] - b[4]) / (np.abs(b[4]) + 1e-12 * np.abs(b[4]).max() + tiny)))
-    return float(max(e))
+        e.append(worst(a[4] - b[4], np.abs(b[4]) + 1e-12 * np.abs(b[4]).max() + tiny))
+    return max(e)
 
 
 def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, nmax=3000, fast_paths=False):
