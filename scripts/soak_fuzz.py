@@ -15,7 +15,7 @@ big = len(sys.argv) > 1 and sys.argv[1] == "big"
 fast = len(sys.argv) > 1 and sys.argv[1] == "fast"
 FAST_DIMS = [8, 12, 16, 17, 20, 21, 24, 30, 31, 32, 36, 40, 41, 48, 49, 56, 64]
 BIG_DIMS = [65, 66, 70, 79, 80, 81, 95, 96, 97, 100, 112, 127, 128, 129, 144, 160, 161, 200, 256, 257, 300]
-for seed in (range(10, 22) if big else (range(100, 140) if fast else range(3, 43))):
+for seed in (range(10, 22) if big else (range(100, 100 + int(sys.argv[2]) if len(sys.argv) > 2 else 140) if fast else range(3, 43))):
     if fast:
         w = fuzz_gpu.sweep(seed=seed, rounds=1, be=be, verbose=False, dims=FAST_DIMS, kmax=140, fast_paths=True)
     elif big:
