@@ -26,6 +26,7 @@ a CPU baseline: the C oracle (a bit-exact restatement of the reference's Cython 
 reference itself cannot run on the GPU box) timed on the host cores on a bounded sample.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -368,6 +369,8 @@ def main_single_process(args):
         e = g.vb_estep(samples, None, mu, W, nu, beta, ln_pi, ln_lambda)
         return r, e
 
+    gc.collect()
+    gc.disable()                                         # (no cyclic collection inside the timed steps; see main())
     for _ in range(args.prewarm + args.warmup):
         step()
     g.kernel_timings()
@@ -378,6 +381,7 @@ def main_single_process(args):
         r, e = step()                                    # (synchronous: the K-sized results are on the host)
         marks.append(time.perf_counter())
     elapsed = marks[-1] - t0
+    gc.enable()
     g.kernel_timing(False)
     timings = g.kernel_timings()
     per_step = np.diff(np.array([t0] + marks)) * 1e3
@@ -544,6 +548,11 @@ def main():
     # k_logpdf take 3.75, 3.57, 3.43, 3.39, 3.33 ms, from the sixth on 3.23-3.30: profiles/r04_bench_n1_kernel_stats.csv),
     # so a short warm-up would put the ramp into the timed steps.  Untimed, the same step, reported as `prewarm_steps`.
     # (a COUNT, not a duration: every rank must enter the step's collective the same number of times)
+    # The interpreter's cyclic collector stays out of the timed steps (a full collection is milliseconds of host time in one
+    # step, whatever the step does): collected and switched off HERE, in front of the pre-warm steps -- a pause right in front
+    # of the timed loop would let the chip's clock drop and put its ramp into the first timed steps
+    gc.collect()
+    gc.disable()
     for _ in range(args.prewarm):
         step()
     be.kernel_timing(True)                           # HIP events on the launch stream around every hot kernel -- on for the
@@ -564,6 +573,7 @@ def main():
     if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     be.kernel_timing(False)
     n_sum = float(N)
     if grouped:                                      # MAX over ranks, on the device the backend reduces on
