@@ -429,8 +429,8 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  *   bound, price x its own slope, is tested in the epilogue where maha is known; a workgroup with a pair beyond the
  *   tolerance raises its flag there and is redone by the exact kernel like the others.  (Until round 5 the worst slope
  *   priced every pair and Student-t mixtures of small nu hardly ever took the form.)
- *   Compiled sample dimensions 32, 40, 48 and (round 5) 64, i.e. D = 31 ... 64.  pmc_mixture_logpdf (with or without
- *   d_individual) / pmc_importance_weights[_emit_grouped] / pmc_estep take the form when they are given a workspace, no
+ *   Compiled sample dimensions 32, 40, 48 and (round 5) 64, i.e. D = 31 ... 64.  pmc_mixture_logpdf[_keep] (with or without
+ *   d_individual) / pmc_importance_weights[_keep, _emit_grouped] / pmc_estep take the form when they are given a workspace, no
  *   weight is negative or non-finite -- and, for the emitting passes and pmc_estep, none is zero: the passes that emit no u
  *   take components WITHOUT weight (pruned components of a PMC run) along: they stay out of the sum, and a workgroup in which
  *   such a component's value lies more than 700 above every weighted live one -- the only case in which the reference's

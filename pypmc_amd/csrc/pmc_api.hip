@@ -1445,7 +1445,8 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         // D >= 32: the forms of all components as one matrix product where its guard allows (pmc_mgemm.hip), the exact
         // kernel behind it for the workgroups it refused
         // (with `individual` too since round 5: the N x K matrix is written from the accumulator layout)
-        const int nct = (d_workspace && !d_maha_tiles && !max_init_zero && ks->padded != 2 && (d_out || !d_individual))
+        // (kept forms too since round 5: written from the accumulator layout, recovered from the value)
+        const int nct = (d_workspace && !max_init_zero && ks->padded != 2 && (d_out || !d_individual))
                             ? mgemm_pick(ks, N, K, false) : 0;
         hipError_t e = hipSuccess;
         if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st, true);
@@ -1498,7 +1499,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         // D >= 32: the proposal's forms as one matrix product (pmc_mgemm.hip).  The target mixture -- a handful of
         // components, which would pad a pass of 32 / 64 -- goes first, through the exact kernel, into log P; the matrix
         // kernel reads it as given target values; the two-mixture exact kernel behind does the workgroups the guard refused.
-        const int nct = (d_workspace && !d_maha_tiles && ks->padded != 2 && (!d_u || (kind == PMC_KIND_GAUSS && d_gscale)))
+        const int nct = (d_workspace && ks->padded != 2 && (!d_u || (kind == PMC_KIND_GAUSS && d_gscale)))
                             ? mgemm_pick(ks, N, K, d_u != nullptr) : 0;
         hipError_t e = hipSuccess;
         if (nct) {

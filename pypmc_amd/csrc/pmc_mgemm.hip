@@ -391,8 +391,12 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
     md4 acc[NCT][4];
 
     // ---- epilogue of one pass: a_nk from the forms, the pass's maximum and sums, u'
+    const bool keep_forms = a.atile != nullptr && tile_live && kind != PMC_KIND_VB;
+    double *mt = keep_forms ? a.atile + (size_t)tile * K * 64 + s16 : nullptr;
     auto epilogue = [&](int pass) {
         const double *ct = cts + (pass & 1) * NTP * 64 + half * NCT * 64 + 4 * g;
+        auto kkeep = [&](int c, int r) { return (pass * NTP + half * NCT + c) * 16 + g + 4 * r; };
+        auto kkeep_ok = [&](int c, int r) { return kkeep(c, r) < K; };
         double Mp[4] = {-DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
         // The product already is the component's value a_nk [+ log w_k] for the Gauss and VB kinds (k_theta_build folds
         // their constants into the image); Student-t: t = 1 + maha / nu came out, a = (c0 + log w) + c1 log t
@@ -405,18 +409,35 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                     // the pair's error bound: price of maha x slope, slope = |c1| / (nu t) with t = 1 + maha / nu just computed
                     // and nu = -2 c1 - D (c1 = -(nu + D) / 2); tested as  |c1| / nu * price > tolerance * t  (1 % for the
                     // approximate reciprocal; padding components have c1 = 0)
-                    const double cc = 1.01 * fabs(c01[1]) * __builtin_amdgcn_rcp(-2.0 * c01[1] - (double)a.dreal);
+                    const double nu_cr = -2.0 * c01[1] - (double)a.dreal;
+                    const double cc = 1.01 * fabs(c01[1]) * __builtin_amdgcn_rcp(nu_cr);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
 #ifndef PMC_MG_AB_PLAIN
                         viol |= cc * Et[t] > q.eps_tol * acc[c][t][r];
 #endif
+                        // kept forms (pmc_*_keep): maha = nu (t - 1), tile-major, column = position in the pack
+                        if (keep_forms && kkeep_ok(c, r)) mt[(size_t)kkeep(c, r) * 64 + 16 * t] = nu_cr * (acc[c][t][r] - 1.0);
                         double tt = log_pos(acc[c][t][r]);               // student_t.pyx:161-164
                         tt *= c01[1];
                         tt += c01[0];
                         acc[c][t][r] = tt;
                     }
                 }
+        }
+        // kept forms of a Gauss mixture (pmc_*_keep -> pmc_estep_from_tiles): the product returned a + log w = (c0 + log w) -
+        // maha / 2, so maha = 2 ((c0 + log w) - value): an absolute error of a few ulps of |c0|, 1e-14, where the exact kernel
+        // stores the form itself -- "to rounding", as include/pmc_hip.h says of the large-batch forms
+        if (keep_forms && kind == PMC_KIND_GAUSS) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kkeep_ok(c, r)) {
+                        const double c0lw = ct[(c * 16 + 4 * r) * 4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) mt[(size_t)kkeep(c, r) * 64 + 16 * t] = 2.0 * (c0lw - acc[c][t][r]);
+                    }
         }
         // `individual` (mixture.pyx:138-151: the N x K component log-densities, the reference's own intermediate): straight
         // from the accumulator layout -- lane (g, s) holds components g + 4 r of tile c for the samples 16 t + s, the four

@@ -285,6 +285,54 @@ def test_student_t_pairs_beyond_the_tolerance_are_found_behind_the_product(be, o
     np.testing.assert_array_equal(np.delete(got2, np.arange(1280, 1536)), np.delete(got1, np.arange(1280, 1536)))
 
 
+@pytest.mark.parametrize("D,K,N,student,dead", [(40, 64, 2100, False, False), (32, 32, 1500, False, True), (48, 64, 1300, True, False),
+                                                (64, 64, 1100, False, True), (24, 64, 1500, False, False), (37, 128, 1200, True, True)])
+def test_kept_forms_through_the_matrix_product(be, orc, small, D, K, N, student, dead):
+    """round 5: the *_keep variants (the weighting pass leaves the Mahalanobis forms behind for pmc_estep_from_tiles: a PMC
+    iteration that cannot emit -- pruned components -- evaluates its proposal once) no longer send the pass to the exact engine:
+    the tiles are written from the accumulator layout, maha recovered from the value (Gauss: 2 ((c0 + log w) - value); Student-t:
+    nu (t - 1)).  The kept forms against the exact kernel's and against the oracle's bilinear forms; the update's statistics
+    from them against the exact path's."""
+    from pypmc_amd.backend import ComponentSet
+    mu, cov, w = mk(K, D, 990 + D + K)
+    if dead:
+        w = np.where(np.arange(K) % 4 == 1, 0.0, w)
+        w /= w.sum()
+    x, _ = draw(mu, cov * (1.3 if student else 1.0), np.full(K, 1.0 / K), N, 33)
+    tmu, tcov, tw = mk(4, D, 84)
+    target = gauss_set(0.5 * tmu, tcov, tw)[0]
+    if student:
+        dofs = np.full(K, 5.0) + 0.5 * (np.arange(K) % 3)
+        cs, inv, ln, pf, idf = student_set(mu, cov, w, dofs)
+    else:
+        cs, inv, ln = gauss_set(mu, cov, w)
+    kept = be.importance_weights(x, cs, target, want_out=True, keep=True)
+    rep = report(be, N, K, D)
+    assert rep["refused"] == 0, rep
+    ex = exact(be, lambda: be.importance_weights(x, cs, target, want_out=True, keep=True))
+    t_form, t_ex = be.tohost(kept["tiles"].data), be.tohost(ex["tiles"].data)
+    ntiles = -(-N // 64)
+    form = t_form[:ntiles * K * 64].reshape(ntiles, K, 64).transpose(0, 2, 1).reshape(-1, K)[:N]
+    exa = t_ex[:ntiles * K * 64].reshape(ntiles, K, 64).transpose(0, 2, 1).reshape(-1, K)[:N]
+    d = x[:, None, :] - mu[None]
+    ref = np.einsum('nki,kij,nkj->nk', d, inv, d)                    # bilinear_sym, _linalg.pyx:10-39
+    assert_rel(exa, ref, rtol=1e-11, what="kept forms of the exact kernel")
+    assert np.abs(form - exa).max() > 0, "the form did not run"
+    assert np.abs(form - ref).max() < 2 * TOL                        # (absolute: the guard's unit; maha = -2 (a - c0 - log w))
+    assert 0 < np.abs(be.tohost(kept["out"]) - be.tohost(ex["out"])).max() < TOL
+    # the update from the kept forms: live components only, as _prepare_pmc_update passes them
+    live = np.flatnonzero(w > 0)
+    sub = ComponentSet(cs.kind, mu[live], inv[live], c0=ln[live], c1=(pf[live] if student else None),
+                       c2=(idf[live] if student else None), c3=(dofs[live] if student else None), weight=w[live], column=live, ld=K)
+    wts = be.tohost(kept["weights"])
+    a_ = be.tohost(be.estep_from_tiles(x, sub, kept["tiles"], max_init_zero=dead, sample_w=wts)["stats"])
+    b_ = be.tohost(be.estep_from_tiles(x, sub, ex["tiles"], max_init_zero=dead, sample_w=be.tohost(ex["weights"]))["stats"])
+    ps = 1 + D + D * (D + 1) // 2
+    Kl = len(live)
+    a2, b2 = a_[8:8 + Kl * ps].reshape(Kl, ps), b_[8:8 + Kl * ps].reshape(Kl, ps)
+    assert (np.abs(a2 - b2) / (np.abs(b2).max(axis=1, keepdims=True) + 1e-300)).max() < 1e-10
+
+
 def vb_set(mu, cov, D, K, seed):
     from pypmc_amd.backend import ComponentSet
     rs = np.random.RandomState(seed)
