@@ -310,7 +310,8 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *
  * Two things a caller should know about these large-batch forms (verdict r4):
  *   1. The selection depends on the BATCH SIZE (grouped responsibilities / common-shift statistics from
- *      N * ceil(K / 32) >= 524288, the matrix-product Mahalanobis forms from N >= 256), and each form agrees with the
+ *      N * ceil(K / 32) >= 524288, the matrix-product Mahalanobis forms from N >= 49152, blocks in pieces below
+ *      "split_max_rounds" rounds of the chip), and each form agrees with the
  *      exact kernels to ~1e-11 relative, not bit for bit.  Results are bit-reproducible from run to run for the SAME
  *      shard sizes; a rank or device count that moves a shard across a threshold changes low-order bits of the
  *      statistics (well inside the 1e-10 contract).  pmc_configure can pin either form on or off if bit-identity
@@ -320,8 +321,29 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *      underflows only against the row maximum of another group contributes 0 instead of 2.2e-308 to N_k / x-bar_k / S_k
  *      (at most N * 2.2e-308 per sum -- far below one ulp of any sum that matters).  pmc_responsibilities -- the
  *      form that writes r -- applies the clamp exactly as the reference does.
+ *
+ * Components of a sample block in pieces (round 6; k_logpdf_split / k_resp_groups_split).  A workgroup of the per-sample
+ * kernels walks ALL components of its 256 samples (mixture.pyx:138-151 is a loop over the components too), so a call costs
+ * K component steps whatever N is until the launch fills the chip -- the reference's own batches of 1e3 ... 1e5 samples
+ * (examples/pmc.py:61-65) live there -- and the last round of a launch that does fill it leaves compute units idle.  Below
+ * "split_max_rounds" rounds of the chip the LAST blocks of the launch (all of them when it is less than one round) are
+ * therefore walked by several workgroups, each taking a run of components with the streaming log-sum-exp and leaving
+ * (maximum, sum) per sample; the one that draws the block's last ticket combines the pairs in piece order --
+ * M = max_p m_p, S = sum_p s_p exp(m_p - M), log S + M, logsumexp2D's own form (_regularize.pyx:72-81) about the row
+ * maximum -- and finishes the block.  Bit-reproducible from run to run (the pieces are a function of N, K, D, the
+ * device's CU count and these options); log q of a block in pieces agrees with the one-workgroup walk to the rounding
+ * of the merge (a few ulps); the grouped responsibilities of pmc_estep keep their bits whatever the pieces.
+ *   "split_components"          (default 1; 0: never)
+ *   "split_min_components"      (default 0 = 4 per piece, 2 from compiled D = 32 on): smallest piece of a small launch
+ *   "split_fill"                (default 2): a launch of less than one round is cut until it has this many workgroups per slot
+ *   "split_max_rounds"          (default 24): launches of more rounds than this are not cut at all
+ *   "split_tail_rounds"         (default 0.25): rounds in front of the last, partial one that are walked in pieces too
+ *   "split_tail_pieces"         (default 4), "split_tail_min_components" (default 0 = 8 per piece, 4 from D = 32 on)
+ * pmc_option_get / pmc_option_default read an option's current / built-in value.
  */
 int pmc_configure(const char *key, double value);
+int pmc_option_get(const char *key, double *value);
+int pmc_option_default(const char *key, double *value);
 int pmc_estep_is_fused(int K, int D, int kind, int mode);
 /*
  * pmc_estep_about is pmc_estep with the moments taken about other points than the components' own means:
@@ -437,7 +459,8 @@ int pmc_estep_from_u(const double *d_x, int64_t N, int D, const double *d_pack, 
  *   maximum over ALL unweighted values (_regularize.pyx:73-77) changes the result: its terms underflow -- is done by the exact
  *   kernel behind --, K >= 24 pads to a multiple of 32 / 64 within 20 %, and
  *   pmc_configure("maha_gemm_tolerance", t) (default 5e-11, in units of a_nk; 0 = never) / ("maha_gemm_min_n", default
- *   256: one workgroup of samples; 32768 until round 5) allow it.  Compiled dimensions 20 and 24 (D = 17 ... 24, round 5) have it for the passes that emit no u only --
+ *   49152 -- below, the exact kernels with the components of a block in pieces are the faster ones, round 6; 256 in round 5)
+ *   allow it.  Compiled dimensions 20 and 24 (D = 17 ... 24, round 5) have it for the passes that emit no u only --
  *   pmc_mixture_logpdf, pmc_importance_weights -- and only with four full component tiles per pass (K pads to a multiple of
  *   64 within 20 %, K >= 96 at D <= 20, K >= 48 at D = 21 ... 24): below that, and for the emitting passes and pmc_estep, the
  *   vector kernels are the faster ones.  The log q of an emitting and of a non-emitting pass over the same samples

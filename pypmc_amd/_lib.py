@@ -89,6 +89,8 @@ SIGNATURES = {
     "pmc_timing_enable": (_int, [_int]),
     "pmc_get_timings": (_int, [_vp, _int, C.POINTER(C.c_int)]),
     "pmc_configure": (_int, [C.c_char_p, C.c_double]),
+    "pmc_option_get": (_int, [C.c_char_p, C.POINTER(C.c_double)]),
+    "pmc_option_default": (_int, [C.c_char_p, C.POINTER(C.c_double)]),
     "pmc_estep_is_fused": (_int, [_int, _int, _int, _int]),
     "pmc_estep": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmc_estep_about": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -186,6 +186,21 @@ class HipBackend(object):
         "stats_common_shift_limit")."""
         _lib.check(self.lib.pmc_configure(key.encode(), float(value)), "pmc_configure")
 
+    def option(self, key):
+        """pmc_option_get: the current value of a library option"""
+        v = C.c_double(0.)
+        _lib.check(self.lib.pmc_option_get(key.encode(), C.byref(v)), "pmc_option_get")
+        return v.value
+
+    def option_default(self, key):
+        """pmc_option_default: the built-in value of a library option"""
+        v = C.c_double(0.)
+        _lib.check(self.lib.pmc_option_default(key.encode(), C.byref(v)), "pmc_option_default")
+        return v.value
+
+    def reset_option(self, key):
+        self.configure(key, self.option_default(key))
+
     def kernel_timing(self, on=True):
         """Switch the library's own kernel timing on / off (pmc_timing_enable: HIP events on the launch
         stream around every hot kernel)."""

@@ -22,6 +22,8 @@
     extern "C" hipError_t pmc_launch_logpdf_d##d##_p##p(int, int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t);   \
     extern "C" hipError_t pmc_launch_resp_groups_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
+    extern "C" hipError_t pmc_launch_logpdf_split_d##d##_p##p(int, int, const PmcArgsA &, unsigned, hipStream_t); \
+    extern "C" hipError_t pmc_launch_resp_groups_split_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t);       \
     extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);                                        \
     extern "C" hipError_t pmc_launch_propose_d##d##_p##p(const PmcArgsP &, unsigned, hipStream_t);         \
@@ -52,7 +54,7 @@ namespace {
      &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p, \
      &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p, &pmc_launch_stats_gemm_d##d##_p##p, \
      &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0, 0, &pmc_launch_mgemm_d##d##_p0, &pmc_launch_theta_d##d##_p0, \
-     &pmc_mgemm_config_d##d##_p0, 0, 0}
+     &pmc_mgemm_config_d##d##_p0, 0, 0, &pmc_launch_logpdf_split_d##d##_p##p, &pmc_launch_resp_groups_split_d##d##_p##p}
 struct DimEntry {
     int dim;
     bool has_padded;
@@ -195,6 +197,8 @@ const PmcKernelSet *big_kernels_for(int D)
     ks->theta = nullptr;
     ks->mgemm_config = nullptr;
     ks->mg_nstepp = ks->mg_nct_max = 0;
+    ks->logpdf_split = nullptr;
+    ks->resp_groups_split = nullptr;
     sets.push_back(ks);
     return ks;
 }
@@ -312,7 +316,18 @@ struct PmcTuning {
     int resp_groups = 1;
     size_t big_scratch_bytes = 256u << 20;
     double mgemm_tol = 5e-11;
-    long long mgemm_min_n = 256;
+    long long mgemm_min_n = 49152;
+    // components of a sample block split over workgroups (k_logpdf_split / k_resp_groups_split; split_plan below)
+    int split = 1;                 // 0: never
+    int split_min_comps = 0;       // components per piece at least (0: by Mahalanobis engine)
+    int split_tail_pieces = 4;     // pieces per block of a launch that fills the chip (its last round only)
+    double split_max_rounds = 24;  // launches of more rounds than this are not split at all
+    double split_fill = 2.0;       // a small launch is split until it has this many workgroups per slot of the chip
+    // rounds of the chip, in front of the last (partial) one, that are walked in pieces too.  Measured (scripts/split_tail_sweep.py,
+    // profiles/r06_split_tail_sweep.txt): 0 -- the remainder alone -- is best or within 1 % of the best at every shape but
+    // config 2's (K = 16: 0.5 by 2.6 %)
+    double split_tail_rounds = 0.25;
+    int split_tail_min_comps = 0;     // components per piece at least in such a launch (0: by Mahalanobis engine)
 };
 PmcTuning g_tuning;
 std::mutex g_tuning_mutex;
@@ -1079,6 +1094,112 @@ int mgemm_report(const PmcKernelSet *ks, const void *d_workspace, long long N, i
     return PMC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// components of a sample block split over workgroups (k_logpdf_split / k_resp_groups_split, pmc_persample.hip): the plan
+// ---------------------------------------------------------------------------------------------
+// A workgroup of the per-sample kernels walks all components of its 256 samples: ~1 us per component at D = 20, 2.7 us at
+// D = 40.  A launch of fewer workgroups than the chip has slots therefore costs K such steps whatever N is (the
+// reference's own batches -- examples/pmc.py:61-65 draws 1e3 samples per step -- live there), and a launch of a few
+// rounds ends with up to one such walk during which the chip runs empty (the 8-way shards of BASELINE's configurations:
+// 5-10 % of their kernels' time).  The plan: the LAST blocks of the launch are walked in pieces (pmc_internal.h,
+// PmcArgsA::split_*) -- all of them when the launch does not fill the chip.
+#define g_split (tun().split)
+#define g_split_min_comps (tun().split_min_comps)
+#define g_split_tail_pieces (tun().split_tail_pieces)
+#define g_split_max_rounds (tun().split_max_rounds)
+#define g_split_fill (tun().split_fill)
+#define g_split_tail_rounds (tun().split_tail_rounds)
+#define g_split_tail_min_comps (tun().split_tail_min_comps)
+int device_cus()
+{
+    static std::mutex m;
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(m);
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount
+                                                                                                        : 256;
+    }
+    return cus[dev];
+}
+// workgroups of the per-sample kernels (4 wavefronts) a compute unit holds at a time: the registers of the compiled dimension
+// decide (pmc_min_waves, pmc_persample.hip; measured occupancies: DESIGN section 6)
+int split_slots_per_cu(int dim) { return dim <= 16 ? 5 : (dim <= 24 ? 4 : (dim <= 32 ? 3 : 2)); }
+// smallest piece in components: a piece pays the load of its samples, its launch slot and the merge once
+int split_min_units(const PmcKernelSet *ks)
+{
+    if (g_split_min_comps > 0) return g_split_min_comps;
+    return ks->dim >= PMC_MFMA_FROM && ks->dim % 4 == 0 ? 2 : 4;
+}
+// ... and in a launch that fills the chip, where the pieces only have to shorten the last round
+int split_tail_min_units(const PmcKernelSet *ks)
+{
+    if (g_split_tail_min_comps > 0) return g_split_tail_min_comps;
+    return ks->dim >= PMC_MFMA_FROM && ks->dim % 4 == 0 ? 4 : 8;
+}
+struct SplitPlan {
+    bool on = false;
+    int b1 = 0, s1 = 0, c1 = 0, s2 = 0, c2 = 0;
+    long long grid = 0;
+};
+// units1 / units2: what the pieces divide -- components of the two mixtures (log-pdf; units2 = 0 without a second one) or
+// groups of 16 components (responsibilities); min_units: smallest piece
+SplitPlan split_plan(const PmcKernelSet *ks, long long nblocks, int units1, int units2, int min_units, int tail_min_units = 0)
+{
+    SplitPlan sp;
+    if (!g_split || nblocks < 1 || min_units < 1) return sp;
+    const long long slots = (long long)device_cus() * split_slots_per_cu(ks->dim);
+    if ((double)nblocks > g_split_max_rounds * (double)slots) return sp;
+    long long bt;
+    int want;
+    if (nblocks <= slots) {                                 // the launch does not fill the chip: every block in pieces
+        bt = nblocks;
+        want = (int)ceil_div((long long)std::ceil(g_split_fill * (double)slots), nblocks);
+    } else {                                                // the last round(s) in pieces
+        bt = nblocks % slots + (long long)(g_split_tail_rounds * (double)slots);
+        if (bt > nblocks) bt = nblocks;
+        if (bt < 1) return sp;
+        want = g_split_tail_pieces;
+        if (tail_min_units > min_units) min_units = tail_min_units;
+    }
+    int s1 = units1 / min_units;
+    if (s1 > want) s1 = want;
+    if (s1 < 1) s1 = 1;
+    const int c1 = (int)ceil_div(units1, s1);
+    s1 = (int)ceil_div(units1, c1);
+    // the second mixture by the same rule on its own: its pieces are then the ones a call on that mixture alone would
+    // make, and pmc_importance_weights' log P stays bitwise pmc_mixture_logpdf(target)'s (pmc_hip.h)
+    int s2 = 0, c2 = 0;
+    if (units2 > 0) {
+        s2 = units2 / min_units;
+        if (s2 > want) s2 = want;
+        if (s2 < 1) s2 = 1;
+        c2 = (int)ceil_div(units2, s2);
+        s2 = (int)ceil_div(units2, c2);
+    }
+    if (s1 + s2 < 2) return sp;
+    const int per_block = (s1 + s2 > units1) ? s1 + s2 : units1;      // (the responsibilities keep three numbers per group)
+    if (bt > PMC_SPLIT_MAX_BLOCKS) bt = PMC_SPLIT_MAX_BLOCKS;
+    if (bt * per_block > PMC_SPLIT_MAX_PIECES) bt = PMC_SPLIT_MAX_PIECES / per_block;
+    if (bt < 1) return sp;
+    sp.on = true;
+    sp.b1 = (int)(nblocks - bt);
+    sp.s1 = s1; sp.c1 = c1; sp.s2 = s2; sp.c2 = c2;
+    sp.grid = (nblocks - bt) + bt * (s1 + s2);
+    return sp;
+}
+// the pieces' region of the workspace: behind everything else (offset: split_offset below)
+size_t split_bytes(long long N, int K)
+{
+    long long blocks = ceil_div(ceil_div(N > 0 ? N : 1, PMC_TILE), PMC_A_WAVES);
+    if (blocks > PMC_SPLIT_MAX_BLOCKS) blocks = PMC_SPLIT_MAX_BLOCKS;
+    const size_t a = (size_t)blocks * 2 * (size_t)K * (2 * PMC_A_WAVES * 64 * sizeof(double));
+    const size_t b = (size_t)PMC_SPLIT_MAX_PIECES * (3 * PMC_A_WAVES * 64 * sizeof(double));
+    return a < b ? a : b;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1143,7 +1264,17 @@ int64_t pmc_stats_stride(int D)
 
 // bytes one call with exactly K components lays out (the regions' offsets are functions of (N, K): stats_geom / gemm_geom
 // halve their chunk counts where ceil(K / 32) steps up, so this is NOT monotone in K)
+static size_t workspace_bytes_nosplit(long long N, int K, const PmcKernelSet *ks);
+// the pieces' region (split_plan) starts behind everything else a call with these N, K places in the workspace
+static size_t split_offset(long long N, int K, const PmcKernelSet *ks)
+{
+    return (workspace_bytes_nosplit(N, K, ks) + 255) & ~(size_t)255;
+}
 static size_t workspace_bytes_exact(long long N, int K, const PmcKernelSet *ks)
+{
+    return split_offset(N, K, ks) + (ks->logpdf_split ? split_bytes(N, K) : 0);
+}
+static size_t workspace_bytes_nosplit(long long N, int K, const PmcKernelSet *ks)
 {
     const size_t stats = mgemm_offset(N, K, ks) + mgemm_bytes(N, K, ks);
     const size_t scal = scalar_partials_bytes(N) +
@@ -1363,6 +1494,7 @@ struct FinScratch {
     hipStream_t stream;
     double *slices;
     unsigned *counter;
+    unsigned *tickets;      // PMC_SPLIT_MAX_BLOCKS ticket counters of the split kernels (zero between launches)
 };
 std::mutex g_fin_mutex;
 std::vector<FinScratch> g_fin_all;
@@ -1376,7 +1508,7 @@ FinScratch *fin_scratch(hipStream_t st)
     std::vector<FinScratch> &all = g_fin_all;
     for (FinScratch &f : all)
         if (f.device == dev && f.stream == st) return &f;
-    const size_t bytes = sizeof(double) * FIN_GROUPS * PMC_NSCALARS + 256;
+    const size_t bytes = sizeof(double) * FIN_GROUPS * PMC_NSCALARS + 256 + sizeof(unsigned) * PMC_SPLIT_MAX_BLOCKS;
     // hipMemset of device memory runs on the NULL stream and may return before it has run: a launch that follows on a
     // NON-BLOCKING stream is not ordered behind it and could take its tickets from a counter that is zeroed under it
     // (found with the handle layer's own stream: the last-ticket block never came and d_scalars was not written).
@@ -1395,7 +1527,8 @@ FinScratch *fin_scratch(hipStream_t st)
         (void)hipFree(p);
         return nullptr;
     }
-    all.push_back(FinScratch{dev, st, (double *)p, (unsigned *)((char *)p + sizeof(double) * FIN_GROUPS * PMC_NSCALARS)});
+    all.push_back(FinScratch{dev, st, (double *)p, (unsigned *)((char *)p + sizeof(double) * FIN_GROUPS * PMC_NSCALARS),
+                             (unsigned *)((char *)p + sizeof(double) * FIN_GROUPS * PMC_NSCALARS + 256)});
     return &all.back();
 }
 
@@ -1415,6 +1548,18 @@ static int finish_scalars(const double *partials, long long nblocks, double *d_s
 static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const double *d_pack, int K,
                                  const double *d_u, double *d_stats, void *d_workspace, void *stream, int kind,
                                  const double *d_gscale = nullptr, const double *d_rpack = nullptr);
+
+// fill the split_* fields of a launch from its plan (the pieces' region of the caller's workspace -- sized for Kws, the
+// larger component count of the call -- and the stream's ticket counters)
+static int split_apply(PmcArgsA &a, const SplitPlan &sp, void *d_workspace, int Kws, const PmcKernelSet *ks, hipStream_t st)
+{
+    FinScratch *f = fin_scratch(st);
+    if (!f) return fail(PMC_EHIP, "finishing scratch allocation failed");
+    a.split_b1 = sp.b1; a.split_s1 = sp.s1; a.split_c1 = sp.c1; a.split_s2 = sp.s2; a.split_c2 = sp.c2;
+    a.split_part = (double *)((char *)d_workspace + split_offset(a.N, Kws, ks));
+    a.split_ticket = f->tickets;
+    return PMC_OK;
+}
 
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,
                             int max_init_zero, double *d_out, double *d_individual, int64_t ld,
@@ -1451,7 +1596,16 @@ int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d
         hipError_t e = hipSuccess;
         if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st, true);
         if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
-        e = ks->padded == 2 ? big_logpdf(ks, kind, kind, a, D, st) : ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
+        // small batches, and the last round of larger ones: the components of a block in pieces (split_plan)
+        const SplitPlan sp = (!nct && d_workspace && ks->logpdf_split) ? split_plan(ks, nblocks, K, 0, split_min_units(ks), split_tail_min_units(ks))
+                                                                       : SplitPlan();
+        if (sp.on) {
+            const int rc = split_apply(a, sp, d_workspace, K, ks, st);
+            if (rc != PMC_OK) return rc;
+            e = ks->logpdf_split(kind, kind, a, (unsigned)sp.grid, st);
+        } else {
+            e = ks->padded == 2 ? big_logpdf(ks, kind, kind, a, D, st) : ks->logpdf(kind, kind, a, (unsigned)nblocks, st);
+        }
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_scalars) return finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
@@ -1515,8 +1669,16 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
             e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st, d_u == nullptr);
             if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
         }
-        e = ks->padded == 2 ? big_logpdf(ks, kind, target_kind, a, D, st)
-                            : ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
+        const SplitPlan sp = (!nct && !d_u && d_workspace && ks->logpdf_split)
+                                 ? split_plan(ks, nblocks, K, K_target, split_min_units(ks), split_tail_min_units(ks)) : SplitPlan();
+        if (sp.on) {
+            const int rc = split_apply(a, sp, d_workspace, K > K_target ? K : K_target, ks, st);
+            if (rc != PMC_OK) return rc;
+            e = ks->logpdf_split(kind, target_kind, a, (unsigned)sp.grid, st);
+        } else {
+            e = ks->padded == 2 ? big_logpdf(ks, kind, target_kind, a, D, st)
+                                : ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
+        }
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_u && kind == PMC_KIND_STUDENT_T) {
@@ -1946,6 +2108,41 @@ static int configure_into(PmcTuning &t, const char *key, double value)
         t.mgemm_min_n = (long long)value;
         return PMC_OK;
     }
+    if (std::strcmp(key, "split_components") == 0) {
+        if (!(value == 0.0 || value == 1.0)) return fail(PMC_EINVAL, "pmc_configure: %s is 0 or 1", key);
+        t.split = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "split_min_components") == 0) {
+        if (!(value >= 0.0 && value <= 1e6)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
+        t.split_min_comps = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "split_tail_pieces") == 0) {
+        if (!(value >= 1.0 && value <= 64.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [1, 64]", key);
+        t.split_tail_pieces = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "split_max_rounds") == 0) {
+        if (!(value >= 0.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
+        t.split_max_rounds = value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "split_tail_rounds") == 0) {
+        if (!(value >= 0.0 && value <= 64.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [0, 64]", key);
+        t.split_tail_rounds = value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "split_tail_min_components") == 0) {
+        if (!(value >= 0.0 && value <= 1e6)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
+        t.split_tail_min_comps = (int)value;
+        return PMC_OK;
+    }
+    if (std::strcmp(key, "split_fill") == 0) {
+        if (!(value > 0.0 && value <= 64.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in (0, 64]", key);
+        t.split_fill = value;
+        return PMC_OK;
+    }
     if (std::strcmp(key, "stats_common_shift_limit") == 0) {
         if (!(value >= 0.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be >= 0", key);
         t.gemm_limit = value;
@@ -1953,6 +2150,31 @@ static int configure_into(PmcTuning &t, const char *key, double value)
     }
     return fail(PMC_EINVAL, "pmc_configure: unknown key '%s'", key);
 }
+
+// the value of an option in `t` (pmc_option_default: in a default-constructed set)
+static int option_get(const PmcTuning &t, const char *key, double *value)
+{
+    if (!key || !value) return fail(PMC_EINVAL, "pmc_option: NULL argument");
+    const struct { const char *name; double v; } all[] = {
+        {"stats_common_shift_min_k", (double)t.gemm_min_k}, {"stats_common_shift_limit", t.gemm_limit},
+        {"stats_common_shift_min_n", (double)t.gemm_min_n}, {"stats_common_shift_min_fill", t.gemm_min_fill},
+        {"estep_grouped_responsibilities", (double)t.resp_groups}, {"big_dim_scratch_bytes", (double)t.big_scratch_bytes},
+        {"maha_gemm_tolerance", t.mgemm_tol}, {"maha_gemm_min_n", (double)t.mgemm_min_n},
+        {"split_components", (double)t.split}, {"split_min_components", (double)t.split_min_comps},
+        {"split_tail_pieces", (double)t.split_tail_pieces}, {"split_max_rounds", t.split_max_rounds},
+        {"split_fill", t.split_fill}, {"split_tail_rounds", t.split_tail_rounds},
+        {"split_tail_min_components", (double)t.split_tail_min_comps}};
+    for (const auto &o : all)
+        if (std::strcmp(key, o.name) == 0) {
+            *value = o.v;
+            return PMC_OK;
+        }
+    return fail(PMC_EINVAL, "pmc_option: unknown key '%s'", key);
+}
+
+int pmc_option_default(const char *key, double *value) { return option_get(PmcTuning(), key, value); }
+
+int pmc_option_get(const char *key, double *value) { return option_get(tun(), key, value); }
 
 int pmc_configure(const char *key, double value)
 {
@@ -2216,7 +2438,16 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
                 hipError_t e = hipSuccess;
                 if (nct) e = mgemm_run(ks, nct, kind, a, a, d_workspace, st, false);
                 if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
-                e = ks->resp_groups(kind, a, (unsigned)nblocks, st);
+                // the last round's groups of 16 components in pieces (split_plan): k_resp_groups' bits either way
+                const SplitPlan sp = (!nct && ks->resp_groups_split) ? split_plan(ks, nblocks, (int)ceil_div(K, PMC_RESP_GROUP), 0, 1)
+                                                                     : SplitPlan();
+                if (sp.on) {
+                    const int rc = split_apply(a, sp, d_workspace, K, ks, st);
+                    if (rc != PMC_OK) return rc;
+                    e = ks->resp_groups_split(kind, a, (unsigned)sp.grid, st);
+                } else {
+                    e = ks->resp_groups(kind, a, (unsigned)nblocks, st);
+                }
                 if (e != hipSuccess) return hipfail(e, "k_resp_groups launch");
             }
             int rc = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);

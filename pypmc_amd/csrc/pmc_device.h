@@ -469,7 +469,61 @@ __device__ __forceinline__ void block_scalars(double (&sc)[NS], double *partials
         partials[(size_t)blockIdx.x * PMC_NSCALARS + threadIdx.x] = v;
     }
 }
+// ... of sample block `blk` (the split kernels: the workgroup that finishes a block is not workgroup `blk` of the launch)
+template <int NS>
+__device__ __forceinline__ void block_scalars_at(double (&sc)[NS], double *partials, long long blk)
+{
+    __shared__ double red[PMC_A_WAVES][PMC_NSCALARS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double v = wave_sum(sc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PMC_NSCALARS) {
+        double v = 0.0;
+        if (threadIdx.x < NS) {
+#pragma unroll
+            for (int w = 0; w < PMC_A_WAVES; ++w) v += red[w][threadIdx.x];
+        }
+        partials[(size_t)blk * PMC_NSCALARS + threadIdx.x] = v;
+    }
+}
 
+// ---------------------------------------------------------------------------------------------
+// Pieces of a sample block (k_logpdf_split / k_resp_groups_split): what a piece leaves for the workgroup that finishes
+// the block crosses compute units -- and XCDs, each with an L2 of its own.  It is written and read with AGENT-scope atomic
+// accesses (relaxed: global_store / global_load with sc1, written through to / read from the level all XCDs share), and the
+// block's ticket -- an agent-scope atomic too -- orders them: every thread waits until its stores are acknowledged
+// (s_waitcnt vmcnt(0)), barrier, one thread draws the ticket, barrier, and only the workgroup that drew the last one goes
+// on to read.  No agent-scope FENCES: a release fence writes the XCD's whole L2 back (buffer_wbl2) and an acquire fence
+// invalidates it (buffer_inv sc1) -- once per piece, that evicted the parameter pack and the samples under every other
+// workgroup of the XCD: the first build of this was 2-3x SLOWER than one workgroup per block from 16384 samples on
+// (profiles/r06_split_fences.txt).  Nothing else a piece writes is read by the finishing workgroup.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void piece_store(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double piece_load(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true in every thread of the workgroup that drew the LAST of the block's `pieces` tickets (the counter wraps to 0 there)
+__device__ __forceinline__ bool piece_ticket_is_last(unsigned *counter, int pieces)
+{
+    __shared__ unsigned ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's piece_stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0)
+        ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)(pieces - 1)) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    asm volatile("" ::: "memory");
+    return true;
+}
 
 // store of a responsibility value: written once, read by the NEXT kernel -- far more than the L2 holds in between
 // (-DPMC_NT_STORES: with the non-temporal hint, an A/B switch)

@@ -137,7 +137,20 @@ struct PmcArgsA {
     // and blockflag[blockIdx.x] != 0 (both NULL: an ordinary launch)
     const int *blockflag;
     const int *redo;
+    // Components of a sample block split over workgroups (k_logpdf_split / k_resp_groups_split, round 6): workgroups
+    // [0, split_b1) of the launch are whole blocks of PMC_A_WAVES tiles as ever; from there on every block is walked by
+    // split_s1 + split_s2 PIECES -- workgroups that take split_c1 components of `pack` each (pieces 0 .. s1 - 1; the
+    // responsibility kernel: split_c1 GROUPS of 16) or split_c2 of `pack2` (pieces s1 .. s1 + s2 - 1) -- and leave their
+    // (maximum, sum [, bound term]) per sample in split_part; the piece that draws the block's last ticket combines them
+    // in piece order and does what follows the component loop.
+    int split_b1, split_s1, split_c1, split_s2, split_c2;
+    double *split_part;       // [block - split_b1][piece][2 or 3][256]
+    unsigned *split_ticket;   // [block - split_b1], zero between launches (the last ticket wraps it)
 };
+// pieces of one launch / blocks that are walked in pieces (the library's ticket counters; the caller's workspace holds
+// PMC_SPLIT_MAX_PIECES x 3 x 256 doubles at most)
+constexpr int PMC_SPLIT_MAX_BLOCKS = 4096;
+constexpr int PMC_SPLIT_MAX_PIECES = 32768;
 
 // the Mahalanobis forms as one matrix product + the fused per-sample epilogues (pmc_mgemm.hip)
 struct PmcArgsQ {
@@ -283,4 +296,7 @@ struct PmcKernelSet {
                         unsigned long long *guard, hipStream_t);
     void (*mgemm_config)(int *nstepp, int *nct_max);
     int mg_nstepp, mg_nct_max;
+    // the per-sample kernels with the components of a block split over workgroups (NULL: the run-time-dimension unit)
+    hipError_t (*logpdf_split)(int kind, int kind2, const PmcArgsA &, unsigned grid, hipStream_t);
+    hipError_t (*resp_groups_split)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
 };

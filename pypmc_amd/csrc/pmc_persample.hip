@@ -524,6 +524,132 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_logpdf_split: k_logpdf with the components of a sample block split over workgroups (round 6).
+//
+// A workgroup of k_logpdf walks ALL K components of its 256 samples, so a call costs K x (1 us at D = 20 ... 2.7 us at
+// D = 40) whatever N is until the launch fills the chip, and the last round of a launch that does fill it leaves
+// compute units idle for up to one such walk.  Here the launch is [whole blocks | pieces]: workgroups [0, split_b1)
+// are k_logpdf's; behind them every remaining block is walked by s1 + s2 PIECES, workgroups that take split_c1
+// components of the mixture (or split_c2 of the target mixture) with the streaming log-sum-exp of k_logpdf and leave
+// their (m, s) -- the row's NaN riding on s -- in split_part.  The piece that draws the block's last ticket combines the
+// pairs IN PIECE ORDER (whichever piece that is: same bits from run to run),
+//     M = max_p m_p,   S = sum_p s_p exp(m_p - M),   lse = log S + M       (_regularize.pyx:72-81 about the row maximum:
+//     a zero-weight component takes part in M through its piece's m_p and adds nothing to S, as in the reference)
+// and does what follows the component loop in k_logpdf: log q, the importance weights and their sums.  Per-pair outputs
+// (`individual`, kept Mahalanobis forms) leave from the pieces themselves.  Small batches (the reference's own:
+// examples/pmc.py:61-65 draws 1e3 samples per step) spread over the chip; large ones end on short pieces.
+// A whole block computes exactly k_logpdf's numbers; a block in pieces agrees with them to the rounding of the merge
+// (a few ulps of lse).  Not for the emitting pass (u needs the row's maximum before the walk ends).
+// ---------------------------------------------------------------------------------------------
+template <int D, bool PADDED, int KIND, int KIND2>
+__global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf_split(const PmcArgsA a)
+{
+    const Dims<D> dm(a.dreal);
+    const int S = a.split_s1 + a.split_s2;
+    long long blk = blockIdx.x;
+    int piece = -1;                                      // workgroup-uniform
+    if ((int)blockIdx.x >= a.split_b1) {
+        const int p = (int)blockIdx.x - a.split_b1;
+        blk = a.split_b1 + p / S;
+        piece = p % S;
+    }
+    const long long n = blk * (PMC_A_WAVES * 64) + threadIdx.x;
+    const bool valid = n < a.N;
+
+    MahaEngine<D, PADDED, pmc_use_mfma<D>()> engine;
+    engine.load(a, blk * PMC_A_WAVES + (threadIdx.x >> 6), threadIdx.x & 63);
+
+    int kb1 = 0, ke1 = a.K, kb2 = 0, ke2 = a.pack2 != nullptr ? a.K2 : 0;
+    if (piece >= 0) {
+        if (piece < a.split_s1) {
+            kb1 = piece * a.split_c1;
+            ke1 = kb1 + a.split_c1 < a.K ? kb1 + a.split_c1 : a.K;
+            ke2 = 0;
+        } else {
+            ke1 = 0;
+            kb2 = (piece - a.split_s1) * a.split_c2;
+            ke2 = kb2 + a.split_c2 < a.K2 ? kb2 + a.split_c2 : a.K2;
+        }
+    }
+    const ExpConst EC;
+    RowPoison rowp;
+    const bool keep_tile = a.atile != nullptr && ((n >> 6) << 6) < a.N;
+    double m = a.max_init_zero ? 0.0 : -DBL_MAX, s = 0.0, mt = -DBL_MAX, st = 0.0;
+    if (ke1 > kb1) {                                     // workgroup-uniform (the engines' barriers)
+        cdouble *pk = (cdouble *)a.pack + (size_t)kb1 * dm.STRIDE;
+        engine.begin(a.pack + (size_t)kb1 * dm.STRIDE, ke1 - kb1);
+        for (int k = kb1; k < ke1; ++k, pk += dm.STRIDE) {
+            const double maha = engine.eval(pk, k - kb1);
+            double expo;
+            const double v = component_value<D, KIND>(maha, pk + dm.DT, expo);
+            if (a.individual != nullptr) {
+                const long long col = ((cint64 *)pk)[dm.DT + 5];
+                if (valid) a.individual[n * a.ld + col] = v;
+            }
+            if (keep_tile) a.atile[((size_t)(n >> 6) * a.K + k) * 64 + (threadIdx.x & 63)] = maha;
+            lse_step(v, pk[dm.DT + 4], m, s, EC);
+            rowp.see(v);
+        }
+    }
+    const double poison1 = rowp.value();
+    if (ke2 > kb2) {
+        cdouble *pk = (cdouble *)a.pack2 + (size_t)kb2 * dm.STRIDE;
+        engine.begin(a.pack2 + (size_t)kb2 * dm.STRIDE, ke2 - kb2);
+        for (int k = kb2; k < ke2; ++k, pk += dm.STRIDE) {
+            const double maha = engine.eval(pk, k - kb2);
+            double expo;
+            const double v = component_value<D, KIND2>(maha, pk + dm.DT, expo);
+            lse_step(v, pk[dm.DT + 4], mt, st, EC);
+            rowp.see(v);
+        }
+    }
+    double lse, lse_target = 0.0;
+    if (piece < 0) {
+        lse = (log_any(s) + m) + poison1;                 // _regularize.pyx:81
+        if (a.pack2 != nullptr) lse_target = (log_any(st) + mt) + rowp.value();
+    } else {
+        const bool second = piece >= a.split_s1;
+        double *part = a.split_part + (size_t)(blk - a.split_b1) * S * (2 * PMC_A_WAVES * 64) + threadIdx.x;
+        piece_store(part + (size_t)piece * (2 * PMC_A_WAVES * 64), second ? mt : m);
+        piece_store(part + (size_t)piece * (2 * PMC_A_WAVES * 64) + PMC_A_WAVES * 64, (second ? st : s) + rowp.value());
+        if (!piece_ticket_is_last(a.split_ticket + (blk - a.split_b1), S)) return;
+        auto merge = [&](int p0, int p1) -> double {
+            double M = -DBL_MAX;
+            for (int p = p0; p < p1; ++p) M = max_f64(piece_load(part + (size_t)p * (2 * PMC_A_WAVES * 64)), M);
+            double sum = 0.0;
+            for (int p = p0; p < p1; ++p) {
+                const double mp = piece_load(part + (size_t)p * (2 * PMC_A_WAVES * 64));
+                const double sp = piece_load(part + (size_t)p * (2 * PMC_A_WAVES * 64) + PMC_A_WAVES * 64);
+                sum = fma(sp, exp_clamped(max_f64(mp - M, -1075.0), EC), sum);
+            }
+            return log_any(sum) + M;
+        };
+        lse = merge(0, a.split_s1);
+        if (a.pack2 != nullptr) {
+            lse_target = merge(a.split_s1, S);
+            if (lse != lse) lse_target = lse;             // (k_logpdf: the first mixture's NaN poisons both)
+        }
+    }
+    if (a.out != nullptr && valid) a.out[n] = lse;
+    if (a.log_target_out != nullptr && valid) a.log_target_out[n] = lse_target;
+
+    if (a.partials == nullptr && a.log_target == nullptr && a.pack2 == nullptr) return;
+
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if ((a.log_target != nullptr || a.pack2 != nullptr) && valid) {
+        const double tmp = (a.pack2 != nullptr ? lse_target : a.log_target[n]) - lse;   // importance_sampling.py:204
+        const double w = exp(tmp);                        // :207
+        a.weights[n] = w;
+        sc[0] = w;
+        sc[1] = (w != 0.0) ? w * tmp : 0.0;               // convergence.py:35-36 (zeros masked)
+        sc[2] = w * w;
+        sc[4] = (isinf(w) && !isinf(tmp)) ? 1.0 : 0.0;    // math.exp OverflowError
+    }
+    if (valid) sc[3] = (a.sample_w != nullptr) ? a.sample_w[n] * lse : lse;   // pmc.pyx:388-391
+    if (a.partials != nullptr) block_scalars_at<5>(sc, a.partials, blk);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_resp: responsibilities in tile-major layout.  Pass 1 = a_nk + streaming log-sum-exp; pass 2 =
 // normalisation.  Between the passes one double per (sample, component) is parked in the output
 // buffer itself (a lane re-reads only what it wrote: no synchronisation).
@@ -889,11 +1015,160 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D, true)) void k_re
     if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_resp_groups_split: k_resp_groups with the GROUPS of a sample block split over workgroups (round 6; the layout of
+// the launch is k_logpdf_split's).  A group of 16 components is complete in itself -- its own maximum M_g, sum s_g and
+// bound term, its u' written once -- so a piece takes split_c1 whole groups, leaves (M_g, s_g, tb_g) per sample and
+// group in split_part, and the piece that draws the block's last ticket runs k_resp_groups' own recurrence over the
+// groups in ascending order and writes the factors: the SAME operations in the SAME order on the same per-group
+// numbers, i.e. the bits of k_resp_groups whatever the number of pieces (tested).
+// ---------------------------------------------------------------------------------------------
+// (the split form's few extra live values must not cost k_resp_groups<20>'s fourth wavefront per SIMD: 125-127 registers there)
+__host__ __device__ constexpr int pmc_min_waves_split(int D) { return (D == 20 || D == 16) ? 4 : pmc_min_waves(D, true); }
+template <int D, bool PADDED, int KIND>
+__global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves_split(D)) void k_resp_groups_split(const PmcArgsA a)
+{
+    static_assert(KIND == PMC_KIND_VB || KIND == PMC_KIND_GAUSS, "k_resp_groups: VB and Gaussian Rao-Blackwell PMC");
+    constexpr int GS = PMC_RESP_GROUP, BT = PMC_A_WAVES * 64;
+    const Dims<D> dm(a.dreal);
+    const int lane = threadIdx.x & 63;
+    long long blk = blockIdx.x;
+    int piece = -1;                                       // workgroup-uniform
+    if ((int)blockIdx.x >= a.split_b1) {
+        const int p = (int)blockIdx.x - a.split_b1;
+        blk = a.split_b1 + p / a.split_s1;
+        piece = p % a.split_s1;
+    }
+    const long long tile = blk * PMC_A_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long n = tile * 64 + lane;
+    const bool valid = n < a.N;
+    const bool tile_live = tile * 64 < a.N;               // wave-uniform
+    const int K = a.K, G = (K + GS - 1) / GS;
+    int g0 = 0, g1 = G;
+    if (piece >= 0) {
+        g0 = piece * a.split_c1;
+        g1 = g0 + a.split_c1 < G ? g0 + a.split_c1 : G;
+    }
+    const int kfirst = g0 * GS, kcount = (g1 * GS < K ? g1 * GS : K) - kfirst;
+    const double *mypack = a.pack + (size_t)kfirst * dm.STRIDE;
+    // (pointers formed where they are used: the kernel sits at the 128-register boundary of four wavefronts per SIMD)
+    auto part_of = [&](int g) { return a.split_part + ((size_t)(blk - a.split_b1) * G + g) * (3 * BT) + threadIdx.x; };
+    auto gs_of = [&](int g) { return a.gscale + ((size_t)tile * G + g) * 64 + lane; };
+
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    using Engine = MahaEngine<D, PADDED, pmc_use_mfma<D>()>;
+    const ExpConst EC;
+    double Mrun = -DBL_MAX, srun = 0.0, tbrun = 0.0;
+    RowPoison rowp;                                       // NaN if a component value of the row is NaN / +inf
+    if (!tile_live) {
+        Engine::idle(mypack, kcount, PMC_RESIDENT_MAX_DIM_RESP);   // keep the workgroup's barriers / staging
+    } else {
+        Engine engine;
+        engine.load(a, tile, lane);
+        double *ut = a.u + (size_t)tile * K * 64 + lane;
+        double *pl = dyn_lds + Engine::LDS_DOUBLES + (size_t)(threadIdx.x >> 6) * GS * 64 + lane;
+        cdouble *pk = (cdouble *)mypack;
+        engine.begin(mypack, kcount, PMC_RESIDENT_MAX_DIM_RESP);
+        for (int g = g0; g < g1; ++g) {
+            const int kb = g * GS, kn = (K - kb < GS) ? K - kb : GS;
+            // pass 1 of the group: a_nk -> LDS, the group's maximum
+            double Mg = -DBL_MAX;
+            for (int j = 0; j < kn; ++j, pk += dm.STRIDE) {
+                const double maha = engine.eval(pk, kb + j - kfirst);
+                double expo = 0.0;
+                const double v = component_value<D, KIND>(maha, pk + dm.DT, expo);
+                Mg = max_f64(v, Mg);
+                rowp.see(v);
+                pl[j * 64] = v;
+            }
+            // pass 2 of the group: u' = exp(a - M_g) [* w_k], written once
+            double sg = 0.0, tbg = 0.0;
+            auto expstep = [&](int j, double v) {
+                const double lr = max_f64(v - Mg, -1075.0);
+                const double e = exp_clamped(lr, EC);
+                if constexpr (KIND == PMC_KIND_VB) {
+                    tbg = fma(e, lr, tbg);
+                    sg += e;
+                    store_u(ut + (size_t)(kb + j) * 64, zero_to_tiny(e));
+                } else {
+                    const double we = ((cdouble *)a.pack + (size_t)(kb + j) * dm.STRIDE)[dm.DT + 4] * e;
+                    sg += we;
+                    store_u(ut + (size_t)(kb + j) * 64, we);
+                }
+            };
+            descend(kn, 0, [&](int j) { return pl[j * 64]; }, expstep);
+            if (piece < 0) {
+                // the group joins the row's running maximum / sum / bound term; its maximum waits in the factor's place
+                const double Mn = max_f64(Mg, Mrun);
+                const double cr = exp_clamped(max_f64(Mrun - Mn, -1075.0), EC), cg = exp_clamped(max_f64(Mg - Mn, -1075.0), EC);
+                if constexpr (KIND == PMC_KIND_VB)
+                    tbrun = cr * fma(max_f64(Mrun - Mn, -1075.0), srun, tbrun) + cg * fma(max_f64(Mg - Mn, -1075.0), sg, tbg);
+                srun = cr * srun + cg * sg;
+                Mrun = Mn;
+                *gs_of(g) = Mg;
+            } else {
+                double *part = part_of(g);
+                piece_store(part, Mg);
+                piece_store(part + BT, sg + rowp.value());
+                piece_store(part + 2 * BT, tbg);
+            }
+        }
+    }
+    double poison = rowp.value();
+    if (piece >= 0) {
+        if (!piece_ticket_is_last(a.split_ticket + (blk - a.split_b1), a.split_s1)) return;
+        if (tile_live) {
+            for (int g = 0; g < G; ++g) {
+                const double *part = part_of(g);
+                const double Mg = piece_load(part), sg = piece_load(part + BT), tbg = piece_load(part + 2 * BT);
+                const double Mn = max_f64(Mg, Mrun);
+                const double cr = exp_clamped(max_f64(Mrun - Mn, -1075.0), EC), cg = exp_clamped(max_f64(Mg - Mn, -1075.0), EC);
+                if constexpr (KIND == PMC_KIND_VB)
+                    tbrun = cr * fma(max_f64(Mrun - Mn, -1075.0), srun, tbrun) + cg * fma(max_f64(Mg - Mn, -1075.0), sg, tbg);
+                srun = cr * srun + cg * sg;
+                Mrun = Mn;
+                *gs_of(g) = Mg;
+            }
+            poison = (srun != srun) ? srun : 0.0;          // (a piece's NaN rides on its sums)
+        }
+    }
+    if (tile_live) {
+        const double sw = (a.sample_w != nullptr && valid) ? a.sample_w[n] : 1.0;
+        const double swv = valid ? sw + poison : 0.0;
+        if constexpr (KIND == PMC_KIND_VB) {
+            // variational.pyx:748-755, :1003-1013
+            const double norm_inv = 1. / srun;
+            sc[0] = swv * fma(tbrun, norm_inv, log_any(norm_inv));
+            const double f = swv * norm_inv;
+            double *gs = gs_of(0);
+            for (int g = 0; g < G; ++g)
+                gs[(size_t)g * 64] = f * exp_clamped(max_f64(gs[(size_t)g * 64] - Mrun, -1075.0), EC);
+        } else {
+            const double lse = log_any(srun) + Mrun;      // _regularize.pyx:81
+            const double f = swv / (exp(lse) + TINY);
+            double *gs = gs_of(0);
+            for (int g = 0; g < G; ++g) gs[(size_t)g * 64] = f * exp(gs[(size_t)g * 64]);
+            sc[3] = swv * lse;
+        }
+    }
+    if (a.partials != nullptr) block_scalars_at<5>(sc, a.partials, blk);
+}
+
 template <int KIND, int KIND2> hipError_t launch_logpdf_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
 {
     constexpr size_t lds = sizeof(double) * MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES;
     hipLaunchKernelGGL((k_logpdf<D_, P_, KIND, KIND2>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
     return hipGetLastError();
+}
+template <int KIND, int KIND2> hipError_t launch_logpdf_split_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
+{
+#if PMC_D == 0
+    return hipErrorNotSupported;
+#else
+    constexpr size_t lds = sizeof(double) * MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES;
+    hipLaunchKernelGGL((k_logpdf_split<D_, P_, KIND, KIND2>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
+    return hipGetLastError();
+#endif
 }
 template <int KIND> hipError_t launch_resp_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
 {
@@ -921,7 +1196,33 @@ template <int KIND> hipError_t launch_resp_groups_k(const PmcArgsA &a, unsigned 
     return hipGetLastError();
 }
 
+template <int KIND> hipError_t launch_resp_groups_split_k(const PmcArgsA &a, unsigned grid, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(double) * (MahaEngine<D_, P_, pmc_use_mfma<D_>()>::LDS_DOUBLES +
+                                             (size_t)PMC_A_WAVES * PMC_RESP_GROUP * 64);
+    if constexpr (lds > 65536) {
+        const hipError_t once = PMC_SET_LDS_PER_DEVICE((&k_resp_groups_split<D_, P_, KIND>), lds);
+        if (once != hipSuccess) return once;
+    }
+    hipLaunchKernelGGL((k_resp_groups_split<D_, P_, KIND>), dim3(grid), dim3(PMC_A_WAVES * 64), lds, st, a);
+    return hipGetLastError();
+}
+
 }  // namespace
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_resp_groups_split_d, PMC_D, PMC_PADDED)(int kind, const PmcArgsA &a,
+                                                                                        unsigned grid, hipStream_t st)
+{
+#if PMC_D == 0
+    return hipErrorNotSupported;
+#else
+    switch (kind) {
+    case PMC_KIND_GAUSS: return launch_resp_groups_split_k<PMC_KIND_GAUSS>(a, grid, st);
+    case PMC_KIND_VB: return launch_resp_groups_split_k<PMC_KIND_VB>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+#endif
+}
 
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_resp_groups_d, PMC_D, PMC_PADDED)(int kind, const PmcArgsA &a,
                                                                                   unsigned grid, hipStream_t st)
@@ -949,6 +1250,20 @@ extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_d, PMC_D, PMC_PADDED)(in
         return launch_logpdf_k<PMC_KIND_GAUSS, PMC_KIND_STUDENT_T>(a, grid, st);
     if (kind == PMC_KIND_STUDENT_T && kind2 == PMC_KIND_GAUSS)
         return launch_logpdf_k<PMC_KIND_STUDENT_T, PMC_KIND_GAUSS>(a, grid, st);
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_split_d, PMC_D, PMC_PADDED)(int kind, int kind2, const PmcArgsA &a,
+                                                                                   unsigned grid, hipStream_t st)
+{
+    if (a.pack2 == nullptr) kind2 = kind;
+    if (kind == PMC_KIND_GAUSS && kind2 == PMC_KIND_GAUSS) return launch_logpdf_split_k<PMC_KIND_GAUSS, PMC_KIND_GAUSS>(a, grid, st);
+    if (kind == PMC_KIND_STUDENT_T && kind2 == PMC_KIND_STUDENT_T)
+        return launch_logpdf_split_k<PMC_KIND_STUDENT_T, PMC_KIND_STUDENT_T>(a, grid, st);
+    if (kind == PMC_KIND_GAUSS && kind2 == PMC_KIND_STUDENT_T)
+        return launch_logpdf_split_k<PMC_KIND_GAUSS, PMC_KIND_STUDENT_T>(a, grid, st);
+    if (kind == PMC_KIND_STUDENT_T && kind2 == PMC_KIND_GAUSS)
+        return launch_logpdf_split_k<PMC_KIND_STUDENT_T, PMC_KIND_GAUSS>(a, grid, st);
     return hipErrorInvalidValue;
 }
 

@@ -77,7 +77,7 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, n
         be.configure("stats_common_shift_min_fill", 0)
         be.configure("stats_common_shift_min_k", 2)
         be.configure("estep_grouped_responsibilities", 2)
-        be.configure("maha_gemm_min_n", 256)                 # the matrix-product form of the Mahalanobis forms (its default)
+        be.configure("maha_gemm_min_n", 256)                 # the matrix-product form of the Mahalanobis forms from one workgroup on
     else:
         be.configure("maha_gemm_min_n", 2 ** 40)             # this sweep holds the exact kernels to bitwise identities
     try:
@@ -89,7 +89,7 @@ def sweep(seed=0, rounds=1, be=None, dims=range(1, 65), verbose=True, kmax=40, n
             be.configure("stats_common_shift_min_fill", 0.63)
             be.configure("stats_common_shift_min_k", 17)
             be.configure("estep_grouped_responsibilities", 1)
-        be.configure("maha_gemm_min_n", 256)
+        be.reset_option("maha_gemm_min_n")
 
 
 def _sweep(seed, rounds, be, dims, verbose, kmax, nmax, fast_paths, rs, worst, orc, ComponentSet, split_stats, centred_moments):

@@ -23,7 +23,7 @@ def be():
     b = HipBackend()
     yield b
     b.configure("maha_gemm_tolerance", TOL)
-    b.configure("maha_gemm_min_n", 256)
+    b.reset_option("maha_gemm_min_n")
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +38,7 @@ def small(be):
     be.configure("maha_gemm_min_n", 1000)
     be.configure("maha_gemm_tolerance", TOL)
     yield
-    be.configure("maha_gemm_min_n", 256)
+    be.reset_option("maha_gemm_min_n")
     be.configure("maha_gemm_tolerance", TOL)
 
 
@@ -204,7 +204,7 @@ def test_dead_components_far_away_against_the_reference_golden(be, small, tag, t
         rep = report(be, len(x), K, D)
     finally:
         be.configure("maha_gemm_tolerance", TOL)
-        be.configure("maha_gemm_min_n", 256)
+        be.reset_option("maha_gemm_min_n")
     assert rep["workgroups"] == 2 and rep["refused"] == 1, rep
     ref = g["out"]
     assert np.array_equal(np.isneginf(got), np.isneginf(ref)) and not np.isnan(got).any()
@@ -233,7 +233,7 @@ def test_student_t_against_the_reference_golden(be, small, tag):
         rep = report(be, len(x), K, D)
     finally:
         be.configure("maha_gemm_tolerance", TOL)
-        be.configure("maha_gemm_min_n", 256)
+        be.reset_option("maha_gemm_min_n")
     assert rep["refused"] == 0 and rep["workgroups"] == 2, rep
     assert_rel(got, g["out"], what="Student-t log q against the reference's golden vector")
     ex = exact(be, lambda: be.tohost(be.logpdf(x, cs, want_scalars=True)["out"]))
@@ -607,8 +607,11 @@ def test_bitwise_determinism_and_selection(be, small):
     assert lib.pmc_maha_gemm_tiles(N, 120, 18) == 4 and lib.pmc_maha_gemm_tiles(N, 100, 18) == 0 and lib.pmc_maha_gemm_tiles(N, 128, 28) == 0
     be.configure("maha_gemm_min_n", 32768)                # (the option: round 4's default)
     assert lib.pmc_maha_gemm_tiles(N, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(32768, 128, 40) == 4
-    be.configure("maha_gemm_min_n", 256)
+    be.configure("maha_gemm_min_n", 256)                  # (round 5's default)
     assert lib.pmc_maha_gemm_tiles(255, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(256, 128, 40) == 4
+    be.reset_option("maha_gemm_min_n")                    # round 6: below 49152 samples the exact kernels in pieces are faster
+    assert be.option("maha_gemm_min_n") == 49152
+    assert lib.pmc_maha_gemm_tiles(49151, 128, 40) == 0 and lib.pmc_maha_gemm_tiles(49152, 128, 40) == 4
 
 
 def test_front_end_iteration_takes_the_form(be):
