@@ -477,6 +477,24 @@ int pmc_importance_weights_emit_grouped(const double *d_x, int64_t N, int D, con
                                         const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                         double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
                                         double *d_u, double *d_gscale, double *d_vsums, void *stream);
+/*
+ * The emitting pass of a mixture that holds PRUNED components (round 6).  gaussian_pmc / student_t_pmc prune by setting a
+ * weight to 0 and leave the component in the mixture (pmc.pyx:109-117); the next weighting pass still evaluates it -- it
+ * takes part in logsumexp2D's row maximum with its unweighted value (_regularize.pyx:73-77) --, the update that follows
+ * forms responsibilities for the live components only (pmc.pyx:98-103, calculate_rho_rb over live_components).  The caller
+ * sorts such a pack LIVE COMPONENTS FIRST: the first K_live components of d_pack have a weight > 0, the K - K_live behind them
+ * have weight 0 (a precondition; a live component behind K_live would silently get no responsibilities).  d_u / d_gscale /
+ * d_vsums then hold K_live columns -- pmc_tile_buffer_len(N, K_live), pmc_gscale_len(N, K_live), 2 K_live -- in the pack's
+ * order, ready for pmc_estep_from_u_grouped with the pack of the K_live live components.  log q and the weights are
+ * pmc_importance_weights' (all K components).  The responsibilities' denominator is this pass's log q, i.e. a log-sum-exp
+ * about the maximum of ALL components' values, where calculate_rho_rb takes it about max(0, live values) (its dead columns are
+ * zeros, pmc.pyx:26-34): the same number unless every live value lies below -700, where the reference's own sum leaves the
+ * normal range.  K_live == K is pmc_importance_weights_emit_grouped.
+ */
+int pmc_importance_weights_emit_live(const double *d_x, int64_t N, int D, const double *d_pack, int K, int K_live, int kind,
+                                     const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                                     double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
+                                     double *d_u, double *d_gscale, double *d_vsums, void *stream);
 int pmc_estep_from_u_grouped(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, double *d_u,
                              double *d_gscale, double *d_stats, void *d_workspace, void *stream);
 int pmc_mixture_logpdf_keep(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind,

@@ -108,6 +108,8 @@ SIGNATURES = {
     "pmc_maha_gemm_report": (_int, [_vp, _i64, _int, _int, _vp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pmc_importance_weights_emit_grouped": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp,
                                                    _vp, _vp, _vp, _vp, _vp]),
+    "pmc_importance_weights_emit_live": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _int, _int, _vp, _vp, _vp, _vp,
+                                                _vp, _vp, _vp, _vp, _vp]),
     "pmc_estep_from_u_grouped": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "pmc_estep_from_tiles": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
                                     _vp]),

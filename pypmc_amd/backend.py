@@ -69,8 +69,12 @@ class Responsibilities(object):
     the update follows (``importance_weights(..., emit=True)``), together with what they belong to.
     ``gaussian_pmc(..., responsibilities=...)`` reduces them to the statistics without any responsibility kernel."""
 
-    def __init__(self, data, N, comps, weights, vsums=None, gscale=None, samples=None):
+    def __init__(self, data, N, comps, weights, vsums=None, gscale=None, samples=None, live=None):
         self.data, self.N, self.K, self.comps, self.weights = data, int(N), int(comps.K), comps, weights
+        # a mixture with pruned components (weight 0): the columns are its LIVE components, in ascending order -- what the
+        # update forms responsibilities for (pmc.pyx:98-103); ``comps`` stays the complete mixture the pass evaluated
+        self.live = list(range(comps.K)) if live is None else [int(k) for k in live]
+        self.K = len(self.live)
         self.vsums = vsums            # Student-t: the 2 K sums of the degree-of-freedom condition (device)
         self.gscale = gscale          # per-(sample, 16 components) factors u is still to be multiplied with (ABI 2)
         # what the values were formed on: the sample tensor's storage, the weight tensor's modification counter
@@ -371,32 +375,47 @@ class HipBackend(object):
     @staticmethod
     def can_emit(comps):
         """does the emitting form of the weighting pass apply to this proposal?  (Gauss / Student-t, a compiled
-        dimension, the complete mixture, every component alive) -- callers that need the update's inputs either way
-        ask BEFORE the pass and keep the Mahalanobis forms instead where it does not"""
+        dimension, the complete mixture, at least one component alive -- pruned components, weight 0, are sorted behind
+        the live ones and get no columns: round 6) -- callers that need the update's inputs either way ask BEFORE the
+        pass and keep the Mahalanobis forms instead where it does not"""
+        w = comps.weight
         return comps.kind in (PMC_KIND_GAUSS, PMC_KIND_STUDENT_T) and comps.D <= 64 and comps.ld == comps.K \
-            and bool((comps.weight != 0).all())
+            and bool((w >= 0).all()) and bool(np.isfinite(w).all()) and bool((w != 0).any())
 
     def _importance_weights_emit(self, x, comps, target, want_out, want_log_target, pack, target_pack):
         x = self.asdevice(x)
         N, D = x.shape
         assert D == comps.D == target.D, "sample / proposal / target dimensions differ"
-        pack = self.pack(comps) if pack is None else pack
+        live = np.nonzero(comps.weight != 0)[0]
+        Kl = len(live)
+        if Kl < comps.K:
+            # pruned components (pmc.pyx:109-117 leaves them in the mixture with weight 0): the pass evaluates them -- they
+            # take part in log q's row maximum -- but the update forms no responsibilities for them (pmc.pyx:98-103).  The
+            # pack is sorted live components first (pmc_importance_weights_emit_live): u gets the Kl live columns only
+            order = np.concatenate([live, np.nonzero(comps.weight == 0)[0]])
+            sorted_set = ComponentSet(comps.kind, comps.mu[order], comps.precision[order], comps.c0[order], comps.c1[order],
+                                      comps.c2[order], comps.c3[order], weight=comps.weight[order], column=comps.column[order],
+                                      ld=comps.ld)
+            pack = self.pack(sorted_set)
+        else:
+            pack = self.pack(comps) if pack is None else pack
         target_pack = self.pack(target) if target_pack is None else target_pack
         out = self.empty(N) if want_out else None
         lt = self.empty(N) if want_log_target else None
         weights = self.empty(N)
         scalars = self.zeros(NSCALARS)
         ws = self._workspace(N, max(comps.K, target.K), D)
-        u = self.empty(max(int(self.lib.pmc_tile_buffer_len(N, comps.K)), 1))      # the caller's: outlives this call
-        gscale = self.empty(max(int(self.lib.pmc_gscale_len(N, comps.K)), 1))
-        vsums = self.zeros(2 * comps.K) if comps.kind == PMC_KIND_STUDENT_T else None
+        u = self.empty(max(int(self.lib.pmc_tile_buffer_len(N, Kl)), 1))           # the caller's: outlives this call
+        gscale = self.empty(max(int(self.lib.pmc_gscale_len(N, Kl)), 1))
+        vsums = self.zeros(2 * Kl) if comps.kind == PMC_KIND_STUDENT_T else None
         _lib.check(self._timed(
-            "pmc_importance_weights_emit[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights_emit_grouped,
-            self._p(x), N, D, self._p(pack), comps.K, comps.kind, self._p(target_pack), target.K, target.kind,
+            "pmc_importance_weights_emit[K=%d+%d]" % (comps.K, target.K), self.lib.pmc_importance_weights_emit_live,
+            self._p(x), N, D, self._p(pack), comps.K, Kl, comps.kind, self._p(target_pack), target.K, target.kind,
             self._p(out), self._p(lt), self._p(weights), self._p(scalars), self._p(ws), self._p(u), self._p(gscale),
-            self._p(vsums), self._stream()), "pmc_importance_weights_emit_grouped")
+            self._p(vsums), self._stream()), "pmc_importance_weights_emit_live")
         return dict(weights=weights, scalars=scalars, out=out, log_target=lt, tiles=None,
-                    responsibilities=Responsibilities(u, N, comps, weights, vsums, gscale, samples=x))
+                    responsibilities=Responsibilities(u, N, comps, weights, vsums, gscale, samples=x,
+                                                      live=live if Kl < comps.K else None))
 
     def estep_from_u(self, x, comps, resp, out=None):
         """pmc_estep_from_u: the statistics of responsibilities a weighting pass left behind (``Responsibilities``).
@@ -404,6 +423,7 @@ class HipBackend(object):
         x = self.asdevice(x)
         N, D = x.shape
         assert resp.N == N and resp.K == comps.K and D == comps.D, "responsibilities belong to another sample set / mixture"
+        # (``comps``: the components the columns stand for -- the LIVE components of the mixture the pass evaluated)
         K = comps.K
         ps = int(self.lib.pmc_stats_stride(D))
         nflat = NSCALARS + K * ps + 2 * K

@@ -1625,7 +1625,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
                                    const double *d_target_pack, int K_target, int target_kind, double *d_out,
                                    double *d_log_target_out, double *d_weights, const double *d_sample_w,
                                    double *d_scalars, void *d_workspace, double *d_maha_tiles, double *d_u,
-                                   double *d_vsums, void *stream, double *d_gscale = nullptr)
+                                   double *d_vsums, void *stream, double *d_gscale = nullptr, int K_live = 0)
 {
     TuneScope options;                                     // one snapshot of the options for the whole call
     if (N < 0 || K < 1 || K_target < 1 || !d_pack || !d_target_pack)
@@ -1648,6 +1648,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         a.partials = d_scalars ? (double *)d_workspace : nullptr;
         if (d_u && kind == PMC_KIND_STUDENT_T) a.vpartials = (double *)((char *)d_workspace + scalar_partials_bytes(N));
         a.gscale = d_u ? d_gscale : nullptr;               // (the exact kernel's u is complete: it writes ones there)
+        a.ku = (d_u && K_live > 0 && K_live < K) ? K_live : 0;   // pruned components at the end of the pack: no columns of u
         Timed t(T_LOGPDF, st, flops_pairs((double)N, K + K_target, D),
                 8.0 * N * (D + 1 + (d_maha_tiles ? K : 0) + (d_u ? K : 0)));
         // D >= 32: the proposal's forms as one matrix product (pmc_mgemm.hip).  The target mixture -- a handful of
@@ -1666,7 +1667,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
             if (e != hipSuccess) return hipfail(e, "k_logpdf (target) launch");
             PmcArgsA ga = a;
             ga.pack2 = nullptr; ga.K2 = 0; ga.log_target_out = nullptr; ga.log_target = lt; ga.vpartials = nullptr;
-            e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st, d_u == nullptr);
+            e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st, d_u == nullptr || a.ku > 0);
             if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
         }
         const SplitPlan sp = (!nct && !d_u && d_workspace && ks->logpdf_split)
@@ -1682,12 +1683,13 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
     }
     if (d_u && kind == PMC_KIND_STUDENT_T) {
+        const int Ku = (K_live > 0 && K_live < K) ? K_live : K;          // columns of u: the components with a weight
         if (N == 0) {
-            hipError_t e0 = hipMemsetAsync(d_vsums, 0, sizeof(double) * 2 * (size_t)K, st);
+            hipError_t e0 = hipMemsetAsync(d_vsums, 0, sizeof(double) * 2 * (size_t)Ku, st);
             if (e0 != hipSuccess) return hipfail(e0, "hipMemsetAsync");
         } else {
-            hipLaunchKernelGGL(k_finish_vsums, dim3((unsigned)(2 * K)), dim3(256), 0, st,
-                               (const double *)((char *)d_workspace + scalar_partials_bytes(N)), ceil_div(N, PMC_TILE), K,
+            hipLaunchKernelGGL(k_finish_vsums, dim3((unsigned)(2 * Ku)), dim3(256), 0, st,
+                               (const double *)((char *)d_workspace + scalar_partials_bytes(N)), ceil_div(N, PMC_TILE), Ku,
                                d_vsums);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hipfail(e, "k_finish_vsums launch");
@@ -1783,6 +1785,22 @@ int pmc_importance_weights_emit_grouped(const double *d_x, int64_t N, int D, con
     return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
                                    d_log_target_out, d_weights, nullptr, d_scalars, d_workspace, nullptr, d_u, d_vsums, stream,
                                    d_gscale);
+}
+
+int pmc_importance_weights_emit_live(const double *d_x, int64_t N, int D, const double *d_pack, int K, int K_live, int kind,
+                                     const double *d_target_pack, int K_target, int target_kind, double *d_out,
+                                     double *d_log_target_out, double *d_weights, double *d_scalars, void *d_workspace,
+                                     double *d_u, double *d_gscale, double *d_vsums, void *stream)
+{
+    if (!d_u || !d_gscale) return fail(PMC_EINVAL, "pmc_importance_weights_emit_live: d_u / d_gscale is NULL");
+    if (K_live < 1 || K_live > K) return fail(PMC_EINVAL, "pmc_importance_weights_emit_live: K_live (%d) not in 1 ... K (%d)", K_live, K);
+    if (kind == PMC_KIND_STUDENT_T && (!d_vsums || !d_workspace))
+        return fail(PMC_EINVAL, "pmc_importance_weights_emit_live: Student-t needs d_vsums and d_workspace");
+    if (D > PMC_MAX_DIM)
+        return fail(PMC_EINVAL, "pmc_importance_weights_emit_live: compiled dimensions only (D <= %d)", PMC_MAX_DIM);
+    return importance_weights_impl(d_x, N, D, d_pack, K, kind, d_target_pack, K_target, target_kind, d_out,
+                                   d_log_target_out, d_weights, nullptr, d_scalars, d_workspace, nullptr, d_u, d_vsums, stream,
+                                   d_gscale, K_live);
 }
 
 int pmc_estep_from_u_grouped(const double *d_x, int64_t N, int D, const double *d_pack, int K, int kind, double *d_u,

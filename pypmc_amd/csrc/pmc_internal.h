@@ -127,6 +127,9 @@ struct PmcArgsA {
     const double *mtile;  // run-time-dimension unit: tile-major maha_nk of `pack` (k_big_maha made them), else NULL
     const double *mtile2; //   ... and of `pack2`
     double *u;            // tile-major responsibilities (output)
+    int ku;               // emitting passes: columns of u -- the first ku components of `pack` (0: all K).  The components behind
+                          // them have no weight (pruned components of a PMC run, sorted to the end by the caller: they take
+                          // part in log q's row maximum and leave no responsibilities)
     double *scratch;      // tile-major scratch (Student-t: maha between the two passes)
     double *vpartials;    // Student-t: ntiles * K * 2 per-wavefront sums of v1, v2
     double *r, *log_rho, *exponent;

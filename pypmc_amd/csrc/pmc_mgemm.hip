@@ -384,8 +384,11 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
     double Mdrun = -DBL_MAX;
     const ExpConst EC;
     const bool emit = a.u != nullptr;
-    const int G = (K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
-    double *ut = emit ? a.u + (size_t)(tile_live ? tile : 0) * K * 64 + s16 : nullptr;
+    // columns of u: the components that get responsibilities -- all K, or the first a.ku when pruned components (no weight:
+    // their values are -DBL_MAX by the time u' is formed, nothing of them is stored) stand at the end of the pack
+    const int KU = (emit && a.ku > 0) ? a.ku : K;
+    const int G = (KU + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
+    double *ut = emit ? a.u + (size_t)(tile_live ? tile : 0) * KU * 64 + s16 : nullptr;
     double *gs = emit ? a.gscale + (size_t)(tile_live ? tile : 0) * G * 64 + lane : nullptr;
 
     md4 acc[NCT][4];
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kk = (pass * NTP + half * NCT + c) * 16 + g + 4 * r;
-                    const bool st = emit && tile_live && kk < K;
+                    const bool st = emit && tile_live && kk < KU;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const double lr = max_f64(acc[c][t][r] - Mp[t], -1075.0);   // variational.pyx:741 / _regularize.pyx:79

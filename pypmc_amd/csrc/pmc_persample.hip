@@ -437,6 +437,9 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
     // responsibilities of the PMC update will stand: the forms are parked there and replaced below
     double *const mkeep = a.u != nullptr ? a.u : a.atile;
     const bool keep_tile = mkeep != nullptr && ((n >> 6) << 6) < a.N;       // (the buffer ends with the last live tile)
+    // columns of the place the forms are kept in: all K, or -- emitting, with pruned components sorted to the end of the
+    // pack (PmcArgsA::ku) -- the components that get responsibilities
+    const int kcols = (a.u != nullptr && a.ku > 0) ? a.ku : a.K;
     double m_first = 0.0;                                // row maximum of the FIRST mixture's component values
     auto mixture = [&](auto kind, const double *gpack, const int K, const bool first) -> double {
         constexpr int KD = decltype(kind)::value;
@@ -451,8 +454,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
                 const long long col = ((cint64 *)pk)[dm.DT + 5];
                 if (valid) a.individual[n * a.ld + col] = v;
             }
-            if (first && keep_tile)                      // wave-uniform: keep maha_nk for the PMC update of these samples
-                mkeep[((size_t)(n >> 6) * K + k) * 64 + (threadIdx.x & 63)] = maha;
+            if (first && keep_tile && k < kcols)         // wave-uniform: keep maha_nk for the PMC update of these samples
+                mkeep[((size_t)(n >> 6) * kcols + k) * 64 + (threadIdx.x & 63)] = maha;
             lse_step(v, pk[dm.DT + 4], m, s, EC);
             rowp.see(v);
         }
@@ -489,16 +492,16 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         const double swv = valid ? wn + rowp.value() : 0.0;
         const double denom = exp(lse) + TINY;                               // pmc.pyx:41
         const double em = exp(m_first), inv_denom = 1. / denom;
-        double *ut = a.u + (size_t)(n >> 6) * a.K * 64 + (threadIdx.x & 63);
-        cdouble *pk = (cdouble *)a.pack + (size_t)(a.K - 1) * dm.STRIDE + dm.DT;
-        double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)(n >> 6) * a.K * 2 : nullptr;
+        double *ut = a.u + (size_t)(n >> 6) * kcols * 64 + (threadIdx.x & 63);
+        cdouble *pk = (cdouble *)a.pack + (size_t)(kcols - 1) * dm.STRIDE + dm.DT;
+        double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)(n >> 6) * kcols * 2 : nullptr;
         if (a.gscale != nullptr) {
             // standing in for k_mgemm, which leaves a factor per (sample, group of 16 components) to the statistics
             // kernel: this u is complete
-            const int G = (a.K + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
+            const int G = (kcols + PMC_RESP_GROUP - 1) / PMC_RESP_GROUP;
             for (int gq = 0; gq < G; ++gq) a.gscale[((size_t)(n >> 6) * G + gq) * 64 + (threadIdx.x & 63)] = 1.0;
         }
-        for (int k = a.K - 1; k >= 0; --k, pk -= dm.STRIDE) {               // last written first: still in L2
+        for (int k = kcols - 1; k >= 0; --k, pk -= dm.STRIDE) {             // last written first: still in L2
             double expo;
             const double maha = ut[(size_t)k * 64];
             const double v = component_value<D, KIND>(maha, pk, expo);

@@ -105,8 +105,9 @@ def _prepare_pmc_update(samples, weights, latent, mincount, density, rb, copy, b
         if responsibilities is not None and rb:
             # the weighting pass left u = w rho of these very samples, weights and parameters: statistics only
             full = component_set(density.components, density.weights)
-            why = 'density' if (len(live_components) < K or responsibilities.N != N_local) else \
-                responsibilities.mismatch(full, weights, samples)
+            # (pruned components have no columns: the pass formed responsibilities for ITS live components, in order)
+            why = 'density' if (list(getattr(responsibilities, 'live', range(K))) != list(live_components) or
+                                responsibilities.N != N_local) else responsibilities.mismatch(full, weights, samples)
             if why == 'samples':
                 # the same density and weights but another storage behind ``samples`` (a copy of the run, a history that
                 # was reallocated by a later append -- advice r4): nothing proves the values are stale, nothing proves

@@ -228,10 +228,10 @@ def _sweep(seed, rounds, be, dims, verbose, kmax, nmax, fast_paths, rs, worst, o
                 if resp is not None:
                     from pypmc_amd.backend import NSCALARS as NSC
                     PS = 1 + D + D * (D + 1) // 2
-                    if D > 24:
-                        assert np.array_equal(be.tohost(em["weights"]), be.tohost(iw["weights"])), ("emit weights", ctx)
-                    else:                                  # (D <= 24: only the pass that emits nothing may be the matrix product)
-                        note("emit weights", rel(be.tohost(em["weights"])[fin], be.tohost(iw["weights"])[fin]), 1e-10, ctx)
+                    # (D <= 24: only the pass that emits nothing may be the matrix product; everywhere: only that pass walks
+                    #  the components of a block in pieces -- the rounding of the merge)
+                    note("emit weights", rel(be.tohost(em["weights"])[fin], be.tohost(iw["weights"])[fin]),
+                         1e-12 if D > 24 else 1e-10, ctx)
                     wts = be.tohost(iw["weights"])
                     viaw = be.tohost(be.estep(x, cs, 1, sample_w=wts, want_r=True)["stats"])
                     got = be.tohost(be.estep_from_u(x, cs, resp)["stats"])

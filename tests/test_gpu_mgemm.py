@@ -43,11 +43,14 @@ def small(be):
 
 
 def exact(be, fn):
+    """the exact kernels, one workgroup per block of samples (what runs behind the form for the workgroups it refused)"""
     be.configure("maha_gemm_tolerance", 0.0)
+    be.configure("split_components", 0)
     try:
         return fn()
     finally:
         be.configure("maha_gemm_tolerance", TOL)
+        be.reset_option("split_components")
 
 
 def report(be, N, K, D):
@@ -620,7 +623,7 @@ def test_front_end_iteration_takes_the_form(be):
     from pypmc_amd.density.mixture import create_gaussian_mixture
     from pypmc_amd.sampler.importance_sampling import ImportanceSampler
     from pypmc_amd.mix_adapt.pmc import gaussian_pmc
-    D, K, N = 40, 64, 40000
+    D, K, N = 40, 64, 60000
     tmu, tcov, tw = mk(4, D, 11)
     tmu /= 3.0
     target = create_gaussian_mixture(tmu, tcov, tw)
@@ -694,7 +697,7 @@ def test_grouped_pair_completed_in_place_bit_for_bit(be, small):
 
 
 @pytest.mark.parametrize("D,K,Kt,N", [(40, 32, 33, 200000), (32, 32, 40, 65536), (48, 64, 65, 70000), (40, 32, 33, 40000)])
-def test_target_with_more_components_than_the_proposal_on_a_fresh_workspace(orc, D, K, Kt, N):
+def test_target_with_more_components_than_the_proposal_on_a_fresh_workspace(orc, small, D, K, Kt, N):
     """advice r4: the workspace is sized for max(K, K_target) while the matrix-product form places its region by the
     PROPOSAL's K, and the layout was not monotone in K (K = 32 needed 62 MB, K = 33 36 MB at D = 40, N = 2e5): 25 MB were
     written past the allocation.  A fresh backend (a workspace of exactly the contract's size) with a poisoned fence

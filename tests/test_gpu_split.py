@@ -213,6 +213,7 @@ def test_last_round_in_pieces(be, orc):
     """a launch that fills the chip: whole blocks first (k_logpdf's numbers, bitwise), the last round in pieces"""
     D, K = 20, 16
     mu, cov, w = mk(K, D, 55)
+    mu *= 0.1                                                 # overlapping components: every piece matters to every sample
     cs, inv, ln = gauss_set(mu, cov, w)
     N = 256 * (2 * 256 * 4 + 300) + 77                        # two rounds of the chip + 300 blocks + a ragged one
     x, _ = draw(mu, cov, w, N, 4)
