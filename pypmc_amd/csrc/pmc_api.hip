@@ -36,6 +36,7 @@
                                                        unsigned long long *, hipStream_t);               \
     extern "C" void pmc_mgemm_config_d##d##_p##p(int *, int *);
 extern "C" hipError_t pmc_launch_resp_tiles(int, const PmcArgsT &, unsigned, hipStream_t);
+extern "C" hipError_t pmc_launch_dof_sums(const PmcArgsV &, unsigned, unsigned, hipStream_t);
 // the run-time-dimension unit (pmc_big.hip, pmc_persample.hip / pmc_propose.hip compiled with PMC_D = 0)
 extern "C" hipError_t pmc_launch_logpdf_d0_p0(int, int, const PmcArgsA &, unsigned, hipStream_t);
 extern "C" hipError_t pmc_launch_resp_d0_p0(int, const PmcArgsA &, unsigned, hipStream_t);
@@ -1018,7 +1019,7 @@ int mgemm_pick(const PmcKernelSet *ks, long long N, int K, bool emit)
     return best;
 }
 struct MgRegion {
-    size_t head, center, ctab, img, flags, lt, bytes;       // byte offsets from the region's start
+    size_t head, center, ctab, img, flags, lt, lse, bytes;  // byte offsets from the region's start
 };
 MgRegion mgemm_region(long long N, int K, const PmcKernelSet *ks)
 {
@@ -1032,7 +1033,8 @@ MgRegion mgemm_region(long long N, int K, const PmcKernelSet *ks)
     r.flags = r.img + up(sizeof(double) * (kpad / 16) * (size_t)ks->mg_nstepp * 64);
     const size_t nblocks = (size_t)ceil_div(ceil_div(N > 0 ? N : 1, PMC_TILE), PMC_A_WAVES);
     r.lt = r.flags + up(sizeof(int) * nblocks);
-    r.bytes = r.lt + up(sizeof(double) * (size_t)(N > 0 ? N : 1));
+    r.lse = r.lt + up(sizeof(double) * (size_t)(N > 0 ? N : 1));     // log q of a Student-t emitting pass (k_dof_sums reads it)
+    r.bytes = r.lse + up(sizeof(double) * (size_t)(N > 0 ? N : 1));
     return r;
 }
 size_t mgemm_bytes(long long N, int K, const PmcKernelSet *ks)
@@ -1047,7 +1049,7 @@ size_t mgemm_offset(long long N, int K, const PmcKernelSet *ks)
 // allow_dead: components with weight 0 are handled by the matrix kernel (the passes that emit no u); otherwise such a
 // mixture is refused as a whole and the exact kernel behind does it
 hipError_t mgemm_run(const PmcKernelSet *ks, int nct, int kind, const PmcArgsA &a, PmcArgsA &fallback, void *d_workspace,
-                     hipStream_t st, bool allow_dead)
+                     hipStream_t st, bool allow_dead, bool emitting = false)
 {
     const MgRegion r = mgemm_region(a.N, a.K, ks);
     char *base = (char *)d_workspace + mgemm_offset(a.N, a.K, ks);
@@ -1065,7 +1067,7 @@ hipError_t mgemm_run(const PmcKernelSet *ks, int nct, int kind, const PmcArgsA &
     q.eps_tol = g_mgemm_tol / mgemm_eps(ks->dim);
     q.blockflag = (int *)(base + r.flags);
     q.redo = (int *)(base + r.head + 32);
-    e = ks->theta(a.pack, a.K, kpad, kind | (allow_dead ? 0x100 : 0), (double *)(base + r.img), (double *)(base + r.ctab), (double *)(base + r.center),
+    e = ks->theta(a.pack, a.K, kpad, kind | (allow_dead ? 0x100 : 0) | (emitting ? 0x200 : 0), (double *)(base + r.img), (double *)(base + r.ctab), (double *)(base + r.center),
                   (unsigned long long *)(base + r.head), st);
     if (e != hipSuccess) return e;
     q.a = a;
@@ -1639,6 +1641,7 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
     if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
     hipStream_t st = (hipStream_t)stream;
     const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    long long dof_sum_count = 0;                           // partial sums of k_dof_sums (0: the exact kernel's, one per tile)
     if (nblocks > 0) {
         PmcArgsA a;
         std::memset(&a, 0, sizeof(a));
@@ -1654,8 +1657,27 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         // D >= 32: the proposal's forms as one matrix product (pmc_mgemm.hip).  The target mixture -- a handful of
         // components, which would pad a pass of 32 / 64 -- goes first, through the exact kernel, into log P; the matrix
         // kernel reads it as given target values; the two-mixture exact kernel behind does the workgroups the guard refused.
-        const int nct = (d_workspace && ks->padded != 2 && (!d_u || (kind == PMC_KIND_GAUSS && d_gscale)))
-                            ? mgemm_pick(ks, N, K, d_u != nullptr) : 0;
+        // (an emitting Student-t pass too since round 6: u' = rho' gamma from the epilogue, the sums of the degree-of-freedom
+        //  condition from k_dof_sums behind it -- they need the row's factor, which a pass does not have yet)
+        int nct = (d_workspace && ks->padded != 2 && (!d_u || d_gscale)) ? mgemm_pick(ks, N, K, d_u != nullptr) : 0;
+        const bool dof_kernel = nct && d_u && kind == PMC_KIND_STUDENT_T;
+        const int Ku = a.ku > 0 ? a.ku : K;
+        long long dof_chunks = 0, dof_tpc = 0;
+        if (dof_kernel) {
+            // its partial sums stand where the exact kernel's per-tile sums would: behind the scalar partials, in front of
+            // everything the matrix kernel keeps in the workspace
+            const long long ntl = ceil_div(N, PMC_TILE), G = ceil_div(Ku, PMC_RESP_GROUP);
+            const size_t spb = scalar_partials_bytes(N), lim = gscale_offset(N, K, ks);
+            const long long room = lim > spb ? (long long)((lim - spb) / (sizeof(double) * 2 * (size_t)Ku)) : 0;
+            dof_chunks = ceil_div(2048, G);
+            if (dof_chunks > ntl) dof_chunks = ntl;
+            if (dof_chunks > room) dof_chunks = room;
+            if (dof_chunks < 1) nct = 0;                   // (no room: the exact kernel)
+            else {
+                dof_tpc = ceil_div(ntl, dof_chunks);
+                dof_chunks = ceil_div(ntl, dof_tpc);
+            }
+        }
         hipError_t e = hipSuccess;
         if (nct) {
             double *lt = d_log_target_out ? d_log_target_out
@@ -1665,9 +1687,15 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
             tg.x = d_x; tg.N = N; tg.dreal = D; tg.pack = d_target_pack; tg.K = K_target; tg.ld = K_target; tg.out = lt;
             e = ks->logpdf(target_kind, target_kind, tg, (unsigned)nblocks, st);
             if (e != hipSuccess) return hipfail(e, "k_logpdf (target) launch");
+            if (dof_kernel) {
+                // log q of every sample is needed behind the pass: into the caller's buffer or the region's own; the exact
+                // kernel behind (the workgroups the guard refused) leaves its sums to k_dof_sums too
+                if (!a.out) a.out = (double *)((char *)d_workspace + mgemm_offset(N, K, ks) + mgemm_region(N, K, ks).lse);
+                a.vpartials = nullptr;
+            }
             PmcArgsA ga = a;
             ga.pack2 = nullptr; ga.K2 = 0; ga.log_target_out = nullptr; ga.log_target = lt; ga.vpartials = nullptr;
-            e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st, d_u == nullptr || a.ku > 0);
+            e = mgemm_run(ks, nct, kind, ga, a, d_workspace, st, d_u == nullptr || a.ku > 0, d_u != nullptr);
             if (e != hipSuccess) return hipfail(e, "k_mgemm launch");
         }
         const SplitPlan sp = (!nct && !d_u && d_workspace && ks->logpdf_split)
@@ -1681,6 +1709,17 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
                                 : ks->logpdf(kind, target_kind, a, (unsigned)nblocks, st);
         }
         if (e != hipSuccess) return hipfail(e, "k_logpdf launch");
+        if (nct && dof_kernel) {
+            PmcArgsV v;
+            std::memset(&v, 0, sizeof(v));
+            v.u = d_u; v.gscale = d_gscale; v.weights = d_weights; v.lse = a.out; v.N = N; v.K = Ku; v.dreal = D;
+            v.pack = d_pack; v.stride = pmc_pack_stride_c(ks->dim); v.coff = ks->dim + pmc_tri(ks->dim);
+            v.ntiles = ceil_div(N, PMC_TILE); v.tiles_per_chunk = (int)dof_tpc;
+            v.vpartials = (double *)((char *)d_workspace + scalar_partials_bytes(N));
+            e = pmc_launch_dof_sums(v, (unsigned)ceil_div(Ku, PMC_RESP_GROUP), (unsigned)dof_chunks, st);
+            if (e != hipSuccess) return hipfail(e, "k_dof_sums launch");
+            dof_sum_count = dof_chunks;
+        }
     }
     if (d_u && kind == PMC_KIND_STUDENT_T) {
         const int Ku = (K_live > 0 && K_live < K) ? K_live : K;          // columns of u: the components with a weight
@@ -1689,8 +1728,8 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
             if (e0 != hipSuccess) return hipfail(e0, "hipMemsetAsync");
         } else {
             hipLaunchKernelGGL(k_finish_vsums, dim3((unsigned)(2 * Ku)), dim3(256), 0, st,
-                               (const double *)((char *)d_workspace + scalar_partials_bytes(N)), ceil_div(N, PMC_TILE), Ku,
-                               d_vsums);
+                               (const double *)((char *)d_workspace + scalar_partials_bytes(N)),
+                               dof_sum_count ? dof_sum_count : ceil_div(N, PMC_TILE), Ku, d_vsums);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hipfail(e, "k_finish_vsums launch");
         }

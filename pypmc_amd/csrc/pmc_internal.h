@@ -188,6 +188,22 @@ struct PmcArgsT {
     double *partials;     // gridDim.x * PMC_NSCALARS (or NULL)
 };
 
+// the two sums of the Student-t degree-of-freedom condition from emitted responsibilities (k_dof_sums, pmc_tiles.hip)
+struct PmcArgsV {
+    const double *u;      // ntiles x K x 64, tile-major: u' of the emitting pass
+    const double *gscale; // ntiles x ceil(K / 16) x 64: the factors u' is still to be multiplied with
+    const double *weights;// N: the importance weights of the pass
+    const double *lse;    // N: log q of the pass
+    long long N;
+    int K;                // columns of u = live components, the first K of the pack
+    int dreal;
+    const double *pack;
+    int stride, coff;     // doubles per component in the pack, offset of c0..c3 | weight | column
+    long long ntiles;
+    int tiles_per_chunk;
+    double *vpartials;    // gridDim.y x K x 2 (output)
+};
+
 // statistics kernel
 struct PmcArgsB {
     const double *x;

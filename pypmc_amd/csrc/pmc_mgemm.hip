@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
     constexpr int STRIDE = pmc_pack_stride_c(D), T = pmc_tri(D), Q = C::Q, ND = C::ND, NQ = C::NQ;
     __shared__ double cen[D], dlt[D], Pd[D], Rm[D][D + 1], Pm[D][D + 1], red[256];
     const int k = blockIdx.x, tid = threadIdx.x;
-    // (bit 8 of `kind`: components without weight are allowed -- see `dead` below)
-    const bool allow_dead = (kind & 0x100) != 0;
+    // (bit 8 of `kind`: components without weight are allowed -- see `dead` below; bit 9: an emitting pass -- Student-t: the
+    //  third constant is log((nu + D) / nu), what the epilogue's u' = rho' gamma needs, instead of log w, what `individual` needs)
+    const bool allow_dead = (kind & 0x100) != 0, emitting = (kind & 0x200) != 0;
     kind &= 0xff;
     // the common centre: midrange of the component means per coordinate (every workgroup for itself, same bits: minimum
     // and maximum do not depend on the order).  Four groups of 64 threads take every fourth component, eight loads in
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256) void k_theta_build(const double *__restrict__ 
         o[0] = c[0] + logw;
         o[1] = c[1];
         o[2] = logw;                                       // the product returns a_nk + log w_k: `individual` takes it off again
+        if (emitting && kind == PMC_KIND_STUDENT_T) o[2] = log(-2.0 * c[1] / c[3]);   // gamma = (nu + D) / (nu t): its constant
         o[3] = (double)((const long long *)c)[5];          // the component's output column (mixture.pyx:138: individual[:, k])
         if (dead) {
             o[3] = -(o[3] + 1.0);
@@ -496,14 +498,30 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
             Mp[t] = max_f64(Mp[t], mg_xor32(Mp[t]));
         }
         double sp[4] = {0.0, 0.0, 0.0, 0.0}, tb[4] = {0.0, 0.0, 0.0, 0.0};
-        auto exps = [&](auto VB_) {
-            constexpr bool VB = decltype(VB_)::value != 0;
+        // MODE 0: Gauss (and every pass that emits nothing), 1: VB, 2: the emitting pass of a Student-t mixture -- u = w rho gamma
+        // (pmc.pyx:602-610) with gamma = (nu + D) / (nu + maha) = ((nu + D) / nu) / t: the value a = c0' + c1 log t is in hand,
+        // so 1 / t = exp(-log t) = exp((c0' - a) / c1) and u' = exp(a - M) exp((c0' - a) / c1 + log((nu + D) / nu)): a second
+        // exponential per pair instead of sixteen more live registers for t or a division per pair (the subtraction loses
+        // |a| eps / |c1| ~ 1e-15 of log t).  The sums of the degree-of-freedom condition need the row's factor and follow in
+        // a kernel of their own (k_dof_sums, pmc_tiles.hip).
+        auto exps = [&](auto MODE_) {
+            constexpr int MODE = decltype(MODE_)::value;
+            constexpr bool VB = MODE == 1;
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kk = (pass * NTP + half * NCT + c) * 16 + g + 4 * r;
                     const bool st = emit && tile_live && kk < KU;
+                    double c0s = 0.0, ic1 = 0.0, lcg = 0.0;
+                    if constexpr (MODE == 2) {
+                        const md2 c01 = *(const md2 *)(ct + (c * 16 + 4 * r) * 4);
+                        c0s = c01[0];
+                        lcg = ct[(c * 16 + 4 * r) * 4 + 2];
+                        ic1 = __builtin_amdgcn_rcp(c01[1]);              // (padding components: c1 = 0, nothing of theirs is stored)
+                        ic1 = fma(fma(-c01[1], ic1, 1.0), ic1, ic1);
+                        ic1 = fma(fma(-c01[1], ic1, 1.0), ic1, ic1);
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const double lr = max_f64(acc[c][t][r] - Mp[t], -1075.0);   // variational.pyx:741 / _regularize.pyx:79
@@ -513,6 +531,9 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                             tb[t] = fma(e, lr, tb[t]);
                             sp[t] += e;
                             uo = zero_to_tiny(e);                        // variational.pyx:751-753
+                        } else if constexpr (MODE == 2) {
+                            sp[t] += e;
+                            uo = e * exp_clamped(max_f64(fma(c0s - acc[c][t][r], ic1, lcg), -1075.0), EC);
                         } else {
                             uo = e;                                      // w_k exp(a - M): _regularize.pyx:79 / pmc.pyx:39
                             sp[t] += e;
@@ -524,6 +545,7 @@ __global__ __launch_bounds__(256 * HW) void k_mgemm(const PmcArgsQ q)
                 }
         };
         if (kind == PMC_KIND_VB) exps(ic<1>{});
+        else if (kind == PMC_KIND_STUDENT_T && emit) exps(ic<2>{});
         else exps(ic<0>{});
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

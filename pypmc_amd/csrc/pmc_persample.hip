@@ -494,7 +494,8 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
         const double em = exp(m_first), inv_denom = 1. / denom;
         double *ut = a.u + (size_t)(n >> 6) * kcols * 64 + (threadIdx.x & 63);
         cdouble *pk = (cdouble *)a.pack + (size_t)(kcols - 1) * dm.STRIDE + dm.DT;
-        double *vp = (KIND == PMC_KIND_STUDENT_T) ? a.vpartials + (size_t)(n >> 6) * kcols * 2 : nullptr;
+        // (behind k_mgemm the sums of the degree-of-freedom condition are k_dof_sums' for every workgroup: a.vpartials is NULL)
+        double *vp = (KIND == PMC_KIND_STUDENT_T && a.vpartials != nullptr) ? a.vpartials + (size_t)(n >> 6) * kcols * 2 : nullptr;
         if (a.gscale != nullptr) {
             // standing in for k_mgemm, which leaves a factor per (sample, group of 16 components) to the statistics
             // kernel: this u is complete
@@ -512,11 +513,13 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
                 const double nu = pk[3];
                 const double gamma = (nu + (double)a.dreal) / (nu + maha);          // pmc.pyx:610
                 ut[(size_t)k * 64] = wr * gamma;
-                const double s1 = wave_sum(wr);                                     // pmc.pyx:612 / :669
-                const double s2 = wave_sum(wr * log_pos(.5 * (maha + nu)));
-                if ((threadIdx.x & 63) == 0) {
-                    vp[2 * k] = s1;
-                    vp[2 * k + 1] = s2;
+                if (vp != nullptr) {                                                // wave-uniform
+                    const double s1 = wave_sum(wr);                                 // pmc.pyx:612 / :669
+                    const double s2 = wave_sum(wr * log_pos(.5 * (maha + nu)));
+                    if ((threadIdx.x & 63) == 0) {
+                        vp[2 * k] = s1;
+                        vp[2 * k + 1] = s2;
+                    }
                 }
             } else {
                 ut[(size_t)k * 64] = wr;

@@ -35,6 +35,7 @@
 PMC_DIM_LIST(STUB_X, STUB_XP)
 
 extern "C" hipError_t pmc_launch_resp_tiles(int, const PmcArgsT &, unsigned, hipStream_t) { return hipSuccess; }
+extern "C" hipError_t pmc_launch_dof_sums(const PmcArgsV &, unsigned, unsigned, hipStream_t) { return hipSuccess; }
 extern "C" hipError_t pmc_launch_logpdf_d0_p0(int, int, const PmcArgsA &, unsigned, hipStream_t) { return hipSuccess; }
 extern "C" hipError_t pmc_launch_resp_d0_p0(int, const PmcArgsA &, unsigned, hipStream_t) { return hipSuccess; }
 extern "C" hipError_t pmc_launch_big_maha(const PmcArgsM &, hipStream_t) { return hipSuccess; }

@@ -108,6 +108,64 @@ def test_student_logpdf_vs_oracle(be, orc, small, D, K, N, dof):
     assert 0 < np.abs(got - ex).max() < TOL
 
 
+@pytest.mark.parametrize("D,K,N,nu,pruned", [(40, 64, 2600, 8., False), (40, 128, 1500, 3., False), (32, 32, 2500, 1.5, False),
+                                             (64, 64, 1200, 8., False), (40, 64, 2600, 5., True), (48, 64, 1300, 30., True)])
+def test_student_t_emitting_pass(be, orc, small, D, K, N, nu, pruned):
+    """round 6: the emitting pass of a Student-t mixture through the matrix-product form (pmc.pyx:602-610: u = w rho gamma,
+    gamma = (nu + D) / (nu + maha) from the t the epilogue holds) and the two sums of the degree-of-freedom condition
+    (pmc.pyx:612, :654-691) from k_dof_sums behind it, which recovers log t from u itself -- against the oracle's rho and the
+    exact kernel's sums; with a workgroup the guard refuses; with pruned components"""
+    mu, cov, w = mk(K, D, 700 + D + K)
+    x, _ = draw(mu, cov * 1.3, w, N, 23)
+    dofs = np.full(K, nu) + 0.5 * (np.arange(K) % 4)
+    wl = w.copy()
+    if pruned:
+        wl[[1, 17, K - 1]] = 0.
+        wl /= wl.sum()
+    live = [k for k in range(K) if wl[k] != 0]
+    prop, inv, ln, pf, idf = student_set(mu, cov, wl, dofs)
+    tmu, tcov, tw = mk(4, D, 78)
+    target, tinv, tln = gauss_set(0.5 * tmu, tcov, tw)
+    logq, _ = orc.mixture_multi_evaluate(1, x, wl, mu, inv, ln, pf, idf)
+    logp, _ = orc.mixture_multi_evaluate(0, x, tw, 0.5 * tmu, tinv, tln)
+    em = be.importance_weights(x, prop, target, want_out=True, emit=True)
+    rep = report(be, N, K, D)
+    assert rep["refused"] == 0, rep
+    assert_rel(be.tohost(em["out"]), logq, what="log q")
+    wts = be.tohost(em["weights"])
+    assert_rel(wts, orc.is_weights(logp, logq), what="importance weights")
+    resp = em["responsibilities"]
+    assert resp.gscale is not None and resp.vsums is not None and resp.K == len(live)
+    rho = orc.rho_rb(1, x, wl, mu, inv, ln, pf, idf, live)[:, live]
+    dl = x[:, None, :] - mu[None, live]
+    maha = np.einsum('nki,kij,nkj->nk', dl, inv[live], dl)
+    wr = wts[:, None] * rho
+    ref = wr * (dofs[live] + D) / (dofs[live] + maha)
+    u = resp.host_matrix(be)
+    normal = ref > 1e-280
+    assert_rel(u[normal], ref[normal], what="u = w rho gamma")
+    vs = be.tohost(resp.vsums).reshape(len(live), 2)
+    np.testing.assert_allclose(vs[:, 0], wr.sum(axis=0), rtol=1e-10)
+    np.testing.assert_allclose(vs[:, 1], (wr * np.log(.5 * (maha + dofs[live]))).sum(axis=0), rtol=1e-10, atol=1e-12 * np.abs(wr).sum())
+    # the exact kernel's numbers (its own sums per tile)
+    ex = exact(be, lambda: be.importance_weights(x, prop, target, emit=True)["responsibilities"])
+    np.testing.assert_allclose(vs, be.tohost(ex.vsums).reshape(len(live), 2), rtol=1e-10, atol=1e-13 * np.abs(wr).sum())
+    np.testing.assert_allclose(u, ex.host_matrix(be), rtol=1e-10, atol=1e-280)
+    # a far outlier: its workgroup is refused and done by the exact kernel; the sums still cover every sample
+    xo = x.copy()
+    xo[300] = mu[0] + 1e5
+    em2 = be.importance_weights(xo, prop, target, emit=True)
+    rep2 = report(be, N, K, D)
+    assert rep2["refused"] >= 1, rep2
+    ex2 = exact(be, lambda: be.importance_weights(xo, prop, target, emit=True)["responsibilities"])
+    v2, e2 = be.tohost(em2["responsibilities"].vsums), be.tohost(ex2.vsums)
+    np.testing.assert_allclose(v2, e2, rtol=1e-10, atol=1e-13 * np.abs(e2).max())
+    np.testing.assert_allclose(em2["responsibilities"].host_matrix(be), ex2.host_matrix(be), rtol=1e-10, atol=1e-280)
+    # run to run
+    em3 = be.importance_weights(xo, prop, target, emit=True)
+    np.testing.assert_array_equal(be.tohost(em3["responsibilities"].vsums), v2)
+
+
 @pytest.mark.parametrize("D,K,N", [(32, 32, 2500), (40, 128, 1500), (40, 64, 1100), (48, 64, 1300), (35, 32, 1200), (64, 64, 1200),
                                    (56, 32, 1100)])
 def test_importance_weights_and_emitted_responsibilities(be, orc, small, D, K, N):
