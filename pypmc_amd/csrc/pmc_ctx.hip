@@ -139,6 +139,7 @@ struct pmc_ctx {
     std::vector<Part *> parts;    // parts[0] holds the exchange with other ranks and the sum over this context's devices
     pmc_comm *comm = nullptr;
     pmc_p2p *p2p = nullptr;       // the one-shot exchange (pmc_ctx_p2p_open / _connect) instead of the RCCL communicator
+    pmc_p2p *p2p_failed = nullptr;// an exchange whose connect failed: out of use, its mailbox alive until pmc_shutdown
     std::recursive_mutex mu;      // calls of one context are serialised here: any thread may call, one at a time
     void *tuning = nullptr;       // this context's copy of the library options (pmc_ctx_configure)
     DevBuf slots;                 // on parts[0]'s device: one statistics vector per part, summed in part order
@@ -664,9 +665,14 @@ int pmc_ctx_p2p_connect(pmc_ctx *ctx, const void *h_handles)
     CtxCall call_(ctx);
     if (!ctx->p2p) return failf(PMC_EINVAL, "pmc_ctx_p2p_connect: call pmc_ctx_p2p_open first");
     const int rc = pmc_p2p_connect(ctx->p2p, h_handles);
-    if (rc < 0) {                                                   // (mapping, peer access or the self-test failed: no exchange
-        (void)pmc_p2p_destroy(ctx->p2p);                            //  is left half-open; the caller joins an RCCL communicator
-        ctx->p2p = nullptr;                                         //  instead, on ALL ranks)
+    if (rc < 0) {
+        // Mapping, peer access or the self-test failed: the exchange is taken out of use -- the caller joins an RCCL communicator
+        // instead, on ALL ranks -- but its mailbox is NOT freed here (advice r5): a peer that mapped it may still be inside its
+        // own self-test round, whose kernel writes into every peer's mailbox, and this layer has no barrier across ranks.  It
+        // stays allocated until pmc_shutdown (or a second failure: then the older one has had a whole connect to drain).
+        if (ctx->p2p_failed) (void)pmc_p2p_destroy(ctx->p2p_failed);
+        ctx->p2p_failed = ctx->p2p;
+        ctx->p2p = nullptr;
     }
     return rc;
 }
@@ -679,6 +685,7 @@ int pmc_shutdown(pmc_ctx *ctx)
     ctx->mu.lock();                                                 // (a call still running in another thread finishes first)
     if (ctx->comm) rc = pmc_comm_destroy(ctx->comm);
     if (ctx->p2p) (void)pmc_p2p_destroy(ctx->p2p);
+    if (ctx->p2p_failed) (void)pmc_p2p_destroy(ctx->p2p_failed);
     ctx->slots.release();
     ctx->mu.unlock();
     destroy_ctx(ctx);

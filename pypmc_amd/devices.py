@@ -54,6 +54,17 @@ class ShardedSamples(object):
         self.has_weights = False
         self.has_sample_weights = False
         self._host_w = None
+        group._live_samples.add(self)                      # (weakly: DeviceGroup.close() frees what is still alive)
+
+    # A sample set on the devices is a handle to buffers the library owns: copies of a front-end object that holds one
+    # (copy.deepcopy of a sampler after a run, of a GaussianInference) SHARE it -- it is never written after its creation
+    # apart from the weights of the latest weighting pass -- and the one Python object frees it once.  It does not pickle:
+    # the front-ends drop it from their pickled state and upload again on first use (advice r5).
+    def __deepcopy__(self, memo):
+        return self
+
+    def __reduce__(self):
+        raise TypeError("ShardedSamples live on the devices of a DeviceGroup and cannot be pickled; pickle .host() instead")
 
     def __len__(self):
         return self.N
@@ -127,6 +138,13 @@ class ShardedMixture(object):
         self._h = h
         self._key = self._fingerprint(arrays)
 
+    # (a device-side copy of a host density, kept by its group: shared by copies, rebuilt from the density -- never pickled)
+    def __deepcopy__(self, memo):
+        return self
+
+    def __reduce__(self):
+        raise TypeError("a ShardedMixture is rebuilt from its host density (DeviceGroup.mixture) and cannot be pickled")
+
     @staticmethod
     def _arrays(density):
         from .density.gauss import Gauss
@@ -188,16 +206,26 @@ class DeviceGroup(object):
         self.lib.pmc_ctx_devices(h, out, n)
         self.devices = list(out)
         self._mixtures = {}
+        import weakref
+        self._live_samples = weakref.WeakSet()             # ShardedSamples of this group that have not been freed
 
-    # a group is a process-wide handle: densities / samplers that hold one are deep-copied by the front-end
+    # a group is a process-wide handle: densities / samplers that hold one are deep-copied by the front-end; a pickled
+    # one becomes a NEW group over the same device ordinals where it is loaded
     def __deepcopy__(self, memo):
         return self
+
+    def __reduce__(self):
+        return (DeviceGroup, (list(self.devices),))
 
     def close(self):
         if self._ctx is not None:
             for m in list(self._mixtures.values()):
                 m.free()
             self._mixtures = {}
+            # sample sets that are still alive (GaussianInference._samples, sampler.last_run): pmc_shutdown does not own
+            # their device buffers, and once the context is gone ShardedSamples.free() can no longer return them (advice r5)
+            for smp in list(self._live_samples):
+                smp.free()
             ctx, self._ctx = self._ctx, None
             self.lib.pmc_shutdown(ctx)
 
@@ -343,6 +371,8 @@ class DeviceGroup(object):
         D = samples.dim
         mean, cov = np.empty(D), (np.empty((D, D)) if want_cov else None)
         on_dev = isinstance(weights, ShardedWeights)
+        if on_dev and weights.samples is not samples:
+            raise ValueError("these device weights belong to another sample set")
         hw = None if (weights is None or on_dev) else _c64(weights).reshape(samples.N)
         _lib.check(self.lib.pmc_weighted_moments(self._ctx, samples._h, _dp(hw), int(on_dev), _dp(mean), _dp(cov)),
                    "pmc_weighted_moments")

@@ -77,6 +77,33 @@ class GaussianInference(object):
             self._parse_initial_guess(initial_guess)
         self._initialize_intermediate()
 
+        self._attach_device_data()
+        self.E_step()
+
+    # ------------------------------------------------------------------------- device state
+    # What lives on the device(s) -- the resident data, the library's sample handles -- is not part of a copy or a pickle
+    # of this object (advice r5: raw ctypes handles neither pickle nor may two objects free one): __getstate__ drops it,
+    # and the first E-step (or N x K attribute) of the copy uploads / wraps again.  The host state -- the parameters, the
+    # latest statistics -- is complete without it.
+    _DEVICE_ATTRS = ('_samples', '_vb_samples', '_data_dev', '_weights_dev')
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        if '_device_ready' in state:                          # (VBMerge keeps nothing on a device)
+            for name in self._DEVICE_ATTRS:
+                state[name] = None
+            state['_device_ready'] = False
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def _ensure_device_data(self):
+        if not getattr(self, '_device_ready', True):
+            self._attach_device_data()
+
+    def _attach_device_data(self):
+        on_device = hasattr(self.data, 'device') and not isinstance(self.data, np.ndarray)    # torch tensor: stays put
         if self._group is not None:
             host = self.data.detach().cpu().numpy() if on_device else self.data
             self._samples = self._group.upload(host)              # contiguous shards, device order = row order
@@ -94,11 +121,12 @@ class GaussianInference(object):
             self._vb_samples = None
             if not parallel.active() and hasattr(be, "wrap_samples") and type(self).E_step is GaussianInference.E_step:
                 self._vb_samples = be.wrap_samples(self._data_dev, self._weights_dev)
-        self.E_step()
+        self._device_ready = True
 
     # ------------------------------------------------------------------------- E / M steps
     def E_step(self):
         """Expectation values and summary statistics (reference: variational.pyx:116-127)."""
+        self._ensure_device_data()
         self._update_expectation_det_ln_lambda()        # first: catches an invalid W early
         self._update_expectation_ln_pi()
         D = self.dim
@@ -203,6 +231,7 @@ class GaussianInference(object):
         """r / log_rho / expectation_gauss_exponent of the latest E-step, computed on demand for
         this rank's shard (the reference keeps all three resident: variational.pyx:636-638)."""
         if name not in self._nk_cache:
+            self._ensure_device_data()
             be = get_backend(self._backend)
             if isinstance(self._estep_set, tuple):
                 m, W, beta, nu, ln_pi, ln_lam = self._estep_set

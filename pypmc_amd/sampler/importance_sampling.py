@@ -116,6 +116,23 @@ class ImportanceSampler(object):
         self.samples = store(proposal.dim)
         self.last_weight_sums = None      # (sum w, sum w log w, sum w^2) of the latest run
 
+    # ``last_run`` is a handle to sample buffers on the devices: a copy.deepcopy of the sampler shares it (ShardedSamples
+    # copies by reference), a pickle leaves it behind -- the histories on the host hold the same samples and weights
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['last_run'] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def __deepcopy__(self, memo):
+        new = type(self).__new__(type(self))
+        memo[id(self)] = new
+        for key, value in self.__dict__.items():
+            new.__dict__[key] = value if key in ('last_run', 'rng', '_group') else deepcopy(value, memo)
+        return new
+
     def clear(self):
         """Forget samples, weights and target values; the proposal is untouched."""
         self.samples.clear()
@@ -147,7 +164,12 @@ class ImportanceSampler(object):
         if not isinstance(prop, MixtureDensity):
             raise TypeError('``devices=[...]`` needs a MixtureDensity proposal (Gauss or StudentT components)')
         counts = self.rng.multinomial(N, prop.weights)                     # mixture.pyx:192
-        seed = int(self.rng.randint(0, 2 ** 31 - 1)) | (int(self.rng.randint(0, 2 ** 31 - 1)) << 32)
+        # the Philox seed of the device stream: two draws from the caller's generator -- ``randint`` of the legacy
+        # numpy.random API (RandomState, the module itself: what the reference takes, importance_sampling.py:146) or
+        # ``integers`` of a numpy Generator (advice r5).  This consumes the generator differently from the reference's
+        # run(), which draws every sample from it: the streams of a device run and a host run are not comparable.
+        draw = getattr(self.rng, 'integers', None) or self.rng.randint
+        seed = int(draw(0, 2 ** 31 - 1)) | (int(draw(0, 2 ** 31 - 1)) << 32)
         run = g.generate(prop, counts, seed)
         tgt = getattr(self._batch_target, '__self__', None)
         mixture_target = isinstance(tgt, MixtureDensity)

@@ -4,7 +4,7 @@
 BUILD CONTAINER ONLY: needs /root/reference.  Builds the reference's Cython extensions in a scratch
 copy (the recipe of tests/golden/make_golden.py), then times the REAL reference and the C oracle
 (oracle/libpmc_oracle.so, single thread) on the same inputs at the SURVEY section 6 shapes and writes
-the ratio table to profiles/r02_cpu_ratio.json.  The ratio ties bench.py's `cpu_baseline` (the oracle
+the ratio table to profiles/r06_cpu_ratio.json (round 2's: r02_cpu_ratio.json).  The ratio ties bench.py's `cpu_baseline` (the oracle
 timed on the GPU box's host, where the reference cannot travel) to the reference itself.
 
     python scripts/cpu_ratio.py [--scale 1.0]
@@ -59,6 +59,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref-build", default="/tmp/pypmc_ref")
     ap.add_argument("--scale", type=float, default=1.0, help="multiplies every N")
+    ap.add_argument("--out", default="r06_cpu_ratio.json", help="file name under profiles/")
     args = ap.parse_args()
     import make_golden
     make_golden.ensure_reference(args.ref_build)
@@ -146,11 +147,12 @@ def main():
     record("gaussian_pmc rb weighted", "K=32 D=20", N,
            best(lambda: pypmc.mix_adapt.pmc.gaussian_pmc(xs, prop, iw), repeat=2), best(orc_pmc, repeat=2))
 
+    import datetime
     out = dict(host=os.uname().nodename, cpu=open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
-               threads=1, note="reference = pypmc 1.2.6 built from /root/reference (Cython, gcc -O2 default flags); "
+               measured=datetime.date.today().isoformat(), threads=1, note="reference = pypmc 1.2.6 built from /root/reference (Cython, gcc -O2 default flags); "
                "oracle = oracle/pmc_oracle.c (gcc -O3 -ffp-contract=off); best of 3, single thread",
                rows=rows)
-    path = os.path.join(ROOT, "profiles", "r02_cpu_ratio.json")
+    path = os.path.join(ROOT, "profiles", args.out)
     json.dump(out, open(path, "w"), indent=1)
     print(path)
 

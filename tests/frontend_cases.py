@@ -934,7 +934,49 @@ def case_big_dimension(be):
         Gauss(np.zeros(1025), np.eye(1025), backend=be)
 
 
-ALL_CASES = [case_local_densities, case_far_start_values, case_big_dimension, case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
+def case_copies_and_pickles(be):
+    """advice r5: the front-end objects hold device state (resident data, library handles) that is neither picklable nor
+    to be freed twice -- copy.deepcopy and pickle go through the host state, the copy finds its device state again on
+    first use and computes the same numbers"""
+    import copy
+    import pickle
+    import pypmc_amd as pypmc
+    from pypmc_amd import backend as backend_module
+    old_default = backend_module._default
+    backend_module.set_default_backend(be)             # (the objects below name no backend: the default travels with a pickle)
+    try:
+        rs = np.random.RandomState(3)
+        data = np.concatenate([rs.normal(-2, 1, (150, 3)), rs.normal(3, 1, (130, 3))])
+        w = rs.uniform(0.5, 1.5, len(data))
+        vb = pypmc.mix_adapt.variational.GaussianInference(data, components=3, weights=w)
+        vb.update()
+        for clone in (copy.deepcopy(vb), pickle.loads(pickle.dumps(vb))):
+            assert getattr(clone, "_vb_samples", None) is None and clone._data_dev is None       # nothing of the device travelled
+            np.testing.assert_array_equal(clone.N_comp, vb.N_comp)
+            a, b = copy.deepcopy(vb), clone
+            a.update()
+            b.update()
+            np.testing.assert_array_equal(a.N_comp, b.N_comp)
+            np.testing.assert_array_equal(a.S, b.S)
+            assert a.likelihood_bound() == b.likelihood_bound()
+            np.testing.assert_array_equal(a.r, b.r)
+        # a sampler after a run
+        target = pypmc.density.mixture.create_gaussian_mixture(np.array([[0., 0.], [3., 3.]]), np.array([np.eye(2)] * 2))
+        prop = pypmc.density.mixture.create_gaussian_mixture(np.array([[1., 1.]]), np.array([4. * np.eye(2)]))
+        smp = pypmc.sampler.importance_sampling.ImportanceSampler(target.evaluate, prop, rng=np.random.RandomState(5))
+        smp.run(500)
+        c1 = copy.deepcopy(smp)
+        c2 = pickle.loads(pickle.dumps(smp))
+        for c in (c1, c2):
+            np.testing.assert_array_equal(c.samples[:], smp.samples[:])
+            np.testing.assert_array_equal(c.weights[:], smp.weights[:])
+        c2.run(100)
+        assert len(c2.samples[:]) == 600 and len(smp.samples[:]) == 500
+    finally:
+        backend_module.set_default_backend(old_default)
+
+
+ALL_CASES = [case_copies_and_pickles, case_local_densities, case_far_start_values, case_big_dimension, case_example_pmc, case_vbmerge_golden, case_tools_kat, case_gauss_student_components, case_mixture_api, case_mixture_golden,
              case_propose_counts_bit_exact, case_importance_sampler, case_combine_weights, case_history,
              case_device_history, case_combine_weights_device_inputs, case_reference_known_answers,
              case_vb_golden, case_vb_hand_computed, case_vb_errors_and_prune, case_gaussian_pmc_golden,

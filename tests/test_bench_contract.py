@@ -48,7 +48,7 @@ def test_flop_and_traffic_helpers():
     assert t is None or (1e9 < t < 2e10 and src.startswith("profiles/"))
     assert bench.measured_traffic("no_such_kernel", 1) == (None, None)
     ratio, where = bench.reference_ratio()
-    assert ratio is None or (1.0 < ratio < 5.0 and "measured on" in where)
+    assert ratio is None or (1.0 < ratio < 5.0 and "measured" in where and " on: " in where)
     assert set(bench.PIPE_OF.values()) <= set(bench.ATTAINABLE_TFLOPS) and all(
         v < bench.FP64_PEAK_TFLOPS for v in bench.ATTAINABLE_TFLOPS.values())
 

@@ -226,3 +226,61 @@ def test_example_script_runs_both_scenarios():
     assert r.returncode == 0, r.stderr[-2000:]
     perps = [float(l.split("perplexity")[1]) for l in r.stdout.splitlines() if l.startswith("iteration")]
     assert len(perps) == 5 and perps[-1] > perps[0] and perps[-1] > 0.5, perps
+
+
+def test_copies_pickles_and_close(be):
+    """advice r5: sharded sample sets are handles to device buffers -- deep copies of the objects that hold them share them
+    (one owner frees), pickles leave them behind and upload again on first use, DeviceGroup.close() returns what is still
+    alive, and device weights of another sample set are refused"""
+    import copy
+    import pickle
+    from pypmc_amd.devices import DeviceGroup, ShardedSamples
+    from pypmc_amd.mix_adapt.variational import GaussianInference
+    from pypmc_amd.sampler.importance_sampling import ImportanceSampler
+    from pypmc_amd.density.mixture import create_gaussian_mixture
+    from pypmc_amd.sampler.importance_sampling import calculate_mean
+    rs = np.random.RandomState(8)
+    data = np.concatenate([rs.normal(-2, 1, (700, 3)), rs.normal(3, 1, (600, 3))])
+    g = DeviceGroup([0, 0])
+    vb = GaussianInference(data, components=3, devices=g)
+    vb.update()
+    twin = copy.deepcopy(vb)
+    assert twin._samples is None and twin._group is g                 # the group is shared, the sample handle is not
+    back = pickle.loads(pickle.dumps(vb))
+    assert back._samples is None and back._group is not g and back._group.devices == g.devices
+    for other in (twin, back):
+        other.update()
+    vb.update()
+    for other in (twin, back):
+        np.testing.assert_array_equal(other.N_comp, vb.N_comp)
+        np.testing.assert_array_equal(other.S, vb.S)
+    back._group.close()
+    # a sampler after a run: the copy shares last_run, a pickle drops it
+    target = create_gaussian_mixture(np.array([[0., 0.], [3., 3.]]), np.array([np.eye(2)] * 2))
+    prop = create_gaussian_mixture(np.array([[1., 1.]]), np.array([4. * np.eye(2)]))
+    smp = ImportanceSampler(target.evaluate, prop, rng=np.random.RandomState(5), devices=g)
+    smp.run(3000)
+    c = copy.deepcopy(smp)
+    assert c.last_run is smp.last_run and isinstance(c.last_run, ShardedSamples)
+    p = pickle.loads(pickle.dumps(smp))
+    assert p.last_run is None
+    np.testing.assert_array_equal(p.samples[:], smp.samples[:])
+    p.run(100)
+    p._group.close()
+    with pytest.raises(TypeError):
+        pickle.dumps(smp.last_run)
+    # a numpy Generator as rng (advice r5: randint is the legacy API only)
+    smp2 = ImportanceSampler(target.evaluate, prop, rng=np.random.default_rng(1), devices=g)
+    smp2.run(500)
+    # device weights of another run are refused
+    run_a = smp.last_run
+    smp.run(3000)
+    run_b = smp.last_run
+    with pytest.raises(ValueError, match="another sample set"):
+        g.weighted_moments(run_b, run_a.weights)
+    # close() with sample sets still alive: they are freed with the context, later frees are no-ops
+    alive = [run_a, run_b, smp2.last_run, vb._samples]
+    g.close()
+    assert all(s._h is None for s in alive)
+    for s in alive:
+        s.free()
