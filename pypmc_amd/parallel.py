@@ -304,6 +304,114 @@ def _p2p_all_reduce(t):
     _lib.check(lib.pmc_p2p_status(h, stream), "pmc_p2p_allreduce_sum")
 
 
+def diagnose(n_doubles, rounds=100, device=None):
+    """First contact with several GPUs, self-diagnosing (verdict r5 #5): the builder has never had more than one.  Outside any
+    timed region, COLLECTIVELY (every rank calls it), never raising: the sum of one statistics-sized device buffer over
+    the ranks through every way this package has --
+
+      * ``default``: torch.distributed's backend ("nccl" = RCCL on ROCm; "gloo" in the tests),
+      * ``rccl_native``: the library's own communicator (pmc_comm_*: ncclAllReduce on the caller's stream),
+      * ``p2p``: the one-shot exchange (pmc_p2p_*: mailboxes mapped through HIP IPC, peer stores over xGMI) -- its connect
+        ends with a bit-exact self-test round, and a failure on any rank leaves all ranks where they were --
+
+    each checked bit for bit against the sum known in closed form (rank-dependent integers: every partial sum is exact)
+    and timed over ``rounds`` rounds.  Returns, on every rank, dict(world_size, backend, ranks_hosts, default | rccl_native |
+    p2p = dict(ok, ms_per_round | error, ...)); the per-rank error texts are gathered so that rank 0's dict shows them
+    all.  The stages stay in lockstep: a stage that fails on one rank is skipped by all (one agreement all-reduce in front
+    of every collective part).  Reference role: the gather of pypmc/tools/parallel_sampler.py:58-71."""
+    import socket
+    import time
+    d = _dist()
+    if d is None:
+        return dict(world_size=1, backend=None, note="no process group")
+    import torch
+    dev = torch.cuda.current_device() if device is None else int(device)
+    cuda = torch.device("cuda", dev)
+    where = _collective_device(d)
+    world, me = d.get_world_size(), d.get_rank()
+    out = dict(world_size=world, backend=d.get_backend(), device=dev)
+    try:
+        names = [None] * world
+        d.all_gather_object(names, "%s:cuda%d" % (socket.gethostname(), dev))
+        out["ranks"] = names
+    except Exception as exc:                              # (reported, never fatal)
+        out["ranks_error"] = repr(exc)
+    n = int(n_doubles)
+    base = (torch.arange(n, dtype=torch.float64, device=cuda) % 97.0 + 1.0) / 128.0
+    expect = base * (world * (world + 1) // 2)            # sum over ranks of (rank + 1) * base: exact in fp64
+
+    def fresh():
+        return (base * float(me + 1)).contiguous()
+
+    def stage(name, reduce_fn, setup=None, teardown=None):
+        rec = {}
+        err = None
+        try:
+            if setup is not None:
+                extra = setup()
+                if isinstance(extra, dict):
+                    rec.update(extra)
+                if rec.get("enabled") is False:
+                    out[name] = rec
+                    return
+        except Exception as exc:
+            err = repr(exc)
+        if not _agree(d, err is None, where):             # (every rank or none)
+            rec.update(ok=False, error=err or "a peer failed to set this stage up")
+            out[name] = rec
+            return
+        try:
+            t = fresh()
+            reduce_fn(t)
+            torch.cuda.synchronize(cuda)
+            rec["ok"] = bool(torch.equal(t, expect))
+            if not rec["ok"]:
+                rec["max_abs_error"] = float((t - expect).abs().max())
+            torch.cuda.synchronize(cuda)
+            d.barrier()
+            t0 = time.perf_counter()
+            for _ in range(int(rounds)):
+                reduce_fn(t)
+            torch.cuda.synchronize(cuda)
+            rec["ms_per_round"] = (time.perf_counter() - t0) / max(int(rounds), 1) * 1e3
+            rec["doubles"] = n
+        except Exception as exc:
+            rec.update(ok=False, error=repr(exc))
+        finally:
+            try:
+                if teardown is not None:
+                    teardown()
+            except Exception as exc:
+                rec["teardown_error"] = repr(exc)
+        out[name] = rec
+
+    def default_reduce(t):
+        if where.type == "cuda":
+            d.all_reduce(t, op=d.ReduceOp.SUM)
+        else:
+            h = t.cpu()
+            d.all_reduce(h, op=d.ReduceOp.SUM)
+            t.copy_(h)
+    stage("default", default_reduce)
+    had_native, had_p2p = _native is not None, _p2p is not None
+    stage("rccl_native", _native_all_reduce, setup=lambda: enable_native_collective(dev),
+          teardown=None if had_native else disable_native_collective)
+
+    def p2p_setup():
+        on = enable_p2p_collective(max_doubles=max(n, 1 << 12), device=dev)
+        st = p2p_status()
+        return dict(enabled=bool(on), info=st.get("info"), reason=st.get("reason"))
+    stage("p2p", _p2p_all_reduce, setup=p2p_setup, teardown=None if had_p2p else disable_p2p_collective)
+    try:
+        errs = [None] * world
+        mine = {k: v.get("error") or v.get("reason") for k, v in out.items() if isinstance(v, dict) and (v.get("error") or v.get("reason"))}
+        d.all_gather_object(errs, mine)
+        out["per_rank_errors"] = {str(r): e for r, e in enumerate(errs) if e}
+    except Exception as exc:
+        out["per_rank_errors_error"] = repr(exc)
+    return out
+
+
 def _collective_device(d):
     """device the default process group's backend reduces on"""
     import torch

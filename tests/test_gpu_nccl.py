@@ -84,6 +84,16 @@ def test_bench_plain_python_has_no_group_unless_forced():
     assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1 and line["dist"]["allreduce_ms"] > 0.0
     line = _bench([sys.executable], ["--force-dist"], dict(os.environ, PMC_NATIVE_COLLECTIVE="1"))
     assert line["dist"]["backend"] == "rccl:libpmc_hip" and line["dist"]["allreduce_ms"] > 0.0
+    assert line["dist"]["diagnostics"] is None          # one rank, not asked for
+    # --diagnose: the self-diagnosis of a multi-GPU run on the one rank a one-GPU box has -- RCCL for real, through
+    # torch.distributed and through the library's own communicator, and the one-shot exchange with itself
+    line = _bench([sys.executable], ["--force-dist", "--diagnose"])
+    diag = line["dist"]["diagnostics"]
+    assert diag["world_size"] == 1 and diag["backend"] == "nccl"
+    for name in ("default", "rccl_native"):
+        assert diag[name]["ok"] is True and diag[name]["ms_per_round"] > 0, (name, diag[name])
+    assert diag["p2p"].get("enabled") is False or diag["p2p"]["ok"] is True, diag["p2p"]
+    assert diag.get("per_rank_errors") in ({}, None) or diag["p2p"].get("enabled") is False
 
 
 def test_bench_single_process_over_virtual_shards():
@@ -100,3 +110,12 @@ def test_bench_single_process_over_virtual_shards():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["unit"].startswith("samples/s")
     assert line["config"]["N_total"] == 600000 and line["dtype"] == "f64"
     assert 0 < line["roofline"]["frac"] < 1 and len(line["step_ms"]["all"]) == 3
+    assert "ordered_sum_check" not in line["dist"]      # virtual shards, not asked for
+    # --diagnose: the check a run over several REAL devices makes by itself -- the devices' ordered sum against the same
+    # shards as virtual shards of the first device, bit for bit
+    r = subprocess.run([sys.executable] + args + ["--diagnose"], cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    chk = line["dist"]["ordered_sum_check"]
+    assert chk.get("matches_virtual_shards_bitwise") is True and len(chk["shards"]) == 2, chk
