@@ -334,8 +334,9 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  * device's CU count and these options); log q of a block in pieces agrees with the one-workgroup walk to the rounding
  * of the merge (a few ulps); the grouped responsibilities of pmc_estep keep their bits whatever the pieces.
  *   "split_components"          (default 1; 0: never)
- *   "split_min_components"      (default 0 = 4 per piece, 2 from compiled D = 32 on): smallest piece of a small launch
- *   "split_fill"                (default 2): a launch of less than one round is cut until it has this many workgroups per slot
+ *   "split_min_components"      (default 0 = 4 per piece): smallest piece of a small launch
+ *   "split_fill"                (default 1): a launch of less than one round is cut until it has this many workgroups per slot
+ *   "split_max_pieces"          (default 16): ... but into at most this many pieces per mixture
  *   "split_max_rounds"          (default 24): launches of more rounds than this are not cut at all
  *   "split_tail_rounds"         (default 0.25): rounds in front of the last, partial one that are walked in pieces too
  *   "split_tail_pieces"         (default 4), "split_tail_min_components" (default 0 = 8 per piece, 4 from D = 32 on)

@@ -323,7 +323,12 @@ struct PmcTuning {
     int split_min_comps = 0;       // components per piece at least (0: by Mahalanobis engine)
     int split_tail_pieces = 4;     // pieces per block of a launch that fills the chip (its last round only)
     double split_max_rounds = 24;  // launches of more rounds than this are not split at all
-    double split_fill = 2.0;       // a small launch is split until it has this many workgroups per slot of the chip
+    // a small launch is split until it has this many workgroups per slot of the chip -- but into at most split_max_pieces
+    // pieces per mixture: every piece pays the load of its samples and a share of the merge, and from ~16 pieces on that is
+    // more than the shorter walk saves (scripts/split_small_sweep.py, profiles/r06_split_small_sweep.txt: D = 40, K = 128,
+    // N = 4096: 64 pieces 66.7 us, 32: 43.3, 16: 37.3; D = 20, K = 128: 32 pieces 31.4, 16: 23.1)
+    double split_fill = 1.0;
+    int split_max_pieces = 16;
     // rounds of the chip, in front of the last (partial) one, that are walked in pieces too.  Measured (scripts/split_tail_sweep.py,
     // profiles/r06_split_tail_sweep.txt): 0 -- the remainder alone -- is best or within 1 % of the best at every shape but
     // config 2's (K = 16: 0.5 by 2.6 %)
@@ -1133,7 +1138,7 @@ int split_slots_per_cu(int dim) { return dim <= 16 ? 5 : (dim <= 24 ? 4 : (dim <
 int split_min_units(const PmcKernelSet *ks)
 {
     if (g_split_min_comps > 0) return g_split_min_comps;
-    return ks->dim >= PMC_MFMA_FROM && ks->dim % 4 == 0 ? 2 : 4;
+    return 4;
 }
 // ... and in a launch that fills the chip, where the pieces only have to shorten the last round
 int split_tail_min_units(const PmcKernelSet *ks)
@@ -1159,6 +1164,7 @@ SplitPlan split_plan(const PmcKernelSet *ks, long long nblocks, int units1, int 
     if (nblocks <= slots) {                                 // the launch does not fill the chip: every block in pieces
         bt = nblocks;
         want = (int)ceil_div((long long)std::ceil(g_split_fill * (double)slots), nblocks);
+        if (want > tun().split_max_pieces) want = tun().split_max_pieces;
     } else {                                                // the last round(s) in pieces
         bt = nblocks % slots + (long long)(g_split_tail_rounds * (double)slots);
         if (bt > nblocks) bt = nblocks;
@@ -2195,6 +2201,11 @@ static int configure_into(PmcTuning &t, const char *key, double value)
         t.split_tail_min_comps = (int)value;
         return PMC_OK;
     }
+    if (std::strcmp(key, "split_max_pieces") == 0) {
+        if (!(value >= 1.0 && value <= 1024.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [1, 1024]", key);
+        t.split_max_pieces = (int)value;
+        return PMC_OK;
+    }
     if (std::strcmp(key, "split_fill") == 0) {
         if (!(value > 0.0 && value <= 64.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in (0, 64]", key);
         t.split_fill = value;
@@ -2219,7 +2230,7 @@ static int option_get(const PmcTuning &t, const char *key, double *value)
         {"maha_gemm_tolerance", t.mgemm_tol}, {"maha_gemm_min_n", (double)t.mgemm_min_n},
         {"split_components", (double)t.split}, {"split_min_components", (double)t.split_min_comps},
         {"split_tail_pieces", (double)t.split_tail_pieces}, {"split_max_rounds", t.split_max_rounds},
-        {"split_fill", t.split_fill}, {"split_tail_rounds", t.split_tail_rounds},
+        {"split_fill", t.split_fill}, {"split_max_pieces", (double)t.split_max_pieces}, {"split_tail_rounds", t.split_tail_rounds},
         {"split_tail_min_components", (double)t.split_tail_min_comps}};
     for (const auto &o : all)
         if (std::strcmp(key, o.name) == 0) {

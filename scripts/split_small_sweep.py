@@ -19,6 +19,7 @@ from test_gpu_kernels import mk, gauss_set  # noqa: E402
 
 be = HipBackend()
 be.configure("maha_gemm_min_n", 2 ** 40)
+be.configure("split_max_pieces", 1024)
 
 
 def us(fn, reps=200):

@@ -15,7 +15,7 @@ from test_gpu_kernels import mk, draw, gauss_set, student_set, assert_rel
 pytestmark = pytest.mark.gpu
 
 SIZES = (1, 63, 64, 65, 255, 256, 257, 4096, 65536)
-DEFAULTS = dict(split_components=1, split_min_components=0, split_tail_pieces=4, split_max_rounds=24, split_fill=2.0,
+DEFAULTS = dict(split_components=1, split_min_components=0, split_tail_pieces=4, split_max_rounds=24, split_fill=1.0, split_max_pieces=16,
                 split_tail_rounds=0.25, split_tail_min_components=0)
 
 
@@ -53,10 +53,11 @@ class options(object):
 
 def plans():
     """(label, options): every piece count of the plan -- one component per piece up to everything in one piece"""
-    return [("auto", {}), ("1 per piece", dict(split_min_components=1, split_fill=64.)),
-            ("2 per piece", dict(split_min_components=2, split_fill=64.)),
-            ("3 per piece", dict(split_min_components=3, split_fill=64.)),
-            ("7 per piece", dict(split_min_components=7, split_fill=64.)),
+    fine = dict(split_fill=64., split_max_pieces=1024)
+    return [("auto", {}), ("1 per piece", dict(split_min_components=1, **fine)),
+            ("2 per piece", dict(split_min_components=2, **fine)),
+            ("3 per piece", dict(split_min_components=3, **fine)),
+            ("7 per piece", dict(split_min_components=7, **fine)),
             ("off", dict(split_components=0))]
 
 
@@ -264,7 +265,7 @@ def test_grouped_responsibilities_in_pieces_keep_their_bits(be, orc, D, K, N, we
     try:
         with options(be, split_components=0):
             whole = be.tohost(be.estep(xd, cs, 0, sample_w=sw)["stats"]).copy()
-        for label, opt in (("auto", {}), ("fine", dict(split_fill=64.)), ("tail 2", dict(split_tail_pieces=2))):
+        for label, opt in (("auto", {}), ("fine", dict(split_fill=64., split_max_pieces=1024)), ("tail 2", dict(split_tail_pieces=2))):
             with options(be, **opt):
                 got = be.tohost(be.estep(xd, cs, 0, sample_w=sw)["stats"])
                 np.testing.assert_array_equal(got, whole, err_msg=label)
@@ -272,7 +273,7 @@ def test_grouped_responsibilities_in_pieces_keep_their_bits(be, orc, D, K, N, we
         gs = gauss_set(mu, cov, w)[0]
         with options(be, split_components=0):
             whole_g = be.tohost(be.estep(xd, gs, 1, sample_w=sw)["stats"]).copy()
-        with options(be, split_fill=64.):
+        with options(be, split_fill=64., split_max_pieces=1024):
             np.testing.assert_array_equal(be.tohost(be.estep(xd, gs, 1, sample_w=sw)["stats"]), whole_g)
     finally:
         be.configure("stats_common_shift_min_n", 524288)
