@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -23,6 +24,7 @@
     extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t);   \
     extern "C" hipError_t pmc_launch_resp_groups_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_logpdf_split_d##d##_p##p(int, int, const PmcArgsA &, unsigned, hipStream_t); \
+    extern "C" hipError_t pmc_launch_logpdf2_d##d##_p##p(const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_resp_groups_split_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t); \
     extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t);       \
     extern "C" void pmc_stats_config_d##d##_p##p(int *, int *);                                        \
@@ -55,7 +57,8 @@ namespace {
      &pmc_launch_stats_d##d##_p##p, &pmc_stats_config_d##d##_p##p, &pmc_launch_propose_d##d##_p##p, \
      &pmc_launch_fused_d##d##_p##p, &pmc_fused_lds_bytes_d##d##_p##p, &pmc_launch_stats_gemm_d##d##_p##p, \
      &pmc_stats_gemm_config_d##d##_p##p, 0, 0, 0, 0, &pmc_launch_mgemm_d##d##_p0, &pmc_launch_theta_d##d##_p0, \
-     &pmc_mgemm_config_d##d##_p0, 0, 0, &pmc_launch_logpdf_split_d##d##_p##p, &pmc_launch_resp_groups_split_d##d##_p##p}
+     &pmc_mgemm_config_d##d##_p0, 0, 0, &pmc_launch_logpdf_split_d##d##_p##p, &pmc_launch_resp_groups_split_d##d##_p##p, \
+     &pmc_launch_logpdf2_d##d##_p##p}
 struct DimEntry {
     int dim;
     bool has_padded;
@@ -200,6 +203,7 @@ const PmcKernelSet *big_kernels_for(int D)
     ks->mg_nstepp = ks->mg_nct_max = 0;
     ks->logpdf_split = nullptr;
     ks->resp_groups_split = nullptr;
+    ks->logpdf2 = nullptr;
     sets.push_back(ks);
     return ks;
 }
@@ -1706,7 +1710,13 @@ static int importance_weights_impl(const double *d_x, int64_t N, int D, const do
         }
         const SplitPlan sp = (!nct && !d_u && d_workspace && ks->logpdf_split)
                                  ? split_plan(ks, nblocks, K, K_target, split_min_units(ks), split_tail_min_units(ks)) : SplitPlan();
-        if (sp.on) {
+        // (A/B build -DPMC_TWO_PER_LANE with PMC_AB_TWO_PER_LANE=1 in the environment: two samples per lane, round 6)
+        static const bool two_per_lane = std::getenv("PMC_AB_TWO_PER_LANE") != nullptr;
+        if (two_per_lane && !nct && !d_u && !d_maha_tiles && !d_sample_w && !d_log_target_out && ks->logpdf2 && kind == PMC_KIND_GAUSS &&
+            target_kind == PMC_KIND_GAUSS &&
+            ks->logpdf2(a, (unsigned)ceil_div(nblocks, 2), st) == hipSuccess) {
+            e = hipSuccess;
+        } else if (sp.on) {
             const int rc = split_apply(a, sp, d_workspace, K > K_target ? K : K_target, ks, st);
             if (rc != PMC_OK) return rc;
             e = ks->logpdf_split(kind, target_kind, a, (unsigned)sp.grid, st);

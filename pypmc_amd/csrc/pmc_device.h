@@ -221,6 +221,71 @@ template <int D, int G> __device__ __forceinline__ double mahalanobis_sp(const d
 #endif
 }
 
+// Two samples per lane (round 6 A/B, verdict r5 #3): the same coefficient stream, every coefficient feeding TWO multiply-adds --
+// half the scalar loads and waits per pair, twice the registers per lane (two wavefronts per SIMD instead of four).
+template <int D, int G> __device__ __forceinline__ void mahalanobis_sp2(const double (&xa)[D], const double (&xb)[D], cdouble *pk,
+                                                                        bool touch, double &maha_a, double &maha_b)
+{
+    static_assert(G == 1 || G == 2, "one or two lines per group");
+    constexpr int T = D + D * (D + 1) / 2, NC = (T + 7) / 8, NG = (NC + G - 1) / G;
+    sgpr8d b[2][G];
+    auto issue = [&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        static_for<0, G>([&](auto E) {
+            constexpr int e = decltype(E)::value, c = g * G + e;
+            if constexpr (c < NC) sp_issue<c * 64>(b[g & 1][e], pk);
+        });
+    };
+    int landing = 0;
+    auto arrive = [&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        if constexpr (g == 0) {
+            if constexpr (G == 2 && 1 < NC)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0][0]), "+s"(b[0][1]), "+s"(landing));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0][0]), "+s"(landing));
+        } else if constexpr (G == 2 && g * G + 1 < NC) sp_wait(b[g & 1][0], b[g & 1][1]);
+        else sp_wait(b[g & 1][0]);
+    };
+    auto coef = [&](auto IDX) -> double {
+        constexpr int idx = decltype(IDX)::value, c = idx / 8, g = c / G;
+        if constexpr (idx % (8 * G) == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            arrive(std::integral_constant<int, g>{});
+            if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return b[g & 1][c % G][idx % 8];
+    };
+    issue(std::integral_constant<int, 0>{});
+    if (touch) {                                          // workgroup-uniform
+        constexpr int LINES = pmc_pack_stride_c(D) * 8 / 64;
+        asm volatile(".set pmc_touch_i, 0\n .rept %2\n s_load_dword %0, %1, pmc_touch_i*64\n .set pmc_touch_i, pmc_touch_i+1\n .endr"
+                     : "+s"(landing) : "s"(pk), "n"(LINES) : "memory");
+    }
+    double da[D], db[D];
+    static_for<0, D>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const double m = coef(J);
+        da[j] = xa[j] - m;
+        db[j] = xb[j] - m;
+    });
+    maha_a = 0.0;
+    maha_b = 0.0;
+    static_for<0, D>([&](auto I) {
+        constexpr int i = decltype(I)::value, base = D + i * D - i * (i - 1) / 2 - i;
+        double ya = 0.0, yb = 0.0;
+        static_for<i, D>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const double c = coef(std::integral_constant<int, base + j>{});
+            ya = fma(c, da[j], ya);
+            yb = fma(c, db[j], yb);
+        });
+        maha_a = fma(ya, ya, maha_a);
+        maha_b = fma(yb, yb, maha_b);
+    });
+}
+
 // acc += coef[lane N of this lane's 16-lane row] * d  -- v_fmac_f64 with a DPP row broadcast on its first
 // source: a coefficient held ONCE per row in a VGPR feeds the FMA of all 64 lanes like an SGPR operand
 // would, at the full fp64 rate (scripts/microbench/dpp_f64.hip: 73 TFLOP/s against 68 with plain VGPR

@@ -318,4 +318,5 @@ struct PmcKernelSet {
     // the per-sample kernels with the components of a block split over workgroups (NULL: the run-time-dimension unit)
     hipError_t (*logpdf_split)(int kind, int kind2, const PmcArgsA &, unsigned grid, hipStream_t);
     hipError_t (*resp_groups_split)(int kind, const PmcArgsA &, unsigned grid, hipStream_t);
+    hipError_t (*logpdf2)(const PmcArgsA &, unsigned grid, hipStream_t);      // A/B builds only (-DPMC_TWO_PER_LANE)
 };

@@ -530,6 +530,68 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves(D)) void k_logpdf(c
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_logpdf2: A/B experiment of round 6 (verdict r5 #3), built only with -DPMC_TWO_PER_LANE and taken only for the plain
+// log q / importance-weight pass at D = 8 ... 30: every lane owns TWO samples (n and n + 256 of a block of 512), every
+// scalar coefficient feeds two multiply-adds.  Same operations per sample in the same order: k_logpdf's bits.
+// What it showed: profiles/r06_two_per_lane_ab.txt.
+// ---------------------------------------------------------------------------------------------
+#ifdef PMC_TWO_PER_LANE
+template <int D, bool PADDED, int KIND, int KIND2>
+__global__ __launch_bounds__(PMC_A_WAVES * 64, 2) void k_logpdf2(const PmcArgsA a)
+{
+    constexpr int STRIDE = pmc_pack_stride_c(D), DT = D + pmc_tri(D);
+    const long long na = (long long)blockIdx.x * (2 * PMC_A_WAVES * 64) + threadIdx.x, nb = na + PMC_A_WAVES * 64;
+    const bool va = na < a.N, vb = nb < a.N;
+    double xa[D], xb[D];
+    load_row<D, PADDED>(a.x, na, a.N, a.dreal, xa);
+    load_row<D, PADDED>(a.x, nb, a.N, a.dreal, xb);
+    const ExpConst EC;
+    RowPoison pa, pb;
+    auto mixture = [&](auto kind, const double *gpack, const int K, double &lsa, double &lsb) {
+        constexpr int KD = decltype(kind)::value;
+        double ma = -DBL_MAX, sa = 0.0, mb = -DBL_MAX, sb = 0.0;
+        cdouble *pk = (cdouble *)gpack;
+        for (int k = 0; k < K; ++k, pk += STRIDE) {
+            component_sync();
+            double qa, qb, expo;
+            mahalanobis_sp2<D, ((D <= 12 || D == 20) ? 1 : 2)>(xa, xb, pk, true, qa, qb);
+            const double v_a = component_value<D, KD>(qa, pk + DT, expo), v_b = component_value<D, KD>(qb, pk + DT, expo);
+            lse_step(v_a, pk[DT + 4], ma, sa, EC);
+            lse_step(v_b, pk[DT + 4], mb, sb, EC);
+            pa.see(v_a);
+            pb.see(v_b);
+        }
+        lsa = (log_any(sa) + ma) + pa.value();
+        lsb = (log_any(sb) + mb) + pb.value();
+    };
+    double la, lb, ta = 0.0, tb = 0.0;
+    mixture(ic<KIND>{}, a.pack, a.K, la, lb);
+    if (a.pack2 != nullptr) mixture(ic<KIND2>{}, a.pack2, a.K2, ta, tb);
+    if (a.out != nullptr) {
+        if (va) a.out[na] = la;
+        if (vb) a.out[nb] = lb;
+    }
+    if (a.partials == nullptr && a.log_target == nullptr && a.pack2 == nullptr) return;
+    double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    auto weigh = [&](bool valid, long long n, double lse, double lt) {
+        if ((a.log_target != nullptr || a.pack2 != nullptr) && valid) {
+            const double tmp = (a.pack2 != nullptr ? lt : a.log_target[n]) - lse;
+            const double w = exp(tmp);
+            a.weights[n] = w;
+            sc[0] += w;
+            sc[1] += (w != 0.0) ? w * tmp : 0.0;
+            sc[2] += w * w;
+            sc[4] += (isinf(w) && !isinf(tmp)) ? 1.0 : 0.0;
+        }
+        if (valid) sc[3] += lse;
+    };
+    weigh(va, na, la, ta);
+    weigh(vb, nb, lb, tb);
+    if (a.partials != nullptr) block_scalars<5>(sc, a.partials);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // k_logpdf_split: k_logpdf with the components of a sample block split over workgroups (round 6).
 //
 // A workgroup of k_logpdf walks ALL K components of its 256 samples, so a call costs K x (1 us at D = 20 ... 2.7 us at
@@ -1257,6 +1319,17 @@ extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_d, PMC_D, PMC_PADDED)(in
     if (kind == PMC_KIND_STUDENT_T && kind2 == PMC_KIND_GAUSS)
         return launch_logpdf_k<PMC_KIND_STUDENT_T, PMC_KIND_GAUSS>(a, grid, st);
     return hipErrorInvalidValue;
+}
+
+// (A/B, -DPMC_TWO_PER_LANE: Gaussian mixtures, the plain pass only; grid = blocks of 512 samples)
+extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf2_d, PMC_D, PMC_PADDED)(const PmcArgsA &a, unsigned grid, hipStream_t st)
+{
+#if defined(PMC_TWO_PER_LANE) && PMC_D >= 8 && PMC_D <= 30
+    hipLaunchKernelGGL((k_logpdf2<D_, P_, PMC_KIND_GAUSS, PMC_KIND_GAUSS>), dim3(grid), dim3(PMC_A_WAVES * 64), 0, st, a);
+    return hipGetLastError();
+#else
+    return hipErrorNotSupported;
+#endif
 }
 
 extern "C" hipError_t PMC_UNIT_NAME_X(pmc_launch_logpdf_split_d, PMC_D, PMC_PADDED)(int kind, int kind2, const PmcArgsA &a,

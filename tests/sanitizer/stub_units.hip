@@ -9,6 +9,7 @@
     extern "C" hipError_t pmc_launch_resp_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t) { return hipSuccess; }       \
     extern "C" hipError_t pmc_launch_resp_groups_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t) { return hipSuccess; } \
     extern "C" hipError_t pmc_launch_logpdf_split_d##d##_p##p(int, int, const PmcArgsA &, unsigned, hipStream_t) { return hipSuccess; } \
+    extern "C" hipError_t pmc_launch_logpdf2_d##d##_p##p(const PmcArgsA &, unsigned, hipStream_t) { return hipErrorNotSupported; } \
     extern "C" hipError_t pmc_launch_resp_groups_split_d##d##_p##p(int, const PmcArgsA &, unsigned, hipStream_t) { return hipSuccess; } \
     extern "C" hipError_t pmc_launch_stats_d##d##_p##p(const PmcArgsB &, unsigned, hipStream_t) { return hipSuccess; }           \
     extern "C" void pmc_stats_config_d##d##_p##p(int *nsub, int *waves) { *nsub = d >= 40 ? 2 : 1; *waves = 16; }               \
