@@ -588,6 +588,15 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
             i1 = i;
             i2 = t - i * (i + 1) / 2;
         }
+#ifdef PMC_AB_NOCONFLICT
+        // A/B switch, TIMING ONLY (wrong numbers; scripts/stats_conflict_ab.sh, verdict r5 #3): another address pattern of the
+        // B-operand reads -- sixteen different coordinates per column tile instead of the monomials' factors.  It was meant to
+        // remove the bank conflicts and turned out to have MORE (conflict fraction 0.21 -> 0.33, the rows of the four lane
+        // groups collide) -- at the same kernel time, 2.62 -> 2.61 ms: the LDS reads hide behind the matrix pipe (84 % busy,
+        // LDS 20-24 %); the conflicts are off the critical path (profiles/r06_stats_conflict_ab.txt).
+        i1 = n16 % (dreal > 0 ? dreal : 1);
+        i2 = (n16 + 7) % (dreal > 0 ? dreal : 1);
+#endif
         off1[c] = rowbase + i1;
         off2[c] = rowbase + i2;
     }
