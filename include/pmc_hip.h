@@ -340,6 +340,10 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *   "split_max_rounds"          (default 24): launches of more rounds than this are not cut at all
  *   "split_tail_rounds"         (default 0.25): rounds in front of the last, partial one that are walked in pieces too
  *   "split_tail_pieces"         (default 4), "split_tail_min_components" (default 0 = 8 per piece, 4 from D = 32 on)
+ *   "estep_small_batch_pieces"  (default 1): pmc_estep of a batch that does not fill the chip (VB, Gaussian Rao-Blackwell PMC,
+ *                                K > 16) forms its responsibilities in groups of 16 components, the groups in pieces, and the
+ *                                workgroup that finishes a block multiplies the groups' factors into u itself -- the per-component
+ *                                statistics kernel behind takes a complete u.  The grouped form's notes (below) apply.
  * pmc_option_get / pmc_option_default read an option's current / built-in value.
  */
 int pmc_configure(const char *key, double value);

@@ -337,6 +337,7 @@ struct PmcTuning {
     // profiles/r06_split_tail_sweep.txt): 0 -- the remainder alone -- is best or within 1 % of the best at every shape but
     // config 2's (K = 16: 0.5 by 2.6 %)
     double split_tail_rounds = 0.25;
+    int small_grouped = 1;            // pmc_estep of a small batch: grouped responsibilities in pieces, completed in place
     int split_tail_min_comps = 0;     // components per piece at least in such a launch (0: by Mahalanobis engine)
 };
 PmcTuning g_tuning;
@@ -2211,6 +2212,11 @@ static int configure_into(PmcTuning &t, const char *key, double value)
         t.split_tail_min_comps = (int)value;
         return PMC_OK;
     }
+    if (std::strcmp(key, "estep_small_batch_pieces") == 0) {
+        if (!(value == 0.0 || value == 1.0)) return fail(PMC_EINVAL, "pmc_configure: %s is 0 or 1", key);
+        t.small_grouped = (int)value;
+        return PMC_OK;
+    }
     if (std::strcmp(key, "split_max_pieces") == 0) {
         if (!(value >= 1.0 && value <= 1024.0)) return fail(PMC_EINVAL, "pmc_configure: %s must be in [1, 1024]", key);
         t.split_max_pieces = (int)value;
@@ -2241,7 +2247,7 @@ static int option_get(const PmcTuning &t, const char *key, double *value)
         {"split_components", (double)t.split}, {"split_min_components", (double)t.split_min_comps},
         {"split_tail_pieces", (double)t.split_tail_pieces}, {"split_max_rounds", t.split_max_rounds},
         {"split_fill", t.split_fill}, {"split_max_pieces", (double)t.split_max_pieces}, {"split_tail_rounds", t.split_tail_rounds},
-        {"split_tail_min_components", (double)t.split_tail_min_comps}};
+        {"split_tail_min_components", (double)t.split_tail_min_comps}, {"estep_small_batch_pieces", (double)t.small_grouped}};
     for (const auto &o : all)
         if (std::strcmp(key, o.name) == 0) {
             *value = o.v;
@@ -2531,6 +2537,36 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
             int rc = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
             if (rc != PMC_OK) return rc;
             return sufficient_stats_impl(d_x, N, D, d_spack, K, d_u, d_stats, d_workspace, stream, kind, gscale, d_pack);
+        }
+        // Small batches (round 6): a launch that does not fill the chip walks its groups of 16 components in pieces
+        // (k_resp_groups_split) -- k_resp would walk all K on a handful of compute units, three passes each -- and the workgroup
+        // that finishes a block multiplies the groups' factors into u itself: the per-component statistics kernel behind takes
+        // a complete u.  VB and Gaussian Rao-Blackwell PMC, from two groups on.
+        if (g_split && tun().small_grouped && ks->resp_groups_split && ks->padded != 2 && d_x && K > PMC_RESP_GROUP &&
+            ((kind == PMC_KIND_VB && mode == PMC_RESP_VB) || (kind == PMC_KIND_GAUSS && mode == PMC_RESP_PMC_RB)) &&
+            gscale_bytes(N, K, ks) > 0) {
+            hipStream_t st = (hipStream_t)stream;
+            const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+            const SplitPlan sp = split_plan(ks, nblocks, (int)ceil_div(K, PMC_RESP_GROUP), 0, 1);
+            if (sp.on && sp.b1 == 0) {
+                PmcArgsA a;
+                std::memset(&a, 0, sizeof(a));
+                a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero; a.mode = mode;
+                a.ld = K; a.sample_w = d_sample_w; a.u = d_u; a.klds = PMC_RESP_GROUP;
+                a.gscale = (double *)((char *)d_workspace + gscale_offset(N, K, ks));     // (the groups' maxima wait there)
+                a.partials = (double *)d_workspace;
+                a.split_complete = 1;
+                {
+                    Timed t(T_RESP, st, flops_pairs((double)N, K, D), 8.0 * N * (D + 2 * K));
+                    const int rc0 = split_apply(a, sp, d_workspace, K, ks, st);
+                    if (rc0 != PMC_OK) return rc0;
+                    const hipError_t e = ks->resp_groups_split(kind, a, (unsigned)sp.grid, st);
+                    if (e != hipSuccess) return hipfail(e, "k_resp_groups launch");
+                }
+                const int rc1 = finish_scalars((const double *)d_workspace, nblocks, d_scalars, st);
+                if (rc1 != PMC_OK) return rc1;
+                return sufficient_stats_impl(d_x, N, D, d_spack, K, d_u, d_stats, d_workspace, stream, kind, nullptr, d_pack);
+            }
         }
         int rc = pmc_responsibilities(d_x, N, D, d_pack, K, kind, mode, max_init_zero, d_sample_w, d_latent, d_u,
                                       d_scratch, d_vsums, nullptr, nullptr, nullptr, K, d_scalars, d_workspace, stream);

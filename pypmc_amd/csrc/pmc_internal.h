@@ -147,6 +147,8 @@ struct PmcArgsA {
     // (maximum, sum [, bound term]) per sample in split_part; the piece that draws the block's last ticket combines them
     // in piece order and does what follows the component loop.
     int split_b1, split_s1, split_c1, split_s2, split_c2;
+    int split_complete;       // k_resp_groups_split: the finishing workgroup multiplies the factors into u itself (u is complete,
+                              // nothing is left to the statistics kernel): small batches, whose statistics run per component
     double *split_part;       // [block - split_b1][piece][2 or 3][256]
     unsigned *split_ticket;   // [block - split_b1], zero between launches (the last ticket wraps it)
 };

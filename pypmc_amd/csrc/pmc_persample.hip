@@ -1154,14 +1154,17 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves_split(D)) void k_re
             auto expstep = [&](int j, double v) {
                 const double lr = max_f64(v - Mg, -1075.0);
                 const double e = exp_clamped(lr, EC);
+                // (split_complete: another workgroup -- the one that finishes the block -- reads u' back: agent-scope stores)
                 if constexpr (KIND == PMC_KIND_VB) {
                     tbg = fma(e, lr, tbg);
                     sg += e;
-                    store_u(ut + (size_t)(kb + j) * 64, zero_to_tiny(e));
+                    if (a.split_complete) piece_store(ut + (size_t)(kb + j) * 64, zero_to_tiny(e));
+                    else store_u(ut + (size_t)(kb + j) * 64, zero_to_tiny(e));
                 } else {
                     const double we = ((cdouble *)a.pack + (size_t)(kb + j) * dm.STRIDE)[dm.DT + 4] * e;
                     sg += we;
-                    store_u(ut + (size_t)(kb + j) * 64, we);
+                    if (a.split_complete) piece_store(ut + (size_t)(kb + j) * 64, we);
+                    else store_u(ut + (size_t)(kb + j) * 64, we);
                 }
             };
             descend(kn, 0, [&](int j) { return pl[j * 64]; }, expstep);
@@ -1217,6 +1220,20 @@ __global__ __launch_bounds__(PMC_A_WAVES * 64, pmc_min_waves_split(D)) void k_re
             double *gs = gs_of(0);
             for (int g = 0; g < G; ++g) gs[(size_t)g * 64] = f * exp(gs[(size_t)g * 64]);
             sc[3] = swv * lse;
+        }
+    }
+    if (a.split_complete && tile_live) {
+        // small batches: the statistics that follow run per component (k_stats) and take u as it stands -- the finishing
+        // workgroup multiplies every group's factor into its values (written by whichever piece walked the group)
+        double *ut = a.u + (size_t)tile * K * 64 + lane;
+        const double *gs = gs_of(0);
+        for (int g = 0; g < G; ++g) {
+            const double fg = gs[(size_t)g * 64];
+            const int kb = g * GS, kn = (K - kb < GS) ? K - kb : GS;
+            for (int j = 0; j < kn; ++j) {
+                double *p = ut + (size_t)(kb + j) * 64;
+                *p = piece_load(p) * fg;
+            }
         }
     }
     if (a.partials != nullptr) block_scalars_at<5>(sc, a.partials, blk);

@@ -104,6 +104,16 @@ if what in ("tail", "all"):
 if what in ("estep", "all"):
     print("# VB E-step at one GPU's share of eight (grouped responsibilities + common-shift statistics), us per call")
     from test_gpu_split import _vb_set
+    for D, K, N in ((20, 32, 10000), (20, 64, 10000), (40, 128, 4096), (20, 32, 100000), (20, 128, 50000)):
+        cs, (mu, cov, w), _ = _vb_set(K, D, 600 + K)
+        x = be.asdevice(np.random.RandomState(1).normal(size=(N, D)) * 3)
+        f = lambda: be.estep(x, cs, 0)
+        row = []
+        for label, on in (("one workgroup per block (k_resp)", 0), ("groups in pieces", 1)):
+            be.configure("estep_small_batch_pieces", on)
+            row.append("%s %7.1f (k_resp %7.1f, k_stats %7.1f)" % (label, timeit(f, reps=100), kernel_us(f, "k_resp", reps=50), kernel_us(f, "k_stats", reps=50)))
+        be.reset_option("estep_small_batch_pieces")
+        print("small batch D=%2d K=%3d N=%7d   %s" % (D, K, N, "   ".join(row)), flush=True)
     for D, K, N in ((20, 64, 1250000), (20, 32, 1250000), (20, 64, 312500), (20, 32, 100000)):
         cs, (mu, cov, w), _ = _vb_set(K, D, 600 + K)
         x = be.asdevice(np.random.RandomState(1).normal(size=(N, D)) * 3)

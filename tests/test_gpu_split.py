@@ -249,8 +249,9 @@ def _vb_set(K, D, seed):
     return cs, (mu, cov, w), (m, W, beta, nu, ln_pi, ln_lambda)
 
 
-@pytest.mark.parametrize("D,K,N,weighted", [(20, 32, 20000, True), (20, 64, 9000, False), (20, 70, 4096, True),
-                                            (8, 48, 5000, False), (40, 48, 3000, True), (20, 64, 300000, True)])
+# (N >= 16384: below, the common-shift statistics -- and with them this pair of kernels -- are never taken, whatever the options)
+@pytest.mark.parametrize("D,K,N,weighted", [(20, 32, 20000, True), (20, 64, 18000, False), (20, 70, 17000, True),
+                                            (8, 48, 20000, False), (40, 48, 16500, True), (20, 64, 300000, True)])
 def test_grouped_responsibilities_in_pieces_keep_their_bits(be, orc, D, K, N, weighted):
     """k_resp_groups_split: groups of 16 components in pieces, k_resp_groups' recurrence over the groups by the piece
     that finishes the block -- the statistics and E[log q(Z)] of the E-step, BITWISE, whatever the pieces; the oracle's
@@ -323,3 +324,51 @@ def test_no_stale_pieces(be, D, K, N):
         if first[i] is None:
             first[i] = out.copy()
         np.testing.assert_array_equal(out, first[i], err_msg="call %d: run to run" % it)
+
+
+@pytest.mark.parametrize("D,K,N,weighted", [(20, 32, 10000, True), (20, 17, 257, False), (8, 64, 4096, True), (40, 128, 3000, False),
+                                            (20, 70, 30000, True), (30, 33, 1000, False), (12, 48, 65, True)])
+def test_small_batch_estep_in_pieces(be, orc, D, K, N, weighted):
+    """pmc_estep of a batch that does not fill the chip (round 6): grouped responsibilities, the groups of 16 components in
+    pieces, the factors multiplied into u by the workgroup that finishes a block, the per-component statistics kernel
+    behind.  Against the oracle (variational.pyx:675-932, pmc.pyx:23-43 + :188-222), against the one-workgroup walk
+    (k_resp), run to run."""
+    from pypmc_amd.mix_adapt._stats import split_stats, centred_moments
+    cs, (mu, cov, w), (m, W, beta, nu, ln_pi, ln_lambda) = _vb_set(K, D, 800 + K + D)
+    x, _ = draw(mu, cov, w, N, 27)
+    sw = np.random.RandomState(4).uniform(0.5, 1.5, N) if weighted else None
+    xd = be.asdevice(x)
+    be.configure("estep_small_batch_pieces", 0)
+    try:
+        walk = be.tohost(be.estep(xd, cs, 0, sample_w=sw)["stats"]).copy()
+    finally:
+        be.reset_option("estep_small_batch_pieces")
+    got = be.tohost(be.estep(xd, cs, 0, sample_w=sw)["stats"]).copy()
+    np.testing.assert_array_equal(be.tohost(be.estep(xd, cs, 0, sample_w=sw)["stats"]), got)
+    ps = 1 + D + D * (D + 1) // 2
+    a, b = got[8:8 + K * ps].reshape(K, ps), walk[8:8 + K * ps].reshape(K, ps)
+    assert (np.abs(a - b) / (np.abs(b).max(axis=1, keepdims=True) + 1e-300)).max() < 1e-11
+    assert abs(got[0] - walk[0]) <= 1e-11 * abs(walk[0]) + 1e-12
+    ref = orc.vb_estep(x, sw, m, W, beta, nu, ln_pi, ln_lambda)
+    sc, S0, M1, M2, _, _ = split_stats(got, K, D)
+    assert_rel(S0, ref["N_comp"], rtol=1e-10, what="N_comp")
+    x_mean, S = centred_moments(S0, M1, M2, m)
+    live = ref["N_comp"] > 1e-6
+    np.testing.assert_allclose(x_mean[live], ref["x_mean_comp"][live], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(S[live], ref["S"][live], rtol=1e-8, atol=1e-10)
+    assert abs(sc[0] - ref["expectation_log_q_Z"]) <= 1e-10 * abs(ref["expectation_log_q_Z"]) + 1e-11
+    # the Gaussian Rao-Blackwell update's statistics (pmc.pyx:23-43, :188-222)
+    gs, inv, ln = gauss_set(mu, cov, w)
+    rho = orc.rho_rb(0, x, w, mu, inv, ln, None, None, list(range(K)))
+    g = be.tohost(be.estep(xd, gs, 1, sample_w=sw)["stats"])
+    swv = np.ones(N) if sw is None else sw
+    _, S0g, M1g, _, _, _ = split_stats(g, K, D)
+    np.testing.assert_allclose(S0g, (swv[:, None] * rho).sum(axis=0), rtol=1e-10, atol=1e-300)
+    d = x[:, None, :] - mu[None]
+    np.testing.assert_allclose(M1g, np.einsum('n,nk,nki->ki', swv, rho, d), rtol=1e-9, atol=1e-10)
+    be.configure("estep_small_batch_pieces", 0)
+    try:
+        gw = be.tohost(be.estep(xd, gs, 1, sample_w=sw)["stats"])
+    finally:
+        be.reset_option("estep_small_batch_pieces")
+    np.testing.assert_allclose(g[3], gw[3], rtol=1e-12)                         # sum w log q
