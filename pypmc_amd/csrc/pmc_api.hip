@@ -2548,7 +2548,10 @@ int pmc_estep_about(const double *d_x, int64_t N, int D, const double *d_pack, i
             hipStream_t st = (hipStream_t)stream;
             const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
             const SplitPlan sp = split_plan(ks, nblocks, (int)ceil_div(K, PMC_RESP_GROUP), 0, 1);
-            if (sp.on && sp.b1 == 0) {
+            // (where it pays: while the pieces have compute units to spread to -- K = 32, two groups: 56 -> 40 us at 40 blocks,
+            //  62 -> 65 at 391; K = 128: 213 -> 146 at 196 blocks: profiles/r06_small_batch_estep.txt)
+            const long long slots = (long long)device_cus() * split_slots_per_cu(ks->dim);
+            if (sp.on && sp.b1 == 0 && nblocks * 16 <= slots * ceil_div(K, PMC_RESP_GROUP)) {
                 PmcArgsA a;
                 std::memset(&a, 0, sizeof(a));
                 a.x = d_x; a.N = N; a.dreal = D; a.pack = d_pack; a.K = K; a.max_init_zero = max_init_zero; a.mode = mode;
