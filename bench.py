@@ -531,6 +531,8 @@ def main():
                     help="run the multi-GPU self-diagnosis (the sum over ranks through every collective this package has, bit-exact "
                          "checks, 100-round timings; --single-process: the devices' ordered sum against virtual shards on one "
                          "device) even with one rank / virtual shards -- it always runs when there are several real devices")
+    ap.add_argument("--diagnose-timeout", type=float, default=120.0,
+                    help="seconds the multi-GPU self-diagnosis may take before the line is printed without it")
     ap.add_argument("--two-streams", action="store_true",
                     help="run the step's two independent halves (IS pass, VB E-step) side by side on two HIP streams: "
                          "about 4 %% more samples/s, but overlapping kernels stretch each other, so the per-kernel "
@@ -693,15 +695,31 @@ def main():
     n_k_sum = float(host.numpy()[8:8 + K * be.stats_stride(D)].reshape(K, -1)[:, 0].sum())
     assert abs(n_k_sum / n_total - 1) < 1e-9, "sum_k N_k != N (the all-reduce did not see every rank)"
 
-    diag = None
+    diag, diag_hung = None, False
     if grouped and (world > 1 or args.diagnose):
         # First contact with several GPUs (verdict r5 #5), outside the timed region and never fatal: the statistics-sized sum
         # through torch.distributed's backend, the library's own RCCL communicator and the one-shot exchange, each checked
         # bit for bit and timed over 100 rounds; every rank takes part, the result rides in rank 0's line (dist.diagnostics)
-        try:
-            diag = parallel.diagnose(int(stats.numel()), rounds=100, device=local_rank)
-        except Exception as exc:
-            diag = {"error": repr(exc)}
+        # ... under a watchdog: a collective between GPUs that have never met may never return, and the headline must
+        # still be printed.  The diagnosis runs in a thread; after --diagnose-timeout seconds the line goes out with the
+        # stage it was stuck in, and the process leaves through os._exit (the process group cannot be torn down then).
+        import threading
+        box = {"stage": "start"}
+
+        def run_diag():
+            try:
+                torch.cuda.set_device(local_rank)
+                box["result"] = parallel.diagnose(int(stats.numel()), rounds=100, device=local_rank, progress=box)
+            except Exception as exc:
+                box["result"] = {"error": repr(exc)}
+        th = threading.Thread(target=run_diag, daemon=True)
+        th.start()
+        th.join(args.diagnose_timeout)
+        if th.is_alive():
+            diag = {"error": "timed out after %g s: a collective did not return" % args.diagnose_timeout, "stage": box.get("stage")}
+            diag_hung = True
+        else:
+            diag = box.get("result")
 
     if rank == 0:
         hot = {k_: v for k_, v in timings.items() if k_ in ("k_logpdf", "k_resp", "k_stats", "k_estep_fused")}
@@ -861,6 +879,10 @@ def main():
             line["configs"] = baseline_configs(be)
             line["small_batches"] = small_batches(be)
         print(json.dumps(line))
+    if diag_hung:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)                                      # (a thread of this process still sits in a collective)
     if grouped:
         parallel.disable_native_collective()
         dist.destroy_process_group()

@@ -304,7 +304,7 @@ def _p2p_all_reduce(t):
     _lib.check(lib.pmc_p2p_status(h, stream), "pmc_p2p_allreduce_sum")
 
 
-def diagnose(n_doubles, rounds=100, device=None):
+def diagnose(n_doubles, rounds=100, device=None, progress=None):
     """First contact with several GPUs, self-diagnosing (verdict r5 #5): the builder has never had more than one.  Outside any
     timed region, COLLECTIVELY (every rank calls it), never raising: the sum of one statistics-sized device buffer over
     the ranks through every way this package has --
@@ -318,7 +318,11 @@ def diagnose(n_doubles, rounds=100, device=None):
     and timed over ``rounds`` rounds.  Returns, on every rank, dict(world_size, backend, ranks_hosts, default | rccl_native |
     p2p = dict(ok, ms_per_round | error, ...)); the per-rank error texts are gathered so that rank 0's dict shows them
     all.  The stages stay in lockstep: a stage that fails on one rank is skipped by all (one agreement all-reduce in front
-    of every collective part).  Reference role: the gather of pypmc/tools/parallel_sampler.py:58-71."""
+    of every collective part).  ``progress`` (a dict): its key "stage" names the stage that is running -- a caller that runs
+    this in a watchdog thread (bench.py) can say where a collective that never returned was stuck.
+    Reference role: the gather of pypmc/tools/parallel_sampler.py:58-71."""
+    progress = progress if progress is not None else {}
+    progress["stage"] = "start"
     import socket
     import time
     d = _dist()
@@ -346,6 +350,7 @@ def diagnose(n_doubles, rounds=100, device=None):
     def stage(name, reduce_fn, setup=None, teardown=None):
         rec = {}
         err = None
+        progress["stage"] = name
         try:
             if setup is not None:
                 extra = setup()
@@ -402,6 +407,7 @@ def diagnose(n_doubles, rounds=100, device=None):
         st = p2p_status()
         return dict(enabled=bool(on), info=st.get("info"), reason=st.get("reason"))
     stage("p2p", _p2p_all_reduce, setup=p2p_setup, teardown=None if had_p2p else disable_p2p_collective)
+    progress["stage"] = "gathering the ranks' errors"
     try:
         errs = [None] * world
         mine = {k: v.get("error") or v.get("reason") for k, v in out.items() if isinstance(v, dict) and (v.get("error") or v.get("reason"))}
@@ -409,6 +415,7 @@ def diagnose(n_doubles, rounds=100, device=None):
         out["per_rank_errors"] = {str(r): e for r, e in enumerate(errs) if e}
     except Exception as exc:
         out["per_rank_errors_error"] = repr(exc)
+    progress["stage"] = "done"
     return out
 
 
