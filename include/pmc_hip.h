@@ -315,7 +315,9 @@ int pmc_sufficient_stats(const double *d_x, int64_t N, int D, const double *d_pa
  *      exact kernels to ~1e-11 relative, not bit for bit.  Results are bit-reproducible from run to run for the SAME
  *      shard sizes; a rank or device count that moves a shard across a threshold changes low-order bits of the
  *      statistics (well inside the 1e-10 contract).  pmc_configure can pin either form on or off if bit-identity
- *      across different shardings matters more than speed.
+ *      across different shardings matters more than speed: with "split_components" 0 and "maha_gemm_tolerance" 0 every
+ *      PER-SAMPLE output (log q, importance weights, responsibilities) is a function of the sample and the mixture alone,
+ *      bit for bit whatever the batch or shard size (the sums over samples still depend on how the samples are chunked).
  *   2. The grouped responsibilities do not materialise r_nk, and with that the reference's clamp r == 0 -> tiny
  *      (variational.pyx:751-753) is applied only to a pair whose exp underflows within its OWN group of 16; a pair that
  *      underflows only against the row maximum of another group contributes 0 instead of 2.2e-308 to N_k / x-bar_k / S_k

@@ -102,7 +102,9 @@ def _sweep(seed, rounds, be, dims, verbose, kmax, nmax, fast_paths, rs, worst, o
     floor2 = 1e-9
 
     def two_forms(one, two, K, D):
-        if fast_paths:
+        # (K > 16: a small batch's E-step forms its responsibilities in groups of 16, the groups in pieces, since round 6 -- u
+        #  to rounding, not bitwise: sums that cancel are compared on the scale of their component, not element by element)
+        if fast_paths or K > 16:
             return stats_err(one, two, K, D, split_stats)
         return float(np.max(np.abs(one - two) / (np.abs(two) + floor2 * np.abs(two).max() + 1e-300)))
     for rnd in range(rounds):

@@ -372,3 +372,19 @@ def test_small_batch_estep_in_pieces(be, orc, D, K, N, weighted):
     finally:
         be.reset_option("estep_small_batch_pieces")
     np.testing.assert_allclose(g[3], gw[3], rtol=1e-12)                         # sum w log q
+
+
+def test_per_sample_outputs_independent_of_the_batch_when_pinned(be):
+    """include/pmc_hip.h: with "split_components" 0 and the matrix-product form off, log q of a sample does not depend on the
+    batch it arrives in -- bit for bit; with the defaults it agrees to the rounding of the merge"""
+    D, K = 20, 32
+    mu, cov, w = mk(K, D, 42)
+    mu *= 0.2
+    cs = gauss_set(mu, cov, w)[0]
+    x = be.asdevice(draw(mu, cov, w, 70000, 9)[0])
+    with options(be, split_components=0):
+        big = be.tohost(be.logpdf(x, cs)["out"]).copy()
+        for n in (1, 255, 1000, 4097, 30000):
+            np.testing.assert_array_equal(be.tohost(be.logpdf(x[:n].contiguous(), cs)["out"]), big[:n])
+    for n in (1, 255, 1000, 4097, 30000, 70000):
+        np.testing.assert_allclose(be.tohost(be.logpdf(x[:n].contiguous(), cs)["out"]), big[:n], rtol=2e-15, atol=1e-14)
