@@ -69,7 +69,8 @@ int pmc_ctx_join(pmc_ctx *ctx, int rank, int world, const void *h_id);
  */
 int pmc_ctx_p2p_open(pmc_ctx *ctx, int rank, int world, int64_t max_doubles, void *h_handle);
 /* (a negative status -- no peer path, another host, a failed self-test, pmc_hip.h -- leaves the context WITHOUT an exchange:
-   join an RCCL communicator instead, on all ranks) */
+   join an RCCL communicator instead, on all ranks.  The failed exchange's mailbox stays allocated until pmc_shutdown: a
+   peer that mapped it may still be inside its own self-test round, and this layer has no barrier across ranks) */
 int pmc_ctx_p2p_connect(pmc_ctx *ctx, const void *h_handles);
 /* Frees the stream, the scratch and the communicator.  Handles made from the context must be freed first. */
 int pmc_shutdown(pmc_ctx *ctx);
