@@ -13,8 +13,8 @@
  *     aborts; pmc_last_error() returns a thread-local message for the last failure.
  *   - launches are asynchronous on `stream`; outputs are valid after the stream is synchronised.
  *   - results are deterministic run-to-run (fixed reduction trees, no floating-point atomics).
- *   - all N-sized and K-sized device memory is the caller's (pmc_workspace_bytes); the library keeps only a
- *     few KB of device scratch per (device, stream) for its finishing reduction and a pool of HIP events
+ *   - all N-sized and K-sized device memory is the caller's (pmc_workspace_bytes); the library keeps only
+ *     20 KB of device scratch per (device, stream) for its finishing reduction and block tickets and a pool of HIP events
  *     while timing is enabled.  Calls on different streams may run concurrently if they are given
  *     different workspaces.
  *
@@ -125,7 +125,7 @@ int pmc_pack_means(int K, int D, const double *h_mu, double *h_pack);
 
 /* ---- streams ---------------------------------------------------------------------------------- */
 /*
- * The library keeps 4.4 KB of device scratch per (device, stream) it has launched a finishing reduction on -- at most
+ * The library keeps 20 KB of device scratch per (device, stream) it has launched a finishing reduction on -- at most
  * 256 such slots.  A caller that creates and destroys streams over its lifetime calls this (current device = the
  * stream's) once the stream is idle, before destroying it: the slot is handed to the next new stream.  Needed for
  * correctness too: a new stream may receive the handle value of a destroyed one.  Callers with a fixed set of streams
