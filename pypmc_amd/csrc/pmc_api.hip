@@ -2463,6 +2463,28 @@ int pmc_internal_get_timings(void *stream, pmc_timing *h_out, int max_entries, i
     return collect_timings((hipStream_t)stream, h_out, max_entries, n_entries);
 }
 
+// What split_plan decides for a shape, for the host-side tests (not in the public header): out[0..9] = on, b1, s1, c1, s2, c2,
+// grid, bytes of the pieces' region the launch uses, bytes reserved for it, its offset in the workspace.  resp != 0: the
+// responsibility kernel's plan (units = groups of 16 components).
+int pmc_internal_split_plan(int64_t N, int K, int K2, int D, int resp, int64_t *out)
+{
+    TuneScope options;
+    if (N < 0 || K < 1 || K2 < 0 || !out) return fail(PMC_EINVAL, "pmc_internal_split_plan: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
+    const long long nblocks = ceil_div(ceil_div(N, PMC_TILE), PMC_A_WAVES);
+    const SplitPlan sp = !ks->logpdf_split ? SplitPlan()
+                         : (resp ? split_plan(ks, nblocks, (int)ceil_div(K, PMC_RESP_GROUP), 0, 1)
+                                 : split_plan(ks, nblocks, K, K2, split_min_units(ks), split_tail_min_units(ks)));
+    const int Kws = K > K2 ? K : K2;
+    const long long bt = sp.on ? nblocks - sp.b1 : 0;
+    const long long used = resp ? bt * ceil_div(K, PMC_RESP_GROUP) * 3 * PMC_A_WAVES * 64 * (long long)sizeof(double)
+                                : bt * (sp.s1 + sp.s2) * 2 * PMC_A_WAVES * 64 * (long long)sizeof(double);
+    out[0] = sp.on; out[1] = sp.b1; out[2] = sp.s1; out[3] = sp.c1; out[4] = sp.s2; out[5] = sp.c2; out[6] = sp.grid;
+    out[7] = used; out[8] = (int64_t)split_bytes(N, Kws); out[9] = (int64_t)split_offset(N, Kws, ks);
+    return PMC_OK;
+}
+
 int pmc_estep_is_fused(int K, int D, int kind, int mode)
 {
     const PmcKernelSet *ks = kernels_for(D);

@@ -193,3 +193,52 @@ def test_host_convert_stats_is_bit_identical_to_numpy():
         for a, b in ((sc, got[0]), (S0, got[1]), (M1, got[2]), (mean, got[3]), (cov, got[4]), (V1, got[6]), (V2, got[7])):
             assert np.array_equal(a, b, equal_nan=True), trial
         assert far == got[5], trial
+
+
+def test_split_plan_invariants():
+    """round 6: the components of a sample block in pieces (include/pmc_hip.h, "split_components").  What the plan decides
+    for a shape is host arithmetic: for a sweep of shapes -- every compiled dimension class, K = 1 ... 1000, a target mixture
+    larger than the proposal, launches from one block to beyond split_max_rounds -- the pieces cover every component exactly
+    once, the grid is whole blocks + blocks x pieces, the blocks in pieces fit the library's ticket counters, and what the
+    launch writes into the pieces' region fits the bytes pmc_workspace_bytes reserved for it behind everything else."""
+    from pypmc_amd import _lib
+    lib = _lib.load()
+    fn = lib.pmc_internal_split_plan
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    out = (C.c_int64 * 10)()
+    rs = np.random.RandomState(0)
+    seen_on = seen_tail = 0
+    shapes = [(N, K, K2, D) for D in (2, 8, 16, 20, 24, 30, 32, 40, 64)
+              for N in (1, 255, 256, 257, 4096, 65536, 262144, 300000, 1_000_000, 1_250_000, 5_000_000, 10_000_000, 40_000_000)
+              for K, K2 in ((1, 0), (3, 0), (4, 4), (16, 0), (32, 4), (33, 40), (64, 0), (128, 4), (1000, 7), (5, 300))]
+    for N, K, K2, D in shapes:
+        nblocks = -(-(-(-N // 64)) // 4)
+        ws = int(lib.pmc_workspace_bytes(N, max(K, K2), D))
+        for resp in (0, 1):
+            assert fn(N, K, K2 if not resp else 0, D, resp, out) == 0, lib.pmc_last_error()
+            on, b1, s1, c1, s2, c2, grid, used, reserved, offset = [int(v) for v in out]
+            if not on:
+                continue
+            seen_on += 1
+            bt = nblocks - b1
+            seen_tail += b1 > 0
+            assert 0 <= b1 < nblocks and 1 <= bt <= 4096, (N, K, D, resp, b1)
+            units1 = -(-K // 16) if resp else K
+            assert s1 >= 1 and c1 >= 1 and (s1 - 1) * c1 < units1 <= s1 * c1, "the pieces cover the components exactly"
+            if not resp and K2:
+                assert s2 >= 1 and (s2 - 1) * c2 < K2 <= s2 * c2
+            else:
+                assert s2 == 0
+            assert s1 + s2 >= 2 and grid == b1 + bt * (s1 + s2) and grid < 2 ** 31
+            assert used <= reserved, (N, K, K2, D, resp, used, reserved)
+            assert offset % 256 == 0 and offset + used <= ws, "the pieces' region lies inside the workspace"
+    assert seen_on > 200 and seen_tail > 20
+    # switched off: no plan
+    assert lib.pmc_configure(b"split_components", 0.0) == 0
+    try:
+        assert fn(4096, 128, 0, 40, 0, out) == 0 and out[0] == 0
+    finally:
+        d = C.c_double()
+        assert lib.pmc_option_default(b"split_components", C.byref(d)) == 0
+        assert lib.pmc_configure(b"split_components", d.value) == 0
