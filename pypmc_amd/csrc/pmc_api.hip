@@ -1138,7 +1138,7 @@ int device_cus()
 }
 // workgroups of the per-sample kernels (4 wavefronts) a compute unit holds at a time: the registers of the compiled dimension
 // decide (pmc_min_waves, pmc_persample.hip; measured occupancies: DESIGN section 6)
-int split_slots_per_cu(int dim) { return dim <= 16 ? 5 : (dim <= 24 ? 4 : (dim <= 32 ? 3 : 2)); }
+int split_slots_per_cu(int dim) { return dim <= 16 ? 5 : (dim <= 20 ? 4 : (dim <= 32 ? 3 : 2)); }
 // smallest piece in components: a piece pays the load of its samples, its launch slot and the merge once
 int split_min_units(const PmcKernelSet *ks)
 {
@@ -1193,6 +1193,11 @@ SplitPlan split_plan(const PmcKernelSet *ks, long long nblocks, int units1, int 
         s2 = (int)ceil_div(units2, c2);
     }
     if (s1 + s2 < 2) return sp;
+    // A launch that fills the chip: only where the FIRST mixture is cut (a piece for the target mixture alone costs a second
+    // load of the block's samples for a handful of components: K = 8 + 4: +3 ... +9 %) and not at compiled dimension 64 (the
+    // split kernel spills a little more than k_logpdf<64>, which its whole blocks pay: K = 32: +2.6 %) --
+    // scripts/split_regression_check.py, profiles/r06_split_regression_check.txt
+    if (nblocks > slots && (s1 < 2 || ks->dim > 48)) return sp;
     const int per_block = (s1 + s2 > units1) ? s1 + s2 : units1;      // (the responsibilities keep three numbers per group)
     if (bt > PMC_SPLIT_MAX_BLOCKS) bt = PMC_SPLIT_MAX_BLOCKS;
     if (bt * per_block > PMC_SPLIT_MAX_PIECES) bt = PMC_SPLIT_MAX_PIECES / per_block;
