@@ -323,6 +323,10 @@ def diagnose(n_doubles, rounds=100, device=None, progress=None):
     Reference role: the gather of pypmc/tools/parallel_sampler.py:58-71."""
     progress = progress if progress is not None else {}
     progress["stage"] = "start"
+    if _os.environ.get("PMC_DIAG_TEST_HANG"):             # (test switch: a collective that never returns -- the caller's
+        import time as _t                                 #  watchdog has to get the headline out without this function)
+        progress["stage"] = "test hang"
+        _t.sleep(1e9)
     import socket
     import time
     d = _dist()

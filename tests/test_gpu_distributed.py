@@ -62,6 +62,21 @@ def test_bench_two_ranks_one_gpu():
     assert p2p.get("enabled") is False or (p2p["ok"] is True and p2p["ms_per_round"] > 0 and "selftest=passed" in p2p["info"]), p2p
 
 
+def test_bench_line_survives_a_diagnosis_that_never_returns():
+    """the watchdog around the multi-GPU self-diagnosis: with a collective that hangs (PMC_DIAG_TEST_HANG) the line still goes
+    out -- with the stage the diagnosis was stuck in -- and every rank leaves with status 0"""
+    env = dict(os.environ, PMC_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", PMC_DIAG_TEST_HANG="1")
+    r = run_torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "2",
+                         "--samples-per-gpu", "200000", "--diagnose-timeout", "3"], env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    diag = line["dist"]["diagnostics"]
+    assert "timed out" in diag["error"] and diag["stage"] == "test hang"
+
+
 @pytest.mark.parametrize("script,args", [("pmc_device_loop.py", ["100000", "2"]), ("variational.py", ["60000"]),
                                          ("pmc_torchrun.py", ["4000"])])
 def test_examples_under_torchrun(script, args):
