@@ -758,7 +758,13 @@ def main():
                      "group": "torch.distributed process group" if grouped else "none (single process, no collective)",
                      # several real devices (or --diagnose): the same sum through every collective this package has,
                      # bit-exact checks, 100-round timings, per-rank errors (parallel.diagnose)
-                     "diagnostics": diag},
+                     "diagnostics": diag,
+                     # (the same, flat: what the verdict asked to find at a glance)
+                     "p2p_status": (diag or {}).get("p2p") if isinstance(diag, dict) else None,
+                     "allreduce_ms_by_backend": ({k_: v_.get("ms_per_round") for k_, v_ in diag.items()
+                                                  if k_ in ("default", "rccl_native", "p2p") and isinstance(v_, dict)}
+                                                 if isinstance(diag, dict) else None),
+                     "world_size_as_the_backend_reports_it": (diag or {}).get("world_size") if isinstance(diag, dict) else None},
             "is_samples_per_s": n_total / (is_ms * 1e-3),
             "vb_estep_samples_per_s": n_total / (vb_ms * 1e-3),
             # lower bound: the launch evaluates the K=32 proposal AND the K_t=4 target per sample
