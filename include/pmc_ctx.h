@@ -198,6 +198,52 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
                  const double *h_ln_lambda, const double *h_shift, double *h_N_k, double *h_xbar, double *h_S,
                  double *h_elogqz, double *h_r, double *h_log_rho);
 
+/* ---- a VB fit whose K-sized state stays on the device (round 6) --------------------------------------- */
+/*
+ * GaussianInference.update() = M_step + E_step (pypmc/mix_adapt/variational.pyx:571-578, :129-136, :116-127) and
+ * likelihood_bound() (:194-209) for an object whose hyper-parameters live on the context's device between the calls: with
+ * pmc_vb_estep the K x D x D arrays W and S cross the bus twice per iteration and the M-step's K inversions, the digamma
+ * sums and the bound run in the caller's interpreter -- at one GPU's share of eight that was an eighth of an iteration.
+ * One-device contexts, D <= pmc_vb_max_dim().
+ *
+ * Fields (enum pmc_vb_field; K, K x D or K x D x D doubles, row-major): the prior ALPHA0, BETA0, NU0, M0, INV_W0 (the
+ *   INVERSE of the constructor's W0), LOG_DET_W0 (of W0); the posterior ALPHA, BETA, NU, M, W, LOG_DET_W; the expectations
+ *   LN_LAMBDA, LN_PI (written by every E-step); the latest E-step's N_COMP, X_MEAN, S; SHIFT_PREV (the means the next
+ *   E-step may take its moments about); and, read-only, E_M ... E_LN_LAMBDA: the parameters the latest E-step ran with
+ *   (the object's r / log_rho attributes belong to THEM even after a later M-step).
+ * pmc_vb_state_put queues a copy from the host (pinned staging: the call returns before the copy ran); pmc_vb_state_get
+ *   waits for everything queued and copies one field back.
+ * pmc_vb_state_step(st, samples, flags, h_psi_parts, h_result): the steps named in `flags`, in this order --
+ *   PMC_VB_DO_MSTEP   M-step from the prior and N_COMP / X_MEAN / S (pmc_vb_mstep_device);
+ *   PMC_VB_DO_ESTEP   expectations -> pack -> responsibilities and statistics over `samples` (and the ranks of a joined
+ *                     context) -> N_COMP, X_MEAN, S; with PMC_VB_ABOUT_PREV the moments are taken about SHIFT_PREV instead
+ *                     of M (pmc_vb_estep's h_shift); a second pass about the mean just found happens inside when needed;
+ *                     h_psi_parts (2 K doubles or NULL) = the caller's own psi parts of the expectations
+ *                     (pmc_vb_expectations_device: [E[ln pi] | sum psi + D ln 2]; both depend on N_COMP alone, which the
+ *                     caller holds) -- NULL: the device's psi;
+ *   PMC_VB_DO_BOUND   the bound of the state as it is then;
+ *   and ONE copy brings back h_result (pmc_vb_state_result_len(K) = 8 K + 16 doubles) = [N_comp K | far K | 1 if
+ *   x_mean_k is finite, K | 1 if S_k has a finite entry, K | the E-step's 8 scalars (first: E log q(Z)) | pack status 2 K |
+ *   M-step status 2 K | L(Q) and its seven terms (pmc_vb_bound_device)].  h_result may be NULL for an M-step alone: it is
+ *   queued, and a W_k^-1 that does not factorise is reported (PMC_ENOTPOSDEF, naming the component) by the next call
+ *   that copies a block back.  The reference's checks of N_comp and S (variational.pyx:122-126) stay with the caller.
+ */
+typedef struct pmc_vb_state pmc_vb_state;
+enum pmc_vb_field {
+    PMC_VB_ALPHA0 = 0, PMC_VB_BETA0, PMC_VB_NU0, PMC_VB_M0, PMC_VB_INV_W0, PMC_VB_LOG_DET_W0,
+    PMC_VB_ALPHA, PMC_VB_BETA, PMC_VB_NU, PMC_VB_M, PMC_VB_W, PMC_VB_LOG_DET_W,
+    PMC_VB_LN_LAMBDA, PMC_VB_LN_PI, PMC_VB_N_COMP, PMC_VB_X_MEAN, PMC_VB_S, PMC_VB_SHIFT_PREV,
+    PMC_VB_E_M, PMC_VB_E_W, PMC_VB_E_BETA, PMC_VB_E_NU, PMC_VB_E_LN_PI, PMC_VB_E_LN_LAMBDA,
+    PMC_VB_NFIELDS
+};
+enum { PMC_VB_DO_MSTEP = 1, PMC_VB_DO_ESTEP = 2, PMC_VB_DO_BOUND = 4, PMC_VB_ABOUT_PREV = 8 };
+int pmc_vb_state_create(pmc_ctx *ctx, int K, int D, pmc_vb_state **out);
+int pmc_vb_state_destroy(pmc_vb_state *st);
+int pmc_vb_state_put(pmc_vb_state *st, int field, const double *h);
+int pmc_vb_state_get(pmc_vb_state *st, int field, double *h);
+int64_t pmc_vb_state_result_len(int K);
+int pmc_vb_state_step(pmc_vb_state *st, const pmc_samples *s, int flags, const double *h_psi_parts, double *h_result);
+
 /* ---- PMC update --------------------------------------------------------------------------------------- */
 /*
  * The N-sized part of gaussian_pmc / student_t_pmc (pypmc/mix_adapt/pmc.pyx:120-246, :499-739) for the proposal

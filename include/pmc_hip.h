@@ -397,6 +397,64 @@ int64_t pmc_convert_stats_len(int K, int D);
 int pmc_convert_stats_device(int K, int D, const double *d_stats, const double *d_shift, const double *d_n_cov,
                              const double *d_scalars, double *d_out, void *stream);
 
+/* ---- the K-sized half of a variational-Bayes iteration on the device (round 6) --------------------- */
+/*
+ * What pypmc's GaussianInference does between two E-steps on K-sized arrays -- M_step (pypmc/mix_adapt/variational.pyx:
+ * 129-136 with _update_m :693-697 and _update_W :934-946), the expectations an E-step starts with (:759-772, :800-804)
+ * and likelihood_bound (:194-209, :948-1034, Wishart_log_B :1220-1247, Dirichlet_log_C :1269-1275) -- as kernels on
+ * device-resident hyper-parameters, so that nothing K x D x D crosses the bus per iteration (pmc_ctx.h: pmc_vb_state is
+ * the object that owns the arrays and strings the calls together).  D <= pmc_vb_max_dim() (64): one wavefront per
+ * component, its matrix in LDS.
+ *
+ * pmc_vb_fields: DEVICE arrays, row-major -- the prior (alpha0, beta0, nu0: K; m0: K x D; inv_W0: K x D x D; log_det_W0:
+ *   K), the posterior (alpha, beta, nu, m, W, log_det_W likewise), the expectations (ln_lambda = E[ln|Lambda_k|] (10.65),
+ *   ln_pi = E[ln pi_k] (10.66): K) and the latest E-step's sums (N_comp K -- a zero counts as numpy's tiny, :699-709 --,
+ *   x_mean K x D, S K x D x D).
+ * pmc_vb_mstep_device: alpha, beta, nu, m, W, log_det_W from the prior and the sums.  W_k = inv(W_k^-1) through the
+ *   Cholesky factor (the algorithm of LAPACK's potrf / potri, which the host path calls: the two agree to rounding,
+ *   not bitwise; W comes out symmetric bit for bit).  d_status: 2 K doubles ([1 + failing pivot or 0 | its value], every
+ *   slot written); pmc_vb_mstep_status(K, h_status) turns a copy of them into PMC_OK / PMC_ENOTPOSDEF naming the lowest
+ *   component (its W is NaN then).
+ * pmc_vb_expectations_device: ln_lambda, ln_pi from alpha, nu, log_det_W; and, if not NULL, the two constants of the
+ *   posterior's pack (enum pmc_kind, PMC_KIND_VB) that are not fields: d_c0 = D / beta, d_c3 = ln_lambda - D ln 2 pi.
+ *   d_psi_parts (2 K doubles or NULL): the caller's own [E[ln pi_k] K | sum_i psi((nu_k + 1 - i) / 2) + D ln 2, K]; the
+ *   kernel then only adds ln|W_k|.  For callers that need the REFERENCE's psi bit for bit: with the default prior
+ *   nu0 = D - 1 + 1e-5 the sum holds psi(5e-6) = -2e5, and one ulp of that is 3e-11 of every exponent of the E-step.
+ * pmc_vb_after_device: behind an E-step -- d_conv = pmc_convert_stats_device's block; copies its means and covariances
+ *   into x_mean / S (and the means into d_shift_prev, K x D: the next E-step's shifts), N_comp = its S0 with zeros
+ *   replaced, *d_log_q_Z = the E-step's first scalar (10.75), and writes what a host reads after an E-step,
+ *   d_small (pmc_vb_small_len(K) = 4 K + 8 doubles) = [N_comp K | far K | 1 if x_mean_k is finite, K | 1 if S_k has a
+ *   finite entry, K | the call's 8 scalars].
+ * pmc_vb_newshift_device: the shifts of a second statistics pass (a mean far from its shift: variational.pyx:806-932's two
+ *   passes): d_out = d_shift + M1 / S0 where S0 > 1e-200, d_shift elsewhere.
+ * pmc_vb_bound_device: d_out[8] = [L(Q) | E log p(X) | E log p(Z) | E log p(pi) | E log p(mu, Lambda) | E log q(Z) |
+ *   E log q(pi) | E log q(mu, Lambda)]; d_scratch: pmc_vb_bound_scratch_len(K) doubles.  Sums over components run in
+ *   component order: the same input gives the same bits.
+ * pmc_host_digamma / pmc_host_lgamma: the psi and ln Gamma the kernels use (x > 0; NaN otherwise), on the host, for
+ *   tests: |error| <= 2e-15 (1 + |value|) for psi, 1e-14 (1 + |value|) for ln Gamma (the recurrence below x = 10 costs the
+ *   difference of two logarithms of about 17).
+ */
+typedef struct pmc_vb_fields {
+    double *alpha0, *beta0, *nu0, *m0, *inv_W0, *log_det_W0;
+    double *alpha, *beta, *nu, *m, *W, *log_det_W;
+    double *ln_lambda, *ln_pi;
+    double *N_comp, *x_mean, *S;
+} pmc_vb_fields;
+int pmc_vb_max_dim(void);
+int pmc_vb_mstep_device(int K, int D, const pmc_vb_fields *f, double *d_status, void *stream);
+int pmc_vb_mstep_status(int K, const double *h_status);
+int pmc_vb_expectations_device(int K, int D, const pmc_vb_fields *f, const double *d_psi_parts, double *d_c0, double *d_c3,
+                               void *stream);
+int64_t pmc_vb_small_len(int K);
+int pmc_vb_after_device(int K, int D, const double *d_conv, const pmc_vb_fields *f, double *d_small, double *d_shift_prev,
+                        double *d_log_q_Z, void *stream);
+int pmc_vb_newshift_device(int K, int D, const double *d_conv, const double *d_shift, double *d_out, void *stream);
+int64_t pmc_vb_bound_scratch_len(int K);
+int pmc_vb_bound_device(int K, int D, const pmc_vb_fields *f, const double *d_log_q_Z, double *d_scratch, double *d_out,
+                        void *stream);
+double pmc_host_digamma(double x);
+double pmc_host_lgamma(double x);
+
 /* ---- a PMC iteration without evaluating the proposal twice --------------------------------------- */
 /*
  * The reference evaluates the proposal's component densities on the same samples twice per PMC iteration:

@@ -113,6 +113,18 @@ SIGNATURES = {
     "pmc_estep_from_u_grouped": (_int, [_vp, _i64, _int, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "pmc_estep_from_tiles": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
                                     _vp]),
+    # the K-sized half of a VB iteration on the device (struct pmc_vb_fields * travels as a plain pointer)
+    "pmc_vb_max_dim": (_int, []),
+    "pmc_vb_mstep_device": (_int, [_int, _int, _vp, _vp, _vp]),
+    "pmc_vb_mstep_status": (_int, [_int, _dp]),
+    "pmc_vb_expectations_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_vb_small_len": (_i64, [_int]),
+    "pmc_vb_after_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_vb_newshift_device": (_int, [_int, _int, _vp, _vp, _vp, _vp]),
+    "pmc_vb_bound_scratch_len": (_i64, [_int]),
+    "pmc_vb_bound_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_host_digamma": (C.c_double, [C.c_double]),
+    "pmc_host_lgamma": (C.c_double, [C.c_double]),
 }
 
 
@@ -153,7 +165,20 @@ CTX_SIGNATURES = {
     "pmc_weighted_moments": (_int, [_vp, _vp, _dp, _int, _dp, _dp]),
     "pmc_host_convert_stats": (_int, [_int, _int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "pmc_host_chol_inv_det_batch": (_int, [_int, _int, _dp, _vp, _vp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
+    "pmc_vb_state_create": (_int, [_vp, _int, _int, _pp]),
+    "pmc_vb_state_destroy": (_int, [_vp]),
+    "pmc_vb_state_put": (_int, [_vp, _int, _dp]),
+    "pmc_vb_state_get": (_int, [_vp, _int, _dp]),
+    "pmc_vb_state_result_len": (_i64, [_int]),
+    "pmc_vb_state_step": (_int, [_vp, _vp, _int, _dp, _dp]),
 }
+
+# enum pmc_vb_field / the step flags (include/pmc_ctx.h)
+VB_FIELDS = ("alpha0", "beta0", "nu0", "m0", "inv_W0", "log_det_W0", "alpha", "beta", "nu", "m", "W", "log_det_W",
+             "expectation_det_ln_lambda", "expectation_ln_pi", "N_comp", "x_mean_comp", "S", "_shift_prev",
+             "E_m", "E_W", "E_beta", "E_nu", "E_ln_pi", "E_ln_lambda")
+VB_FIELD_ID = dict((n, i) for i, n in enumerate(VB_FIELDS))
+VB_DO_MSTEP, VB_DO_ESTEP, VB_DO_BOUND, VB_ABOUT_PREV = 1, 2, 4, 8
 
 
 class Timing(C.Structure):

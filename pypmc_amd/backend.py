@@ -649,12 +649,81 @@ class HipBackend(object):
                                _dptr(xbar), _dptr(S), _dptr(elq), None, None), "pmc_vb_estep")
         return dict(N_comp=Nk, x_mean_comp=xbar, S=S, log_q_Z=float(elq[0]))
 
+    def vb_state_supported(self, D):
+        """True where the device-resident VB update exists (pmc_vb_state: D <= 64, compiled dimensions)"""
+        return 1 <= D <= min(int(self.lib.pmc_vb_max_dim()), int(self.lib.pmc_max_compiled_dim()))
+
+    def vb_state(self, K, D):
+        """the K-sized state of a GaussianInference on this backend's device (pmc_vb_state, include/pmc_ctx.h)"""
+        return VBState(self, K, D)
+
     def stats_len(self, K, D):
         """length of the flat statistics buffer of estep()"""
         return NSCALARS + K * int(self.lib.pmc_stats_stride(D)) + 2 * K
 
     def stats_stride(self, D):
         return int(self.lib.pmc_stats_stride(D))
+
+
+class VBState(object):
+    """Prior, posterior and latest sums of a variational-Bayes fit on the device (``pmc_vb_state``): ``put`` / ``get`` move
+    one field, ``step`` runs M-step / E-step / bound there and returns the small block a host needs per iteration."""
+
+    def __init__(self, be, K, D):
+        self.be, self.K, self.D, self._h = be, int(K), int(D), None
+        h = C.c_void_p()
+        _lib.check(be.lib.pmc_vb_state_create(be.ctx(), self.K, self.D, C.byref(h)), "pmc_vb_state_create")
+        self._h = h
+        self._result = np.empty(int(be.lib.pmc_vb_state_result_len(self.K)))
+
+    def shape(self, name):
+        K, D = self.K, self.D
+        if name in ("m0", "m", "x_mean_comp", "_shift_prev", "E_m"):
+            return (K, D)
+        if name in ("inv_W0", "W", "S", "E_W"):
+            return (K, D, D)
+        return (K,)
+
+    def put(self, name, value):
+        a = np.ascontiguousarray(value, dtype=np.float64)
+        if a.shape != self.shape(name):
+            raise ValueError("field %s: shape %s, expected %s" % (name, a.shape, self.shape(name)))
+        _lib.check(self.be.lib.pmc_vb_state_put(self._h, _lib.VB_FIELD_ID[name], _dptr(a)), "pmc_vb_state_put")
+
+    def get(self, name):
+        out = np.empty(self.shape(name))
+        _lib.check(self.be.lib.pmc_vb_state_get(self._h, _lib.VB_FIELD_ID[name], _dptr(out)), "pmc_vb_state_get")
+        return out
+
+    def step(self, samples, mstep=False, estep=False, bound=False, about_prev=False, psi_parts=None):
+        """dict(N_comp, far, mean_finite, S_any_finite, log_q_Z, bound (8: L(Q) and its terms)) -- None for an M-step alone
+        (queued; a matrix that does not factorise is reported by the next step that returns a block).  ``psi_parts``
+        (2 K): the caller's own [E[ln pi] | sum psi + D ln 2] for the E-step (pmc_ctx.h), None = the device's psi."""
+        flags = (_lib.VB_DO_MSTEP if mstep else 0) | (_lib.VB_DO_ESTEP if estep else 0) | (_lib.VB_DO_BOUND if bound else 0) | \
+            (_lib.VB_ABOUT_PREV if about_prev else 0)
+        want = estep or bound
+        if psi_parts is not None:
+            psi_parts = np.ascontiguousarray(psi_parts, dtype=np.float64)
+            assert psi_parts.shape == (2 * self.K,)
+        _lib.check(self.be._timed("pmc_vb_state_step", self.be.lib.pmc_vb_state_step, self._h, samples._h if samples is not None else None,
+                                  flags, _dptr(psi_parts) if psi_parts is not None else None, _dptr(self._result) if want else None),
+                   "pmc_vb_state_step")
+        if not want:
+            return None
+        K, r = self.K, self._result
+        return dict(N_comp=r[:K].copy(), far=r[K:2 * K], mean_finite=r[2 * K:3 * K], S_any_finite=r[3 * K:4 * K],
+                    log_q_Z=float(r[4 * K]), bound=r[8 * K + 8:8 * K + 16].copy())
+
+    def close(self):
+        if self._h is not None:
+            self.be.lib.pmc_vb_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
 
 
 class _WrappedSamples(object):

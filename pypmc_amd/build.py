@@ -94,6 +94,8 @@ def build(jobs=None, force=False, verbose=False):
     work.append((os.path.join(OBJ, "pmc_ctx.o"), csrc, [], [csrc, ctx_h, headers[2]], force))
     psrc = os.path.join(CSRC, "pmc_p2p.hip")          # the one-shot exchange among the ranks of a node (HIP IPC)
     work.append((os.path.join(OBJ, "pmc_p2p.o"), psrc, [], [psrc] + headers, force))
+    vsrc = os.path.join(CSRC, "pmc_vbstate.hip")      # the K-sized half of a VB iteration as kernels (any D <= 64)
+    work.append((os.path.join(OBJ, "pmc_vbstate.o"), vsrc, [], [vsrc] + headers, force))
     tsrc = os.path.join(CSRC, "pmc_tiles.hip")        # one unit for all dimensions (PMC_D is not used by it)
     work.append((os.path.join(OBJ, "pmc_tiles.o"), tsrc, ["-DPMC_D=1"], [tsrc] + headers, force))
     # the run-time-dimension unit (sample dimensions beyond the compiled ones): its own kernels plus the per-sample

@@ -1249,6 +1249,208 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
     return PMC_OK;
 }
 
+// ---- a VB fit whose K-sized state stays on the device (round 6, verdict r5 #6) ------------------------------
+// GaussianInference.update / .likelihood_bound (variational.pyx:571-578, :194-209) without K x D x D arrays crossing the
+// bus: the prior, the posterior and the latest sums live in ONE allocation on the context's device, pmc_vb_state_step
+// strings the kernels of pmc_hip.h ("the K-sized half of a variational-Bayes iteration") and the E-step's together on the
+// part's stream and brings back one small block.
+struct pmc_vb_state {
+    pmc_ctx *ctx;
+    int K, D;
+    DevBuf buf, pack, spack;
+    double *field[PMC_VB_NFIELDS];
+    pmc_vb_fields f;
+    double *c0, *c3, *log_q_Z, *result, *conv, *terms, *shift2, *shift_next, *psi_parts;
+    size_t nresult, nconv;
+    bool stepped;                                                   // an E-step has run: the E_* fields mean something
+};
+
+static size_t vb_field_len(int field, int K, int D)
+{
+    switch (field) {
+    case PMC_VB_M0: case PMC_VB_M: case PMC_VB_X_MEAN: case PMC_VB_SHIFT_PREV: case PMC_VB_E_M:
+        return (size_t)K * D;
+    case PMC_VB_INV_W0: case PMC_VB_W: case PMC_VB_S: case PMC_VB_E_W:
+        return (size_t)K * D * D;
+    default:
+        return (size_t)K;
+    }
+}
+
+// one pass of the E-step from the resident state: the pack (and the shifts' pack) -> responsibilities + statistics ->
+// the sum over ranks -> conversion -> the state's sums and the small block
+static int vb_state_pass(pmc_vb_state *st, const pmc_samples *s, Part &pt, const double *d_shift, bool with_pack, bool own_psi)
+{
+    pmc_ctx *ctx = st->ctx;
+    const int K = st->K, D = st->D;
+    const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
+    const size_t nflat = NSC + (size_t)K * PS;
+    const int64_t N = s->n(0);
+    double *d_pstatus = st->result + (size_t)pmc_vb_small_len(K);
+    if (with_pack) {
+        CK(pmc_vb_expectations_device(K, D, &st->f, own_psi ? nullptr : st->psi_parts, st->c0, st->c3, pt.stream));
+        CK(st->pack.ensure((size_t)K * stride * sizeof(double)));
+        if (d_shift) CK(st->spack.ensure((size_t)K * stride * sizeof(double)));
+        CK(pmc_pack_components_device(K, D, st->f.m, st->f.W, st->c0, st->f.nu, st->f.ln_pi, st->c3, nullptr, nullptr, st->pack.d(),
+                                      d_pstatus, d_shift, d_shift ? st->spack.d() : nullptr, pt.stream));
+    } else {
+        CK(st->spack.ensure((size_t)K * stride * sizeof(double)));
+        CK(pmc_pack_means_device(K, D, d_shift, st->spack.d(), pt.stream));
+    }
+    CK(workspace(pt, N, K, D));
+    CK(pt.u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, K)));
+    CK(pt.flat.ensure(sizeof(double) * nflat));
+    const double *d_sw = (N > 0 && s->has_sw) ? s->sw[0].d() : nullptr;
+    double *d_flat = pt.flat.d();
+    CK(pmc_estep_about(s->x[0].d(), N, D, st->pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, pt.u.d(), nullptr, nullptr,
+                       d_flat + NSC, d_flat, pt.ws.p, d_shift ? st->spack.d() : nullptr, pt.stream));
+    CK(reduce(ctx, d_flat, nflat));
+    CK(pmc_convert_stats_device(K, D, d_flat + NSC, d_shift ? d_shift : st->f.m, nullptr, d_flat, st->conv, pt.stream));
+    return pmc_vb_after_device(K, D, st->conv, &st->f, st->result, st->shift_next, st->log_q_Z, pt.stream);
+}
+
+int pmc_vb_state_create(pmc_ctx *ctx, int K, int D, pmc_vb_state **out)
+{
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    if (!out || K < 1 || D < 1) return failf(PMC_EINVAL, "pmc_vb_state_create: bad argument");
+    if (ctx->nparts() != 1) return failf(PMC_EINVAL, "pmc_vb_state_create: a context of one device only");
+    if (D > pmc_vb_max_dim() || D > pmc_max_compiled_dim())
+        return failf(PMC_EINVAL, "pmc_vb_state_create: D = %d: the device-resident update covers D <= %d", D, pmc_vb_max_dim());
+    pmc_vb_state *st = new pmc_vb_state();
+    st->ctx = ctx;
+    st->K = K;
+    st->D = D;
+    st->stepped = false;
+    st->nconv = (size_t)pmc_convert_stats_len(K, D);
+    st->nresult = (size_t)pmc_vb_state_result_len(K);
+    const size_t KD = (size_t)K * D;
+    // the fields; [m | W | beta | nu | ln_pi | ln_lambda] and their E-step copies in the same order, each contiguous
+    static const int order[PMC_VB_NFIELDS] = {PMC_VB_ALPHA0, PMC_VB_BETA0, PMC_VB_NU0, PMC_VB_M0, PMC_VB_INV_W0, PMC_VB_LOG_DET_W0,
+                                              PMC_VB_ALPHA, PMC_VB_LOG_DET_W, PMC_VB_N_COMP, PMC_VB_X_MEAN, PMC_VB_S, PMC_VB_SHIFT_PREV,
+                                              PMC_VB_M, PMC_VB_W, PMC_VB_BETA, PMC_VB_NU, PMC_VB_LN_PI, PMC_VB_LN_LAMBDA,
+                                              PMC_VB_E_M, PMC_VB_E_W, PMC_VB_E_BETA, PMC_VB_E_NU, PMC_VB_E_LN_PI, PMC_VB_E_LN_LAMBDA};
+    size_t total = 0;
+    for (int i = 0; i < PMC_VB_NFIELDS; ++i) total += vb_field_len(order[i], K, D);
+    const size_t extra = 4 * (size_t)K + 8 + st->nresult + st->nconv + (size_t)pmc_vb_bound_scratch_len(K) + 2 * KD;
+    if (st->buf.ensure(sizeof(double) * (total + extra)) < 0) {
+        delete st;
+        return PMC_EHIP;
+    }
+    double *p = st->buf.d();
+    for (int i = 0; i < PMC_VB_NFIELDS; ++i) {
+        st->field[order[i]] = p;
+        p += vb_field_len(order[i], K, D);
+    }
+    st->c0 = p; p += K;
+    st->c3 = p; p += K;
+    st->psi_parts = p; p += 2 * (size_t)K;
+    st->log_q_Z = p; p += 8;
+    st->result = p; p += st->nresult;
+    st->conv = p; p += st->nconv;
+    st->terms = p; p += (size_t)pmc_vb_bound_scratch_len(K);
+    st->shift2 = p; p += KD;
+    st->shift_next = p; p += KD;
+    Part &pt = *ctx->parts[0];
+    const hipError_t e = hipMemsetAsync(st->buf.p, 0, sizeof(double) * (total + extra), pt.stream);
+    if (e != hipSuccess) {
+        st->buf.release();
+        delete st;
+        return hipf(e, "hipMemsetAsync");
+    }
+    pmc_vb_fields &f = st->f;
+    f.alpha0 = st->field[PMC_VB_ALPHA0]; f.beta0 = st->field[PMC_VB_BETA0]; f.nu0 = st->field[PMC_VB_NU0];
+    f.m0 = st->field[PMC_VB_M0]; f.inv_W0 = st->field[PMC_VB_INV_W0]; f.log_det_W0 = st->field[PMC_VB_LOG_DET_W0];
+    f.alpha = st->field[PMC_VB_ALPHA]; f.beta = st->field[PMC_VB_BETA]; f.nu = st->field[PMC_VB_NU];
+    f.m = st->field[PMC_VB_M]; f.W = st->field[PMC_VB_W]; f.log_det_W = st->field[PMC_VB_LOG_DET_W];
+    f.ln_lambda = st->field[PMC_VB_LN_LAMBDA]; f.ln_pi = st->field[PMC_VB_LN_PI];
+    f.N_comp = st->field[PMC_VB_N_COMP]; f.x_mean = st->field[PMC_VB_X_MEAN]; f.S = st->field[PMC_VB_S];
+    *out = st;
+    return PMC_OK;
+}
+
+int pmc_vb_state_destroy(pmc_vb_state *st)
+{
+    if (!st) return PMC_OK;
+    CK(use(st->ctx));
+    CtxCall call_(st->ctx);
+    (void)hipStreamSynchronize(st->ctx->parts[0]->stream);
+    st->buf.release();
+    st->pack.release();
+    st->spack.release();
+    delete st;
+    return PMC_OK;
+}
+
+int64_t pmc_vb_state_result_len(int K) { return K < 1 ? (int64_t)failf(PMC_EINVAL, "pmc_vb_state_result_len: bad K") : pmc_vb_small_len(K) + 4 * (int64_t)K + 8; }
+
+int pmc_vb_state_put(pmc_vb_state *st, int field, const double *h)
+{
+    if (!st || !h || field < 0 || field >= PMC_VB_E_M) return failf(PMC_EINVAL, "pmc_vb_state_put: bad argument (the E_* fields are read-only)");
+    CK(use(st->ctx));
+    CtxCall call_(st->ctx);
+    Part &pt = *st->ctx->parts[0];
+    if (field == PMC_VB_W)                                          // (W from outside replaces the M-step's: a failed one's flags go)
+        HK(hipMemsetAsync(st->result + (size_t)pmc_vb_small_len(st->K) + 2 * (size_t)st->K, 0, sizeof(double) * 2 * (size_t)st->K, pt.stream),
+           "hipMemsetAsync");
+    return h2d(pt, st->field[field], h, sizeof(double) * vb_field_len(field, st->K, st->D));
+}
+
+int pmc_vb_state_get(pmc_vb_state *st, int field, double *h)
+{
+    if (!st || !h || field < 0 || field >= PMC_VB_NFIELDS) return failf(PMC_EINVAL, "pmc_vb_state_get: bad argument");
+    if (field >= PMC_VB_E_M && !st->stepped) return failf(PMC_EINVAL, "pmc_vb_state_get: no E-step has run on this state yet");
+    CK(use(st->ctx));
+    CtxCall call_(st->ctx);
+    return d2h(*st->ctx->parts[0], h, st->field[field], sizeof(double) * vb_field_len(field, st->K, st->D));
+}
+
+int pmc_vb_state_step(pmc_vb_state *st, const pmc_samples *s, int flags, const double *h_psi_parts, double *h_result)
+{
+    if (!st) return failf(PMC_EINVAL, "pmc_vb_state_step: NULL state");
+    pmc_ctx *ctx = st->ctx;
+    CK(use(ctx));
+    CtxCall call_(ctx);
+    const bool do_m = flags & PMC_VB_DO_MSTEP, do_e = flags & PMC_VB_DO_ESTEP, do_b = flags & PMC_VB_DO_BOUND;
+    if (do_e && (!s || s->ctx != ctx || s->D != st->D)) return failf(PMC_EINVAL, "pmc_vb_state_step: the E-step needs samples of this context and dimension");
+    if ((do_e || do_b) && !h_result) return failf(PMC_EINVAL, "pmc_vb_state_step: h_result is required with an E-step or the bound");
+    const int K = st->K, D = st->D;
+    Part &pt = *ctx->parts[0];
+    CallLog log_(ctx, "pmc_vb_state_step", do_e ? s->N : 0, K, D);
+    const size_t nsmall = (size_t)pmc_vb_small_len(K);
+    double *d_mstatus = st->result + nsmall + 2 * (size_t)K, *d_bound = d_mstatus + 2 * (size_t)K;
+    if (do_m) CK(pmc_vb_mstep_device(K, D, &st->f, d_mstatus, pt.stream));
+    if (do_e && h_psi_parts) CK(h2d(pt, st->psi_parts, h_psi_parts, sizeof(double) * 2 * (size_t)K));
+    const size_t KD = (size_t)K * D, KDD = KD * D;
+    for (int pass = 0; pass < (do_e ? 2 : 1); ++pass) {
+        if (do_e) {
+            const double *d_shift = pass == 1 ? st->shift2 : ((flags & PMC_VB_ABOUT_PREV) ? st->field[PMC_VB_SHIFT_PREV] : nullptr);
+            CK(vb_state_pass(st, s, pt, d_shift, pass == 0, h_psi_parts == nullptr));
+        }
+        if (do_b) CK(pmc_vb_bound_device(K, D, &st->f, st->log_q_Z, st->terms, d_bound, pt.stream));
+        if (!h_result) return PMC_OK;                               // (an M-step alone: queued; its flags travel with the next block)
+        CK(d2h(pt, h_result, st->result, sizeof(double) * st->nresult));
+        if (ctx->p2p && do_e) CK(pmc_p2p_status(ctx->p2p, pt.stream));
+        CK(pmc_vb_mstep_status(K, h_result + nsmall + 2 * (size_t)K));
+        if (!do_e) return PMC_OK;
+        if (pass == 0) CK(pmc_pack_status(K, h_result + nsmall));
+        bool far = false;
+        for (int k = 0; k < K; ++k) far = far || h_result[(size_t)K + k] != 0.0;
+        if (pass == 1 || !far) break;
+        // second pass about the mean just found (variational.pyx:806-932 takes the mean first, then the covariance about it)
+        const double *d_old = (flags & PMC_VB_ABOUT_PREV) ? st->field[PMC_VB_SHIFT_PREV] : st->f.m;
+        CK(pmc_vb_newshift_device(K, D, st->conv, d_old, st->shift2, pt.stream));
+    }
+    // the next E-step's shifts = this one's means; the parameters this E-step ran with, for whoever asks for r / log rho later
+    double *old = st->field[PMC_VB_SHIFT_PREV];
+    st->field[PMC_VB_SHIFT_PREV] = st->shift_next;
+    st->shift_next = old;
+    HK(hipMemcpyAsync(st->field[PMC_VB_E_M], st->field[PMC_VB_M], sizeof(double) * (KD + KDD + 4 * (size_t)K), hipMemcpyDeviceToDevice,
+                      pt.stream), "hipMemcpyAsync (E-step parameters)");
+    st->stepped = true;
+    return PMC_OK;
+}
+
 // ---- PMC update -------------------------------------------------------------------------------------------
 int pmc_pmc_update_stats(pmc_ctx *ctx, const pmc_mix *mix, const pmc_samples *s, const double *h_w, int weights_on_device,
                          const int64_t *h_latent, int rb, double *h_alpha, double *h_mu, double *h_sigma,

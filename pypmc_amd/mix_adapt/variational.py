@@ -12,8 +12,16 @@ With torch.distributed initialised each rank holds a shard of the data; the stat
 all-reduced once per E-step (pypmc_amd.parallel).  ``GaussianInference(data, ..., devices=[0, 1, 2, 3])`` instead shards
 the data over the GPUs of this node from ONE process (pypmc_amd.devices.DeviceGroup: the library owns the shards and adds
 the statistics in device order).
+
+One process on one device (round 6): the K-sized state -- prior, posterior, the latest sums -- lives on the device as well
+(``pmc_vb_state``, include/pmc_ctx.h).  ``update()`` is then ONE library call (M-step, expectations, pack, E-step, bound
+as kernels) that returns 8 K + 16 doubles, and the attributes below (``W``, ``S``, ``m`` ...) are fetched when they are
+read.  The M-step's inversions run there through the same algorithm LAPACK uses, not through LAPACK: such a fit agrees
+with the host path to rounding, not bitwise.  ``PMC_VB_DEVICE_STATE=0`` (environment) or ``device_update = False`` (class
+or instance attribute, before the first step) keeps the K-sized work on the host.
 """
 import logging
+import os
 
 import numpy as np
 from scipy.special import digamma, gammaln
@@ -27,6 +35,26 @@ from ..tools._linalg import chol_inv_det, chol_inv_det_batch
 from ._stats import regularize, split_stats, centred_moments, shift_is_far, convert_stats
 
 logger = logging.getLogger(__name__)
+
+
+# The K-sized arrays that may live on the device (pmc_vb_state's fields; _lib.VB_FIELDS).  On the object they are
+# properties: reading one fetches it if the device holds the newer value, assigning one marks it for upload before the
+# next device step.  An array handed out may be edited in place by the caller (the reference's attributes are plain
+# arrays): a field read from outside is therefore uploaded again before every device step for as long as the host copy
+# is the current one ("sticky").  Without a device state (VBMerge, sharded fits) they behave as plain attributes.
+_STATE_FIELDS = ('alpha0', 'beta0', 'nu0', 'm0', 'inv_W0', 'log_det_W0', 'alpha', 'beta', 'nu', 'm', 'W', 'log_det_W',
+                 'expectation_det_ln_lambda', 'expectation_ln_pi', 'N_comp', 'x_mean_comp', 'S', '_shift_prev')
+_MSTEP_OUT = ('alpha', 'beta', 'nu', 'm', 'W', 'log_det_W')
+_ESTEP_OUT = ('expectation_det_ln_lambda', 'expectation_ln_pi', 'x_mean_comp', 'S', '_shift_prev')
+
+
+def _state_field(name):
+    def getter(self):
+        return self._field_get(name)
+
+    def setter(self, value):
+        self._field_set(name, value)
+    return property(getter, setter)
 
 
 class GaussianInference(object):
@@ -77,6 +105,7 @@ class GaussianInference(object):
             self._parse_initial_guess(initial_guess)
         self._initialize_intermediate()
 
+        self._settled()
         self._attach_device_data()
         self.E_step()
 
@@ -85,18 +114,108 @@ class GaussianInference(object):
     # of this object (advice r5: raw ctypes handles neither pickle nor may two objects free one): __getstate__ drops it,
     # and the first E-step (or N x K attribute) of the copy uploads / wraps again.  The host state -- the parameters, the
     # latest statistics -- is complete without it.
-    _DEVICE_ATTRS = ('_samples', '_vb_samples', '_data_dev', '_weights_dev')
+    _DEVICE_ATTRS = ('_samples', '_vb_samples', '_data_dev', '_weights_dev', '_state')
+    device_update = True          # (False: the K-sized work of update() / likelihood_bound() stays on the host)
+    device_psi = False            # (True: psi of the expectations on the device too -- see _psi_parts)
 
     def __getstate__(self):
+        self._fetch_all()                                     # what only the device holds comes to the host first
         state = dict(self.__dict__)
         if '_device_ready' in state:                          # (VBMerge keeps nothing on a device)
             for name in self._DEVICE_ATTRS:
                 state[name] = None
             state['_device_ready'] = False
+        for name in ('_vbf', '_vbf_dev', '_vbf_sticky', '_vbf_dirty'):
+            if name in state:
+                state[name] = type(state[name])(state[name])  # (the copy's bookkeeping is its own)
         return state
 
     def __setstate__(self, state):
+        state = dict(state)
+        fields = state.setdefault('_vbf', {})
+        for name in _STATE_FIELDS:                            # (a pickle of rounds 1-5: plain attributes)
+            if name in state:
+                fields[name] = state.pop(name)
         self.__dict__.update(state)
+
+    # ------------------------------------------------------------------------- K-sized fields, host or device
+    def _fields(self):
+        d = self.__dict__
+        if '_vbf_dev' not in d:
+            d.setdefault('_vbf', {})
+            d['_vbf_dev'], d['_vbf_dirty'], d['_vbf_sticky'] = set(), set(), set()
+        return d['_vbf'], d['_vbf_dev'], d['_vbf_dirty'], d['_vbf_sticky']
+
+    def _peek(self, name):
+        """the field's current value for reading only (no upload follows from it)"""
+        host, dev, _, _ = self._fields()
+        if name in dev:
+            host[name] = self._state.get(name)
+            dev.discard(name)
+        if name not in host:
+            if name == '_shift_prev':
+                return None
+            raise AttributeError(name)
+        return host[name]
+
+    def _field_get(self, name):
+        value = self._peek(name)
+        if value is not None:
+            self._fields()[3].add(name)                       # the caller may edit it in place
+            self._estep_current = False
+        return value
+
+    def _field_set(self, name, value):
+        host, dev, dirty, sticky = self._fields()
+        host[name] = value
+        dev.discard(name)
+        sticky.discard(name)
+        dirty.add(name)
+        self._estep_current = False
+        self._bound_cache = None
+
+    def _fetch_all(self):
+        if self.__dict__.get('_vbf_dev'):
+            for name in list(self._vbf_dev):
+                self._peek(name)
+
+    def _settled(self):
+        """end of a piece of this class's own code that read or edited fields in place: they count as assigned, and the
+        arrays are nobody else's"""
+        host, dev, dirty, sticky = self._fields()
+        dirty |= sticky
+        sticky.clear()
+
+    def _state_active(self):
+        return getattr(self, '_vb_samples', None) is not None and getattr(self, '_use_state', False) and self.device_update
+
+    def _state_sync(self):
+        """the device state exists for this K and holds every field the host has changed"""
+        host, dev, dirty, sticky = self._fields()
+        st = self.__dict__.get('_state')
+        if st is None or st.K != self.K:
+            if st is not None:
+                self._fetch_all()
+                st.close()
+            st = self._state = get_backend(self._backend).vb_state(self.K, self.dim)
+            dirty.update(n for n in _STATE_FIELDS if host.get(n) is not None)
+            self._shift_valid = False
+        for name in dirty | sticky:
+            value = host.get(name)
+            if value is not None and name not in dev:
+                st.put(name, value)
+        dirty.clear()
+        if sticky:
+            self._bound_cache = None
+        return st
+
+    def _state_outputs(self, names):
+        host, dev, dirty, sticky = self._fields()
+        for name in names:
+            host.pop(name, None)
+            dirty.discard(name)
+            sticky.discard(name)
+            dev.add(name)
 
     def _ensure_device_data(self):
         if not getattr(self, '_device_ready', True):
@@ -121,12 +240,19 @@ class GaussianInference(object):
             self._vb_samples = None
             if not parallel.active() and hasattr(be, "wrap_samples") and type(self).E_step is GaussianInference.E_step:
                 self._vb_samples = be.wrap_samples(self._data_dev, self._weights_dev)
+            # ... and so is the K-sized state (pmc_vb_state): M-step, expectations and bound as kernels beside the E-step's
+            self._use_state = self._vb_samples is not None and hasattr(be, "vb_state") and be.vb_state_supported(self.dim) and \
+                type(self).M_step is GaussianInference.M_step and os.environ.get('PMC_VB_DEVICE_STATE', '1') != '0'
         self._device_ready = True
 
     # ------------------------------------------------------------------------- E / M steps
     def E_step(self):
         """Expectation values and summary statistics (reference: variational.pyx:116-127)."""
         self._ensure_device_data()
+        if self._state_active():
+            st = self._state_sync()
+            return self._after_state_estep(st.step(self._vb_samples, estep=True, about_prev=self._shift_valid,
+                                                   psi_parts=self._psi_parts()))
         self._update_expectation_det_ln_lambda()        # first: catches an invalid W early
         self._update_expectation_ln_pi()
         D = self.dim
@@ -168,6 +294,8 @@ class GaussianInference(object):
         self._expectation_log_q_Z = float(scalars[0])
         self._estep_set = cs            # parameters the current r / log_rho belong to
         self._nk_cache = {}
+        self._settled()
+        self._estep_current = True
 
     def _E_step_group(self):
         """the E-step as one call of the handle layer (pmc_vb_estep) -- over the devices of ``self._group`` (every device
@@ -193,9 +321,65 @@ class GaussianInference(object):
         # (the parameters the current r / log_rho belong to; the arrays are replaced, never edited in place, by M_step / prune)
         self._estep_set = (self.m, self.W, self.beta, self.nu, self.expectation_ln_pi, self.expectation_det_ln_lambda)
         self._nk_cache = {}
+        self._settled()
+        self._estep_current = True
+
+    def _psi_parts(self):
+        """[E[ln pi] | sum_i psi((nu + 1 - i) / 2) + D ln 2] for the device's E-step, with scipy's psi -- the reference's
+        (variational.pyx:759-772, :800-804).  Both depend on alpha and nu alone, K-vectors the host holds (alpha0 + N_comp,
+        nu0 + N_comp), so nothing waits for the device; the kernel adds ln|W|.  Why not the device's psi: with the default
+        nu0 = D - 1 + 1e-5 the sum holds psi(5e-6) = -2e5 and an ulp of it moves every exponent of the E-step by 3e-11 --
+        responsibilities of 1e-79 agree with the reference's to 1e-10 only if these constants agree bit for bit.
+        ``device_psi = True`` takes the device's (25 us less host work per E-step at K = 64, D = 20)."""
+        if self.device_psi:
+            return None
+        alpha, nu = self._peek('alpha'), self._peek('nu')
+        K = self.K
+        out = np.empty(2 * K)
+        out[:K] = digamma(alpha) - digamma(alpha.sum())
+        i = np.arange(1, self.dim + 1)
+        out[K:] = digamma(0.5 * (nu[:, None] + 1. - i[None, :])).sum(axis=1) + self.dim * np.log(2.)
+        return out
+
+    def _host_mstep_vectors(self):
+        """alpha, beta, nu of the M-step on the host as well (K additions, the device's bits): the next E-step's psi
+        parts need them and nothing should wait for a copy"""
+        host, dev, dirty, sticky = self._fields()
+        n = self._peek('N_comp')
+        for name, prior in (('nu', 'nu0'), ('alpha', 'alpha0'), ('beta', 'beta0')):
+            host[name] = self._peek(prior) + n
+            dev.discard(name)
+            dirty.discard(name)
+            sticky.discard(name)
+
+    def _after_state_estep(self, res):
+        """bookkeeping behind an E-step that ran from the device state (``res``: VBState.step's block)"""
+        self._state_outputs(_ESTEP_OUT)
+        host = self._fields()[0]
+        if not np.isfinite(res["N_comp"]).any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(res["N_comp"]))
+        if not res["S_any_finite"].any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of sample covariance\n' + str(self.S))
+        host['N_comp'] = res["N_comp"]                         # (host and device agree: neither is behind)
+        self._fields()[2].discard('N_comp')
+        self._fields()[3].discard('N_comp')
+        self._shift_valid = bool(res["mean_finite"].all())
+        self._expectation_log_q_Z = res["log_q_Z"]
+        self._estep_set = 'state'                              # the parameters are the state's E_* fields
+        self._nk_cache = {}
+        self._estep_current = True
 
     def M_step(self):
         """Update the Gauss-Wishart / Dirichlet parameters (reference: variational.pyx:129-136)."""
+        self._bound_cache = None
+        if self._state_active():
+            # queued on the device (pmc_vb_mstep_device); a W_k^-1 that does not factorise is reported by the next step
+            # that brings a block back (the E-step of update(), likelihood_bound()) or by reading W
+            self._state_sync().step(None, mstep=True)
+            self._state_outputs(_MSTEP_OUT)
+            self._host_mstep_vectors()
+            self._estep_current = False
+            return
         self.nu = self.nu0 + self.N_comp
         self.alpha = self.alpha0 + self.N_comp
         self.beta = self.beta0 + self.N_comp
@@ -213,16 +397,31 @@ class GaussianInference(object):
             _, W, log_det = chol_inv_det_batch(inv_w, check_symmetric=False)    # sums of symmetric terms
             self.W = W
             self.log_det_W = -log_det
+            self._settled()
             return
         except np.linalg.LinAlgError:
             pass
-        self.W = np.array(self.W)
-        for k in range(self.K):
-            self.W[k], log_det = chol_inv_det(inv_w[k])[1:]
-            self.log_det_W[k] = -log_det
+        W, log_det_W = np.array(self.W), np.array(self.log_det_W)
+        try:
+            for k in range(self.K):
+                W[k], log_det = chol_inv_det(inv_w[k])[1:]
+                log_det_W[k] = -log_det
+        finally:
+            self.W, self.log_det_W = W, log_det_W               # (as far as the loop came, like the reference's in-place loop)
+            self._settled()
 
     def update(self):
         """One M-step followed by one E-step (reference: variational.pyx:571-578)."""
+        if self._state_active() and type(self).E_step is GaussianInference.E_step and getattr(self, '_device_ready', False):
+            # M-step, expectations, pack, E-step and the bound as kernels, 8 K + 16 doubles back
+            st = self._state_sync()
+            st.step(None, mstep=True)                            # queued: runs while the host takes the psi parts
+            self._state_outputs(_MSTEP_OUT)
+            self._host_mstep_vectors()
+            res = st.step(self._vb_samples, estep=True, bound=True, about_prev=self._shift_valid, psi_parts=self._psi_parts())
+            self._after_state_estep(res)
+            self._bound_cache = res["bound"]
+            return
         self.M_step()
         self.E_step()
 
@@ -233,6 +432,9 @@ class GaussianInference(object):
         if name not in self._nk_cache:
             self._ensure_device_data()
             be = get_backend(self._backend)
+            if isinstance(self._estep_set, str):                # 'state': what the latest E-step ran with is on the device
+                st = self._state
+                self._estep_set = tuple(st.get(n) for n in ('E_m', 'E_W', 'E_beta', 'E_nu', 'E_ln_pi', 'E_ln_lambda'))
             if isinstance(self._estep_set, tuple):
                 m, W, beta, nu, ln_pi, ln_lam = self._estep_set
                 self._estep_set = ComponentSet(PMC_KIND_VB, m, W, c0=self.dim / beta, c1=nu, c2=ln_pi,
@@ -291,6 +493,25 @@ class GaussianInference(object):
 
     def likelihood_bound(self):
         """Lower bound L(Q) on the log marginal likelihood (reference: variational.pyx:194-209)."""
+        if self._state_active() and getattr(self, '_device_ready', False) and self.__dict__.get('_state') is not None:
+            _, dev, dirty, sticky = self._fields()
+            b = self.__dict__.get('_bound_cache')
+            if b is None or dirty or sticky:
+                b = self._state_sync().step(None, bound=True)["bound"]
+                self._bound_cache = None if sticky else b
+            if np.isfinite(b[0]):
+                (self._expectation_log_p_X, self._expectation_log_p_Z, self._expectation_log_p_pi,
+                 self._expectation_log_p_mu_lambda, _, self._expectation_log_q_pi, self._expectation_log_q_mu_lambda) = \
+                    [float(v) for v in b[1:8]]
+                return float(b[0])
+            # not finite: the host's terms say why (the reference's assertions on nu and ln|W|, :1220-1260)
+        current = getattr(self, '_estep_current', False)        # (the terms below only read)
+        try:
+            return self._likelihood_bound_host()
+        finally:
+            self._estep_current = current
+
+    def _likelihood_bound_host(self):
         bound = self._update_expectation_log_p_X()
         bound += self._update_expectation_log_p_Z()
         bound += self._update_expectation_log_p_pi()
@@ -317,16 +538,23 @@ class GaussianInference(object):
         (reference: variational.pyx:233-281)."""
         if not threshold:
             return
-        keep = np.where(self.N_comp >= threshold)[0]
+        keep = np.where(self._peek('N_comp') >= threshold)[0]
         if len(keep) == 0:
             raise ValueError("Prune threshold %g too large, would remove all components" % threshold)
+        if len(keep) == self.K and getattr(self, '_estep_current', False):
+            # Nothing to remove, and the expectations and sums ARE those of the current parameters: the E-step the
+            # reference repeats here (variational.pyx:281) is a function of the data and these parameters alone and would
+            # reproduce what the object holds.  (Half of run()'s E-steps.)
+            return
         self.K = len(keep)
         for name in ('alpha0', 'alpha', 'beta0', 'beta', 'expectation_det_ln_lambda',
                      'expectation_ln_pi', 'N_comp', 'nu0', 'nu', 'm0', 'm', 'S', 'W0', 'inv_W0', 'W',
                      'log_det_W', 'log_det_W0', 'x_mean_comp'):
             setattr(self, name, np.array(getattr(self, name))[keep])
-        if getattr(self, '_shift_prev', None) is not None:
-            self._shift_prev = self._shift_prev[keep]
+        prev = self._peek('_shift_prev')
+        if prev is not None:
+            self._shift_prev = prev[keep]
+        self._settled()
         self.E_step()
 
     def run(self, iterations=1000, prune=1., rel_tol=1e-10, abs_tol=1e-5, verbose=False):
@@ -339,10 +567,10 @@ class GaussianInference(object):
                 old_bound = bound
             else:
                 old_bound = self.likelihood_bound()
-                logger.info('New bound=%g, K=%d, N_k=%s' % (old_bound, self.K, self.N_comp))
+                logger.info('New bound=%g, K=%d, N_k=%s' % (old_bound, self.K, self._peek('N_comp')))
             self.update()
             bound = self.likelihood_bound()
-            logger.info('After update %d: bound=%.15g, K=%d, N_k=%s' % (i, bound, self.K, self.N_comp))
+            logger.info('After update %d: bound=%.15g, K=%d, N_k=%s' % (i, bound, self.K, self._peek('N_comp')))
             if bound < old_bound:
                 logger.warning('Bound decreased from %g to %g' % (old_bound, bound))
             if bound == old_bound:
@@ -422,6 +650,7 @@ class GaussianInference(object):
         if self.W.shape != (K, D, D):
             raise ValueError('Shape of W %s does not match (K, d, d)=%s' % (self.W.shape, (K, D, D)))
         self.log_det_W = np.array([chol_inv_det(W)[2] for W in self.W])     # also validates W
+        self._settled()
         if kwargs:
             raise TypeError('unexpected keyword(s): ' + str(kwargs.keys()))
 
@@ -493,6 +722,7 @@ class GaussianInference(object):
         for k in range(K):
             self.W[k], self.log_det_W[k] = chol_inv_det(covs[k] * (self.nu[k] - self.dim))[1:]
         self.log_det_W *= -1          # det W = 1 / det(scaled covariance)
+        self._settled()
 
     # ------------------------------------------------------------------------- bound terms
     def _quad(self, v, M):
@@ -559,6 +789,12 @@ class GaussianInference(object):
             res -= entropy[k]
         self._expectation_log_q_mu_lambda = res
         return self._expectation_log_q_mu_lambda
+
+
+for _name in _STATE_FIELDS:
+    setattr(GaussianInference, _name, _state_field(_name))
+# 1 / N_comp (variational.pyx:699-709 keeps it beside N_comp): derived when read; assignments are accepted and ignored
+GaussianInference.inv_N_comp = property(lambda self: 1. / self._peek('N_comp'), lambda self, value: None)
 
 
 # ----------------------------------------------------------------------------- Wishart / Dirichlet

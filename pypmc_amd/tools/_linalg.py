@@ -98,7 +98,7 @@ def chol_inv_det_batch(ms, check_symmetric=True):
         lower = np.linalg.cholesky(ms)                           # batched potrf; LinAlgError if one is not PD
         # potri has no batched form.  Each call gets its factor as a Fortran-ordered view of a transposed copy
         # and works in place there (f2py copies and transposes a C-ordered argument: 27 -> 10 us per call)
-        work = np.ascontiguousarray(lower.transpose(0, 2, 1))
+        work = np.array(lower.transpose(0, 2, 1), order='C', copy=True)   # (a copy also at D = 1, where the transpose is contiguous)
         for k in range(K):
             res = _POTRI(work[k].T, True, overwrite_c=True)[0]
             if res.__array_interface__['data'][0] != work[k].__array_interface__['data'][0]:

@@ -187,6 +187,37 @@ static void handle_layer(int nparts, int K, int D, int64_t N, uint64_t seed)
                         Nk.data(), xbar.data(), S.data(), elq.data(), rr.data(), lr.data()) == PMC_OK);
     EXPECT(pmc_vb_estep(ctx, s, w.data(), K, m.mu.data(), W.data(), nu.data(), beta.data(), lnpi.data(), lnlam.data(), m.mu.data(),
                         Nk.data(), xbar.data(), S.data(), elq.data(), nullptr, nullptr) == PMC_OK);
+    // the K-sized state of a VB fit on the device (one-device contexts): every call path, buffers of exactly the documented sizes
+    {
+        pmc_vb_state *vs = nullptr;
+        if (nparts != 1 || D > pmc_vb_max_dim()) {
+            EXPECT(pmc_vb_state_create(ctx, K, D, &vs) == PMC_EINVAL);
+        } else {
+            EXPECT(pmc_vb_state_create(ctx, K, D, &vs) == PMC_OK);
+            EXPECT(pmc_vb_state_result_len(K) == 8 * K + 16);
+            std::vector<double> res((size_t)pmc_vb_state_result_len(K)), parts(2 * (size_t)K, -1.0);
+            for (int fld = 0; fld < PMC_VB_E_M; ++fld) {
+                const size_t len = (fld == PMC_VB_M0 || fld == PMC_VB_M || fld == PMC_VB_X_MEAN || fld == PMC_VB_SHIFT_PREV) ? (size_t)K * D
+                                   : (fld == PMC_VB_INV_W0 || fld == PMC_VB_W || fld == PMC_VB_S) ? (size_t)K * D * D : (size_t)K;
+                std::vector<double> v(len, 1.0), back(len, 0.0);
+                EXPECT(pmc_vb_state_put(vs, fld, v.data()) == PMC_OK);
+                EXPECT(pmc_vb_state_get(vs, fld, back.data()) == PMC_OK && back == v);
+            }
+            std::vector<double> big((size_t)K * D * D);
+            EXPECT(pmc_vb_state_put(vs, PMC_VB_E_M, big.data()) == PMC_EINVAL);          // read-only
+            EXPECT(pmc_vb_state_get(vs, PMC_VB_E_W, big.data()) == PMC_EINVAL);          // no E-step yet
+            EXPECT(pmc_vb_state_step(vs, nullptr, PMC_VB_DO_MSTEP, nullptr, nullptr) == PMC_OK);  // queued
+            EXPECT(pmc_vb_state_step(vs, nullptr, PMC_VB_DO_ESTEP, nullptr, res.data()) == PMC_EINVAL);
+            EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_ESTEP, nullptr, nullptr) == PMC_EINVAL);
+            EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_ESTEP, nullptr, res.data()) == PMC_OK);
+            EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_MSTEP | PMC_VB_DO_ESTEP | PMC_VB_DO_BOUND | PMC_VB_ABOUT_PREV, parts.data(), res.data()) == PMC_OK);
+            EXPECT(pmc_vb_state_step(vs, nullptr, PMC_VB_DO_BOUND, nullptr, res.data()) == PMC_OK);
+            EXPECT(pmc_vb_state_get(vs, PMC_VB_E_W, big.data()) == PMC_OK);
+            EXPECT(pmc_vb_state_destroy(vs) == PMC_OK);
+            EXPECT(pmc_vb_state_create(ctx, K, 65, &vs) == PMC_EINVAL);
+        }
+        EXPECT(pmc_vb_state_destroy(nullptr) == PMC_OK);
+    }
     // PMC updates
     std::vector<double> alpha(K), mu2((size_t)K * D), sig((size_t)K * D * D), dofc(K), ll(1), nrm(1);
     std::vector<int64_t> latent(N);

@@ -242,3 +242,21 @@ def test_split_plan_invariants():
         d = C.c_double()
         assert lib.pmc_option_default(b"split_components", C.byref(d)) == 0
         assert lib.pmc_configure(b"split_components", d.value) == 0
+
+
+def test_psi_and_ln_gamma_of_the_device_update_agree_with_scipy():
+    """pmc_host_digamma / pmc_host_lgamma are the functions the device-resident VB update uses (pmc_vbstate.hip:
+    recurrence + asymptotic series); scipy's are what the reference's M-step and bound call
+    (variational.pyx:759-772, :1220-1275)."""
+    from scipy.special import digamma, gammaln
+    from pypmc_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    xs = np.concatenate([10 ** rng.uniform(-8, 8, 4000), np.linspace(0.01, 30, 2000),
+                         [1.0, 2.0, 1.4616321449683623, 0.5, 1e-5, 1e7, 9.999999, 10.0]])
+    d = np.array([lib.pmc_host_digamma(float(x)) for x in xs])
+    g = np.array([lib.pmc_host_lgamma(float(x)) for x in xs])
+    assert np.max(np.abs(d - digamma(xs)) / (1 + np.abs(digamma(xs)))) < 2e-15
+    assert np.max(np.abs(g - gammaln(xs)) / (1 + np.abs(gammaln(xs)))) < 1e-14
+    for bad in (0.0, -1.5, float("nan")):
+        assert np.isnan(lib.pmc_host_digamma(bad)) and np.isnan(lib.pmc_host_lgamma(bad))

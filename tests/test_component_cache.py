@@ -77,3 +77,15 @@ def test_batched_update_renews_the_stamps():
         c._assign(c.mu.copy(), sig[k], chol[k], inv[k], float(logdet[k]))
     b = component_set(m.components, m.weights)
     assert b is not a and np.allclose(b.precision, inv)
+
+
+def test_batched_factorisation_in_one_dimension():
+    """D = 1: the transposed copy potri works in must be a copy (a (K, 1, 1) transpose is already contiguous, and
+    potri overwrote the factor the determinant is taken from -- found in round 6 by the device-resident M-step)."""
+    from pypmc_amd.tools._linalg import chol_inv_det_batch, chol_inv_det
+    ms = np.array([[[4.0]], [[0.25]], [[9.0]]])
+    lower, inverse, log_det = chol_inv_det_batch(ms, check_symmetric=False)
+    for k in range(3):
+        l, i, d = chol_inv_det(ms[k])
+        assert np.array_equal(lower[k], l) and np.array_equal(inverse[k], i) and log_det[k] == d
+    np.testing.assert_allclose(log_det, np.log(ms[:, 0, 0]))

@@ -28,7 +28,7 @@ def test_host_side_under_asan_and_ubsan(tmp_path):
     objs = []
     jobs = []
     for src in (os.path.join(CSRC, "pmc_api.hip"), os.path.join(CSRC, "pmc_ctx.hip"), os.path.join(CSRC, "pmc_p2p.hip"),
-                os.path.join(SAN, "stub_units.hip"),
+                os.path.join(CSRC, "pmc_vbstate.hip"), os.path.join(SAN, "stub_units.hip"),
                 os.path.join(SAN, "hip_stub.cpp"), os.path.join(SAN, "host_checks.cpp")):
         obj = str(tmp_path / (os.path.basename(src) + ".o"))
         # --cuda-host-only: the host pass alone (kernels become launch stubs; no device code object is built or needed)
