@@ -318,7 +318,28 @@ def baseline_configs(be, reps=5, select=None):
         t, kern, ex = timed(vb.E_step)
         out[label] = entry("GaussianInference.E_step D=20 K=64 (host conversion of the K-sized sums included)",
                            N4, f4, t, kern, **ex)
-        del vb, x4
+
+        # one iteration of GaussianInference.run(): update() = M-step + E-step, likelihood_bound(), prune()
+        # (variational.pyx:283-359) -- with the K-sized state on the device (round 6: pmc_vb_state) and with the K-sized
+        # work on the host (rounds 1-5: LAPACK inversions, scipy psi, numpy bound; W and S cross the bus twice)
+        def iteration_of(obj):
+            def iteration():
+                obj.update()
+                obj.likelihood_bound()
+                obj.prune()
+            return iteration
+        ti, kerni, exi = timed(iteration_of(vb))
+        vb_host = GaussianInference.__new__(GaussianInference)
+        vb_host.device_update = False
+        vb_host.__init__(x4, initial_guess=mix4)
+        th, kernh, exh = timed(iteration_of(vb_host))
+        out[label]["run_iteration"] = {
+            "what": "update() + likelihood_bound() + prune() on the same data",
+            "state_on_device": bool(vb._state_active()),
+            "ms": ti * 1e3, "host_ms": exi["host_ms"], "kernel_ms_per_call": kerni,
+            "ms_K_sized_work_on_host": th * 1e3, "host_ms_K_sized_work_on_host": exh["host_ms"],
+            "speedup": th / ti}
+        del vb, vb_host, x4
 
     if not want("cfg5"):
         out["seconds"] = time.perf_counter() - t_all

@@ -70,6 +70,42 @@ __device__ inline double wave_sum(double v)
     return __shfl(v, 0, 64);
 }
 
+// s - sum_{l < n} a[l * sa] * b[l * sb], subtracted in order (the plain loop's bits) with the loads issued eight at a time:
+// one wavefront per component is latency from end to end, and a loop that waits for two LDS reads per term spends
+// 128 cycles on each of them
+__device__ inline double dot_sub(double s, const double *a, int sa, const double *b, int sb, int n)
+{
+    int l = 0;
+    for (; l + 8 <= n; l += 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            x[q] = a[(l + q) * sa];
+            y[q] = b[(l + q) * sb];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s -= x[q] * y[q];
+    }
+    for (; l < n; ++l) s -= a[l * sa] * b[l * sb];
+    return s;
+}
+__device__ inline double dot_add(double s, const double *a, int sa, const double *b, int sb, int n)
+{
+    int l = 0;
+    for (; l + 8 <= n; l += 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            x[q] = a[(l + q) * sa];
+            y[q] = b[(l + q) * sb];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += x[q] * y[q];
+    }
+    for (; l < n; ++l) s += a[l * sa] * b[l * sb];
+    return s;
+}
+
 // ---- M-step (variational.pyx:129-136) -----------------------------------------------------------------------
 // One wavefront per component.  nu, alpha, beta (10.58, 10.60, 10.63); m (10.61); W^-1 (10.62) in the operation order of
 // pypmc_amd/mix_adapt/variational.py::M_step; W = inv(W^-1) and ln|W| through the Cholesky factor.
@@ -96,6 +132,7 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
     }
     const double fac = b0 / (b0 + n);
     const double *S = f.S + (size_t)k * D * D, *iW0 = f.inv_W0 + (size_t)k * D * D;
+#pragma unroll 4
     for (int i = 0; i < D; ++i) {
         const double dxi = __shfl(dx, i, 64);
         if (t < D) {
@@ -113,8 +150,7 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
     for (int c = 0; c < D; ++c) {
         double s = 0.0;
         if (t >= c && t < D) {
-            s = A[t * LD + c];
-            for (int l = 0; l < c; ++l) s -= A[t * LD + l] * A[c * LD + l];
+            s = dot_sub(A[t * LD + c], A + t * LD, 1, A + c * LD, 1, c);
         }
         const double piv = __shfl(s, c, 64);
         if (!(piv > 0.0) || !isfinite(piv)) {
@@ -123,11 +159,15 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
             break;                                                  // (wave-uniform)
         }
         const double lcc = sqrt(piv);
-        logdet += log(lcc);                                         // left to right, as the host sums
-        __syncthreads();                                            // (everyone has read column c's old entries)
-        if (t == c) A[c * LD + c] = lcc;
+        if (t == c) A[c * LD + c] = lcc;                            // (column c's old entries were read by their own lanes only)
         else if (t > c && t < D) A[t * LD + c] = s / lcc;
         __syncthreads();
+    }
+    if (bad < 0) {
+        // ln|W^-1| / 2 = sum_c ln L_cc: the logarithms side by side (they are off the factorisation's critical path), added
+        // left to right as the host adds them; the reciprocals of the diagonal for the inverse below
+        const double lg = t < D ? log(A[t * LD + t]) : 0.0;
+        for (int c = 0; c < D; ++c) logdet += __shfl(lg, c, 64);
     }
     if (t == 0) {
         status[k] = (double)(bad + 1);
@@ -146,9 +186,7 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
             if (i == t) {
                 v = 1.0 / A[i * LD + i];
             } else if (i > t) {
-                double acc = 0.0;
-                for (int l = t; l < i; ++l) acc -= A[i * LD + l] * X[l * LD + t];
-                v = acc / A[i * LD + i];
+                v = dot_sub(0.0, A + i * LD + t, 1, X + t * LD + t, LD, i - t) / A[i * LD + i];
             }
             X[i * LD + t] = v;
         }
@@ -157,9 +195,7 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
     // W = X^T X: lane = column; the leading terms of the shorter of the two sums are exact zeros, so W is symmetric bit for bit
     if (t < D) {
         for (int i = 0; i < D; ++i) {
-            double acc = 0.0;
-            for (int l = i; l < D; ++l) acc += X[l * LD + i] * X[l * LD + t];
-            W[i * D + t] = acc;
+            W[i * D + t] = dot_add(0.0, X + i * LD + i, LD, X + i * LD + t, LD, D - i);
         }
     }
     if (t == 0) f.log_det_W[k] = -(2.0 * logdet);
@@ -271,6 +307,7 @@ __global__ __launch_bounds__(64) void k_vb_bound_terms(pmc_vb_fields f, int K, i
     }
     // lane j: sums over i of S_ij W_ji, inv_W0_ij W_ji, dx_i W_ij dx_j, dm_i W_ij dm_j
     double tr_sw = 0.0, tr_0 = 0.0, q_x = 0.0, q_m = 0.0;
+#pragma unroll 4
     for (int i = 0; i < D; ++i) {
         const double dxi = __shfl(dx, i, 64), dmi = __shfl(dm, i, 64);
         if (t < D) {
@@ -315,8 +352,17 @@ __global__ __launch_bounds__(64) void k_vb_bound_sum(const double *terms, int K,
 {
     const int t = threadIdx.x;
     double s = 0.0;
-    if (t < VB_NTERMS)
-        for (int k = 0; k < K; ++k) s += terms[(size_t)k * VB_NTERMS + t];
+    if (t < VB_NTERMS) {
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {                                // (loads eight at a time, the sum in component order)
+            double v8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v8[q] = terms[(size_t)(k + q) * VB_NTERMS + t];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v8[q];
+        }
+        for (; k < K; ++k) s += terms[(size_t)k * VB_NTERMS + t];
+    }
     double v[VB_NTERMS];
     for (int i = 0; i < VB_NTERMS; ++i) v[i] = __shfl(s, i, 64);
     if (t != 0) return;

@@ -233,3 +233,25 @@ def test_the_devices_own_psi_is_an_option(be):
         own.update()
         ref.update()
     _close(own, ref, 1e-9, "device psi")                           # (three updates apart: the trajectories, not the function)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_against_the_host_path(be, seed):
+    """random K, D, N, weights, priors: two updates and the bound on both paths"""
+    rng = np.random.RandomState(1000 + seed)
+    D = int(rng.choice([1, 2, 3, 7, 8, 13, 20, 31, 40, 64]))
+    K = int(rng.randint(1, 24))
+    N = int(rng.randint(max(K, 50), 40000))
+    x = _data(N, D, max(1, K // 2), seed, spread=float(rng.uniform(2, 10)))
+    kw = dict(alpha0=float(rng.uniform(1e-3, 2)), beta0=float(rng.uniform(1e-3, 2)), nu0=D - 1 + float(rng.uniform(1e-2, 5)),
+              W0=np.eye(D) * float(rng.uniform(0.1, 10)), m0=rng.normal(size=D))
+    if seed % 3 == 0:
+        kw["weights"] = rng.uniform(0.05, 3.0, size=N)
+    dev, host = _fit(x, K, True, **kw), _fit(x, K, False, **kw)
+    _close(dev, host, 0.0, "constructor")
+    for it in range(2):
+        dev.update()
+        host.update()
+        _close(dev, host, 1e-9, "update %d (K=%d D=%d N=%d)" % (it, K, D, N))
+        bd, bh = dev.likelihood_bound(), host.likelihood_bound()
+        assert abs(bd - bh) <= 1e-10 * abs(bh), (bd, bh)
