@@ -147,7 +147,11 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
     // W^-1 = L L^T, in place in the lower triangle: lane = row
     int bad = -1;
     double badv = 0.0, logdet = 0.0;
+#ifdef VB_AB_NO_CHOL
+    for (int c = 0; c < 0; ++c) {
+#else
     for (int c = 0; c < D; ++c) {
+#endif
         double s = 0.0;
         if (t >= c && t < D) {
             s = dot_sub(A[t * LD + c], A + t * LD, 1, A + c * LD, 1, c);
@@ -180,7 +184,11 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
         return;
     }
     // X = L^-1 (lower): lane = column
+#ifdef VB_AB_NO_INV
+    if (t < 0) {
+#else
     if (t < D) {
+#endif
         for (int i = 0; i < D; ++i) {
             double v = 0.0;
             if (i == t) {
@@ -193,7 +201,11 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
     }
     __syncthreads();
     // W = X^T X: lane = column; the leading terms of the shorter of the two sums are exact zeros, so W is symmetric bit for bit
+#ifdef VB_AB_NO_GRAM
+    if (t < 0) {
+#else
     if (t < D) {
+#endif
         for (int i = 0; i < D; ++i) {
             W[i * D + t] = dot_add(0.0, X + i * LD + i, LD, X + i * LD + t, LD, D - i);
         }
