@@ -1429,6 +1429,11 @@ int pmc_vb_state_step(pmc_vb_state *st, const pmc_samples *s, int flags, const d
         }
         if (do_b) CK(pmc_vb_bound_device(K, D, &st->f, st->log_q_Z, st->terms, d_bound, pt.stream));
         if (!h_result) return PMC_OK;                               // (an M-step alone: queued; its flags travel with the next block)
+        if (do_e && pass == 0)
+            // the parameters this E-step runs with, for whoever asks for r / log rho later (queued in front of the wait
+            // for the block: behind it, it would sit between the block's arrival and the caller's next launch)
+            HK(hipMemcpyAsync(st->field[PMC_VB_E_M], st->field[PMC_VB_M], sizeof(double) * (KD + KDD + 4 * (size_t)K),
+                              hipMemcpyDeviceToDevice, pt.stream), "hipMemcpyAsync (E-step parameters)");
         CK(d2h(pt, h_result, st->result, sizeof(double) * st->nresult));
         if (ctx->p2p && do_e) CK(pmc_p2p_status(ctx->p2p, pt.stream));
         CK(pmc_vb_mstep_status(K, h_result + nsmall + 2 * (size_t)K));
@@ -1441,12 +1446,10 @@ int pmc_vb_state_step(pmc_vb_state *st, const pmc_samples *s, int flags, const d
         const double *d_old = (flags & PMC_VB_ABOUT_PREV) ? st->field[PMC_VB_SHIFT_PREV] : st->f.m;
         CK(pmc_vb_newshift_device(K, D, st->conv, d_old, st->shift2, pt.stream));
     }
-    // the next E-step's shifts = this one's means; the parameters this E-step ran with, for whoever asks for r / log rho later
+    // the next E-step's shifts = this one's means
     double *old = st->field[PMC_VB_SHIFT_PREV];
     st->field[PMC_VB_SHIFT_PREV] = st->shift_next;
     st->shift_next = old;
-    HK(hipMemcpyAsync(st->field[PMC_VB_E_M], st->field[PMC_VB_M], sizeof(double) * (KD + KDD + 4 * (size_t)K), hipMemcpyDeviceToDevice,
-                      pt.stream), "hipMemcpyAsync (E-step parameters)");
     st->stepped = true;
     return PMC_OK;
 }

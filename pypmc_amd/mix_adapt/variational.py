@@ -354,15 +354,22 @@ class GaussianInference(object):
 
     def _after_state_estep(self, res):
         """bookkeeping behind an E-step that ran from the device state (``res``: VBState.step's block)"""
-        self._state_outputs(_ESTEP_OUT)
-        host = self._fields()[0]
-        if not np.isfinite(res["N_comp"]).any():
-            raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(res["N_comp"]))
+        host, dev, dirty, sticky = self._fields()
+        for name in _ESTEP_OUT:
+            host.pop(name, None)
+            dirty.discard(name)
+            sticky.discard(name)
+            dev.add(name)
+        n_comp = res["N_comp"]
+        # (one pass over the block's flags: sum of N_comp finite <=> all finite, which is the common case; the reference's
+        #  tests -- any finite entry -- only when it is not)
+        if not np.isfinite(n_comp.sum()) and not np.isfinite(n_comp).any():
+            raise np.linalg.LinAlgError('Encountered inf or nan in update of responsibilities\n' + str(n_comp))
         if not res["S_any_finite"].any():
             raise np.linalg.LinAlgError('Encountered inf or nan in update of sample covariance\n' + str(self.S))
-        host['N_comp'] = res["N_comp"]                         # (host and device agree: neither is behind)
-        self._fields()[2].discard('N_comp')
-        self._fields()[3].discard('N_comp')
+        host['N_comp'] = n_comp                                # (host and device agree: neither is behind)
+        dirty.discard('N_comp')
+        sticky.discard('N_comp')
         self._shift_valid = bool(res["mean_finite"].all())
         self._expectation_log_q_Z = res["log_q_Z"]
         self._estep_set = 'state'                              # the parameters are the state's E_* fields
@@ -567,10 +574,12 @@ class GaussianInference(object):
                 old_bound = bound
             else:
                 old_bound = self.likelihood_bound()
-                logger.info('New bound=%g, K=%d, N_k=%s' % (old_bound, self.K, self._peek('N_comp')))
+                if logger.isEnabledFor(logging.INFO):            # (formatting K numbers costs more than a K-sized kernel)
+                    logger.info('New bound=%g, K=%d, N_k=%s' % (old_bound, self.K, self._peek('N_comp')))
             self.update()
             bound = self.likelihood_bound()
-            logger.info('After update %d: bound=%.15g, K=%d, N_k=%s' % (i, bound, self.K, self._peek('N_comp')))
+            if logger.isEnabledFor(logging.INFO):
+                logger.info('After update %d: bound=%.15g, K=%d, N_k=%s' % (i, bound, self.K, self._peek('N_comp')))
             if bound < old_bound:
                 logger.warning('Bound decreased from %g to %g' % (old_bound, bound))
             if bound == old_bound:
