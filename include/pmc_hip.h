@@ -434,6 +434,16 @@ int pmc_convert_stats_device(int K, int D, const double *d_stats, const double *
  *   tests: |error| <= 2e-15 (1 + |value|) for psi, 1e-14 (1 + |value|) for ln Gamma (the recurrence below x = 10 costs the
  *   difference of two logarithms of about 17).
  */
+/*
+ * pmc_spd_inverse_device: chol_inv_det (pypmc/tools/_linalg.pyx:41-95) of K symmetric positive definite D x D matrices on
+ *   the device, D <= 64 -- the K factorisations of a PMC update (Gauss.update, gauss.pyx:46-57, called per component from
+ *   pmc.pyx:227-244) without LAPACK.  d_A: K x D x D row-major; d_out: pmc_spd_inverse_len(K, D) = K (2 D^2 + 3) doubles,
+ *   per matrix [lower Cholesky factor D x D | inverse D x D | ln det | 1 + failing pivot or 0 | its value] (a matrix that
+ *   does not factorise: NaN and its pivot).  The algorithm is potrf / potri's; the numbers agree with LAPACK's to rounding.
+ */
+int64_t pmc_spd_inverse_len(int K, int D);
+int pmc_spd_inverse_device(int K, int D, const double *d_A, double *d_out, void *stream);
+
 typedef struct pmc_vb_fields {
     double *alpha0, *beta0, *nu0, *m0, *inv_W0, *log_det_W0;
     double *alpha, *beta, *nu, *m, *W, *log_det_W;

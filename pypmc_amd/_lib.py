@@ -114,6 +114,8 @@ SIGNATURES = {
     "pmc_estep_from_tiles": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
                                     _vp]),
     # the K-sized half of a VB iteration on the device (struct pmc_vb_fields * travels as a plain pointer)
+    "pmc_spd_inverse_len": (_i64, [_int, _int]),
+    "pmc_spd_inverse_device": (_int, [_int, _int, _vp, _vp, _vp]),
     "pmc_vb_max_dim": (_int, []),
     "pmc_vb_mstep_device": (_int, [_int, _int, _vp, _vp, _vp]),
     "pmc_vb_mstep_status": (_int, [_int, _dp]),

@@ -288,7 +288,68 @@ class HipBackend(object):
         comps._pack = (self, self._build_pack(comps))
         return comps._pack[1]
 
+    # K-sized linear algebra of a PMC update where it is big enough to matter (K = 128, D = 40: 1.4 ms of LAPACK and
+    # 0.4 ms of host Cholesky per iteration, with the GPU idle): from this many matrix elements on, on the device
+    DEVICE_LINALG_FROM = 60000
+
+    def chol_inv_det_batch(self, sig):
+        """tools._linalg.chol_inv_det_batch (lower factors, inverses, log determinants of K symmetric positive definite
+        matrices) on the device: pmc_spd_inverse_device -- potrf / potri's algorithm, one wavefront per matrix; agrees
+        with LAPACK to rounding.  Raises numpy.linalg.LinAlgError if a matrix does not factorise (callers fall back to
+        the per-component loop, as with the host batch).  None where it does not apply (D > 64)."""
+        sig = np.ascontiguousarray(sig, dtype=np.float64)
+        K, D = sig.shape[0], sig.shape[1]
+        if sig.ndim != 3 or sig.shape[2] != D or D > int(self.lib.pmc_vb_max_dim()):
+            return None
+        if not np.isfinite(sig).all():
+            raise np.linalg.LinAlgError('array must not contain infs or NaNs')
+        d_in = self.torch.from_numpy(sig).to(self.device)
+        n = int(self.lib.pmc_spd_inverse_len(K, D))
+        d_out = self.empty(n)
+        _lib.check(self.lib.pmc_spd_inverse_device(K, D, self._p(d_in), self._p(d_out), self._stream()), "pmc_spd_inverse_device")
+        # (3.3 MB at K = 128, D = 40: through torch's cached pinned allocator, 0.13 ms instead of 0.35 from pageable memory)
+        pinned = self.torch.empty(n, dtype=self.torch.float64, pin_memory=True)
+        pinned.copy_(d_out, non_blocking=True)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        out = pinned.numpy().reshape(K, 2 * D * D + 3)
+        if (out[:, 2 * D * D + 1] != 0).any() or not np.isfinite(out[:, 2 * D * D]).all():
+            raise np.linalg.LinAlgError('a matrix of the batch is not positive definite (or its determinant is not finite)')
+        return (np.ascontiguousarray(out[:, :D * D]).reshape(K, D, D), np.ascontiguousarray(out[:, D * D:2 * D * D]).reshape(K, D, D),
+                out[:, 2 * D * D].copy())
+
+    def _build_pack_device(self, comps):
+        """the parameter pack built by the device's builder (pmc_pack_components_device: the host builder's bits) from
+        ONE upload of the raw parameters; None where the device builder does not apply"""
+        K, D = comps.K, comps.D
+        if D > int(self.lib.pmc_max_compiled_dim()):
+            return None
+        KD, KDD = K * D, K * D * D
+        raw = np.empty(KD + KDD + 5 * K + (K + 1) // 2 + 1)
+        raw[:KD] = comps.mu.reshape(-1)
+        raw[KD:KD + KDD] = comps.precision.reshape(-1)
+        o = KD + KDD
+        for i, v in enumerate((comps.c0, comps.c1, comps.c2, comps.c3, comps.weight)):
+            raw[o + i * K:o + (i + 1) * K] = v
+        col = raw[o + 5 * K:o + 5 * K + (K + 1) // 2].view(np.int32)
+        col[:K] = comps.column
+        d = self.torch.from_numpy(raw).to(self.device)
+        stride = _lib.check(self.lib.pmc_pack_stride(D), "pmc_pack_stride")
+        pack, status = self.empty(K * stride), self.empty(2 * K)
+        base, f8 = d.data_ptr(), 8
+        at = lambda off: C.c_void_p(base + f8 * off)
+        rc = self.lib.pmc_pack_components_device(K, D, at(0), at(KD), at(o), at(o + K), at(o + 2 * K), at(o + 3 * K), at(o + 4 * K),
+                                                 at(o + 5 * K), self._p(pack), self._p(status), None, None, self._stream())
+        if rc < 0:
+            return None                                        # (a layout the device builder does not serve: the host's)
+        st = status.cpu().numpy()
+        _lib.check(self.lib.pmc_pack_status(K, _dptr(st)), "pmc_pack_components_device")
+        return pack
+
     def _build_pack(self, comps):
+        if comps.K * comps.D * comps.D >= self.DEVICE_LINALG_FROM:
+            pack = self._build_pack_device(comps)
+            if pack is not None:
+                return pack
         stride = _lib.check(self.lib.pmc_pack_stride(comps.D), "pmc_pack_stride")
         host = np.empty(comps.K * stride, dtype=np.float64)
         _lib.check(self.lib.pmc_pack_components(

@@ -213,6 +213,66 @@ __global__ __launch_bounds__(64) void k_vb_mstep(pmc_vb_fields f, int K, int D, 
     if (t == 0) f.log_det_W[k] = -(2.0 * logdet);
 }
 
+// ---- chol_inv_det of K matrices (pypmc/tools/_linalg.pyx:41-95: lower factor, inverse, ln det) -----------------------
+// The PMC update's K factorisations (pmc.pyx:227-244 through Gauss.update, gauss.pyx:46-57): one wavefront per matrix,
+// the stages of k_vb_mstep.  out_k = [L (D x D, zeros above the diagonal) | A^-1 (D x D, symmetric bit for bit) | ln det A |
+// 1 + failing pivot or 0 | its value]: everything a caller reads, one block per matrix for one copy.
+__global__ __launch_bounds__(64) void k_spd_inverse(const double *A_all, int K, int D, double *out)
+{
+    extern __shared__ double lds[];
+    const int LD = D + 1;
+    double *A = lds, *X = lds + (size_t)D * LD;
+    const int k = blockIdx.x, t = threadIdx.x;
+    const double *src = A_all + (size_t)k * D * D;
+    double *o = out + (size_t)k * (2 * (size_t)D * D + 3), *oL = o, *oI = o + (size_t)D * D, *tail = oI + (size_t)D * D;
+    for (int idx = t; idx < D * D; idx += 64) A[(idx / D) * LD + idx % D] = src[idx];
+    __syncthreads();
+    int bad = -1;
+    double badv = 0.0, logdet = 0.0;
+    for (int c = 0; c < D; ++c) {
+        double s = 0.0;
+        if (t >= c && t < D) s = dot_sub(A[t * LD + c], A + t * LD, 1, A + c * LD, 1, c);
+        const double piv = __shfl(s, c, 64);
+        if (!(piv > 0.0) || !isfinite(piv)) {
+            bad = c;
+            badv = piv;
+            break;
+        }
+        const double lcc = sqrt(piv);
+        if (t == c) A[c * LD + c] = lcc;
+        else if (t > c && t < D) A[t * LD + c] = s / lcc;
+        __syncthreads();
+    }
+    if (bad >= 0) {
+        for (int idx = t; idx < 2 * D * D; idx += 64) o[idx] = NAN;
+        if (t == 0) {
+            tail[0] = NAN;
+            tail[1] = (double)(bad + 1);
+            tail[2] = badv;
+        }
+        return;
+    }
+    const double lg = t < D ? log(A[t * LD + t]) : 0.0;
+    for (int c = 0; c < D; ++c) logdet += __shfl(lg, c, 64);        // left to right, as the reference sums
+    if (t < D) {
+        for (int i = 0; i < D; ++i) {
+            double v = 0.0;
+            if (i == t) v = 1.0 / A[i * LD + i];
+            else if (i > t) v = dot_sub(0.0, A + i * LD + t, 1, X + t * LD + t, LD, i - t) / A[i * LD + i];
+            X[i * LD + t] = v;
+            oL[i * D + t] = i >= t ? A[i * LD + t] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (t < D)
+        for (int i = 0; i < D; ++i) oI[i * D + t] = dot_add(0.0, X + i * LD + i, LD, X + i * LD + t, LD, D - i);
+    if (t == 0) {
+        tail[0] = 2.0 * logdet;
+        tail[1] = 0.0;
+        tail[2] = 0.0;
+    }
+}
+
 // ---- the expectations an E-step starts with (variational.pyx:759-772, :800-804) and the pack's constants --------
 // E[ln|Lambda_k|] = sum_i psi((nu_k + 1 - i) / 2) + D ln 2 + ln|W_k|   (10.65)
 // E[ln pi_k]      = psi(alpha_k) - psi(sum alpha)                         (10.66)
@@ -433,6 +493,19 @@ int pmc_vb_mstep_device(int K, int D, const pmc_vb_fields *f, double *d_status, 
     hipLaunchKernelGGL(k_vb_mstep, dim3((unsigned)K), dim3(64), sizeof(double) * 2 * (size_t)D * (D + 1), (hipStream_t)stream, *f, K, D,
                        d_status);
     return launched("k_vb_mstep launch");
+}
+
+int64_t pmc_spd_inverse_len(int K, int D)
+{
+    return (K < 1 || D < 1) ? (int64_t)vfail(PMC_EINVAL, "pmc_spd_inverse_len: bad K / D") : (int64_t)K * (2 * (int64_t)D * D + 3);
+}
+
+int pmc_spd_inverse_device(int K, int D, const double *d_A, double *d_out, void *stream)
+{
+    if (K < 1 || D < 1 || D > 64 || !d_A || !d_out) return vfail(PMC_EINVAL, "pmc_spd_inverse_device: bad argument (1 <= D <= 64)");
+    hipLaunchKernelGGL(k_spd_inverse, dim3((unsigned)K), dim3(64), sizeof(double) * 2 * (size_t)D * (D + 1), (hipStream_t)stream, d_A, K, D,
+                       d_out);
+    return launched("k_spd_inverse launch");
 }
 
 int pmc_vb_mstep_status(int K, const double *h_status)

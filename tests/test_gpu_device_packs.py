@@ -139,3 +139,58 @@ def test_convert_stats_on_the_device_is_the_host_conversion(be, K, D, student):
         assert bool(h[o:o + K].any()) == bool(far), trial
         assert set(np.unique(h[o:o + K])) <= {0.0, 1.0}
         assert np.array_equal(h[o + K:], flat[:8], equal_nan=True)
+
+
+# ---- round 6: the PMC update's K factorisations and the pack of a big mixture on the device -------------------------------
+@pytest.mark.parametrize("K,D,cond", [(1, 1, 1), (3, 2, 1), (17, 5, 1e4), (128, 40, 1), (128, 40, 1e6), (40, 64, 1e3), (300, 20, 1e2)])
+def test_chol_inv_det_batch_on_the_device_agrees_with_lapack(be, K, D, cond):
+    """backend.chol_inv_det_batch (pmc_spd_inverse_device: potrf / potri's algorithm, one wavefront per matrix) against
+    tools._linalg.chol_inv_det_batch (LAPACK; pypmc/tools/_linalg.pyx:41-95): to rounding, scaled by the condition number"""
+    from pypmc_amd.tools._linalg import chol_inv_det_batch
+    rs = np.random.RandomState(7 * K + D)
+    sig = spd(rs, K, D, cond=cond)
+    L, I, ld = be.chol_inv_det_batch(sig)
+    L0, I0, ld0 = chol_inv_det_batch(sig, check_symmetric=False)
+    scale = lambda a: np.abs(a).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(L - L0) <= 1e-14 * np.sqrt(cond) * scale(L0)).all()
+    assert (np.abs(I - I0) <= 4e-15 * cond * scale(I0)).all()
+    np.testing.assert_allclose(ld, ld0, rtol=1e-13, atol=1e-12)
+    np.testing.assert_array_equal(I, I.transpose(0, 2, 1))
+    assert (np.triu(L, 1) == 0).all()
+    # and the inverse IS an inverse
+    assert np.abs(np.einsum('kij,kjl->kil', sig, I) - np.eye(D)).max() < 1e-12 * cond
+
+
+def test_chol_inv_det_batch_on_the_device_reports_failures(be):
+    rs = np.random.RandomState(3)
+    sig = spd(rs, 6, 5)
+    sig[4] = -sig[4]
+    with pytest.raises(np.linalg.LinAlgError):
+        be.chol_inv_det_batch(sig)
+    sig = spd(rs, 6, 5)
+    sig[2, 1, 1] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        be.chol_inv_det_batch(sig)
+    assert be.chol_inv_det_batch(spd(rs, 2, 65)) is None           # beyond one wavefront per matrix: the caller's LAPACK
+
+
+@pytest.mark.parametrize("K,D,kind", [(128, 40, "gauss"), (64, 32, "student"), (200, 20, "gauss"), (5, 3, "gauss")])
+def test_the_pack_of_a_big_mixture_built_on_the_device_is_the_host_pack(be, K, D, kind):
+    """backend._build_pack takes the device's builder from DEVICE_LINALG_FROM matrix elements on: the same bits"""
+    from pypmc_amd.backend import ComponentSet
+    from pypmc_amd._lib import PMC_KIND_GAUSS, PMC_KIND_STUDENT_T
+    rs = np.random.RandomState(K + D)
+    cs = ComponentSet(PMC_KIND_STUDENT_T if kind == "student" else PMC_KIND_GAUSS, rs.normal(size=(K, D)), spd(rs, K, D),
+                      c0=rs.normal(size=K), c1=rs.normal(size=K), c2=rs.uniform(size=K), c3=rs.uniform(1, 9, size=K),
+                      weight=rs.uniform(size=K), column=rs.permutation(K))
+    dev = be._build_pack_device(cs)
+    assert dev is not None
+    saved, type(be).DEVICE_LINALG_FROM = type(be).DEVICE_LINALG_FROM, 1 << 62
+    try:
+        host = be._build_pack(cs)
+    finally:
+        type(be).DEVICE_LINALG_FROM = saved
+    np.testing.assert_array_equal(dev.cpu().numpy(), host.cpu().numpy())
+    bad = ComponentSet(PMC_KIND_GAUSS, rs.normal(size=(K, D)), -spd(rs, K, D))
+    with pytest.raises(np.linalg.LinAlgError):
+        be._build_pack_device(bad)
