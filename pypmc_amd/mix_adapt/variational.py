@@ -375,6 +375,7 @@ class GaussianInference(object):
         self._estep_set = 'state'                              # the parameters are the state's E_* fields
         self._nk_cache = {}
         self._estep_current = True
+        self._bound_cache = None                               # (update() puts the bound of the same block here)
 
     def M_step(self):
         """Update the Gauss-Wishart / Dirichlet parameters (reference: variational.pyx:129-136)."""
