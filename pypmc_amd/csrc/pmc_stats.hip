@@ -519,6 +519,14 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
     // precision / nu] > limit says "too far apart" -- conservatively; whoever passes is tested again a posteriori,
     // on the data, by k_gemm_convert.  Workgroup 0 publishes c and the decision for the finishing kernels.
     double *cen = us + 2 * BUFU;                           // 64 doubles behind the buffers; scratch: the u buffers
+#ifdef PMC_AB_NOPLAN
+    // A/B switch, TIMING ONLY (wrong numbers unless the means straddle 0; scripts/stats_plan_ab.sh): no plan -- what the
+    // K x D numbers every workgroup reads and reduces before its first tile cost per launch
+    if (tid < 64) cen[tid] = 0.0;
+    if (blockIdx.x == 0 && tid == 0) { b.ctl[PMC_CTL_GO] = 1; b.ctl[PMC_CTL_REDO] = 0; }
+    if (blockIdx.x == 0 && tid < dreal) b.center[tid] = 0.0;
+    __syncthreads();
+#else
     {
         constexpr int STRIDE = pmc_pack_stride_c(D);
         double *lo = us, *hi = us + W * 64;
@@ -569,6 +577,7 @@ __device__ __forceinline__ void stats_gemm_run(const PmcArgsG &b, double *xs)
         }
         if (isfar) return;
     }
+#endif
 
     // this lane's two factors of each of the wavefront's column tiles: LDS offsets (doubles) incl. the lane's rows.
     // Monomial m in the order of the statistics vector: 0 -> 1 * 1, 1 + j -> 1 * d_j, 1 + D + i(i+1)/2 + j -> d_i * d_j.
