@@ -2103,6 +2103,8 @@ static int sufficient_stats_impl(const double *d_x, int64_t N, int D, const doub
     b.partials = (double *)d_workspace; b.ntiles = g.ntiles; b.nchunks = g.nchunks;
     b.tiles_per_chunk = g.tiles_per_chunk; b.ngroups = g.ngroups; b.ctl = ctl;
     const long long total = (long long)K * PS;
+    static const bool ab_skip_fallback = std::getenv("PMC_AB_SKIP_FALLBACK") != nullptr;   // TIMING ONLY (profiles/r06_fallback_launches_ab.txt)
+    if (!counted && ab_skip_fallback) return PMC_OK;
     if (!counted) {
         // behind the common-shift form: its fall-back -- the factors k_resp_groups left to the statistics kernel applied to
         // u, the per-component-shift kernel, its finishing reduction -- three launches that return at once unless the
