@@ -450,13 +450,15 @@ class PMC(object):
             self.normalized_weights = self.weights / self._norm
         be = get_backend(self._backend)
         self._samples_dev = be.asdevice(self.samples)
+        # (the weights too: every update and every log-likelihood of run() would upload the N numbers again)
+        self._weights_dev = be.asdevice(self.weights) if self.weights is not None and hasattr(be, 'torch') else self.weights
 
     def log_likelihood(self):
         """sum_n wbar_n log q(x_n), eq. (5) of [Cap+08] (reference: pmc.pyx:367-391); the sum is
         reduced on the device by the log-pdf kernel."""
         be = get_backend(self._backend)
         cs = component_set(self.density.components, self.density.weights)
-        res = be.logpdf(self._samples_dev, cs, want_out=False, sample_w=self.weights, want_scalars=True)
+        res = be.logpdf(self._samples_dev, cs, want_out=False, sample_w=self._weights_dev, want_scalars=True)
         total = be.tohost(parallel.all_reduce_sum(res["scalars"]))[3]
         return float(total / self._norm)
 
@@ -472,11 +474,12 @@ class PMC(object):
                 old_bound = self.log_likelihood()
                 logger.info('New bound=%g, K=%i' % (old_bound, len(self.density)))
             self.pmc(self._samples_dev, self.density,
-                     self.weights, self.latent, self.rb, mincount=self.mincount, copy=False,
+                     self._weights_dev, self.latent, self.rb, mincount=self.mincount, copy=False,
                      backend=self._backend, **self.additional_args)
             bound = self.log_likelihood()
-            logger.info('After update %d: bound=%.15g, K=%i, component_weights=%s'
-                        % (i, bound, len(self.density), self.density.weights))
+            if logger.isEnabledFor(logging.INFO):               # (formatting K weights costs more than a K-sized kernel)
+                logger.info('After update %d: bound=%.15g, K=%i, component_weights=%s'
+                            % (i, bound, len(self.density), self.density.weights))
             if bound < old_bound:
                 logger.warning('Bound decreased from %g to %g' % (old_bound, bound))
             if bound == old_bound:
