@@ -89,3 +89,34 @@ def test_batched_factorisation_in_one_dimension():
         l, i, d = chol_inv_det(ms[k])
         assert np.array_equal(lower[k], l) and np.array_equal(inverse[k], i) and log_det[k] == d
     np.testing.assert_allclose(log_det, np.log(ms[:, 0, 0]))
+
+
+def test_history_append_keeps_the_reference_bookkeeping_without_its_quadratic_copy():
+    """tools.History (pypmc/tools/_history.py:60-110): runs, slices and ``memleft`` as the reference's -- whose append copies the
+    whole store every time the preallocation is used up; here the store keeps spare rows (2000 runs stay cheap)."""
+    import time
+    from pypmc_amd.tools._history import History
+    h = History(3, prealloc=5)
+    rs = np.random.RandomState(0)
+    runs = []
+    first = h.append(2)
+    first[:] = 1.0
+    assert h.memleft == 3
+    h.append(3)[:] = 2.0
+    assert h.memleft == 0
+    runs = [np.full((2, 3), 1.0), np.full((3, 3), 2.0)]
+    t0 = time.perf_counter()
+    for i in range(2000):
+        n = int(rs.randint(1, 40))
+        a = rs.normal(size=(n, 3))
+        h.append(n)[:] = a
+        runs.append(a)
+        assert h.memleft == 0
+    assert time.perf_counter() - t0 < 2.0
+    assert len(h) == 2002
+    np.testing.assert_array_equal(h[:], np.vstack(runs))
+    np.testing.assert_array_equal(h[17], runs[17])
+    np.testing.assert_array_equal(h[5:9], np.vstack(runs[5:9]))
+    np.testing.assert_array_equal(h[-1], runs[-1])
+    h.clear()
+    assert len(h) == 0 and h.memleft == 5 and h[:].size == 0
