@@ -243,6 +243,26 @@ int pmc_vb_state_put(pmc_vb_state *st, int field, const double *h);
 int pmc_vb_state_get(pmc_vb_state *st, int field, double *h);
 int64_t pmc_vb_state_result_len(int K);
 int pmc_vb_state_step(pmc_vb_state *st, const pmc_samples *s, int flags, const double *h_psi_parts, double *h_result);
+/*
+ * GaussianInference.run's loop (variational.pyx:283-359) for as long as no component has to go: per iteration update() (M-step,
+ * then E-step and bound as in pmc_vb_state_step) and the reference's convergence rules (:330-352), with nothing between two
+ * iterations but `psi` -- the caller's psi parts (pmc_vb_state_step; called with the N_comp the queued M-step uses, while that
+ * kernel runs; NULL: the device's psi).  Starts from `old_bound` (the bound of the state as it is) and h_N_comp (the latest
+ * N_comp, K), moments about the previous means from the first E-step on if about_prev.  Returns when
+ *   h_info[1] = PMC_VB_RUN_CONVERGED  the rules say so;
+ *               PMC_VB_RUN_PRUNE      an update left a component with N_k < prune_threshold (the caller prunes and calls again);
+ *               PMC_VB_RUN_LOOK       N_comp, S or the bound of the latest block is not finite (the reference's checks, :122-126,
+ *                                     are the caller's);
+ *               PMC_VB_RUN_CAP        max_iterations updates are done;
+ * h_info[0] = updates done, h_info[2] = how often the bound decreased, h_info[3] = whether the next E-step may take its moments
+ * about the latest means; h_bounds = [bound, the bound before the last update]; h_result = the last update's block.  A matrix
+ * that does not factorise ends the loop with PMC_ENOTPOSDEF (h_info[0] = updates completed before it).
+ */
+typedef void (*pmc_vb_psi_fn)(void *user, int K, const double *h_N_comp, double *h_psi_parts);
+enum { PMC_VB_RUN_CAP = 0, PMC_VB_RUN_CONVERGED = 1, PMC_VB_RUN_PRUNE = 2, PMC_VB_RUN_LOOK = 3 };
+int pmc_vb_state_run(pmc_vb_state *st, const pmc_samples *s, int max_iterations, double old_bound, double prune_threshold,
+                     double rel_tol, double abs_tol, int about_prev, const double *h_N_comp, pmc_vb_psi_fn psi, void *user,
+                     double *h_result, int *h_info, double *h_bounds);
 
 /* ---- PMC update --------------------------------------------------------------------------------------- */
 /*

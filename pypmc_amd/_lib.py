@@ -173,7 +173,11 @@ CTX_SIGNATURES = {
     "pmc_vb_state_get": (_int, [_vp, _int, _dp]),
     "pmc_vb_state_result_len": (_i64, [_int]),
     "pmc_vb_state_step": (_int, [_vp, _vp, _int, _dp, _dp]),
+    "pmc_vb_state_run": (_int, [_vp, _vp, _int, C.c_double, C.c_double, C.c_double, C.c_double, _int, _dp, _vp, _vp, _dp,
+                                C.POINTER(C.c_int), _dp]),
 }
+VB_PSI_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
+VB_RUN_CAP, VB_RUN_CONVERGED, VB_RUN_PRUNE, VB_RUN_LOOK = 0, 1, 2, 3
 
 # enum pmc_vb_field / the step flags (include/pmc_ctx.h)
 VB_FIELDS = ("alpha0", "beta0", "nu0", "m0", "inv_W0", "log_det_W0", "alpha", "beta", "nu", "m", "W", "log_det_W",

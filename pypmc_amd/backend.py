@@ -775,6 +775,39 @@ class VBState(object):
         return dict(N_comp=r[:K].copy(), far=r[K:2 * K], mean_finite=r[2 * K:3 * K], S_any_finite=r[3 * K:4 * K],
                     log_q_Z=float(r[4 * K]), bound=r[8 * K + 8:8 * K + 16].copy())
 
+    def run(self, samples, max_iterations, old_bound, prune_threshold, rel_tol, abs_tol, about_prev, n_comp, psi_parts=None):
+        """``pmc_vb_state_run``: updates until the reference's convergence rules hold, a component falls below
+        ``prune_threshold``, the block needs a look, or ``max_iterations`` are done.  ``psi_parts(N_comp) -> 2 K numbers``
+        is called once per update (None: the device's psi).  Returns dict(done, reason, decreased, about_prev, bound,
+        old_bound) + the last block's entries as ``step`` returns them."""
+        K = self.K
+        n_comp = np.ascontiguousarray(n_comp, dtype=np.float64)
+        assert n_comp.shape == (K,)
+        error = []
+
+        def callback(user, k, n_ptr, out_ptr):
+            try:
+                out = np.ctypeslib.as_array(out_ptr, shape=(2 * k,))
+                out[:] = psi_parts(np.ctypeslib.as_array(n_ptr, shape=(k,)))
+            except BaseException as exc:                  # (an exception must not unwind through the library's frames)
+                error.append(exc)
+                np.ctypeslib.as_array(out_ptr, shape=(2 * k,))[:] = np.nan
+        cb = _lib.VB_PSI_FN(callback) if psi_parts is not None else None
+        info, bounds = (C.c_int * 4)(), np.zeros(2)
+        rc = self.be._timed("pmc_vb_state_run", self.be.lib.pmc_vb_state_run, self._h, samples._h, int(max_iterations), float(old_bound),
+                            float(prune_threshold), float(rel_tol), float(abs_tol), 1 if about_prev else 0, _dptr(n_comp),
+                            C.cast(cb, C.c_void_p) if cb is not None else None, None, _dptr(self._result), info, _dptr(bounds))
+        if error:
+            raise error[0]
+        done = int(info[0])
+        out = dict(done=done, reason=int(info[1]), decreased=int(info[2]), about_prev=bool(info[3]), bound=float(bounds[0]),
+                   old_bound=float(bounds[1]), rc=rc)
+        if done:
+            r = self._result
+            out.update(N_comp=r[:K].copy(), far=r[K:2 * K], mean_finite=r[2 * K:3 * K], S_any_finite=r[3 * K:4 * K],
+                       log_q_Z=float(r[4 * K]), bound_terms=r[8 * K + 8:8 * K + 16].copy())
+        return out
+
     def close(self):
         if self._h is not None:
             self.be.lib.pmc_vb_state_destroy(self._h)

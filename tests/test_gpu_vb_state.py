@@ -255,3 +255,38 @@ def test_random_shapes_against_the_host_path(be, seed):
         _close(dev, host, 1e-9, "update %d (K=%d D=%d N=%d)" % (it, K, D, N))
         bd, bh = dev.likelihood_bound(), host.likelihood_bound()
         assert abs(bd - bh) <= 1e-10 * abs(bh), (bd, bh)
+
+
+@pytest.mark.parametrize("K,D,N,clusters,prune", [(10, 3, 20000, 3, 300.), (12, 8, 40000, 5, 1.), (4, 2, 3000, 4, 1.), (6, 20, 30000, 2, 50.),
+                                                  (5, 5, 5000, 5, 0.)])
+def test_run_inside_the_library_is_the_loop_of_this_file(be, K, D, N, clusters, prune):
+    """run() as pmc_vb_state_run (the iterations between two prunings in one call) against the same steps driven from
+    variational.py: the same kernels in the same order -- the same iteration count, the same survivors, the same bits"""
+    x = _data(N, D, clusters, 17 * K + D)
+    lib, loop = _fit(x, K, True), _fit(x, K, True)
+    loop.run_in_library = False
+    assert lib._run_in_library_ok() and not loop._run_in_library_ok()
+    n_lib, n_loop = lib.run(80, prune=prune), loop.run(80, prune=prune)
+    assert n_lib == n_loop and lib.K == loop.K
+    _close(lib, loop, 0.0, "library loop")
+    assert lib.likelihood_bound() == loop.likelihood_bound()
+    assert lib._shift_valid == loop._shift_valid
+    # and the object goes on as usual afterwards
+    lib.update()
+    loop.update()
+    _close(lib, loop, 0.0, "one more update")
+
+
+def test_run_inside_the_library_reports_what_the_loop_reports(be):
+    K, D = 3, 3
+    x = _data(2000, D, K, 3)
+    vb = _fit(x, K, True)
+    S = vb.S
+    S[1] = -np.eye(D) * 1e6                                       # W^-1 of component 1 becomes indefinite in the first M-step
+    with pytest.raises(np.linalg.LinAlgError) as e:
+        vb.run(5)
+    assert "component 1" in str(e.value)
+    # an iteration cap of zero, and a cap that is reached
+    vb = _fit(x, K, True)
+    assert vb.run(0) is None
+    assert vb.run(1, rel_tol=0., abs_tol=0.) is None
