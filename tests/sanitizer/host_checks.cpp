@@ -213,6 +213,25 @@ static void handle_layer(int nparts, int K, int D, int64_t N, uint64_t seed)
             EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_MSTEP | PMC_VB_DO_ESTEP | PMC_VB_DO_BOUND | PMC_VB_ABOUT_PREV, parts.data(), res.data()) == PMC_OK);
             EXPECT(pmc_vb_state_step(vs, nullptr, PMC_VB_DO_BOUND, nullptr, res.data()) == PMC_OK);
             EXPECT(pmc_vb_state_get(vs, PMC_VB_E_W, big.data()) == PMC_OK);
+            // run()'s loop in the library: with the device's psi and with a callback; the stub's kernels leave zeros behind
+            // (no finite entry flagged in S): the first update hands the block back for a look
+            int info[4] = {-1, -1, -1, -1};
+            double bounds[2] = {1.0, 1.0};
+            std::vector<double> n0((size_t)K, 1.0);
+            EXPECT(pmc_vb_state_run(vs, s, 3, 0.0, 1.0, 1e-10, 1e-5, 0, n0.data(), nullptr, nullptr, res.data(), info, bounds) == PMC_OK);
+            EXPECT(info[0] == 1 && info[1] == PMC_VB_RUN_LOOK);
+            struct Seen { int calls, K; } seen = {0, 0};
+            auto psi = [](void *user, int k, const double *n, double *parts) {
+                Seen *sn = (Seen *)user;
+                sn->calls += 1;
+                sn->K = k;
+                for (int i = 0; i < 2 * k; ++i) parts[i] = n[i % k];
+            };
+            EXPECT(pmc_vb_state_run(vs, s, 2, 5.0, 0.0, 0.0, 0.0, 1, n0.data(), psi, &seen, res.data(), info, bounds) == PMC_OK);
+            EXPECT(seen.calls == info[0] && seen.K == K && info[0] >= 1);
+            EXPECT(pmc_vb_state_run(vs, s, 0, 5.0, 0.0, 0.0, 0.0, 1, n0.data(), nullptr, nullptr, res.data(), info, bounds) == PMC_OK && info[0] == 0 &&
+                   info[1] == PMC_VB_RUN_CAP);
+            EXPECT(pmc_vb_state_run(vs, nullptr, 1, 5.0, 0.0, 0.0, 0.0, 1, n0.data(), nullptr, nullptr, res.data(), info, bounds) == PMC_EINVAL);
             EXPECT(pmc_vb_state_destroy(vs) == PMC_OK);
             EXPECT(pmc_vb_state_create(ctx, K, 65, &vs) == PMC_EINVAL);
         }
