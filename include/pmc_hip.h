@@ -428,8 +428,9 @@ int pmc_convert_stats_device(int K, int D, const double *d_stats, const double *
  * pmc_vb_newshift_device: the shifts of a second statistics pass (a mean far from its shift: variational.pyx:806-932's two
  *   passes): d_out = d_shift + M1 / S0 where S0 > 1e-200, d_shift elsewhere.
  * pmc_vb_bound_device: d_out[8] = [L(Q) | E log p(X) | E log p(Z) | E log p(pi) | E log p(mu, Lambda) | E log q(Z) |
- *   E log q(pi) | E log q(mu, Lambda)]; d_scratch: pmc_vb_bound_scratch_len(K) doubles.  Sums over components run in
- *   component order: the same input gives the same bits.
+ *   E log q(pi) | E log q(mu, Lambda)]; d_scratch: pmc_vb_bound_scratch_len(K) doubles whose LAST EIGHT are zero before the
+ *   first call (a ticket counter: the workgroup that finishes last adds the terms up and leaves it zero).  Sums over
+ *   components run in component order: the same input gives the same bits.
  * pmc_host_digamma / pmc_host_lgamma: the psi and ln Gamma the kernels use (x > 0; NaN otherwise), on the host, for
  *   tests: |error| <= 2e-15 (1 + |value|) for psi, 1e-14 (1 + |value|) for ln Gamma (the recurrence below x = 10 costs the
  *   difference of two logarithms of about 17).
@@ -455,6 +456,14 @@ int pmc_vb_mstep_device(int K, int D, const pmc_vb_fields *f, double *d_status, 
 int pmc_vb_mstep_status(int K, const double *h_status);
 int pmc_vb_expectations_device(int K, int D, const pmc_vb_fields *f, const double *d_psi_parts, double *d_c0, double *d_c3,
                                void *stream);
+/* pmc_vb_pack_device: the posterior's pack (pmc_pack_components_device's kernel and bits) with the E-step's expectations formed
+ *   in the same launch from the caller's psi parts (pmc_vb_expectations_device with d_psi_parts, without its launch).
+ * pmc_vb_convert_after_device: pmc_convert_stats_device + pmc_vb_after_device in one launch (K-sized kernels cost 4-5 us each
+ *   whatever they do): d_stats / d_shift / d_scalars as there, d_conv receives the conversion's block. */
+int pmc_vb_pack_device(int K, int D, const pmc_vb_fields *f, const double *d_psi_parts, double *d_pack, double *d_status,
+                       const double *d_shift, double *d_shift_pack, void *stream);
+int pmc_vb_convert_after_device(int K, int D, const double *d_stats, const double *d_shift, const double *d_scalars, double *d_conv,
+                                const pmc_vb_fields *f, double *d_small, double *d_shift_prev, double *d_log_q_Z, void *stream);
 int64_t pmc_vb_small_len(int K);
 int pmc_vb_after_device(int K, int D, const double *d_conv, const pmc_vb_fields *f, double *d_small, double *d_shift_prev,
                         double *d_log_q_Z, void *stream);

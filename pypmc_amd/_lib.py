@@ -120,6 +120,8 @@ SIGNATURES = {
     "pmc_vb_mstep_device": (_int, [_int, _int, _vp, _vp, _vp]),
     "pmc_vb_mstep_status": (_int, [_int, _dp]),
     "pmc_vb_expectations_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_vb_pack_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmc_vb_convert_after_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmc_vb_small_len": (_i64, [_int]),
     "pmc_vb_after_device": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmc_vb_newshift_device": (_int, [_int, _int, _vp, _vp, _vp, _vp]),

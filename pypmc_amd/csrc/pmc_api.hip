@@ -4,6 +4,7 @@
 #include "../../include/pmc_hip.h"
 #include "pmc_dims.h"
 #include "pmc_internal.h"
+#include "pmc_convert.h"
 
 #include <dlfcn.h>
 
@@ -629,10 +630,20 @@ __global__ __launch_bounds__(256) void k_combine_weights(const double *__restric
 // front of each of its D dependent steps).  status = [1 + failing pivot, or 0 (K) | its value (K)]: nothing to initialise,
 // every component writes its two slots.
 // blocks K ... 2K-1 (when means != NULL): the pack of the shifts of a statistics pass (pmc_pack_means) in the same launch.
+// vbx.on: the constants of a VB posterior's pack (enum pmc_kind, PMC_KIND_VB) formed here from the state's fields and the
+// caller's psi parts -- k_vb_expect's work (pmc_vbstate.hip) without its launch: c0 = D / beta, c1 = nu, c2 = E[ln pi],
+// c3 = E[ln|Lambda|] - D ln 2 pi with E[ln|Lambda|] = (sum psi + D ln 2) + ln|W|; the two expectations are stored as well.
+struct PmcVbExpect {
+    int on;
+    const double *beta, *nu, *log_det_W, *parts;
+    double *ln_lambda, *ln_pi;
+    double d_ln_2pi;
+};
+
 __global__ __launch_bounds__(64) void k_pack_build(const double *mu, const double *prec, const double *c0, const double *c1,
                                                   const double *c2, const double *c3, const double *weight, const int *column,
                                                   int K, int D, int Dp, int stride, double *pack, double *status,
-                                                  const double *means, double *mpack)
+                                                  const double *means, double *mpack, PmcVbExpect vbx)
 {
     extern __shared__ double lds[];
     const int j = threadIdx.x;
@@ -699,69 +710,30 @@ __global__ __launch_bounds__(64) void k_pack_build(const double *mu, const doubl
         if (j >= i && j < D) pk[Dp + i * Dp - i * (i - 1) / 2 + (j - i)] = Rl[i * D + j];
     if (j == 0) {
         double *c = pk + Dp + Dp * (Dp + 1) / 2;
-        c[0] = c0 ? c0[k] : 0.0;
-        c[1] = c1 ? c1[k] : 0.0;
-        c[2] = c2 ? c2[k] : 0.0;
-        c[3] = c3 ? c3[k] : 0.0;
+        if (vbx.on) {
+            const double lam = vbx.parts[K + k] + vbx.log_det_W[k];
+            vbx.ln_lambda[k] = lam;
+            vbx.ln_pi[k] = vbx.parts[k];
+            c[0] = D / vbx.beta[k];
+            c[1] = vbx.nu[k];
+            c[2] = vbx.parts[k];
+            c[3] = lam - vbx.d_ln_2pi;
+        } else {
+            c[0] = c0 ? c0[k] : 0.0;
+            c[1] = c1 ? c1[k] : 0.0;
+            c[2] = c2 ? c2[k] : 0.0;
+            c[3] = c3 ? c3[k] : 0.0;
+        }
         c[4] = weight ? weight[k] : 1.0;
         ((long long *)c)[5] = column ? (long long)column[k] : (long long)k;
     }
 }
 
-// pmc_host_convert_stats on the device.  out = [S0 K | M1 K D | mean K D | cov K D D | far K (0 / 1 per component) |
-// scalars PMC_NSCALARS (a copy of `scalars`, or zeros)]: everything a caller reads after an E-step in ONE block of memory
+// pmc_host_convert_stats on the device (pmc_convert.h: shared with the VB state's fused conversion).
 __global__ __launch_bounds__(256) void k_convert_stats(const double *stats, const double *shift, const double *ncov, int K, int D,
                                                       const double *scalars, double *out)
 {
-    __shared__ double s0s[1024];
-    __shared__ double total_s;
-    const int k = blockIdx.x, PS = 1 + D + D * (D + 1) / 2;
-    const double *b = stats + (size_t)k * PS;
-    double *S0 = out, *M1 = S0 + K, *mean = M1 + (size_t)K * D, *cov = mean + (size_t)K * D, *far = cov + (size_t)K * D * D;
-    const double tiny = 2.2250738585072014e-308;
-    // the total over the components, added in their order (shift_is_far's threshold): loads side by side, one lane adds
-    double total = 0.0;
-    for (int q0 = 0; q0 < K; q0 += 1024) {
-        const int nq = K - q0 < 1024 ? K - q0 : 1024;
-        __syncthreads();
-        for (int q = threadIdx.x; q < nq; q += 256) s0s[q] = stats[(size_t)(q0 + q) * PS];
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int q = 0; q < nq; ++q)
-                if (isfinite(s0s[q])) total += s0s[q];
-    }
-    if (threadIdx.x == 0) total_s = total;
-    const double s0 = b[0];
-    const double nm = s0 == 0.0 ? tiny : s0;
-    const double ncr = ncov ? ncov[k] : s0;
-    const double nc = ncr == 0.0 ? tiny : ncr;
-    if (threadIdx.x == 0) S0[k] = s0;
-    if (k == 0 && threadIdx.x < PMC_NSCALARS) (far + K)[threadIdx.x] = scalars ? scalars[threadIdx.x] : 0.0;
-    for (int i = threadIdx.x; i < D; i += 256) {
-        M1[(size_t)k * D + i] = b[1 + i];
-        mean[(size_t)k * D + i] = shift[(size_t)k * D + i] + b[1 + i] / nm;
-    }
-    for (int e = threadIdx.x; e < D * D; e += 256) {
-        const int i = e / D, jj = e % D;
-        const int hi = i > jj ? i : jj, lo = i > jj ? jj : i;
-        const double m2 = b[1 + D + hi * (hi + 1) / 2 + lo];
-        const double prod = (b[1 + i] / nm) * (b[1 + jj] / nm);
-        cov[((size_t)k * D + i) * D + jj] = (m2 - nm * prod) / nc;
-    }
-    __syncthreads();
-    // _stats.py::shift_is_far (limit 100) for this component: the D coordinates side by side, any hit counts
-    int hit = 0;
-    if (isfinite(s0) && s0 > 1e-200 && s0 > 1e-6 * total_s) {
-        for (int i = threadIdx.x; i < D; i += 256) {
-            const double db = b[1 + i] / s0, dbar2 = db * db;
-            const double raw = b[1 + D + i * (i + 1) / 2 + i] / s0;
-            const double v = raw - dbar2, t = 1e-14 * raw;
-            const double var = (v != v || t != t) ? v + t : (v > t ? v : t);
-            if (dbar2 > 100. * var) hit = 1;
-        }
-    }
-    hit = __syncthreads_or(hit);
-    if (threadIdx.x == 0) far[k] = hit ? 1.0 : 0.0;
+    pmc_convert_stats_block(stats, shift, ncov, K, D, scalars, out);
 }
 
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
@@ -1450,9 +1422,35 @@ int pmc_pack_components_device(int K, int D, const double *d_mu, const double *d
                     "build the pack on the host (pmc_pack_components)", PMC_MAX_DIM, D);
     hipLaunchKernelGGL(k_pack_build, dim3((unsigned)(d_shift ? 2 * K : K)), dim3(64), sizeof(double) * 2 * (size_t)D * D,
                        (hipStream_t)stream, d_mu, d_prec, d_c0, d_c1, d_c2, d_c3, d_weight, (const int *)d_column, K, D, ks->dim,
-                       pmc_pack_stride_c(ks->dim), d_pack, d_status, d_shift, d_shift_pack);
+                       pmc_pack_stride_c(ks->dim), d_pack, d_status, d_shift, d_shift_pack, PmcVbExpect{});
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_pack_build launch");
+    return PMC_OK;
+}
+
+// pmc_pack_components_device for the posterior of a VB state, the expectations of the E-step formed in the same launch
+int pmc_vb_pack_device(int K, int D, const pmc_vb_fields *f, const double *d_psi_parts, double *d_pack, double *d_status,
+                       const double *d_shift, double *d_shift_pack, void *stream)
+{
+    if (K < 1 || !f || !f->m || !f->W || !f->beta || !f->nu || !f->log_det_W || !f->ln_lambda || !f->ln_pi || !d_psi_parts || !d_pack ||
+        !d_status || ((d_shift != nullptr) != (d_shift_pack != nullptr)))
+        return fail(PMC_EINVAL, "pmc_vb_pack_device: bad argument");
+    const PmcKernelSet *ks = kernels_for(D);
+    if (!ks) return fail(PMC_EINVAL, "sample dimension %d is not supported (max %d)", D, PMC_BIG_MAX_DIM);
+    if (D > PMC_MAX_DIM || pmc_engine(ks->dim) == PMC_ENG_DPP)
+        return fail(PMC_EINVAL, "pmc_vb_pack_device: compiled dimensions up to %d in the row-major layout only (D = %d)", PMC_MAX_DIM, D);
+    PmcVbExpect vbx;
+    vbx.on = 1;
+    vbx.beta = f->beta; vbx.nu = f->nu; vbx.log_det_W = f->log_det_W; vbx.parts = d_psi_parts;
+    vbx.ln_lambda = f->ln_lambda; vbx.ln_pi = f->ln_pi;
+    // (D ln 2 pi with the host's log(2 pi): the logarithm of the DOUBLE 2 pi, as pmc_vb_estep and variational.py compute it)
+    vbx.d_ln_2pi = D * 0x1.d67f1c864beb4p+0;
+    hipLaunchKernelGGL(k_pack_build, dim3((unsigned)(d_shift ? 2 * K : K)), dim3(64), sizeof(double) * 2 * (size_t)D * D,
+                       (hipStream_t)stream, (const double *)f->m, (const double *)f->W, (const double *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const int *)nullptr, K, D, ks->dim,
+                       pmc_pack_stride_c(ks->dim), d_pack, d_status, d_shift, d_shift_pack, vbx);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hipfail(e, "k_pack_build (VB) launch");
     return PMC_OK;
 }
 
@@ -1475,7 +1473,7 @@ int pmc_pack_means_device(int K, int D, const double *d_mu, double *d_pack, void
     hipLaunchKernelGGL(k_pack_build, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, (const double *)nullptr,
                        (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
                        (const double *)nullptr, (const double *)nullptr, (const int *)nullptr, 0, D, ks->dim,
-                       pmc_pack_stride_c(ks->dim), (double *)nullptr, (double *)nullptr, d_mu, d_pack);
+                       pmc_pack_stride_c(ks->dim), (double *)nullptr, (double *)nullptr, d_mu, d_pack, PmcVbExpect{});
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hipfail(e, "k_pack_build (means) launch");
     return PMC_OK;

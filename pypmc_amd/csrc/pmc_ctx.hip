@@ -1288,11 +1288,17 @@ static int vb_state_pass(pmc_vb_state *st, const pmc_samples *s, Part &pt, const
     const int64_t N = s->n(0);
     double *d_pstatus = st->result + (size_t)pmc_vb_small_len(K);
     if (with_pack) {
-        CK(pmc_vb_expectations_device(K, D, &st->f, own_psi ? nullptr : st->psi_parts, st->c0, st->c3, pt.stream));
         CK(st->pack.ensure((size_t)K * stride * sizeof(double)));
         if (d_shift) CK(st->spack.ensure((size_t)K * stride * sizeof(double)));
-        CK(pmc_pack_components_device(K, D, st->f.m, st->f.W, st->c0, st->f.nu, st->f.ln_pi, st->c3, nullptr, nullptr, st->pack.d(),
-                                      d_pstatus, d_shift, d_shift ? st->spack.d() : nullptr, pt.stream));
+        if (own_psi) {
+            // the device's psi: the expectations in a launch of their own, then the pack
+            CK(pmc_vb_expectations_device(K, D, &st->f, nullptr, st->c0, st->c3, pt.stream));
+            CK(pmc_pack_components_device(K, D, st->f.m, st->f.W, st->c0, st->f.nu, st->f.ln_pi, st->c3, nullptr, nullptr, st->pack.d(),
+                                          d_pstatus, d_shift, d_shift ? st->spack.d() : nullptr, pt.stream));
+        } else {
+            CK(pmc_vb_pack_device(K, D, &st->f, st->psi_parts, st->pack.d(), d_pstatus, d_shift, d_shift ? st->spack.d() : nullptr,
+                                  pt.stream));
+        }
     } else {
         CK(st->spack.ensure((size_t)K * stride * sizeof(double)));
         CK(pmc_pack_means_device(K, D, d_shift, st->spack.d(), pt.stream));
@@ -1305,8 +1311,8 @@ static int vb_state_pass(pmc_vb_state *st, const pmc_samples *s, Part &pt, const
     CK(pmc_estep_about(s->x[0].d(), N, D, st->pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, pt.u.d(), nullptr, nullptr,
                        d_flat + NSC, d_flat, pt.ws.p, d_shift ? st->spack.d() : nullptr, pt.stream));
     CK(reduce(ctx, d_flat, nflat));
-    CK(pmc_convert_stats_device(K, D, d_flat + NSC, d_shift ? d_shift : st->f.m, nullptr, d_flat, st->conv, pt.stream));
-    return pmc_vb_after_device(K, D, st->conv, &st->f, st->result, st->shift_next, st->log_q_Z, pt.stream);
+    return pmc_vb_convert_after_device(K, D, d_flat + NSC, d_shift ? d_shift : st->f.m, d_flat, st->conv, &st->f, st->result,
+                                       st->shift_next, st->log_q_Z, pt.stream);
 }
 
 int pmc_vb_state_create(pmc_ctx *ctx, int K, int D, pmc_vb_state **out)

@@ -13,6 +13,7 @@
 // below (|error| <= 2e-15 (1 + |psi|), 1e-14 (1 + |ln Gamma|): tests/test_cabi.py holds them to scipy's).  One wavefront per
 // component, the matrix in LDS: K-sized work is latency, not throughput.
 #include "../../include/pmc_hip.h"
+#include "pmc_convert.h"
 
 #include <hip/hip_runtime.h>
 
@@ -344,6 +345,41 @@ __global__ __launch_bounds__(64) void k_vb_after(const double *conv, pmc_vb_fiel
     if (k == 0 && t == 0) *log_q_Z = far[K];
 }
 
+// conversion (pmc_convert.h) and k_vb_after in one launch: K-sized kernels cost 4-5 us each whatever they do
+__global__ __launch_bounds__(256) void k_vb_convert_after(const double *stats, const double *shift, const double *scalars, double *conv,
+                                                         pmc_vb_fields f, int K, int D, double *small, double *shift_prev, double *log_q_Z)
+{
+    pmc_convert_stats_block(stats, shift, nullptr, K, D, scalars, conv);
+    __syncthreads();                                                // (this workgroup's means and covariances are written)
+    const int k = blockIdx.x, t = threadIdx.x;
+    const double *S0 = conv, *mean = S0 + K + (size_t)K * D, *cov = mean + (size_t)K * D, *far = cov + (size_t)K * D * D;
+    const double s0 = S0[k], n = s0 == 0.0 ? VB_TINY : s0;
+    int mean_ok = 1, s_any = 0;
+    for (int i = t; i < D; i += 256) {
+        const double v = mean[(size_t)k * D + i];
+        f.x_mean[(size_t)k * D + i] = v;
+        shift_prev[(size_t)k * D + i] = v;
+        if (!isfinite(v)) mean_ok = 0;
+    }
+    for (int e = t; e < D * D; e += 256) {
+        const double v = cov[(size_t)k * D * D + e];
+        f.S[(size_t)k * D * D + e] = v;
+        if (isfinite(v)) s_any = 1;
+    }
+    mean_ok = __syncthreads_and(mean_ok);
+    s_any = __syncthreads_or(s_any);
+    if (t == 0) {
+        f.N_comp[k] = n;
+        small[k] = n;
+        small[K + k] = far[k];
+        small[2 * K + k] = mean_ok ? 1.0 : 0.0;
+        small[3 * K + k] = s_any ? 1.0 : 0.0;
+    }
+    // (the scalars: from the launch's argument, not from workgroup 0's copy in `conv`, which another workgroup may not see yet)
+    if (k == 0 && t < PMC_NSCALARS) small[4 * K + t] = scalars ? scalars[t] : 0.0;
+    if (k == 0 && t == 0) *log_q_Z = scalars ? scalars[0] : 0.0;
+}
+
 // the shifts of a second statistics pass: about the mean just found (variational.py::E_step, _stats.py)
 __global__ void k_vb_newshift(const double *conv, const double *shift, int K, int D, double *out)
 {
@@ -363,7 +399,12 @@ __device__ inline double wishart_log_B(int D, double nu, double log_det, int t)
 }
 
 // per component: the summands of the seven terms, terms[k][VB_NTERMS]
-__global__ __launch_bounds__(64) void k_vb_bound_terms(pmc_vb_fields f, int K, int D, double *terms)
+__device__ inline void vb_bound_total(const double *terms, int K, int D, const double *log_q_Z, double *out, int t, bool coherent);
+
+// (ticket != NULL: the workgroup that draws the last ticket adds the terms up -- one launch instead of two; the terms travel as
+//  agent-scope relaxed atomics, written back before the ticket is drawn, as the pieces of k_logpdf_split do)
+__global__ __launch_bounds__(64) void k_vb_bound_terms(pmc_vb_fields f, int K, int D, double *terms, unsigned *ticket,
+                                                      const double *log_q_Z, double *out)
 {
     const int k = blockIdx.x, t = threadIdx.x;
     const double *W = f.W + (size_t)k * D * D, *S = f.S + (size_t)k * D * D, *iW0 = f.inv_W0 + (size_t)k * D * D;
@@ -395,45 +436,65 @@ __global__ __launch_bounds__(64) void k_vb_bound_terms(pmc_vb_fields f, int K, i
     q_x = wave_sum(q_x);
     q_m = wave_sum(q_m);
     const double log_b0 = wishart_log_B(D, nu0, ldw0, t), log_b = wishart_log_B(D, nu, ldw, t);
-    if (t != 0) return;
-    double *o = terms + (size_t)k * VB_NTERMS;
-    // (10.71) N_k (E[ln|Lambda|] - D / beta - nu (tr(S W) + dx^T W dx) - D ln 2 pi)
-    o[0] = n * (lam - D / beta - nu * (tr_sw + q_x) - D * VB_LN2PI);
-    o[1] = n * lpi;                                                 // (10.72)
-    o[2] = (alpha0 - 1.0) * lpi;                                    // (10.73)
-    // (10.74)
-    double r = D * log(beta0 / (2. * 3.14159265358979323846));
-    r += lam - D * beta0 / beta - beta0 * nu * q_m;
-    r += 2 * log_b0;
-    r += (nu0 - D - 1) * lam;
-    r -= nu * tr_0;
-    o[3] = r;
-    o[4] = (alpha - 1.0) * lpi;                                     // (10.76)
-    // (10.77): H[Wishart] (B.82) with E[ln|Lambda|] (B.81) = lam
-    const double entropy = -log_b - 0.5 * (nu - D - 1) * lam + 0.5 * nu * D;
-    o[5] = 0.5 * (lam + D * log(beta / (2. * 3.14159265358979323846))) - entropy;
-    o[6] = vb_lgamma(alpha0);
-    o[7] = vb_lgamma(alpha);
-    o[8] = alpha0;
-    o[9] = alpha;
+    unsigned drawn = 0;
+    if (t == 0) {
+        double o[VB_NTERMS];
+        // (10.71) N_k (E[ln|Lambda|] - D / beta - nu (tr(S W) + dx^T W dx) - D ln 2 pi)
+        o[0] = n * (lam - D / beta - nu * (tr_sw + q_x) - D * VB_LN2PI);
+        o[1] = n * lpi;                                             // (10.72)
+        o[2] = (alpha0 - 1.0) * lpi;                                // (10.73)
+        // (10.74)
+        double r = D * log(beta0 / (2. * 3.14159265358979323846));
+        r += lam - D * beta0 / beta - beta0 * nu * q_m;
+        r += 2 * log_b0;
+        r += (nu0 - D - 1) * lam;
+        r -= nu * tr_0;
+        o[3] = r;
+        o[4] = (alpha - 1.0) * lpi;                                 // (10.76)
+        // (10.77): H[Wishart] (B.82) with E[ln|Lambda|] (B.81) = lam
+        const double entropy = -log_b - 0.5 * (nu - D - 1) * lam + 0.5 * nu * D;
+        o[5] = 0.5 * (lam + D * log(beta / (2. * 3.14159265358979323846))) - entropy;
+        o[6] = vb_lgamma(alpha0);
+        o[7] = vb_lgamma(alpha);
+        o[8] = alpha0;
+        o[9] = alpha;
+        double *dst = terms + (size_t)k * VB_NTERMS;
+        if (!ticket) {
+            for (int i = 0; i < VB_NTERMS; ++i) dst[i] = o[i];
+        } else {
+            for (int i = 0; i < VB_NTERMS; ++i) __hip_atomic_store(dst + i, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!ticket) return;
+    drawn = __shfl(drawn, 0, 64);
+    if (drawn != (unsigned)(K - 1)) return;
+    if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next launch)
+    vb_bound_total(terms, K, D, log_q_Z, out, t, true);
 }
 
 // the sums over the components, each in component order; out = [bound | log p(X) | log p(Z) | log p(pi) | log p(mu, Lambda) |
-// log q(Z) | log q(pi) | log q(mu, Lambda)]
-__global__ __launch_bounds__(64) void k_vb_bound_sum(const double *terms, int K, int D, const double *log_q_Z, double *out)
+// log q(Z) | log q(pi) | log q(mu, Lambda)].  One wavefront; coherent: the terms were written by other workgroups of this launch.
+__device__ inline void vb_bound_total(const double *terms, int K, int D, const double *log_q_Z, double *out, int t, bool coherent)
 {
-    const int t = threadIdx.x;
     double s = 0.0;
     if (t < VB_NTERMS) {
         int k = 0;
         for (; k + 8 <= K; k += 8) {                                // (loads eight at a time, the sum in component order)
             double v8[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v8[q] = terms[(size_t)(k + q) * VB_NTERMS + t];
+            for (int q = 0; q < 8; ++q) {
+                const double *src = terms + (size_t)(k + q) * VB_NTERMS + t;
+                v8[q] = coherent ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += v8[q];
         }
-        for (; k < K; ++k) s += terms[(size_t)k * VB_NTERMS + t];
+        for (; k < K; ++k) {
+            const double *src = terms + (size_t)k * VB_NTERMS + t;
+            s += coherent ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+        }
     }
     double v[VB_NTERMS];
     for (int i = 0; i < VB_NTERMS; ++i) v[i] = __shfl(s, i, 64);
@@ -540,6 +601,16 @@ int pmc_vb_after_device(int K, int D, const double *d_conv, const pmc_vb_fields 
     return launched("k_vb_after launch");
 }
 
+int pmc_vb_convert_after_device(int K, int D, const double *d_stats, const double *d_shift, const double *d_scalars, double *d_conv,
+                                const pmc_vb_fields *f, double *d_small, double *d_shift_prev, double *d_log_q_Z, void *stream)
+{
+    if (K < 1 || D < 1 || !d_stats || !d_shift || !d_conv || !fields_ok(f) || !d_small || !d_shift_prev || !d_log_q_Z)
+        return vfail(PMC_EINVAL, "pmc_vb_convert_after_device: bad argument");
+    hipLaunchKernelGGL(k_vb_convert_after, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, d_stats, d_shift, d_scalars, d_conv, *f, K,
+                       D, d_small, d_shift_prev, d_log_q_Z);
+    return launched("k_vb_convert_after launch");
+}
+
 int pmc_vb_newshift_device(int K, int D, const double *d_conv, const double *d_shift, double *d_out, void *stream)
 {
     if (K < 1 || D < 1 || !d_conv || !d_shift || !d_out) return vfail(PMC_EINVAL, "pmc_vb_newshift_device: bad argument");
@@ -548,17 +619,16 @@ int pmc_vb_newshift_device(int K, int D, const double *d_conv, const double *d_s
     return launched("k_vb_newshift launch");
 }
 
-int64_t pmc_vb_bound_scratch_len(int K) { return K < 1 ? (int64_t)vfail(PMC_EINVAL, "pmc_vb_bound_scratch_len: bad K") : (int64_t)K * VB_NTERMS; }
+int64_t pmc_vb_bound_scratch_len(int K) { return K < 1 ? (int64_t)vfail(PMC_EINVAL, "pmc_vb_bound_scratch_len: bad K") : (int64_t)K * VB_NTERMS + 8; }
 
 int pmc_vb_bound_device(int K, int D, const pmc_vb_fields *f, const double *d_log_q_Z, double *d_scratch, double *d_out, void *stream)
 {
     if (K < 1 || D < 1 || D > 64 || !fields_ok(f) || !d_log_q_Z || !d_scratch || !d_out)
         return vfail(PMC_EINVAL, "pmc_vb_bound_device: bad argument (1 <= D <= 64)");
-    hipLaunchKernelGGL(k_vb_bound_terms, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, *f, K, D, d_scratch);
-    const int rc = launched("k_vb_bound_terms launch");
-    if (rc < 0) return rc;
-    hipLaunchKernelGGL(k_vb_bound_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)d_scratch, K, D, d_log_q_Z, d_out);
-    return launched("k_vb_bound_sum launch");
+    // one launch: the workgroup that draws the last ticket (the counter behind the terms: zero between launches) adds up
+    hipLaunchKernelGGL(k_vb_bound_terms, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, *f, K, D, d_scratch,
+                       (unsigned *)(d_scratch + (size_t)K * VB_NTERMS), d_log_q_Z, d_out);
+    return launched("k_vb_bound_terms launch");
 }
 
 }  // extern "C"

@@ -209,7 +209,7 @@ def test_kernel_level_calls_refuse_bad_arguments(be):
     lib = be.lib
     assert lib.pmc_vb_max_dim() == 64
     assert lib.pmc_vb_small_len(5) == 28 and lib.pmc_vb_small_len(0) < 0
-    assert lib.pmc_vb_bound_scratch_len(5) == 50
+    assert lib.pmc_vb_bound_scratch_len(5) == 58                   # (10 terms per component + the ticket)
     assert lib.pmc_vb_mstep_device(0, 3, None, None, None) < 0
     assert lib.pmc_vb_bound_device(2, 65, None, None, None, None, None) < 0
     st = np.zeros(6)
