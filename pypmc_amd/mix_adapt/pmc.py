@@ -332,10 +332,77 @@ def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=
     return _apply_updates(density, live, new, renorm)
 
 
+DOF_BATCH_FROM = 16        # live components from which student_t_pmc solves all degree-of-freedom conditions at once
+
+
 def _dof_condition(const):
     """First-order condition for nu, [HOD12] eq. (16): const + log(nu/2) - psi(nu/2) = 0
     (reference: pmc.pyx:478-497)."""
     return lambda nu: const + np.log(.5 * nu) - digamma(.5 * nu)
+
+
+def _trigamma(x):
+    """psi'(x), x > 0, to ~1e-12 (the slope of a Newton step, not a result): six steps of psi'(x) = psi'(x + 1) + 1 / x^2,
+    then the asymptotic series (scipy's polygamma goes through a zeta function: 33 us per 128 values)"""
+    x = np.asarray(x, dtype=np.float64)
+    acc = np.zeros_like(x)
+    for _ in range(6):
+        acc += 1. / (x * x)
+        x = x + 1.
+    i = 1. / x
+    i2 = i * i
+    return acc + i * (1. + i * (.5 + i * (1. / 6. + i2 * (-1. / 30. + i2 * (1. / 42. + i2 * (-1. / 30.))))))
+
+
+def _solve_dofs(const, mindof, maxdof, start=None):
+    """The roots of ``_dof_condition(const[i])`` in [mindof, maxdof] for all i at once (round 6): safeguarded Newton steps in
+    log nu on the whole vector instead of one ``brentq`` per component (K = 128: 3.2 ms of scalar root findings -> 0.2 ms).
+    The condition decreases in nu (1 / nu < psi'(nu / 2) / 2), so a sign at an end decides a clamp exactly as the reference's
+    handling of brentq's ValueError does (pmc.pyx:700-710).  Roots are iterated until the step is below 1e-15 of log nu;
+    brentq stops within its xtol = 2e-12 of the root -- the two agree to 2e-12 absolutely (and to the conditioning of the root,
+    1e-9 at nu = 1e3, where the condition is flat).  Returns None if a constant is not finite or the iteration does not settle
+    (the caller's loop and its error handling take over)."""
+    const = np.asarray(const, dtype=np.float64)
+    if not np.isfinite(const).all():
+        return None
+    f = lambda nu: const + np.log(.5 * nu) - digamma(.5 * nu)
+    lo, hi = np.full(const.shape, float(mindof)), np.full(const.shape, float(maxdof))
+    f_lo, f_hi = f(lo), f(hi)
+    if not (np.isfinite(f_lo).all() and np.isfinite(f_hi).all()):
+        return None
+    aconst = np.abs(const)
+    below, above = f_lo < 0., f_hi > 0.                    # (no root inside: the condition is negative / positive throughout)
+    work = ~(below | above)
+    exact_lo, exact_hi = work & (f_lo == 0.), work & (f_hi == 0.)
+    t_lo, t_hi = np.log(lo), np.log(hi)
+    t = .5 * (t_lo + t_hi)
+    if start is not None:                                  # (the previous iteration's dof: a few steps from the new one)
+        ts = np.log(np.asarray(start, dtype=np.float64))
+        t = np.where(np.isfinite(ts) & (ts > t_lo) & (ts < t_hi), ts, t)
+    settled = ~work
+    for _ in range(80):
+        nu = np.exp(t)
+        lg, ps = np.log(.5 * nu), digamma(.5 * nu)
+        ft = const + lg - ps
+        noise = 4e-16 * (aconst + np.abs(lg) + np.abs(ps))  # the condition is zero to the rounding of its three terms
+        pos = ft > 0.                                      # the condition decreases: a positive value moves the lower end up
+        t_lo = np.where(work & pos, t, t_lo)
+        t_hi = np.where(work & ~pos, t, t_hi)
+        dfdt = 1. - .5 * nu * _trigamma(.5 * nu)          # d/dt of log(nu/2) - psi(nu/2) with nu = e^t: negative
+        t_new = t - np.where(dfdt < 0., ft / np.where(dfdt < 0., dfdt, -1.), 0.)
+        outside = ~((t_new > t_lo) & (t_new < t_hi)) | (dfdt >= 0.)
+        t_new = np.where(outside, .5 * (t_lo + t_hi), t_new)
+        settled = settled | (np.abs(ft) <= noise) | (np.abs(t_new - t) <= 1e-15 * np.maximum(1., np.abs(t))) | \
+            (t_hi - t_lo <= 2e-16 * np.maximum(1., np.abs(t_lo)))
+        t = np.where(settled, t, t_new)
+        if settled.all():
+            break
+    else:
+        return None
+    dof = np.exp(t)
+    dof = np.where(below | exact_lo, mindof, dof)
+    dof = np.where(above | exact_hi, maxdof, dof)
+    return np.clip(dof, mindof, maxdof)
 
 
 def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solver_steps=100,
@@ -380,8 +447,14 @@ def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solv
                 + (norm - V1) * (np.log(.5 * old_dof) - digamma(.5 * old_dof)) + S0g + (norm - V1)
             const = 1. - total / norm
         pos = {k: i for i, k in enumerate(stat_comps)}
+        # many components: all roots at once (brentq always converges within 50 steps on this range, so a cap of 50 or
+        # more never takes its "not converged" branch; below that, and for a handful of components, the reference's loop)
+        batch_dof = _solve_dofs(const, mindof, maxdof, old_dof) if (dof_solver_steps >= 50 and len(live) >= DOF_BATCH_FROM) else None
         for k in live:
             i = pos[k]
+            if batch_dof is not None:
+                new[k] = (alpha[i], (mu[i], cov[i], float(batch_dof[i])))
+                continue
             if dof_solver_steps:
                 condition = _dof_condition(const[i])
                 try:

@@ -120,3 +120,37 @@ def test_history_append_keeps_the_reference_bookkeeping_without_its_quadratic_co
     np.testing.assert_array_equal(h[-1], runs[-1])
     h.clear()
     assert len(h) == 0 and h.memleft == 5 and h[:].size == 0
+
+
+def test_all_degree_of_freedom_conditions_at_once_find_brentqs_roots():
+    """mix_adapt.pmc._solve_dofs (student_t_pmc with many components) against the reference's loop -- scipy's brentq on the
+    condition of pmc.pyx:478-497 per component, its ValueError handled as pmc.pyx:700-710 does: the same clamps exactly, the
+    roots to brentq's own tolerance (xtol = 2e-12) and the conditioning of a root where the condition is flat."""
+    from scipy.optimize import brentq
+    from scipy.special import digamma
+    from pypmc_amd.mix_adapt.pmc import _solve_dofs, _dof_condition, _trigamma
+    from scipy.special import polygamma
+    x = 10 ** np.random.RandomState(1).uniform(-6, 4, 500)
+    assert np.max(np.abs(_trigamma(x) - polygamma(1, x)) / polygamma(1, x)) < 1e-9
+    rs = np.random.RandomState(0)
+    nu_true = 10 ** rs.uniform(-5.5, 3.5, 300)               # some roots outside [mindof, maxdof]
+    const = -(np.log(.5 * nu_true) - digamma(.5 * nu_true))
+    mindof, maxdof = 1e-5, 1e3
+    for start in (None, nu_true * 1.5, np.full(300, 7.)):
+        got = _solve_dofs(const, mindof, maxdof, start)
+        ref = np.empty_like(got)
+        for i, c in enumerate(const):
+            cond = _dof_condition(c)
+            try:
+                ref[i] = brentq(cond, mindof, maxdof, maxiter=100)
+            except ValueError:
+                ref[i] = mindof if cond(mindof) < 0. else maxdof
+        clamped = (ref == mindof) | (ref == maxdof)
+        assert clamped.sum() > 10 and np.array_equal(got[clamped], ref[clamped])
+        assert (np.abs(got - ref) <= 4e-12 + 1e-11 * ref).all()
+        inside = (nu_true > mindof) & (nu_true < maxdof)
+        assert (np.abs(got[inside] - nu_true[inside]) <= 1e-11 * nu_true[inside]).all()
+    assert _solve_dofs(np.array([1.0, np.nan]), mindof, maxdof) is None
+    # clamp bounds as the golden case uses them
+    got = _solve_dofs(const[:20], 5., 5.5)
+    assert ((got >= 5.) & (got <= 5.5)).all()

@@ -330,3 +330,33 @@ def test_front_end_iteration_after_a_prune(be):
     with pytest.raises(ValueError):
         gaussian_pmc(r["samples"], sampler.proposal, r["weights"], r["origin"], mincount=0, rb=True, copy=True,
                      responsibilities=r["responsibilities"])
+
+
+def test_student_t_pmc_solves_its_degrees_of_freedom_at_once(be):
+    """student_t_pmc with 16 or more live components takes all roots of the degree-of-freedom condition at once
+    (mix_adapt.pmc._solve_dofs) instead of one brentq per component (pmc.pyx:693-710): the same update, the dofs to brentq's
+    tolerance"""
+    import pypmc_amd.mix_adapt.pmc as pmc_mod
+    from pypmc_amd.density.mixture import create_t_mixture
+    from pypmc_amd.mix_adapt.pmc import student_t_pmc
+    rs = np.random.RandomState(4)
+    K, D, N = 24, 6, 40000
+    mu = rs.normal(size=(K, D)) * 4
+    cov = np.array([np.eye(D) * rs.uniform(0.5, 2.0) for _ in range(K)])
+    dofs = rs.uniform(2., 30., size=K)
+    prop = create_t_mixture(mu, cov, dofs, rs.uniform(0.5, 1.5, size=K))
+    np.random.seed(5)
+    x = prop.propose(N)
+    w = rs.uniform(0.2, 2.0, size=N)
+    batched = student_t_pmc(x, prop, weights=w, copy=True, backend=be)
+    saved, pmc_mod.DOF_BATCH_FROM = pmc_mod.DOF_BATCH_FROM, 1 << 30
+    try:
+        loop = student_t_pmc(x, prop, weights=w, copy=True, backend=be)
+    finally:
+        pmc_mod.DOF_BATCH_FROM = saved
+    np.testing.assert_array_equal(batched.weights, loop.weights)
+    for a, b in zip(batched.components, loop.components):
+        np.testing.assert_array_equal(a.mu, b.mu)
+        np.testing.assert_array_equal(a.sigma, b.sigma)
+        assert abs(a.dof - b.dof) <= 4e-12 + 1e-11 * b.dof, (a.dof, b.dof)
+    assert len({round(c.dof, 6) for c in batched.components}) > K // 2      # (the dofs did move, each its own way)
