@@ -41,4 +41,4 @@ for _ in range(5):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats(os.environ.get("PROFILE_SORT", "tottime")).print_stats(int(os.environ.get("PROFILE_ROWS", "28")))
