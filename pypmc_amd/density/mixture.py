@@ -16,6 +16,32 @@ _SETS = OrderedDict()        # the last few ComponentSets built, with the parame
 _SETS_MAX = 8
 
 
+# What a batched K-sized update left behind (mix_adapt.pmc._apply_updates): the K Cholesky factors and inverses as ONE array
+# each, of which the components' own arrays are the rows.  The next pack / the next device-side propose take those arrays
+# instead of gathering 2 x K x D x D numbers out of K objects again (K = 128, D = 40: 0.2-0.3 ms each).  Keyed by the components'
+# parameter stamps in order; used only while every component's array still IS its row (``.base is`` the stacked array).
+_STACKED = OrderedDict()
+_STACKED_MAX = 4
+
+
+def register_stacked(components, cholesky, inverse):
+    _STACKED[tuple(c._stamp for c in components)] = (cholesky, inverse)
+    while len(_STACKED) > _STACKED_MAX:
+        _STACKED.popitem(last=False)
+
+
+def _stacked(components, attribute):
+    """the stacked array behind ``attribute`` ('cholesky_sigma' / 'inv_sigma') of these components, or None"""
+    hit = _STACKED.get(tuple(c._stamp for c in components))
+    if hit is None:
+        return None
+    arr = hit[0 if attribute == 'cholesky_sigma' else 1]
+    owner = arr if arr.base is None else arr.base           # (numpy names the owning array as the base of a row)
+    if len(arr) != len(components) or any(getattr(c, attribute).base is not owner for c in components):
+        return None
+    return arr
+
+
 def component_set(components, weights, columns=None, ld=None):
     """ComponentSet of homogeneous Gauss / StudentT ``components`` (None if they are of another
     or of mixed type).  ``columns`` selects a subset, ``ld`` is the total component count.
@@ -50,7 +76,8 @@ def component_set(components, weights, columns=None, ld=None):
             _SETS.move_to_end(key)
             return hit
     consts = np.array([c._kernel_constants() for c in sel], dtype=np.float64).reshape(len(sel), 4)
-    cs = ComponentSet(first.kind, mu, np.array([c.inv_sigma for c in sel], dtype=np.float64),
+    inv = _stacked(sel, 'inv_sigma') if cacheable else None
+    cs = ComponentSet(first.kind, mu, inv if inv is not None else np.array([c.inv_sigma for c in sel], dtype=np.float64),
                       consts[:, 0], consts[:, 1], consts[:, 2], consts[:, 3],
                       weight=wts, column=idx, ld=total)
     if cacheable:
@@ -63,6 +90,7 @@ def component_set(components, weights, columns=None, ld=None):
 def clear_component_cache():
     """Forget the cached ComponentSets (and the device parameter packs kept with them)."""
     _SETS.clear()
+    _STACKED.clear()
 
 
 class MixtureDensity(ProbabilityDensity):
@@ -199,8 +227,9 @@ class MixtureDensity(ProbabilityDensity):
             raise TypeError('device-side propose needs only Gauss or only StudentT components')
         be = get_backend(self._backend)
         seed = int(rng.randint(0, 2 ** 31 - 1)) | (int(rng.randint(0, 2 ** 31 - 1)) << 32)
+        chol = _stacked(comps, 'cholesky_sigma')
         x, origin = be.propose(np.array([c.mu for c in comps]),
-                               np.array([c.cholesky_sigma for c in comps]),
+                               chol if chol is not None else np.array([c.cholesky_sigma for c in comps]),
                                np.array([c.dof for c in comps]) if first is StudentT else None,
                                counts, seed, first_sample=first_sample, want_origin=trace,
                                out=None if (shuffle and not trace) else out)

@@ -258,7 +258,7 @@ def _linalg_backend(density, sig):
     return be
 
 
-def _apply_updates(density, live_components, new_params, need_renormalize):
+def _apply_updates(density, live_components, new_params, need_renormalize, stacked=None):
     """``component.update`` with the reference's fall-back: a LinAlgError restores the old
     parameters and zeroes the component's weight (pmc.pyx:227-244, :713-737).
 
@@ -269,7 +269,10 @@ def _apply_updates(density, live_components, new_params, need_renormalize):
         batch = None
         if len(live) > 1:
             try:
-                sig = np.array([np.asarray(new_params[k][1][1], dtype=np.float64) for k in live])
+                if stacked is not None and list(stacked[0]) == live and stacked[1].dtype == np.float64 and stacked[1].ndim == 3:
+                    sig = stacked[1]                              # (the statistics' covariances are one array already)
+                else:
+                    sig = np.array([np.asarray(new_params[k][1][1], dtype=np.float64) for k in live])
                 if sig.ndim == 3 and all(float(new_params[k][1][2]) > 0. for k in live if len(new_params[k][1]) == 3):
                     done = None
                     be = _linalg_backend(density, sig)
@@ -296,6 +299,10 @@ def _apply_updates(density, live_components, new_params, need_renormalize):
                 component.update(*old)
                 density.weights[k] = 0.
                 need_renormalize = True
+        if batch is not None and len(live) == len(density.components) and live == list(range(len(live))):
+            # the factors and inverses as they are: one array each, the components' own arrays their rows
+            from ..density.mixture import register_stacked
+            register_stacked(density.components, batch[1], batch[2])
     if need_renormalize:
         density.normalize()
     return density
@@ -327,9 +334,8 @@ def gaussian_pmc(samples, density, weights=None, latent=None, rb=True, mincount=
         alpha = S0 / norm                                         # :191-193
         pos = {k: i for i, k in enumerate(stat_comps)}
         new = {k: (alpha[pos[k]], (mu[pos[k]], cov[pos[k]])) for k in live}
-    else:
-        new = {}
-    return _apply_updates(density, live, new, renorm)
+        return _apply_updates(density, live, new, renorm, stacked=(stat_comps, cov))
+    return _apply_updates(density, live, {}, renorm)
 
 
 DOF_BATCH_FROM = 16        # live components from which student_t_pmc solves all degree-of-freedom conditions at once
@@ -473,7 +479,7 @@ def student_t_pmc(samples, density, weights=None, latent=None, rb=True, dof_solv
             else:
                 dof = density.components[k].dof
             new[k] = (alpha[i], (mu[i], cov[i], dof))
-    return _apply_updates(density, live, new, renorm)
+    return _apply_updates(density, live, new, renorm, stacked=(stat_comps, np.asarray(cov)) if stat_comps else None)
 
 
 class PMC(object):

@@ -154,3 +154,28 @@ def test_all_degree_of_freedom_conditions_at_once_find_brentqs_roots():
     # clamp bounds as the golden case uses them
     got = _solve_dofs(const[:20], 5., 5.5)
     assert ((got >= 5.) & (got <= 5.5)).all()
+
+
+def test_stacked_arrays_of_a_batched_update_are_used_while_they_are_the_components_rows():
+    """density.mixture._stacked: the factor / inverse arrays a batched update registered stand in for the gather out of the
+    components only while every component's array still IS a row of them and the stamps are those of the registration"""
+    from pypmc_amd.density.mixture import register_stacked, _stacked, clear_component_cache
+    from pypmc_amd.tools._linalg import chol_inv_det_batch
+    m = _mix()
+    sig = np.array([c.sigma * 2. for c in m.components])
+    chol, inv, logdet = chol_inv_det_batch(sig)
+    for k, c in enumerate(m.components):
+        c._assign(c.mu.copy(), sig[k].copy(), chol[k], inv[k], float(logdet[k]))
+    assert _stacked(m.components, 'inv_sigma') is None                       # (nothing registered)
+    register_stacked(m.components, chol, inv)
+    assert _stacked(m.components, 'inv_sigma') is inv and _stacked(m.components, 'cholesky_sigma') is chol
+    cs = component_set(m.components, m.weights)
+    assert cs.precision is inv or np.shares_memory(cs.precision, inv)
+    m.components[1].inv_sigma[0, 0] *= 1.5                                    # edited in place: still the row, still the truth
+    assert _stacked(m.components, 'inv_sigma')[1, 0, 0] == m.components[1].inv_sigma[0, 0]
+    m.components[0].inv_sigma = m.components[0].inv_sigma.copy()             # replaced: no longer the row
+    assert _stacked(m.components, 'inv_sigma') is None
+    c = m.components[2]
+    c.update(c.mu, c.sigma)                                                  # a new stamp
+    assert _stacked(m.components, 'cholesky_sigma') is None
+    clear_component_cache()
