@@ -290,3 +290,20 @@ def test_run_inside_the_library_reports_what_the_loop_reports(be):
     vb = _fit(x, K, True)
     assert vb.run(0) is None
     assert vb.run(1, rel_tol=0., abs_tol=0.) is None
+
+
+@pytest.mark.parametrize("K,D", [(64, 20), (1000, 3), (7, 64)])
+def test_the_one_launch_bound_has_the_same_bits_every_time(be, K, D):
+    """k_vb_bound_terms: the workgroup that draws the last ticket adds the terms up (they travel as agent-scope atomics across
+    the eight L2s); the same state must give the same eight numbers call after call"""
+    x = _data(max(4 * K, 2000), D, 4, K + D)
+    vb = _fit(x, K, True)
+    vb.update()
+    st = vb._state
+    first = st.step(None, bound=True)["bound"].copy()
+    assert np.isfinite(first).all()
+    for _ in range(400):
+        np.testing.assert_array_equal(st.step(None, bound=True)["bound"], first)
+    host = _fit(x, K, False)
+    host.update()
+    assert abs(first[0] - host.likelihood_bound()) <= 1e-11 * abs(first[0])
