@@ -87,6 +87,7 @@ def build(jobs=None, force=False, verbose=False):
     headers = [os.path.join(CSRC, h) for h in ("pmc_dims.h", "pmc_internal.h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "pmc_hip.h"))
     headers.append(os.path.join(CSRC, "pmc_device.h"))
+    headers.append(os.path.join(CSRC, "pmc_convert.h"))
     asrc = os.path.join(CSRC, "pmc_api.hip")
     work = [(os.path.join(OBJ, "pmc_api.o"), asrc, [], [asrc] + headers, force)]
     csrc = os.path.join(CSRC, "pmc_ctx.hip")           # the handle layer (include/pmc_ctx.h): host code only
