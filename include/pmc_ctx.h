@@ -204,7 +204,9 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
  * likelihood_bound() (:194-209) for an object whose hyper-parameters live on the context's device between the calls: with
  * pmc_vb_estep the K x D x D arrays W and S cross the bus twice per iteration and the M-step's K inversions, the digamma
  * sums and the bound run in the caller's interpreter -- at one GPU's share of eight that was an eighth of an iteration.
- * One-device contexts, D <= pmc_vb_max_dim().
+ * D <= pmc_vb_max_dim().  A context over several devices (pmc_init_devices) keeps the state on its first device; per E-step
+ * the other devices get the posterior they build their pack from in one peer copy, the statistics come back as in pmc_vb_estep
+ * (slots on the first device, added in device order); such a context needs the caller's psi parts (h_psi_parts != NULL).
  *
  * Fields (enum pmc_vb_field; K, K x D or K x D x D doubles, row-major): the prior ALPHA0, BETA0, NU0, M0, INV_W0 (the
  *   INVERSE of the constructor's W0), LOG_DET_W0 (of W0); the posterior ALPHA, BETA, NU, M, W, LOG_DET_W; the expectations
@@ -228,6 +230,8 @@ int pmc_vb_estep(pmc_ctx *ctx, const pmc_samples *s, const double *h_sample_w, i
  *   queued, and a W_k^-1 that does not factorise is reported (PMC_ENOTPOSDEF, naming the component) by the next call
  *   that copies a block back.  The reference's checks of N_comp and S (variational.pyx:122-126) stay with the caller.
  */
+/* Lifetime: pmc_shutdown destroys the states of its context; a handle that outlives it is refused by every call
+ * (PMC_EINVAL) and pmc_vb_state_destroy of it is a no-op -- a garbage collector may finalise in either order. */
 typedef struct pmc_vb_state pmc_vb_state;
 enum pmc_vb_field {
     PMC_VB_ALPHA0 = 0, PMC_VB_BETA0, PMC_VB_NU0, PMC_VB_M0, PMC_VB_INV_W0, PMC_VB_LOG_DET_W0,

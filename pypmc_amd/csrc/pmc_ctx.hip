@@ -677,12 +677,15 @@ int pmc_ctx_p2p_connect(pmc_ctx *ctx, const void *h_handles)
     return rc;
 }
 
+static void vb_states_of_context_gone(pmc_ctx *ctx);                // (below, with the VB state)
+
 int pmc_shutdown(pmc_ctx *ctx)
 {
     if (!ctx) return PMC_OK;
     (void)hipSetDevice(ctx->parts[0]->device);
     int rc = PMC_OK;
     ctx->mu.lock();                                                 // (a call still running in another thread finishes first)
+    vb_states_of_context_gone(ctx);
     if (ctx->comm) rc = pmc_comm_destroy(ctx->comm);
     if (ctx->p2p) (void)pmc_p2p_destroy(ctx->p2p);
     if (ctx->p2p_failed) (void)pmc_p2p_destroy(ctx->p2p_failed);
@@ -1260,10 +1263,39 @@ struct pmc_vb_state {
     DevBuf buf, pack, spack;
     double *field[PMC_VB_NFIELDS];
     pmc_vb_fields f;
-    double *c0, *c3, *log_q_Z, *result, *conv, *terms, *shift2, *shift_next, *psi_parts;
+    double *c0, *c3, *log_q_Z, *result, *conv, *terms, *shift2, *shift_next, *psi_parts, *bcast;
     size_t nresult, nconv;
     bool stepped;                                                   // an E-step has run: the E_* fields mean something
 };
+
+// The states that are alive, by address: a front-end's garbage collector may finalise a state AFTER the context it lived on was
+// shut down (weak references to unreachable objects are cleared before their finalisers run, so the owner cannot close them
+// first).  pmc_shutdown destroys the states of its context; every entry point checks that its handle is still here.
+static std::mutex g_vb_states_mu;
+static std::vector<pmc_vb_state *> g_vb_states;
+static bool vb_state_alive(const pmc_vb_state *st)
+{
+    std::lock_guard<std::mutex> lk(g_vb_states_mu);
+    for (const pmc_vb_state *q : g_vb_states)
+        if (q == st) return true;
+    return false;
+}
+static void vb_states_of_context_gone(pmc_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lk(g_vb_states_mu);
+    for (size_t i = 0; i < g_vb_states.size();) {
+        pmc_vb_state *st = g_vb_states[i];
+        if (st->ctx != ctx) {
+            ++i;
+            continue;
+        }
+        st->buf.release();
+        st->pack.release();
+        st->spack.release();
+        delete st;
+        g_vb_states.erase(g_vb_states.begin() + (long)i);
+    }
+}
 
 static size_t vb_field_len(int field, int K, int D)
 {
@@ -1279,9 +1311,76 @@ static size_t vb_field_len(int field, int K, int D)
 
 // one pass of the E-step from the resident state: the pack (and the shifts' pack) -> responsibilities + statistics ->
 // the sum over ranks -> conversion -> the state's sums and the small block
+// Several devices (a context of pmc_init_devices): the state lives on the first; what the other devices' pack builders need --
+// [m | W | beta | nu | E ln pi | E ln|Lambda|] | ln|W| | the psi parts | the shifts -- is gathered into one block there and
+// peer-copied to each of them (K x D x D numbers per device and E-step, over the links the statistics come back on); every
+// device builds the same pack, runs its shard, publishes its sums; the first adds them in device order and converts.
+static int vb_state_pass_parts(pmc_vb_state *st, const pmc_samples *s, const double *d_shift, bool with_pack, bool own_psi)
+{
+    pmc_ctx *ctx = st->ctx;
+    Part &p0 = *ctx->parts[0];
+    const int K = st->K, D = st->D;
+    const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
+    const size_t nflat = NSC + (size_t)K * PS, KD = (size_t)K * D, KDD = KD * D;
+    if (own_psi && with_pack)
+        return failf(PMC_EINVAL, "pmc_vb_state_step: the device's own psi is not available over several devices (hand in h_psi_parts)");
+    // the block: [six fields KD + KDD + 4K | ln|W| K | psi parts 2K | shifts KD]
+    const size_t o_ld = KD + KDD + 4 * (size_t)K, o_parts = o_ld + K, o_shift = o_parts + 2 * (size_t)K, nblock = o_shift + KD;
+    double *blk = st->bcast;
+    HK(hipMemcpyAsync(blk, st->field[PMC_VB_M], sizeof(double) * o_ld, hipMemcpyDeviceToDevice, p0.stream), "hipMemcpyAsync (block)");
+    HK(hipMemcpyAsync(blk + o_ld, st->f.log_det_W, sizeof(double) * K, hipMemcpyDeviceToDevice, p0.stream), "hipMemcpyAsync (block)");
+    HK(hipMemcpyAsync(blk + o_parts, st->psi_parts, sizeof(double) * 2 * (size_t)K, hipMemcpyDeviceToDevice, p0.stream), "hipMemcpyAsync (block)");
+    if (d_shift) HK(hipMemcpyAsync(blk + o_shift, d_shift, sizeof(double) * KD, hipMemcpyDeviceToDevice, p0.stream), "hipMemcpyAsync (block)");
+    HK(hipStreamSynchronize(p0.stream), "hipStreamSynchronize");     // (the M-step and the fields the host put are behind this)
+    CK(prepare_slots(ctx, nflat));
+    double *d_pstatus = st->result + (size_t)pmc_vb_small_len(K);
+    CK(for_parts(ctx, [&](Part &pt) -> int {
+        const int i = pt.index;
+        const int64_t N = s->n(i);
+        const bool first = &pt == &p0;
+        DevBuf &pack = first ? st->pack : pt.pack, &spack = first ? st->spack : pt.spack;
+        double *d = blk;
+        if (!first) {
+            CK(pt.params.ensure(sizeof(double) * (nblock + 2 * (size_t)K)));
+            d = pt.params.d();
+            if (pt.device == p0.device)
+                HK(hipMemcpyAsync(d, blk, sizeof(double) * nblock, hipMemcpyDeviceToDevice, pt.stream), "hipMemcpyAsync (block to a device)");
+            else
+                HK(hipMemcpyPeerAsync(d, pt.device, blk, p0.device, sizeof(double) * nblock, pt.stream), "hipMemcpyPeerAsync (block to a device)");
+        }
+        const double *shift_here = d_shift ? (first ? d_shift : d + o_shift) : nullptr;
+        if (with_pack) {
+            CK(pack.ensure((size_t)K * stride * sizeof(double)));
+            if (d_shift) CK(spack.ensure((size_t)K * stride * sizeof(double)));
+            pmc_vb_fields f = st->f;                                // (the first device: the state itself)
+            if (!first) {
+                f.m = d; f.W = d + KD; f.beta = d + KD + KDD; f.nu = f.beta + K; f.ln_pi = f.nu + K; f.ln_lambda = f.ln_pi + K;
+                f.log_det_W = d + o_ld;
+            }
+            CK(pmc_vb_pack_device(K, D, &f, first ? st->psi_parts : d + o_parts, pack.d(), first ? d_pstatus : d + nblock, shift_here,
+                                  d_shift ? spack.d() : nullptr, pt.stream));
+        } else {
+            CK(spack.ensure((size_t)K * stride * sizeof(double)));
+            CK(pmc_pack_means_device(K, D, shift_here, spack.d(), pt.stream));
+        }
+        CK(workspace(pt, N, K, D));
+        CK(pt.u.ensure(sizeof(double) * (size_t)pmc_tile_buffer_len(N > 0 ? N : 1, K)));
+        CK(pt.flat.ensure(sizeof(double) * nflat));
+        const double *d_sw = (N > 0 && s->has_sw) ? s->sw[i].d() : nullptr;
+        CK(pmc_estep_about(s->x[i].d(), N, D, pack.d(), K, PMC_KIND_VB, PMC_RESP_VB, 0, d_sw, nullptr, pt.u.d(), nullptr, nullptr,
+                           pt.flat.d() + NSC, pt.flat.d(), pt.ws.p, d_shift ? spack.d() : nullptr, pt.stream));
+        return publish(ctx, pt, pt.flat.d(), nflat);
+    }));
+    CK(use(ctx));
+    CK(reduce(ctx, p0.flat.d(), nflat));
+    return pmc_vb_convert_after_device(K, D, p0.flat.d() + NSC, d_shift ? d_shift : st->f.m, p0.flat.d(), st->conv, &st->f, st->result,
+                                       st->shift_next, st->log_q_Z, p0.stream);
+}
+
 static int vb_state_pass(pmc_vb_state *st, const pmc_samples *s, Part &pt, const double *d_shift, bool with_pack, bool own_psi)
 {
     pmc_ctx *ctx = st->ctx;
+    if (ctx->nparts() > 1) return vb_state_pass_parts(st, s, d_shift, with_pack, own_psi);
     const int K = st->K, D = st->D;
     const int64_t stride = pmc_pack_stride(D), PS = pmc_stats_stride(D);
     const size_t nflat = NSC + (size_t)K * PS;
@@ -1320,7 +1419,6 @@ int pmc_vb_state_create(pmc_ctx *ctx, int K, int D, pmc_vb_state **out)
     CK(use(ctx));
     CtxCall call_(ctx);
     if (!out || K < 1 || D < 1) return failf(PMC_EINVAL, "pmc_vb_state_create: bad argument");
-    if (ctx->nparts() != 1) return failf(PMC_EINVAL, "pmc_vb_state_create: a context of one device only");
     if (D > pmc_vb_max_dim() || D > pmc_max_compiled_dim())
         return failf(PMC_EINVAL, "pmc_vb_state_create: D = %d: the device-resident update covers D <= %d", D, pmc_vb_max_dim());
     pmc_vb_state *st = new pmc_vb_state();
@@ -1338,7 +1436,8 @@ int pmc_vb_state_create(pmc_ctx *ctx, int K, int D, pmc_vb_state **out)
                                               PMC_VB_E_M, PMC_VB_E_W, PMC_VB_E_BETA, PMC_VB_E_NU, PMC_VB_E_LN_PI, PMC_VB_E_LN_LAMBDA};
     size_t total = 0;
     for (int i = 0; i < PMC_VB_NFIELDS; ++i) total += vb_field_len(order[i], K, D);
-    const size_t extra = 4 * (size_t)K + 8 + st->nresult + st->nconv + (size_t)pmc_vb_bound_scratch_len(K) + 2 * KD;
+    const size_t nbcast = ctx->nparts() > 1 ? 2 * KD + KD * D + 7 * (size_t)K : 0;   // (the block the other devices get: vb_state_pass_parts)
+    const size_t extra = 4 * (size_t)K + 8 + st->nresult + st->nconv + (size_t)pmc_vb_bound_scratch_len(K) + 2 * KD + nbcast;
     if (st->buf.ensure(sizeof(double) * (total + extra)) < 0) {
         delete st;
         return PMC_EHIP;
@@ -1357,6 +1456,7 @@ int pmc_vb_state_create(pmc_ctx *ctx, int K, int D, pmc_vb_state **out)
     st->terms = p; p += (size_t)pmc_vb_bound_scratch_len(K);
     st->shift2 = p; p += KD;
     st->shift_next = p; p += KD;
+    st->bcast = p; p += nbcast;
     Part &pt = *ctx->parts[0];
     const hipError_t e = hipMemsetAsync(st->buf.p, 0, sizeof(double) * (total + extra), pt.stream);
     if (e != hipSuccess) {
@@ -1371,16 +1471,28 @@ int pmc_vb_state_create(pmc_ctx *ctx, int K, int D, pmc_vb_state **out)
     f.m = st->field[PMC_VB_M]; f.W = st->field[PMC_VB_W]; f.log_det_W = st->field[PMC_VB_LOG_DET_W];
     f.ln_lambda = st->field[PMC_VB_LN_LAMBDA]; f.ln_pi = st->field[PMC_VB_LN_PI];
     f.N_comp = st->field[PMC_VB_N_COMP]; f.x_mean = st->field[PMC_VB_X_MEAN]; f.S = st->field[PMC_VB_S];
+    {
+        std::lock_guard<std::mutex> lk(g_vb_states_mu);
+        g_vb_states.push_back(st);
+    }
     *out = st;
     return PMC_OK;
 }
 
 int pmc_vb_state_destroy(pmc_vb_state *st)
 {
-    if (!st) return PMC_OK;
+    if (!st || !vb_state_alive(st)) return PMC_OK;                  // (gone with its context: pmc_shutdown)
     CK(use(st->ctx));
     CtxCall call_(st->ctx);
     (void)hipStreamSynchronize(st->ctx->parts[0]->stream);
+    {
+        std::lock_guard<std::mutex> lk(g_vb_states_mu);
+        for (size_t i = 0; i < g_vb_states.size(); ++i)
+            if (g_vb_states[i] == st) {
+                g_vb_states.erase(g_vb_states.begin() + (long)i);
+                break;
+            }
+    }
     st->buf.release();
     st->pack.release();
     st->spack.release();
@@ -1393,6 +1505,7 @@ int64_t pmc_vb_state_result_len(int K) { return K < 1 ? (int64_t)failf(PMC_EINVA
 int pmc_vb_state_put(pmc_vb_state *st, int field, const double *h)
 {
     if (!st || !h || field < 0 || field >= PMC_VB_E_M) return failf(PMC_EINVAL, "pmc_vb_state_put: bad argument (the E_* fields are read-only)");
+    if (!vb_state_alive(st)) return failf(PMC_EINVAL, "pmc_vb_state_put: this state is gone (its context was shut down)");
     CK(use(st->ctx));
     CtxCall call_(st->ctx);
     Part &pt = *st->ctx->parts[0];
@@ -1405,6 +1518,7 @@ int pmc_vb_state_put(pmc_vb_state *st, int field, const double *h)
 int pmc_vb_state_get(pmc_vb_state *st, int field, double *h)
 {
     if (!st || !h || field < 0 || field >= PMC_VB_NFIELDS) return failf(PMC_EINVAL, "pmc_vb_state_get: bad argument");
+    if (!vb_state_alive(st)) return failf(PMC_EINVAL, "pmc_vb_state_get: this state is gone (its context was shut down)");
     if (field >= PMC_VB_E_M && !st->stepped) return failf(PMC_EINVAL, "pmc_vb_state_get: no E-step has run on this state yet");
     CK(use(st->ctx));
     CtxCall call_(st->ctx);
@@ -1414,6 +1528,7 @@ int pmc_vb_state_get(pmc_vb_state *st, int field, double *h)
 int pmc_vb_state_step(pmc_vb_state *st, const pmc_samples *s, int flags, const double *h_psi_parts, double *h_result)
 {
     if (!st) return failf(PMC_EINVAL, "pmc_vb_state_step: NULL state");
+    if (!vb_state_alive(st)) return failf(PMC_EINVAL, "pmc_vb_state_step: this state is gone (its context was shut down)");
     pmc_ctx *ctx = st->ctx;
     CK(use(ctx));
     CtxCall call_(ctx);

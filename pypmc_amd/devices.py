@@ -208,6 +208,7 @@ class DeviceGroup(object):
         self._mixtures = {}
         import weakref
         self._live_samples = weakref.WeakSet()             # ShardedSamples of this group that have not been freed
+        self._live_states = weakref.WeakSet()              # VBStates on this group's context
 
     # a group is a process-wide handle: densities / samplers that hold one are deep-copied by the front-end; a pickled
     # one becomes a NEW group over the same device ordinals where it is loaded
@@ -224,6 +225,8 @@ class DeviceGroup(object):
             self._mixtures = {}
             # sample sets that are still alive (GaussianInference._samples, sampler.last_run): pmc_shutdown does not own
             # their device buffers, and once the context is gone ShardedSamples.free() can no longer return them (advice r5)
+            for state in list(self._live_states):
+                state.close()
             for smp in list(self._live_samples):
                 smp.free()
             ctx, self._ctx = self._ctx, None
@@ -245,6 +248,25 @@ class DeviceGroup(object):
     def of(devices):
         """a DeviceGroup from what a front-end class was given as ``devices=`` (a group passes through)"""
         return devices if isinstance(devices, DeviceGroup) else DeviceGroup(devices)
+
+    # ------------------------------------------------------------------ the K-sized state of a VB fit (backend.VBState)
+    def ctx(self):
+        return self._ctx
+
+    @staticmethod
+    def _timed(name, fn, *args):
+        return fn(*args)
+
+    def vb_state_supported(self, D):
+        return 1 <= D <= min(int(self.lib.pmc_vb_max_dim()), int(self.lib.pmc_max_compiled_dim()))
+
+    def vb_state(self, K, D):
+        """prior, posterior and latest sums of a GaussianInference on this group's FIRST device (pmc_vb_state over a context of
+        several devices: per E-step the others get the posterior in one peer copy, the statistics come back in device order)"""
+        from .backend import VBState
+        state = VBState(self, K, D)
+        self._live_states.add(state)                           # (close() destroys what is still alive before the context goes)
+        return state
 
     # ------------------------------------------------------------------ handles
     def configure(self, key, value):

@@ -197,9 +197,13 @@ class GaussianInference(object):
             if st is not None:
                 self._fetch_all()
                 st.close()
-            st = self._state = get_backend(self._backend).vb_state(self.K, self.dim)
+            owner = self._group if self._group is not None else get_backend(self._backend)
+            st = self._state = owner.vb_state(self.K, self.dim)
             dirty.update(n for n in _STATE_FIELDS if host.get(n) is not None)
-            self._shift_valid = False
+            # (moments about the previous means from the new state's first E-step on, by the host path's rule: they are there,
+            #  one per component, and finite -- a copy, a pickle and a pruned fit go on exactly as the original would)
+            prev = host.get('_shift_prev')
+            self._shift_valid = prev is not None and prev.shape == (self.K, self.dim) and bool(np.isfinite(prev).all())
         for name in dirty | sticky:
             value = host.get(name)
             if value is not None and name not in dev:
@@ -230,6 +234,12 @@ class GaussianInference(object):
                 np.ascontiguousarray(self.weights.detach().cpu().numpy() if hasattr(self.weights, 'detach') else self.weights)
             self._samples.set_sample_weights(self._weights_host)  # resident: every E-step uses them
             self._data_dev = self._weights_dev = None
+            # the K-sized state on the group's first device (pmc_vb_state over several devices: every device builds its pack
+            # from one peer copy of the posterior, the statistics come back in device order as in pmc_vb_estep)
+            self._vb_samples = self._samples
+            self._use_state = hasattr(self._group, "vb_state") and self._group.vb_state_supported(self.dim) and \
+                type(self).M_step is GaussianInference.M_step and type(self).E_step is GaussianInference.E_step and \
+                os.environ.get('PMC_VB_DEVICE_STATE', '1') != '0'
         else:
             be = get_backend(self._backend)
             self._data_dev = be.asdevice(self.data if on_device else np.ascontiguousarray(self.data))
@@ -382,6 +392,7 @@ class GaussianInference(object):
     def M_step(self):
         """Update the Gauss-Wishart / Dirichlet parameters (reference: variational.pyx:129-136)."""
         self._bound_cache = None
+        self._ensure_device_data()                              # (a copy / an unpickled fit: the same route as its original)
         if self._state_active():
             # queued on the device (pmc_vb_mstep_device); a W_k^-1 that does not factorise is reported by the next step
             # that brings a block back (the E-step of update(), likelihood_bound()) or by reading W
@@ -422,6 +433,7 @@ class GaussianInference(object):
 
     def update(self):
         """One M-step followed by one E-step (reference: variational.pyx:571-578)."""
+        self._ensure_device_data()
         if self._state_active() and type(self).E_step is GaussianInference.E_step and getattr(self, '_device_ready', False):
             # M-step, expectations, pack, E-step and the bound as kernels, 8 K + 16 doubles back
             st = self._state_sync()

@@ -187,10 +187,11 @@ static void handle_layer(int nparts, int K, int D, int64_t N, uint64_t seed)
                         Nk.data(), xbar.data(), S.data(), elq.data(), rr.data(), lr.data()) == PMC_OK);
     EXPECT(pmc_vb_estep(ctx, s, w.data(), K, m.mu.data(), W.data(), nu.data(), beta.data(), lnpi.data(), lnlam.data(), m.mu.data(),
                         Nk.data(), xbar.data(), S.data(), elq.data(), nullptr, nullptr) == PMC_OK);
-    // the K-sized state of a VB fit on the device (one-device contexts): every call path, buffers of exactly the documented sizes
+    // the K-sized state of a VB fit on the device (one device, or several: the state on the first): every call path, buffers of
+    // exactly the documented sizes
     {
         pmc_vb_state *vs = nullptr;
-        if (nparts != 1 || D > pmc_vb_max_dim()) {
+        if (D > pmc_vb_max_dim()) {
             EXPECT(pmc_vb_state_create(ctx, K, D, &vs) == PMC_EINVAL);
         } else {
             EXPECT(pmc_vb_state_create(ctx, K, D, &vs) == PMC_OK);
@@ -209,7 +210,8 @@ static void handle_layer(int nparts, int K, int D, int64_t N, uint64_t seed)
             EXPECT(pmc_vb_state_step(vs, nullptr, PMC_VB_DO_MSTEP, nullptr, nullptr) == PMC_OK);  // queued
             EXPECT(pmc_vb_state_step(vs, nullptr, PMC_VB_DO_ESTEP, nullptr, res.data()) == PMC_EINVAL);
             EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_ESTEP, nullptr, nullptr) == PMC_EINVAL);
-            EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_ESTEP, nullptr, res.data()) == PMC_OK);
+            EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_ESTEP, nullptr, res.data()) == (nparts == 1 ? PMC_OK : PMC_EINVAL));   // (the device's psi: one device)
+            EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_ESTEP, parts.data(), res.data()) == PMC_OK);
             EXPECT(pmc_vb_state_step(vs, s, PMC_VB_DO_MSTEP | PMC_VB_DO_ESTEP | PMC_VB_DO_BOUND | PMC_VB_ABOUT_PREV, parts.data(), res.data()) == PMC_OK);
             EXPECT(pmc_vb_state_step(vs, nullptr, PMC_VB_DO_BOUND, nullptr, res.data()) == PMC_OK);
             EXPECT(pmc_vb_state_get(vs, PMC_VB_E_W, big.data()) == PMC_OK);
@@ -218,8 +220,10 @@ static void handle_layer(int nparts, int K, int D, int64_t N, uint64_t seed)
             int info[4] = {-1, -1, -1, -1};
             double bounds[2] = {1.0, 1.0};
             std::vector<double> n0((size_t)K, 1.0);
-            EXPECT(pmc_vb_state_run(vs, s, 3, 0.0, 1.0, 1e-10, 1e-5, 0, n0.data(), nullptr, nullptr, res.data(), info, bounds) == PMC_OK);
-            EXPECT(info[0] == 1 && info[1] == PMC_VB_RUN_LOOK);
+            if (nparts == 1) {
+                EXPECT(pmc_vb_state_run(vs, s, 3, 0.0, 1.0, 1e-10, 1e-5, 0, n0.data(), nullptr, nullptr, res.data(), info, bounds) == PMC_OK);
+                EXPECT(info[0] == 1 && info[1] == PMC_VB_RUN_LOOK);
+            }
             struct Seen { int calls, K; } seen = {0, 0};
             auto psi = [](void *user, int k, const double *n, double *parts) {
                 Seen *sn = (Seen *)user;
@@ -263,7 +267,14 @@ static void handle_layer(int nparts, int K, int D, int64_t N, uint64_t seed)
     pmc_samples *so = nullptr;
     EXPECT(pmc_samples_upload(other, x.data(), 4, D, &so) == PMC_OK);
     EXPECT(pmc_mix_logpdf(q, so, out.data(), nullptr) == PMC_EINVAL);
+    pmc_vb_state *orphan = nullptr;
+    EXPECT(pmc_vb_state_create(other, 2, 3, &orphan) == PMC_OK);
     EXPECT(pmc_samples_free(so) == PMC_OK && pmc_shutdown(other) == PMC_OK);
+    // a state that outlives its context (a garbage collector's order): refused by every call, destroyed already
+    std::vector<double> three(3 * 2 * 3, 0.0);
+    EXPECT(pmc_vb_state_get(orphan, PMC_VB_M, three.data()) == PMC_EINVAL && pmc_vb_state_put(orphan, PMC_VB_M, three.data()) == PMC_EINVAL);
+    EXPECT(pmc_vb_state_step(orphan, nullptr, PMC_VB_DO_MSTEP, nullptr, nullptr) == PMC_EINVAL);
+    EXPECT(pmc_vb_state_destroy(orphan) == PMC_OK);
     EXPECT(pmc_samples_free(s) == PMC_OK && pmc_samples_free(gen) == PMC_OK);
     EXPECT(pmc_mixture_destroy(q) == PMC_OK && pmc_mixture_destroy(tq) == PMC_OK && pmc_mixture_destroy(st) == PMC_OK);
     EXPECT(pmc_shutdown(ctx) == PMC_OK);
