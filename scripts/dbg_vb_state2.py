@@ -1,3 +1,5 @@
+"""Development aid: the constructor E-step of a GaussianInference from the device-resident state against the host path, field by field
+(bitwise), and the E-step repeated on the same object."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
